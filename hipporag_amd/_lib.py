@@ -1,0 +1,111 @@
+"""ctypes binding of libhrag.so (include/hrag.h).  No fallback: if the library is missing and
+cannot be built the import of the compute path fails loudly."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhrag.so")
+
+HRAG_OK, HRAG_EINVAL, HRAG_ENOMEM, HRAG_EHIP, HRAG_EZERO_RESET, HRAG_ECAPACITY = range(6)
+SEED_STRIDE = 32
+FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE = 1, 2, 4
+
+
+class HragError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libhrag status {status}: {message}")
+        self.status = status
+
+
+class GraphDesc(C.Structure):
+    _fields_ = [("num_vertices", C.c_int64), ("row_offset", C.c_int64), ("n_rows", C.c_int64),
+                ("nnz", C.c_int64), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p),
+                ("val", C.c_void_p), ("n_passages", C.c_int64), ("passage_vertex", C.c_void_p)]
+
+
+class EmbedDesc(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("row_offset", C.c_int64), ("dim", C.c_int32),
+                ("dtype", C.c_int32), ("data", C.c_void_p)]
+
+
+class FactDesc(C.Structure):
+    _fields_ = [("n_facts", C.c_int64), ("subj_vertex", C.c_void_p), ("obj_vertex", C.c_void_p),
+                ("num_chunks", C.c_void_p)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("max_batch", C.c_int32), ("max_topk", C.c_int32), ("slab_width", C.c_int32),
+                ("long_row_nnz", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32 * 11)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("fact_sim_ms", C.c_float), ("pass_sim_ms", C.c_float), ("seed_ms", C.c_float),
+                ("ppr_ms", C.c_float), ("rank_ms", C.c_float), ("total_ms", C.c_float),
+                ("ppr_iters", C.c_int32), ("n_slabs", C.c_int32), ("slab_width", C.c_int32),
+                ("n_long_rows", C.c_int32)]
+
+
+_P = C.c_void_p
+_I32, _I64, _F32 = C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/hrag.h declares
+SIGNATURES = {
+    "hrag_last_error": (C.c_char_p, []),
+    "hrag_version": (C.c_int, []),
+    "hrag_engine_create": (C.c_int, [C.POINTER(GraphDesc), C.POINTER(EmbedDesc), C.POINTER(EmbedDesc),
+                                     C.POINTER(FactDesc), C.POINTER(Opts), C.POINTER(_P)]),
+    "hrag_engine_destroy": (C.c_int, [_P]),
+    "hrag_score_facts": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),
+    "hrag_retrieve": (C.c_int, [_P, _P, _I32, _P, _P, _P, _I32, _I32, _F32, _F32, _I32, _I32, _P, _P, _P, _P]),
+    "hrag_dense_retrieve": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),
+    "hrag_sim_scores": (C.c_int, [_P, _I32, _P, _I32, _P, _P]),
+    "hrag_ppr": (C.c_int, [_P, _P, _I32, _F32, _I32, _P, _P, _P]),
+    "hrag_topk_rows": (C.c_int, [_P, _I32, _I64, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "hrag_ppr_sweeps": (C.c_int, [_P, _I32, _I32, _F32, _I32, _P]),
+    "hrag_ppr_layout": (C.c_int, [_P, _I32, C.POINTER(_I32), C.POINTER(_I32)]),
+    "hrag_row_minmax": (C.c_int, [_P, _I32, _I64, _I64, _P, _P, _P]),
+    "hrag_stage_seeds": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "hrag_stage_teleport": (C.c_int, [_P, _P, _I64, _P, _P, _F32, _P, _I32, _P, _P]),
+    "hrag_stage_ppr_init": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P]),
+    "hrag_stage_ppr_step": (C.c_int, [_P, _P, _P, _P, _P, _I32, _F32, _P, _P, _P]),
+    "hrag_stage_colsum": (C.c_int, [_P, _P, _I32, _P, _P, _P]),
+    "hrag_colsum_workspace_bytes": (C.c_int64, [_P, _I32]),
+    "hrag_stage_doc_scores": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _P, _P, _P, _P, _I64, _P]),
+    "hrag_get_timings": (C.c_int, [_P, C.POINTER(Timings)]),
+    "hrag_set_profiling": (C.c_int, [_P, _I32]),
+}
+
+_lib = None
+
+
+def build_library(force: bool = False) -> str:
+    from .csrc.build import build
+    return build(force=force)
+
+
+def load(build_if_missing: bool = True):
+    """Load libhrag.so (building it with hipcc first if it is not there)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise ImportError(f"{LIB_PATH} is missing; run `python -m hipporag_amd.csrc.build`")
+        build_library()
+    # RTLD_LAZY: the CPU-only container has no HIP driver; symbols resolve at first use on a GPU box
+    lib = C.CDLL(LIB_PATH, mode=os.RTLD_LAZY if hasattr(os, "RTLD_LAZY") else C.DEFAULT_MODE)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError => the library does not export what hrag.h declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != HRAG_OK:
+        msg = load().hrag_last_error()
+        raise HragError(status, msg.decode() if msg else "")

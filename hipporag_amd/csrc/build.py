@@ -1,0 +1,79 @@
+"""Build libhrag.so for gfx950 with hipcc (no cmake, no torch extension machinery).
+
+    python -m hipporag_amd.csrc.build        # or: from hipporag_amd.csrc.build import build
+
+The library is written IN-TREE (hipporag_amd/libhrag.so) so that it travels with the repository
+snapshot to the GPU box.  hipcc cross-compiles for gfx950 without a GPU present.
+"""
+
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+INCLUDE = os.path.join(ROOT, "include")
+OBJ_DIR = os.path.join(HERE, "_obj")
+LIB = os.path.join(PKG, "libhrag.so")
+SOURCES = ["errors.cpp", "ppr_spmm.hip", "layout.hip", "sim_gemm.hip", "topk.hip", "seeds.hip",
+           "engine.hip"]
+HEADERS = [os.path.join(HERE, "common.h"), os.path.join(INCLUDE, "hrag.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-I" + INCLUDE, "-I" + HERE]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libhrag.so cannot be built (ROCm toolchain required)")
+    return exe
+
+
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_digest = _digest(HEADERS)
+
+    def compile_one(src: str):
+        src_path = os.path.join(HERE, src)
+        obj = os.path.join(OBJ_DIR, src + ".o")
+        stamp = obj + ".sha"
+        want = _digest([src_path]) + hdr_digest
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
+            return obj, False
+        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src_path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(want)
+        return obj, True
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    objs = [o for o, _ in results]
+    if force or any(changed for _, changed in results) or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

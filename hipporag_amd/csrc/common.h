@@ -1,0 +1,136 @@
+// Internal helpers shared by the libhrag.so translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hrag.h"
+
+namespace hrag {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define HRAG_HIP_TRY(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _err = (expr);                                                           \
+        if (_err != hipSuccess) {                                                           \
+            ::hrag::set_error("%s -> %s (%s:%d)", #expr, hipGetErrorString(_err), __FILE__, \
+                              __LINE__);                                                    \
+            return HRAG_EHIP;                                                               \
+        }                                                                                   \
+    } while (0)
+
+#define HRAG_TRY(expr)                     \
+    do {                                   \
+        hrag_status _st = (expr);          \
+        if (_st != HRAG_OK) return _st;    \
+    } while (0)
+
+#define HRAG_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            ::hrag::set_error(__VA_ARGS__); \
+            return HRAG_EINVAL;            \
+        }                                  \
+    } while (0)
+
+// Launch check: hipGetLastError after every kernel launch (cheap, no sync).
+#define HRAG_LAUNCH_CHECK() HRAG_HIP_TRY(hipGetLastError())
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// ---- monotone float <-> uint32 key (larger float => larger key); -0.0 is folded into +0.0
+__device__ __forceinline__ uint32_t f32_to_ordered(float f) {
+    f += 0.0f;  // -0.0 -> +0.0 so that the two zeros tie like they do in numpy
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_f32(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+// ranking key: score descending, then index descending  <=>  larger 64-bit key first
+__device__ __forceinline__ uint64_t rank_key(float score, uint32_t idx) {
+    return ((uint64_t)f32_to_ordered(score) << 32) | (uint64_t)idx;
+}
+
+// ---- PPR state layout: [n_slabs][rows][BC] fp32, query q lives in slab q / BC, column q % BC.
+struct SlabLayout {
+    int32_t bc;       // slab width (4 * lanes-per-row)
+    int32_t n_slabs;  // ceil(B / bc)
+};
+
+// ------------------------------------------------------------------ kernel launchers
+// ppr_spmm.hip
+struct SpmmArgs {
+    const int32_t *row_ptr;   // [n_rows + 1] local
+    const int32_t *col_idx;   // [nnz] global column ids
+    const float *val;         // [nnz]
+    const int32_t *row_order; // [n_short] local rows handled by the group-per-row kernel
+    int32_t n_short;
+    const int32_t *long_rows; // [n_long] local rows handled by the block-per-row kernel
+    int32_t n_long;
+    int64_t n_rows;           // local rows
+    int64_t row_offset;       // global id of local row 0
+    int64_t num_vertices;     // V (rows per slab of x / y)
+    const float *x;           // [n_slabs][V][BC]
+    float *y;                 // [n_slabs][V][BC]
+    const int32_t *row_to_tele; // [n_rows] teleport slot of local row (-1 none); nullptr => slot = global row
+    const float *tele;        // [n_slabs][tele_rows][BC]
+    int64_t tele_rows;
+    float alpha;              // damping
+    float beta;               // 1 - damping
+};
+hrag_status launch_ppr_spmm(const SpmmArgs &a, SlabLayout lay, bool main_only, hipStream_t s);
+hrag_status launch_ppr_init(const SpmmArgs &a, SlabLayout lay, hipStream_t s); // y = tele (x unused)
+hrag_status launch_seed_scatter(float *y, int64_t num_vertices, int64_t row_offset, int64_t n_rows,
+                                const int32_t *seed_vtx, const float *seed_w,
+                                const int32_t *seed_cnt, int32_t max_seeds, int32_t batch,
+                                float scale, SlabLayout lay, hipStream_t s);
+// column sums of the owned rows: partial [n_slabs][kColsumBlocks][BC] doubles, then sums[B] doubles
+constexpr int kColsumBlocks = 256;
+hrag_status launch_colsum(const float *x, int64_t num_vertices, int64_t row_offset, int64_t n_rows,
+                          int32_t batch, SlabLayout lay, double *partial, double *sums,
+                          hipStream_t s);
+
+// layout.hip : [B, n] row-major  <->  slab layout, with the fused element-wise stages
+enum ToSlabMode { kSanitize = 0, kMinMaxScale = 1 };
+hrag_status launch_rows_to_slab(const float *rows, int64_t ld, int64_t n, int32_t batch,
+                                ToSlabMode mode, const float *mn, const float *mx, float scale,
+                                const int32_t *skip_flags, float *slab, SlabLayout lay,
+                                hipStream_t s);
+// out[q][i] = x[slab(q)][gather ? gather[i] : i][col(q)] / sums[q]
+//   alt != nullptr and (flags[q] & 1): out[q][i] = minmax(alt[q][i]) instead (DPR fallback)
+hrag_status launch_slab_to_rows(const float *slab, int64_t slab_rows, const int32_t *gather,
+                                int64_t n, int32_t batch, const double *sums, float *out,
+                                int64_t ld, const float *alt, int64_t alt_ld, const float *mn,
+                                const float *mx, const int32_t *flags, SlabLayout lay,
+                                hipStream_t s);
+hrag_status launch_flag_zero_mass(const double *sums, int32_t batch, int32_t *flags, int32_t bit,
+                                  hipStream_t s);
+
+// sim_gemm.hip : S[b][m] = sum_k Q[b][k] * E[m][k]   (bf16 in, fp32 out, ld in elements)
+hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
+                            int32_t batch, float *out, int64_t ld, hipStream_t s);
+
+// topk.hip
+constexpr int kTopkMax = 2048;
+enum TopkNorm { kNormNone = 0, kNormMinMax = 1 };
+hrag_status launch_row_topk(const float *scores, int32_t batch, int64_t n, int64_t ld, int32_t k,
+                            int32_t idx_offset, TopkNorm norm, int32_t *idx_out, float *val_out,
+                            float *mn_out, float *mx_out, hipStream_t s);
+hrag_status launch_row_minmax(const float *scores, int32_t batch, int64_t n, int64_t ld,
+                              float *mn_out, float *mx_out, hipStream_t s);
+
+// seeds.hip
+constexpr int kMaxKeptFacts = 16; // kf upper bound
+constexpr int kMaxSeeds = 32;     // 2 * kMaxKeptFacts
+hrag_status launch_build_seeds(const int32_t *kept_idx, const float *kept_score,
+                               const int32_t *kept_count, int32_t kf, int32_t link_top_k,
+                               int32_t batch, const int32_t *subj, const int32_t *obj,
+                               int64_t n_facts, const int32_t *num_chunks, int64_t num_vertices,
+                               int32_t *seed_vtx, float *seed_w, int32_t *seed_cnt,
+                               int32_t *flags, hipStream_t s);
+
+}  // namespace hrag

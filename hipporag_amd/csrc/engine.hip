@@ -1,0 +1,555 @@
+// libhrag.so C ABI (include/hrag.h): engine object, stage operators and the fused
+// hrag_score_facts / hrag_retrieve / hrag_dense_retrieve / hrag_ppr entry points.
+//
+// hrag_engine_create stages what HippoRAG.prepare_retrieval_objects builds on the host
+// (reference src/hipporag/HippoRAG.py:1287-1389) into device memory once; every compute call
+// afterwards only enqueues kernels on the caller's stream (no allocation, no synchronisation).
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+using namespace hrag;
+
+namespace {
+
+enum EvId { EV_START = 0, EV_SIM, EV_SEED, EV_PPR, EV_RANK, EV_FACT0, EV_FACT1, EV_COUNT };
+
+template <typename T>
+hrag_status dev_alloc(T **p, int64_t count) {
+    *p = nullptr;
+    if (count <= 0) return HRAG_OK;
+    hipError_t err = hipMalloc(reinterpret_cast<void **>(p), (size_t)count * sizeof(T));
+    if (err != hipSuccess) {
+        set_error("hipMalloc of %lld bytes failed: %s", (long long)(count * (int64_t)sizeof(T)),
+                  hipGetErrorString(err));
+        *p = nullptr;
+        return HRAG_ENOMEM;
+    }
+    return HRAG_OK;
+}
+
+template <typename T>
+hrag_status dev_upload(T **p, const T *src, int64_t count) {
+    HRAG_TRY(dev_alloc(p, count));
+    if (count > 0) HRAG_HIP_TRY(hipMemcpy(*p, src, (size_t)count * sizeof(T), hipMemcpyDefault));
+    return HRAG_OK;
+}
+
+int auto_slab_width(int batch, int cap) {
+    int bc = 4;
+    while (bc < batch && bc < cap) bc <<= 1;
+    return bc;
+}
+
+}  // namespace
+
+struct hrag_engine {
+    int device = 0;
+    // graph (owned rows)
+    int64_t V = 0, row_offset = 0, n_rows = 0, nnz = 0, n_passages = 0;
+    int32_t *d_row_ptr = nullptr, *d_col = nullptr;
+    float *d_val = nullptr;
+    int32_t *d_row_order = nullptr, *d_long_rows = nullptr;
+    int32_t n_short = 0, n_long = 0;
+    int32_t *d_passage_vertex = nullptr;  // [Np] global vertex ids
+    int32_t *d_row_to_tele = nullptr;     // [n_rows] global passage index of an owned row, or -1
+    // embeddings (owned rows)
+    int32_t dim = 0;
+    int64_t p_rows = 0, p_offset = 0, f_rows = 0, f_offset = 0, n_facts = 0;
+    uint16_t *d_pemb = nullptr, *d_femb = nullptr;
+    int32_t *d_subj = nullptr, *d_obj = nullptr, *d_num_chunks = nullptr;
+    // options
+    int32_t max_batch = 0, max_topk = 0, slab_cap = 32, long_thresh = 0;
+    // workspace
+    int64_t state_elems = 0;  // floats in each of d_x / d_y
+    float *d_x = nullptr, *d_y = nullptr, *d_tele = nullptr, *d_tele_dense = nullptr;
+    int64_t ld_p = 0, ld_f = 0;
+    float *d_spass = nullptr, *d_sfact = nullptr, *d_doc = nullptr;
+    float *d_mn_p = nullptr, *d_mx_p = nullptr;
+    int32_t *d_seed_vtx = nullptr, *d_seed_cnt = nullptr, *d_flags = nullptr;
+    float *d_seed_w = nullptr;
+    double *d_colsum_partial = nullptr, *d_sums = nullptr;
+    // timing
+    hipEvent_t ev[EV_COUNT] = {};
+    bool profiling = false, have_retrieve_ev = false, have_fact_ev = false;
+    hrag_timings last = {};
+
+    SlabLayout layout(int batch) const {
+        SlabLayout l;
+        l.bc = auto_slab_width(batch, slab_cap);
+        l.n_slabs = (int)ceil_div(batch, l.bc);
+        return l;
+    }
+    SpmmArgs spmm_args(const float *x, float *y, const float *tele, int64_t tele_rows,
+                       const int32_t *row_to_tele, float damping) const {
+        SpmmArgs a;
+        a.row_ptr = d_row_ptr; a.col_idx = d_col; a.val = d_val;
+        a.row_order = d_row_order; a.n_short = n_short;
+        a.long_rows = d_long_rows; a.n_long = n_long;
+        a.n_rows = n_rows; a.row_offset = row_offset; a.num_vertices = V;
+        a.x = x; a.y = y; a.row_to_tele = row_to_tele; a.tele = tele; a.tele_rows = tele_rows;
+        a.alpha = damping; a.beta = 1.0f - damping;
+        return a;
+    }
+};
+
+namespace {
+
+void free_engine(hrag_engine *e) {
+    if (!e) return;
+    void *ptrs[] = {e->d_row_ptr, e->d_col, e->d_val, e->d_row_order, e->d_long_rows,
+                    e->d_passage_vertex, e->d_row_to_tele, e->d_pemb, e->d_femb, e->d_subj, e->d_obj,
+                    e->d_num_chunks, e->d_x, e->d_y, e->d_tele, e->d_tele_dense, e->d_spass,
+                    e->d_sfact, e->d_doc, e->d_mn_p, e->d_mx_p, e->d_seed_vtx, e->d_seed_cnt,
+                    e->d_flags, e->d_seed_w, e->d_colsum_partial, e->d_sums};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto &ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+hrag_status check_batch(const hrag_engine *e, int32_t batch) {
+    HRAG_REQUIRE(e != nullptr, "engine is NULL");
+    if (batch < 1 || batch > e->max_batch) {
+        set_error("batch %d outside [1, max_batch=%d]", batch, e->max_batch);
+        return HRAG_ECAPACITY;
+    }
+    return HRAG_OK;
+}
+
+// seeds + teleport are applied the same way at init (scale 1) and in every sweep (scale 1-alpha)
+hrag_status ppr_init(hrag_engine *e, const float *tele, int64_t tele_rows, const int32_t *r2t,
+                     const int32_t *sv, const float *sw, const int32_t *sc, int batch, float *x,
+                     SlabLayout lay, hipStream_t s) {
+    SpmmArgs a = e->spmm_args(nullptr, x, tele, tele_rows, r2t, 0.f);
+    HRAG_TRY(launch_ppr_init(a, lay, s));
+    if (sv)
+        HRAG_TRY(launch_seed_scatter(x, e->V, e->row_offset, e->n_rows, sv, sw, sc, kMaxSeeds, batch,
+                                     1.0f, lay, s));
+    return HRAG_OK;
+}
+
+hrag_status ppr_step(hrag_engine *e, const float *tele, int64_t tele_rows, const int32_t *r2t,
+                     const int32_t *sv, const float *sw, const int32_t *sc, int batch, float damping,
+                     const float *x, float *y, SlabLayout lay, bool main_only, hipStream_t s) {
+    SpmmArgs a = e->spmm_args(x, y, tele, tele_rows, r2t, damping);
+    HRAG_TRY(launch_ppr_spmm(a, lay, main_only, s));
+    if (sv && !main_only)
+        HRAG_TRY(launch_seed_scatter(y, e->V, e->row_offset, e->n_rows, sv, sw, sc, kMaxSeeds, batch,
+                                     1.0f - damping, lay, s));
+    return HRAG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *facts,
+                               const hrag_embed_desc *passages, const hrag_fact_desc *fd,
+                               const hrag_opts *opts, hrag_engine **out) {
+    HRAG_REQUIRE(g && passages && opts && out, "graph, passages, opts and out must be non-NULL");
+    *out = nullptr;
+    HRAG_REQUIRE(g->num_vertices > 0 && g->num_vertices < (int64_t)0x7fffffff, "bad num_vertices");
+    HRAG_REQUIRE(g->n_rows >= 0 && g->row_offset >= 0 && g->row_offset + g->n_rows <= g->num_vertices,
+                 "owned row range [%lld, +%lld) outside the graph", (long long)g->row_offset,
+                 (long long)g->n_rows);
+    HRAG_REQUIRE(g->nnz >= 0 && g->nnz < (int64_t)0x7fffffff, "nnz must fit int32");
+    HRAG_REQUIRE(g->row_ptr && (g->nnz == 0 || (g->col_idx && g->val)), "CSR arrays missing");
+    HRAG_REQUIRE(g->n_passages >= 0 && (g->n_passages == 0 || g->passage_vertex), "passage_vertex missing");
+    HRAG_REQUIRE(passages->dtype == HRAG_BF16 && (!facts || facts->dtype == HRAG_BF16), "only bf16 embeddings");
+    HRAG_REQUIRE(passages->dim > 0 && passages->dim % 8 == 0, "embedding dim must be a multiple of 8");
+    HRAG_REQUIRE(!facts || facts->dim == passages->dim, "fact / passage dims differ");
+    HRAG_REQUIRE((facts == nullptr) == (fd == nullptr), "facts and fact_desc go together");
+    HRAG_REQUIRE(passages->row_offset >= 0 && passages->row_offset + passages->rows <= g->n_passages,
+                 "passage shard outside [0, n_passages)");
+    HRAG_REQUIRE(!facts || (fd->n_facts >= 0 && facts->row_offset >= 0 &&
+                            facts->row_offset + facts->rows <= fd->n_facts && fd->subj_vertex &&
+                            fd->obj_vertex && fd->num_chunks),
+                 "fact shard outside [0, n_facts) or fact_desc arrays missing");
+    HRAG_REQUIRE(opts->max_batch >= 1, "max_batch must be >= 1");
+    HRAG_REQUIRE(opts->max_topk >= 1 && opts->max_topk <= kTopkMax, "max_topk outside [1, %d]", kTopkMax);
+    const int sw = opts->slab_width;
+    HRAG_REQUIRE(sw == 0 || sw == 4 || sw == 8 || sw == 16 || sw == 32 || sw == 64,
+                 "slab_width must be 0 or one of 4, 8, 16, 32, 64");
+
+    if (opts->device >= 0) HRAG_HIP_TRY(hipSetDevice(opts->device));
+    hrag_engine *e = new (std::nothrow) hrag_engine();
+    if (!e) { set_error("out of host memory"); return HRAG_ENOMEM; }
+    HRAG_HIP_TRY(hipGetDevice(&e->device));
+    hrag_status st = HRAG_OK;
+#define E_TRY(expr) do { st = (expr); if (st != HRAG_OK) { free_engine(e); return st; } } while (0)
+#define E_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s -> %s", #expr, hipGetErrorString(_e)); free_engine(e); return HRAG_EHIP; } } while (0)
+
+    e->V = g->num_vertices; e->row_offset = g->row_offset; e->n_rows = g->n_rows; e->nnz = g->nnz;
+    e->n_passages = g->n_passages;
+    e->max_batch = opts->max_batch; e->max_topk = opts->max_topk;
+    e->slab_cap = sw ? sw : 32;
+    e->long_thresh = opts->long_row_nnz > 0 ? opts->long_row_nnz : 1024;
+
+    // ---- CSR to the device; row lists on the host (copy row_ptr back if it came from the device)
+    std::vector<int32_t> h_row_ptr((size_t)e->n_rows + 1);
+    E_HIP(hipMemcpy(h_row_ptr.data(), g->row_ptr, h_row_ptr.size() * sizeof(int32_t), hipMemcpyDefault));
+    if (h_row_ptr[0] != 0 || h_row_ptr[(size_t)e->n_rows] != (int32_t)e->nnz) {
+        set_error("row_ptr[0]=%d / row_ptr[n_rows]=%d inconsistent with nnz=%lld", h_row_ptr[0],
+                  h_row_ptr[(size_t)e->n_rows], (long long)e->nnz);
+        free_engine(e);
+        return HRAG_EINVAL;
+    }
+    E_TRY(dev_upload(&e->d_row_ptr, h_row_ptr.data(), (int64_t)h_row_ptr.size()));
+    E_TRY(dev_upload(&e->d_col, g->col_idx, e->nnz));
+    E_TRY(dev_upload(&e->d_val, g->val, e->nnz));
+    {
+        // short rows in degree-descending order (stable => deterministic), long rows apart
+        std::vector<int32_t> order, longs;
+        order.reserve((size_t)e->n_rows);
+        for (int64_t r = 0; r < e->n_rows; ++r) {
+            const int32_t deg = h_row_ptr[(size_t)r + 1] - h_row_ptr[(size_t)r];
+            if (deg > e->long_thresh) longs.push_back((int32_t)r);
+            else if (deg > 0) order.push_back((int32_t)r);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            return h_row_ptr[(size_t)a + 1] - h_row_ptr[(size_t)a] > h_row_ptr[(size_t)b + 1] - h_row_ptr[(size_t)b];
+        });
+        // rows without entries still need y = (1-alpha) v written: append them at the end
+        for (int64_t r = 0; r < e->n_rows; ++r)
+            if (h_row_ptr[(size_t)r + 1] == h_row_ptr[(size_t)r]) order.push_back((int32_t)r);
+        e->n_short = (int32_t)order.size();
+        e->n_long = (int32_t)longs.size();
+        E_TRY(dev_upload(&e->d_row_order, order.data(), (int64_t)order.size()));
+        E_TRY(dev_upload(&e->d_long_rows, longs.data(), (int64_t)longs.size()));
+    }
+    // ---- passages: vertex map and its inverse on the owned rows
+    {
+        std::vector<int32_t> h_pv((size_t)e->n_passages);
+        if (e->n_passages)
+            E_HIP(hipMemcpy(h_pv.data(), g->passage_vertex, h_pv.size() * sizeof(int32_t), hipMemcpyDefault));
+        std::vector<int32_t> r2t((size_t)e->n_rows, -1);
+        for (int64_t p = 0; p < e->n_passages; ++p) {
+            const int64_t v = h_pv[(size_t)p];
+            if (v < 0 || v >= e->V) {
+                set_error("passage_vertex[%lld]=%lld outside [0, V)", (long long)p, (long long)v);
+                free_engine(e);
+                return HRAG_EINVAL;
+            }
+            const int64_t lr = v - e->row_offset;
+            if (lr >= 0 && lr < e->n_rows) r2t[(size_t)lr] = (int32_t)p;
+        }
+        E_TRY(dev_upload(&e->d_passage_vertex, h_pv.data(), e->n_passages));
+        E_TRY(dev_upload(&e->d_row_to_tele, r2t.data(), e->n_rows));
+    }
+    // ---- embeddings + fact lookup arrays
+    e->dim = passages->dim;
+    e->p_rows = passages->rows; e->p_offset = passages->row_offset;
+    E_TRY(dev_upload(&e->d_pemb, static_cast<const uint16_t *>(passages->data), e->p_rows * e->dim));
+    if (facts) {
+        e->f_rows = facts->rows; e->f_offset = facts->row_offset; e->n_facts = fd->n_facts;
+        E_TRY(dev_upload(&e->d_femb, static_cast<const uint16_t *>(facts->data), e->f_rows * e->dim));
+        E_TRY(dev_upload(&e->d_subj, fd->subj_vertex, e->n_facts));
+        E_TRY(dev_upload(&e->d_obj, fd->obj_vertex, e->n_facts));
+        E_TRY(dev_upload(&e->d_num_chunks, fd->num_chunks, e->V));
+    }
+    // ---- workspace, sized once for max_batch
+    const int B = e->max_batch;
+    SlabLayout lay = e->layout(B);
+    e->state_elems = (int64_t)lay.n_slabs * e->V * lay.bc;
+    E_TRY(dev_alloc(&e->d_x, e->state_elems));
+    E_TRY(dev_alloc(&e->d_y, e->state_elems));
+    E_TRY(dev_alloc(&e->d_tele, (int64_t)lay.n_slabs * std::max<int64_t>(e->n_passages, 1) * lay.bc));
+    e->ld_p = round_up(std::max<int64_t>(e->n_passages, 1), 4);
+    e->ld_f = round_up(std::max<int64_t>(e->f_rows, 1), 4);
+    E_TRY(dev_alloc(&e->d_spass, (int64_t)B * e->ld_p));
+    E_TRY(dev_alloc(&e->d_doc, (int64_t)B * e->ld_p));
+    if (facts) E_TRY(dev_alloc(&e->d_sfact, (int64_t)B * e->ld_f));
+    E_TRY(dev_alloc(&e->d_mn_p, B));
+    E_TRY(dev_alloc(&e->d_mx_p, B));
+    E_TRY(dev_alloc(&e->d_seed_vtx, (int64_t)B * kMaxSeeds));
+    E_TRY(dev_alloc(&e->d_seed_w, (int64_t)B * kMaxSeeds));
+    E_TRY(dev_alloc(&e->d_seed_cnt, B));
+    E_TRY(dev_alloc(&e->d_flags, B));
+    // colsum partials: worst case is the narrowest slab (most slabs * bc stays ~B, padded)
+    E_TRY(dev_alloc(&e->d_colsum_partial, (int64_t)kColsumBlocks * (round_up(B, 4) + 64)));
+    E_TRY(dev_alloc(&e->d_sums, B));
+    E_HIP(hipMemset(e->d_x, 0, (size_t)e->state_elems * sizeof(float)));
+    E_HIP(hipMemset(e->d_y, 0, (size_t)e->state_elems * sizeof(float)));
+    E_HIP(hipMemset(e->d_seed_cnt, 0, (size_t)B * sizeof(int32_t)));
+    for (auto &ev : e->ev) E_HIP(hipEventCreate(&ev));
+    E_HIP(hipDeviceSynchronize());
+#undef E_TRY
+#undef E_HIP
+    *out = e;
+    return HRAG_OK;
+}
+
+hrag_status hrag_engine_destroy(hrag_engine *e) {
+    if (e) {
+        (void)hipSetDevice(e->device);
+        (void)hipDeviceSynchronize();
+        free_engine(e);
+    }
+    return HRAG_OK;
+}
+
+hrag_status hrag_set_profiling(hrag_engine *e, int32_t enabled) {
+    HRAG_REQUIRE(e != nullptr, "engine is NULL");
+    e->profiling = enabled != 0;
+    return HRAG_OK;
+}
+
+hrag_status hrag_get_timings(hrag_engine *e, hrag_timings *out) {
+    HRAG_REQUIRE(e && out, "NULL argument");
+    hrag_timings t = e->last;
+    if (e->have_retrieve_ev) {
+        HRAG_HIP_TRY(hipEventSynchronize(e->ev[EV_RANK]));
+        HRAG_HIP_TRY(hipEventElapsedTime(&t.pass_sim_ms, e->ev[EV_START], e->ev[EV_SIM]));
+        HRAG_HIP_TRY(hipEventElapsedTime(&t.seed_ms, e->ev[EV_SIM], e->ev[EV_SEED]));
+        HRAG_HIP_TRY(hipEventElapsedTime(&t.ppr_ms, e->ev[EV_SEED], e->ev[EV_PPR]));
+        HRAG_HIP_TRY(hipEventElapsedTime(&t.rank_ms, e->ev[EV_PPR], e->ev[EV_RANK]));
+        HRAG_HIP_TRY(hipEventElapsedTime(&t.total_ms, e->ev[EV_START], e->ev[EV_RANK]));
+    }
+    if (e->have_fact_ev) {
+        HRAG_HIP_TRY(hipEventSynchronize(e->ev[EV_FACT1]));
+        HRAG_HIP_TRY(hipEventElapsedTime(&t.fact_sim_ms, e->ev[EV_FACT0], e->ev[EV_FACT1]));
+    }
+    t.n_long_rows = e->n_long;
+    *out = t;
+    return HRAG_OK;
+}
+
+hrag_status hrag_ppr_layout(hrag_engine *e, int32_t batch, int32_t *bc, int32_t *n_slabs) {
+    HRAG_TRY(check_batch(e, batch));
+    SlabLayout l = e->layout(batch);
+    if (bc) *bc = l.bc;
+    if (n_slabs) *n_slabs = l.n_slabs;
+    return HRAG_OK;
+}
+
+hrag_status hrag_sim_scores(hrag_engine *e, int32_t which, const uint16_t *q, int32_t batch,
+                            float *out, hrag_stream stream) {
+    HRAG_REQUIRE(e && q && out, "NULL argument");
+    HRAG_REQUIRE(batch >= 1, "batch must be >= 1");
+    HRAG_REQUIRE(which == 0 || which == 1, "which must be 0 (facts) or 1 (passages)");
+    if (which == 0) {
+        HRAG_REQUIRE(e->d_femb != nullptr || e->f_rows == 0, "engine has no fact embeddings");
+        return launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, out, e->f_rows, (hipStream_t)stream);
+    }
+    return launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q, batch, out, e->p_rows, (hipStream_t)stream);
+}
+
+hrag_status hrag_row_minmax(const float *scores, int32_t batch, int64_t n, int64_t ld, float *mn,
+                            float *mx, hrag_stream stream) {
+    HRAG_REQUIRE(scores && mn && mx && batch >= 1 && n >= 1 && ld >= n, "bad argument");
+    return launch_row_minmax(scores, batch, n, ld, mn, mx, (hipStream_t)stream);
+}
+
+hrag_status hrag_topk_rows(const float *scores, int32_t batch, int64_t n, int64_t ld, int32_t k,
+                           int32_t idx_offset, int32_t normalize, int32_t *idx_out, float *val_out,
+                           float *mn, float *mx, hrag_stream stream) {
+    HRAG_REQUIRE(scores && idx_out && val_out && batch >= 1 && n >= 0 && ld >= n, "bad argument");
+    return launch_row_topk(scores, batch, n, ld, k, idx_offset, normalize ? kNormMinMax : kNormNone,
+                           idx_out, val_out, mn, mx, (hipStream_t)stream);
+}
+
+hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q, int32_t batch, int32_t k,
+                             int32_t *idx_out, float *score_out, hrag_stream stream) {
+    HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(q && idx_out && score_out, "NULL argument");
+    HRAG_REQUIRE(e->d_sfact != nullptr || e->f_rows == 0, "engine has no fact embeddings");
+    HRAG_REQUIRE(e->f_rows == e->n_facts, "hrag_score_facts needs the whole fact matrix; a sharded "
+                 "engine goes through hrag_sim_scores + hrag_topk_rows + an all-gather");
+    hipStream_t s = (hipStream_t)stream;
+    if (e->profiling) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_FACT0], s));
+    HRAG_TRY(launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, e->d_sfact, e->ld_f, s));
+    // get_fact_scores' min_max_normalize + rerank_facts' argsort prefix in one kernel
+    HRAG_TRY(launch_row_topk(e->d_sfact, batch, e->f_rows, e->ld_f, k, 0, kNormMinMax, idx_out, score_out,
+                             nullptr, nullptr, s));
+    if (e->profiling) {
+        HRAG_HIP_TRY(hipEventRecord(e->ev[EV_FACT1], s));
+        e->have_fact_ev = true;
+    }
+    return HRAG_OK;
+}
+
+hrag_status hrag_stage_seeds(hrag_engine *e, const int32_t *kept_idx, const float *kept_score,
+                             const int32_t *kept_count, int32_t kf, int32_t link_top_k, int32_t batch,
+                             int32_t *seed_vtx, float *seed_w, int32_t *seed_cnt, int32_t *flags,
+                             hrag_stream stream) {
+    HRAG_REQUIRE(e && kept_idx && kept_score && kept_count && seed_vtx && seed_w && seed_cnt && flags,
+                 "NULL argument");
+    HRAG_REQUIRE(e->d_subj != nullptr, "engine was created without fact_desc");
+    return launch_build_seeds(kept_idx, kept_score, kept_count, kf, link_top_k, batch, e->d_subj, e->d_obj,
+                              e->n_facts, e->d_num_chunks, e->V, seed_vtx, seed_w, seed_cnt, flags,
+                              (hipStream_t)stream);
+}
+
+hrag_status hrag_stage_teleport(hrag_engine *e, const float *scores, int64_t ld, const float *mn,
+                                const float *mx, float weight, const int32_t *flags, int32_t batch,
+                                float *tele_out, hrag_stream stream) {
+    HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(scores && mn && mx && tele_out && ld >= e->n_passages, "bad argument");
+    return launch_rows_to_slab(scores, ld, e->n_passages, batch, kMinMaxScale, mn, mx, weight, flags,
+                               tele_out, e->layout(batch), (hipStream_t)stream);
+}
+
+hrag_status hrag_stage_ppr_init(hrag_engine *e, const float *tele, const int32_t *sv, const float *sw,
+                                const int32_t *sc, int32_t batch, float *x, hrag_stream stream) {
+    HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(tele && x, "NULL argument");
+    return ppr_init(e, tele, e->n_passages, e->d_row_to_tele, sv, sw, sc, batch, x, e->layout(batch),
+                    (hipStream_t)stream);
+}
+
+hrag_status hrag_stage_ppr_step(hrag_engine *e, const float *tele, const int32_t *sv, const float *sw,
+                                const int32_t *sc, int32_t batch, float damping, const float *x,
+                                float *y, hrag_stream stream) {
+    HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(tele && x && y && x != y, "bad argument");
+    return ppr_step(e, tele, e->n_passages, e->d_row_to_tele, sv, sw, sc, batch, damping, x, y,
+                    e->layout(batch), false, (hipStream_t)stream);
+}
+
+int64_t hrag_colsum_workspace_bytes(hrag_engine *e, int32_t batch) {
+    if (!e || batch < 1) return 0;
+    SlabLayout l = e->layout(batch);
+    return (int64_t)l.n_slabs * kColsumBlocks * l.bc * (int64_t)sizeof(double);
+}
+
+hrag_status hrag_stage_colsum(hrag_engine *e, const float *x, int32_t batch, void *ws, double *sums,
+                              hrag_stream stream) {
+    HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(x && ws && sums, "NULL argument");
+    return launch_colsum(x, e->V, e->row_offset, e->n_rows, batch, e->layout(batch),
+                         static_cast<double *>(ws), sums, (hipStream_t)stream);
+}
+
+hrag_status hrag_stage_doc_scores(hrag_engine *e, const float *x, const double *sums, int32_t batch,
+                                  const float *scores, int64_t ld, const float *mn, const float *mx,
+                                  int32_t *flags, float *out, int64_t out_ld, hrag_stream stream) {
+    HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(x && sums && out && out_ld >= e->n_passages, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    SlabLayout lay = e->layout(batch);
+    HRAG_TRY(launch_slab_to_rows(x, e->V, e->d_passage_vertex, e->n_passages, batch, sums, out, out_ld,
+                                 scores, ld, mn, mx, flags, lay, s));
+    if (flags) HRAG_TRY(launch_flag_zero_mass(sums, batch, flags, 2, s));
+    return HRAG_OK;
+}
+
+hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
+                          const int32_t *kept_idx, const float *kept_score, const int32_t *kept_count,
+                          int32_t kf, int32_t link_top_k, float damping, float passage_node_weight,
+                          int32_t ppr_iters, int32_t k, int32_t *doc_idx_out, float *doc_score_out,
+                          int32_t *flags_out, hrag_stream stream) {
+    HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(q_pass && kept_idx && kept_score && kept_count && doc_idx_out && doc_score_out, "NULL argument");
+    HRAG_REQUIRE(e->n_rows == e->V && e->p_rows == e->n_passages,
+                 "hrag_retrieve needs an unsharded engine; sharded engines use the hrag_stage_* operators");
+    HRAG_REQUIRE(k >= 1 && k <= e->max_topk, "k=%d outside [1, max_topk=%d]", k, e->max_topk);
+    HRAG_REQUIRE(ppr_iters >= 0, "ppr_iters must be >= 0");
+    HRAG_REQUIRE(e->n_passages >= 1, "engine has no passages");
+    hipStream_t s = (hipStream_t)stream;
+    const SlabLayout lay = e->layout(batch);
+    const bool prof = e->profiling;
+
+    HRAG_HIP_TRY(hipMemsetAsync(e->d_flags, 0, (size_t)batch * sizeof(int32_t), s));
+    if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_START], s));
+    // dense_passage_retrieval: raw scores + min / max (HippoRAG.py:1496-1498)
+    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s));
+    HRAG_TRY(launch_row_minmax(e->d_spass, batch, e->n_passages, e->ld_p, e->d_mn_p, e->d_mx_p, s));
+    if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SIM], s));
+    // reset vector: entity seeds + passage prior (HippoRAG.py:1574-1638)
+    HRAG_TRY(hrag_stage_seeds(e, kept_idx, kept_score, kept_count, kf, link_top_k, batch, e->d_seed_vtx,
+                              e->d_seed_w, e->d_seed_cnt, e->d_flags, stream));
+    HRAG_TRY(hrag_stage_teleport(e, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, passage_node_weight,
+                                 e->d_flags, batch, e->d_tele, stream));
+    if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SEED], s));
+    // PPR (HippoRAG.py:1736-1743): fixed-count leaky power iteration
+    float *x = e->d_x, *y = e->d_y;
+    HRAG_TRY(ppr_init(e, e->d_tele, e->n_passages, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w,
+                      e->d_seed_cnt, batch, x, lay, s));
+    for (int it = 0; it < ppr_iters; ++it) {
+        HRAG_TRY(ppr_step(e, e->d_tele, e->n_passages, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w,
+                          e->d_seed_cnt, batch, damping, x, y, lay, false, s));
+        std::swap(x, y);
+    }
+    if (x != e->d_x) std::swap(e->d_x, e->d_y);  // keep the final state in d_x
+    if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_PPR], s));
+    // doc scores + ranking (HippoRAG.py:1745-1747, :503)
+    HRAG_TRY(launch_colsum(e->d_x, e->V, 0, e->V, batch, lay, e->d_colsum_partial, e->d_sums, s));
+    HRAG_TRY(hrag_stage_doc_scores(e, e->d_x, e->d_sums, batch, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p,
+                                   e->d_flags, e->d_doc, e->ld_p, stream));
+    HRAG_TRY(launch_row_topk(e->d_doc, batch, e->n_passages, e->ld_p, k, 0, kNormNone, doc_idx_out,
+                             doc_score_out, nullptr, nullptr, s));
+    if (flags_out)
+        HRAG_HIP_TRY(hipMemcpyAsync(flags_out, e->d_flags, (size_t)batch * sizeof(int32_t),
+                                    hipMemcpyDeviceToDevice, s));
+    if (prof) {
+        HRAG_HIP_TRY(hipEventRecord(e->ev[EV_RANK], s));
+        e->have_retrieve_ev = true;
+    }
+    e->last.ppr_iters = ppr_iters;
+    e->last.n_slabs = lay.n_slabs;
+    e->last.slab_width = lay.bc;
+    return HRAG_OK;
+}
+
+hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch, int32_t k,
+                                int32_t *doc_idx_out, float *doc_score_out, hrag_stream stream) {
+    HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(q_pass && doc_idx_out && doc_score_out, "NULL argument");
+    HRAG_REQUIRE(e->p_rows == e->n_passages, "hrag_dense_retrieve needs the whole passage matrix");
+    HRAG_REQUIRE(k >= 1 && k <= e->max_topk, "k=%d outside [1, max_topk=%d]", k, e->max_topk);
+    hipStream_t s = (hipStream_t)stream;
+    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s));
+    return launch_row_topk(e->d_spass, batch, e->n_passages, e->ld_p, k, 0, kNormMinMax, doc_idx_out,
+                           doc_score_out, nullptr, nullptr, s);
+}
+
+hrag_status hrag_ppr(hrag_engine *e, const float *reset, int32_t batch, float damping, int32_t iters,
+                     float *x_out, int32_t *flags_out, hrag_stream stream) {
+    HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(reset && x_out && iters >= 0, "bad argument");
+    HRAG_REQUIRE(e->n_rows == e->V, "hrag_ppr needs an unsharded engine");
+    hipStream_t s = (hipStream_t)stream;
+    if (!e->d_tele_dense) HRAG_TRY(dev_alloc(&e->d_tele_dense, e->state_elems));  // first use only
+    const SlabLayout lay = e->layout(batch);
+    HRAG_TRY(launch_rows_to_slab(reset, e->V, e->V, batch, kSanitize, nullptr, nullptr, 1.f, nullptr,
+                                 e->d_tele_dense, lay, s));
+    float *x = e->d_x, *y = e->d_y;
+    HRAG_TRY(ppr_init(e, e->d_tele_dense, e->V, nullptr, nullptr, nullptr, nullptr, batch, x, lay, s));
+    for (int it = 0; it < iters; ++it) {
+        HRAG_TRY(ppr_step(e, e->d_tele_dense, e->V, nullptr, nullptr, nullptr, nullptr, batch, damping, x,
+                          y, lay, false, s));
+        std::swap(x, y);
+    }
+    if (x != e->d_x) std::swap(e->d_x, e->d_y);
+    HRAG_TRY(launch_colsum(e->d_x, e->V, 0, e->V, batch, lay, e->d_colsum_partial, e->d_sums, s));
+    HRAG_TRY(launch_slab_to_rows(e->d_x, e->V, nullptr, e->V, batch, e->d_sums, x_out, e->V, nullptr, 0,
+                                 nullptr, nullptr, nullptr, lay, s));
+    if (flags_out) {
+        HRAG_HIP_TRY(hipMemsetAsync(flags_out, 0, (size_t)batch * sizeof(int32_t), s));
+        HRAG_TRY(launch_flag_zero_mass(e->d_sums, batch, flags_out, 2, s));
+    }
+    return HRAG_OK;
+}
+
+hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damping, int32_t flags,
+                            hrag_stream stream) {
+    HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(n >= 0, "n must be >= 0");
+    const SlabLayout lay = e->layout(batch);
+    float *x = e->d_x, *y = e->d_y;
+    for (int it = 0; it < n; ++it) {
+        HRAG_TRY(ppr_step(e, e->d_tele, e->n_passages, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w,
+                          e->d_seed_cnt, batch, damping, x, y, lay, (flags & 1) != 0, (hipStream_t)stream));
+        std::swap(x, y);
+    }
+    if (x != e->d_x) std::swap(e->d_x, e->d_y);
+    return HRAG_OK;
+}
+
+}  // extern "C"

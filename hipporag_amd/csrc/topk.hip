@@ -1,0 +1,248 @@
+// K4 -- row-wise top-k selection with the library ranking rule (score desc, index desc), fused
+// with the row min / max that min_max_normalize needs.
+//
+// Replaces the full np.argsort(...)[::-1] of the reference wherever only a prefix is consumed:
+//   rerank_facts      np.argsort(query_fact_scores)[-link_top_k:][::-1]   HippoRAG.py:1683-1688
+//   run_ppr           np.argsort(doc_scores)[::-1] (top retrieval_top_k)   HippoRAG.py:1746, :503
+//   dense_passage_retrieval  np.argsort(query_doc_scores)[::-1]            HippoRAG.py:1500
+// and min_max_normalize (utils/misc_utils.py:130-139) for the selected entries.
+//
+// One 1024-thread workgroup per row, two streaming passes, everything else in LDS:
+//   pass 1: every thread keeps its 2 largest 64-bit keys (ordered(score) << 32 | index; keys are
+//           unique, so ties need no special casing) and the running min / max.  The k-th largest
+//           of the 2048 thread-local maxima is a lower bound L of the true k-th key (at least k
+//           elements are >= L).
+//   pass 2: keys >= L are appended to an LDS candidate buffer (expected k..~1.3k entries),
+//           bitonic-sorted descending, and the first k are written out.
+// If an adversarial distribution overflows the buffer the exact k-th key is found by bisection on
+// the key space (counting passes) and pass 2 is repeated; correctness never depends on luck.
+#include "common.h"
+
+namespace hrag {
+namespace {
+
+constexpr int TK_THREADS = 1024;
+constexpr int TK_CAP = 4096;  // LDS candidate capacity (32 KiB of keys)
+
+__device__ __forceinline__ void bitonic_sort_desc(uint64_t *buf, int n_pow2, int tid) {
+    for (int size = 2; size <= n_pow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (n_pow2 >> 1); t += TK_THREADS) {
+                const int i = ((t / stride) * (stride << 1)) + (t % stride);
+                const int j = i + stride;
+                const bool first_half = (i & size) == 0;
+                const uint64_t a = buf[i], b = buf[j];
+                if ((a < b) == first_half) {
+                    buf[i] = b;
+                    buf[j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename F>
+__device__ __forceinline__ void for_each_in_row(const float *s, int64_t n, int tid, F f) {
+    const bool vec = (reinterpret_cast<uintptr_t>(s) & 15) == 0;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(s);
+        for (int64_t i = tid; i < n4; i += TK_THREADS) {
+            const float4 v = s4[i];
+            f(v.x, (uint32_t)(4 * i));
+            f(v.y, (uint32_t)(4 * i + 1));
+            f(v.z, (uint32_t)(4 * i + 2));
+            f(v.w, (uint32_t)(4 * i + 3));
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += TK_THREADS) f(s[i], (uint32_t)i);
+    } else {
+        for (int64_t i = tid; i < n; i += TK_THREADS) f(s[i], (uint32_t)i);
+    }
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float minmax_norm(float s, float mn, float mx) {
+    const float range = mx - mn;
+    return range == 0.f ? 1.f : __fdiv_rn(s - mn, range);  // misc_utils.py:130-139
+}
+
+__global__ __launch_bounds__(TK_THREADS) void row_topk_kernel(
+    const float *__restrict__ scores, int64_t n, int64_t ld, int32_t k, int32_t idx_offset,
+    int32_t norm, int32_t *__restrict__ idx_out, float *__restrict__ val_out,
+    float *__restrict__ mn_out, float *__restrict__ mx_out) {
+    __shared__ uint64_t buf[TK_CAP];
+    __shared__ float red_mn[TK_THREADS / 64], red_mx[TK_THREADS / 64];
+    __shared__ unsigned int s_count;
+    __shared__ uint64_t s_key;
+
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;
+    const float *s = scores + (size_t)row * ld;
+    const int kk = (int)((int64_t)k < n ? (int64_t)k : n);
+
+    // ---- pass 1: thread-local top-2 + min / max
+    uint64_t t0 = 0, t1 = 0;
+    float mn = INFINITY, mx = -INFINITY;
+    for_each_in_row(s, n, tid, [&](float v, uint32_t i) {
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+        const uint64_t key = rank_key(v, i);
+        if (key > t1) {
+            if (key > t0) {
+                t1 = t0;
+                t0 = key;
+            } else {
+                t1 = key;
+            }
+        }
+    });
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) {
+        red_mn[tid >> 6] = mn;
+        red_mx[tid >> 6] = mx;
+    }
+    buf[tid] = t0;
+    buf[TK_THREADS + tid] = t1;
+    __syncthreads();
+    mn = red_mn[0];
+    mx = red_mx[0];
+    for (int w = 1; w < TK_THREADS / 64; ++w) {
+        mn = fminf(mn, red_mn[w]);
+        mx = fmaxf(mx, red_mx[w]);
+    }
+    if (tid == 0) {
+        if (mn_out) mn_out[row] = mn;
+        if (mx_out) mx_out[row] = mx;
+    }
+    if (kk == 0) {
+        for (int j = tid; j < k; j += TK_THREADS) {
+            idx_out[(size_t)row * k + j] = -1;
+            val_out[(size_t)row * k + j] = 0.f;
+        }
+        return;
+    }
+    bitonic_sort_desc(buf, 2 * TK_THREADS, tid);
+    uint64_t thresh = buf[kk - 1];
+    __syncthreads();
+
+    // ---- pass 2: collect candidates >= thresh (bisect first if they would not fit)
+    auto count_ge = [&](uint64_t t) -> unsigned int {
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        unsigned int c = 0;
+        for_each_in_row(s, n, tid, [&](float v, uint32_t i) { c += rank_key(v, i) >= t ? 1u : 0u; });
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((tid & 63) == 0 && c) atomicAdd(&s_count, c);
+        __syncthreads();
+        const unsigned int r = s_count;
+        __syncthreads();
+        return r;
+    };
+    unsigned int cnt = count_ge(thresh);
+    if (cnt > TK_CAP) {
+        // exact kk-th largest key by bisection: count(>= lo) >= kk always holds
+        uint64_t lo = thresh, hi = ~0ull;
+        while (lo < hi) {
+            const uint64_t mid = lo + ((hi - lo) >> 1) + 1;
+            if (count_ge(mid) >= (unsigned int)kk)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        thresh = lo;
+    }
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    for_each_in_row(s, n, tid, [&](float v, uint32_t i) {
+        const uint64_t key = rank_key(v, i);
+        if (key >= thresh) {
+            const unsigned int slot = atomicAdd(&s_count, 1u);
+            if (slot < TK_CAP) buf[slot] = key;
+        }
+    });
+    __syncthreads();
+    cnt = s_count < (unsigned int)TK_CAP ? s_count : (unsigned int)TK_CAP;
+    int p2 = 2;
+    while (p2 < (int)cnt) p2 <<= 1;
+    for (int j = (int)cnt + tid; j < p2; j += TK_THREADS) buf[j] = 0;
+    __syncthreads();
+    bitonic_sort_desc(buf, p2, tid);
+
+    for (int j = tid; j < k; j += TK_THREADS) {
+        int32_t idx = -1;
+        float val = 0.f;
+        if (j < kk) {
+            const uint64_t key = buf[j];
+            idx = (int32_t)(uint32_t)key + idx_offset;
+            val = ordered_to_f32((uint32_t)(key >> 32));
+            if (norm == kNormMinMax) val = minmax_norm(val, mn, mx);
+        }
+        idx_out[(size_t)row * k + j] = idx;
+        val_out[(size_t)row * k + j] = val;
+    }
+}
+
+__global__ __launch_bounds__(TK_THREADS) void row_minmax_kernel(const float *__restrict__ scores,
+                                                                int64_t n, int64_t ld,
+                                                                float *__restrict__ mn_out,
+                                                                float *__restrict__ mx_out) {
+    __shared__ float red_mn[TK_THREADS / 64], red_mx[TK_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;
+    const float *s = scores + (size_t)row * ld;
+    float mn = INFINITY, mx = -INFINITY;
+    for_each_in_row(s, n, tid, [&](float v, uint32_t) {
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    });
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) {
+        red_mn[tid >> 6] = mn;
+        red_mx[tid >> 6] = mx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < TK_THREADS / 64; ++w) {
+            mn = fminf(mn, red_mn[w]);
+            mx = fmaxf(mx, red_mx[w]);
+        }
+        mn_out[row] = mn;
+        mx_out[row] = mx;
+    }
+}
+
+}  // namespace
+
+hrag_status launch_row_topk(const float *scores, int32_t batch, int64_t n, int64_t ld, int32_t k,
+                            int32_t idx_offset, TopkNorm norm, int32_t *idx_out, float *val_out,
+                            float *mn_out, float *mx_out, hipStream_t s) {
+    HRAG_REQUIRE(k >= 1 && k <= kTopkMax, "top-k k=%d outside [1, %d]", k, kTopkMax);
+    HRAG_REQUIRE(n >= 0 && n < (int64_t)0xffffffffll, "row length %lld not supported", (long long)n);
+    if (batch == 0) return HRAG_OK;
+    hipLaunchKernelGGL(row_topk_kernel, dim3((unsigned)batch), dim3(TK_THREADS), 0, s, scores, n, ld, k,
+                       idx_offset, (int32_t)norm, idx_out, val_out, mn_out, mx_out);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_row_minmax(const float *scores, int32_t batch, int64_t n, int64_t ld,
+                              float *mn_out, float *mx_out, hipStream_t s) {
+    if (batch == 0) return HRAG_OK;
+    hipLaunchKernelGGL(row_minmax_kernel, dim3((unsigned)batch), dim3(TK_THREADS), 0, s, scores, n, ld,
+                       mn_out, mx_out);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+}  // namespace hrag

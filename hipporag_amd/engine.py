@@ -1,0 +1,262 @@
+"""Torch-facing wrapper of the libhrag.so engine (include/hrag.h).
+
+PyTorch supplies device memory and the current HIP stream; all arithmetic on the path happens in
+the hand-written gfx950 kernels behind the C ABI.  There is no CPU or eager-torch fallback: without
+a GPU (or without libhrag.so) constructing an engine raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import (EmbedDesc, FactDesc, GraphDesc, Opts, Timings, check, FLAG_DPR_FALLBACK,
+                   FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, SEED_STRIDE)
+from .graph import CSRGraph
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(a) -> int:
+    """Address of a numpy array (host) or torch tensor (host or device)."""
+    if a is None:
+        return 0
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return a.ctypes.data
+    if not a.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return a.data_ptr()
+
+
+def _stream() -> int:
+    return _torch().cuda.current_stream().cuda_stream
+
+
+def _as_bf16_bits(emb):
+    """Accept a torch bf16 tensor, or uint16 bit patterns (numpy / torch); return (obj, rows, dim)."""
+    torch = _torch()
+    if isinstance(emb, np.ndarray):
+        if emb.dtype != np.uint16:
+            raise TypeError("numpy embeddings must be uint16 bf16 bit patterns "
+                            "(hipporag_amd.graph.float_to_bf16_bits)")
+        emb = np.ascontiguousarray(emb)
+        return emb, emb.shape[0], emb.shape[1]
+    if emb.dtype not in (torch.bfloat16, torch.uint16, torch.int16):
+        raise TypeError("tensor embeddings must be torch.bfloat16 (or raw 16-bit patterns)")
+    emb = emb.contiguous()
+    return emb, emb.shape[0], emb.shape[1]
+
+
+@dataclass
+class RetrieveOutput:
+    doc_idx: "object"     # torch int32 [B, k] passage positions, best first
+    doc_score: "object"   # torch fp32  [B, k]
+    flags: "object"       # torch int32 [B]
+
+
+class HippoRAGEngine:
+    """Device-resident retrieval state: CSR graph, bf16 fact / passage embeddings, lookup arrays.
+
+    Mirrors what ``HippoRAG.prepare_retrieval_objects`` stages on the host (reference
+    src/hipporag/HippoRAG.py:1287-1389).  Row-sharded construction (multi-GPU): pass the row shard
+    of the CSR (``CSRGraph.rows``) with ``row_offset`` and the embedding shards with their offsets.
+    """
+
+    def __init__(self, graph: CSRGraph, passage_vertex, passage_emb, fact_emb=None,
+                 subj_vertex=None, obj_vertex=None, num_chunks=None, *, max_batch: int = 256,
+                 max_topk: int = 200, slab_width: int = 0, long_row_nnz: int = 0,
+                 row_offset: int = 0, passage_offset: int = 0, fact_offset: int = 0,
+                 n_passages: Optional[int] = None, n_facts: Optional[int] = None,
+                 device: Optional[int] = None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HippoRAGEngine needs an MI355X-class GPU: no HIP device is visible "
+                               "(there is no CPU fallback on this path)")
+        self._lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self._handle = C.c_void_p(0)
+
+        pv = np.ascontiguousarray(passage_vertex, dtype=np.int32)
+        self.n_passages = int(pv.shape[0]) if n_passages is None else int(n_passages)
+        p_obj, p_rows, dim = _as_bf16_bits(passage_emb)
+        row_ptr = np.ascontiguousarray(graph.row_ptr, dtype=np.int32)
+        col_idx = np.ascontiguousarray(graph.col_idx, dtype=np.int32)
+        val = np.ascontiguousarray(graph.val, dtype=np.float32)
+        n_rows = row_ptr.shape[0] - 1
+        gd = GraphDesc(graph.num_vertices, row_offset, n_rows, col_idx.shape[0], _ptr(row_ptr),
+                       _ptr(col_idx), _ptr(val), self.n_passages, _ptr(pv))
+        pd = EmbedDesc(p_rows, passage_offset, dim, 0, _ptr(p_obj))
+        fdesc = fd = None
+        keep = [pv, p_obj, row_ptr, col_idx, val]
+        self.n_facts = 0
+        if fact_emb is not None:
+            f_obj, f_rows, f_dim = _as_bf16_bits(fact_emb)
+            if f_dim != dim:
+                raise ValueError("fact / passage embedding dims differ")
+            sv = np.ascontiguousarray(subj_vertex, dtype=np.int32)
+            ov = np.ascontiguousarray(obj_vertex, dtype=np.int32)
+            nc = np.ascontiguousarray(num_chunks, dtype=np.int32)
+            if nc.shape[0] != graph.num_vertices:
+                raise ValueError("num_chunks must have one entry per vertex")
+            self.n_facts = int(sv.shape[0]) if n_facts is None else int(n_facts)
+            if sv.shape[0] != self.n_facts or ov.shape[0] != self.n_facts:
+                raise ValueError("subj_vertex / obj_vertex must cover all (global) facts")
+            fdesc = EmbedDesc(f_rows, fact_offset, dim, 0, _ptr(f_obj))
+            fd = FactDesc(self.n_facts, _ptr(sv), _ptr(ov), _ptr(nc))
+            keep += [f_obj, sv, ov, nc]
+        opts = Opts(max_batch, max_topk, slab_width, long_row_nnz, self.device.index)
+        with torch.cuda.device(self.device):
+            check(self._lib.hrag_engine_create(C.byref(gd), C.byref(fdesc) if fdesc else None,
+                                               C.byref(pd), C.byref(fd) if fd else None,
+                                               C.byref(opts), C.byref(self._handle)))
+        del keep
+        self.num_vertices = int(graph.num_vertices)
+        self.row_offset, self.n_rows = int(row_offset), int(n_rows)
+        self.passage_rows, self.passage_offset = int(p_rows), int(passage_offset)
+        self.fact_rows = int(fact_emb.shape[0]) if fact_emb is not None else 0
+        self.fact_offset = int(fact_offset)
+        self.dim = int(dim)
+        self.max_batch, self.max_topk = int(max_batch), int(max_topk)
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_handle", None) and self._handle.value:
+            self._lib.hrag_engine_destroy(self._handle)
+            self._handle = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ helpers
+    def _q(self, q):
+        torch = _torch()
+        if q.dtype != torch.bfloat16:
+            q = q.to(torch.bfloat16)
+        q = q.to(self.device).contiguous()
+        if q.dim() != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"queries must be [B, {self.dim}]")
+        return q
+
+    def _empty(self, shape, dtype):
+        return _torch().empty(shape, dtype=dtype, device=self.device)
+
+    def set_profiling(self, on: bool):
+        check(self._lib.hrag_set_profiling(self._handle, 1 if on else 0))
+
+    def timings(self) -> dict:
+        t = Timings()
+        check(self._lib.hrag_get_timings(self._handle, C.byref(t)))
+        return {name: getattr(t, name) for name, _ in Timings._fields_}
+
+    def layout(self, batch: int) -> Tuple[int, int]:
+        bc, ns = C.c_int32(), C.c_int32()
+        check(self._lib.hrag_ppr_layout(self._handle, batch, C.byref(bc), C.byref(ns)))
+        return bc.value, ns.value
+
+    # ------------------------------------------------------------------ fused entry points
+    def score_facts(self, q_fact, k: int = 5):
+        """Phase A: (fact ids int32 [B,k], min-max normalised scores fp32 [B,k])."""
+        torch = _torch()
+        q = self._q(q_fact)
+        b = q.shape[0]
+        idx = self._empty((b, k), torch.int32)
+        sc = self._empty((b, k), torch.float32)
+        check(self._lib.hrag_score_facts(self._handle, q.data_ptr(), b, k, idx.data_ptr(), sc.data_ptr(),
+                                         _stream()))
+        return idx, sc
+
+    def retrieve(self, q_pass, kept_idx, kept_score, kept_count, *, link_top_k: int = 5,
+                 damping: float = 0.5, passage_node_weight: float = 0.05, ppr_iters: int = 20,
+                 k: int = 200) -> RetrieveOutput:
+        """Phase B: seeds + passage prior + PPR + ranking (DPR ranking where kept_count == 0)."""
+        torch = _torch()
+        q = self._q(q_pass)
+        b = q.shape[0]
+        kept_idx = kept_idx.to(self.device, torch.int32).contiguous()
+        kept_score = kept_score.to(self.device, torch.float32).contiguous()
+        kept_count = kept_count.to(self.device, torch.int32).contiguous()
+        kf = kept_idx.shape[1]
+        if kept_idx.shape != (b, kf) or kept_score.shape != (b, kf) or kept_count.shape != (b,):
+            raise ValueError("kept_idx / kept_score must be [B, kf], kept_count [B]")
+        idx = self._empty((b, k), torch.int32)
+        sc = self._empty((b, k), torch.float32)
+        flags = self._empty((b,), torch.int32)
+        check(self._lib.hrag_retrieve(self._handle, q.data_ptr(), b, kept_idx.data_ptr(),
+                                      kept_score.data_ptr(), kept_count.data_ptr(), kf, link_top_k,
+                                      damping, passage_node_weight, ppr_iters, k, idx.data_ptr(),
+                                      sc.data_ptr(), flags.data_ptr(), _stream()))
+        return RetrieveOutput(idx, sc, flags)
+
+    def dense_retrieve(self, q_pass, k: int = 200):
+        torch = _torch()
+        q = self._q(q_pass)
+        b = q.shape[0]
+        idx = self._empty((b, k), torch.int32)
+        sc = self._empty((b, k), torch.float32)
+        check(self._lib.hrag_dense_retrieve(self._handle, q.data_ptr(), b, k, idx.data_ptr(),
+                                            sc.data_ptr(), _stream()))
+        return idx, sc
+
+    # ------------------------------------------------------------------ seams
+    def sim_scores(self, which: str, q):
+        """Raw cosine scores fp32 [B, rows] against "facts" or "passages" (np.dot seam)."""
+        torch = _torch()
+        qq = self._q(q)
+        rows = self.fact_rows if which == "facts" else self.passage_rows
+        out = self._empty((qq.shape[0], rows), torch.float32)
+        check(self._lib.hrag_sim_scores(self._handle, 0 if which == "facts" else 1, qq.data_ptr(),
+                                        qq.shape[0], out.data_ptr(), _stream()))
+        return out
+
+    def ppr(self, reset, damping: float = 0.5, iters: int = 20):
+        """run_ppr core for B reset vectors fp32 [B, V] -> (x fp32 [B, V], flags int32 [B])."""
+        torch = _torch()
+        r = reset.to(self.device, torch.float32).contiguous()
+        if r.dim() != 2 or r.shape[1] != self.num_vertices:
+            raise ValueError(f"reset must be [B, {self.num_vertices}]")
+        b = r.shape[0]
+        x = self._empty((b, self.num_vertices), torch.float32)
+        flags = self._empty((b,), torch.int32)
+        check(self._lib.hrag_ppr(self._handle, r.data_ptr(), b, damping, iters, x.data_ptr(),
+                                 flags.data_ptr(), _stream()))
+        return x, flags
+
+    def ppr_sweeps(self, batch: int, n: int, damping: float = 0.5, main_only: bool = False):
+        check(self._lib.hrag_ppr_sweeps(self._handle, batch, n, damping, 1 if main_only else 0, _stream()))
+
+
+def topk_rows(scores, k: int, *, n: Optional[int] = None, idx_offset: int = 0, normalize: bool = False,
+              want_minmax: bool = False):
+    """Row-wise top-k of a device fp32 matrix with the library ranking rule (hrag_topk_rows)."""
+    torch = _torch()
+    lib = _lib.load()
+    if not scores.is_cuda:
+        raise RuntimeError("topk_rows runs on the GPU only")
+    s = scores.to(torch.float32).contiguous()
+    b, ld = s.shape
+    n = ld if n is None else n
+    idx = torch.empty((b, k), dtype=torch.int32, device=s.device)
+    val = torch.empty((b, k), dtype=torch.float32, device=s.device)
+    mn = torch.empty((b,), dtype=torch.float32, device=s.device)
+    mx = torch.empty((b,), dtype=torch.float32, device=s.device)
+    check(lib.hrag_topk_rows(s.data_ptr(), b, n, ld, k, idx_offset, 1 if normalize else 0, idx.data_ptr(),
+                             val.data_ptr(), mn.data_ptr(), mx.data_ptr(), _stream()))
+    return (idx, val, mn, mx) if want_minmax else (idx, val)

@@ -1,0 +1,88 @@
+"""Knowledge-graph -> CSR, with the reference's edge semantics.
+
+The reference keeps an undirected igraph (``is_directed_graph=False``,
+src/hipporag/utils/config_utils.py:176) filled from ``node_to_node_stats``
+(src/hipporag/HippoRAG.py:1189-1223): every dict key becomes its OWN igraph edge, self pairs are
+dropped (:1201); fact pairs are stored under both (s,o) and (o,s) (:906-910) and therefore end up
+as two parallel edges.  PRPACK then treats every undirected edge as two directed ones and
+normalises the weights per source vertex.  ``build_csr`` applies exactly that:
+
+    for every edge (u, v, w), u != v:   A[u,v] += w ; A[v,u] += w
+    P[i,j] = A[i,j] / sum_i A[i,j]        (column-stochastic; vertices without edges: dangling)
+
+and returns P in CSR over OUTPUT vertices (row i lists its in-neighbours j) with int32 indices
+and fp32 values (sums and the division in fp64, rounded once) -- the layout
+``hrag_graph_desc`` (include/hrag.h) expects.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class CSRGraph:
+    num_vertices: int
+    row_ptr: np.ndarray   # int32 [V+1]
+    col_idx: np.ndarray   # int32 [nnz]
+    val: np.ndarray       # fp32  [nnz]  column-normalised
+    raw: np.ndarray       # fp64  [nnz]  summed adjacency weights A[i,j] (before normalisation)
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col_idx.shape[0])
+
+    def rows(self, lo: int, hi: int) -> "CSRGraph":
+        """Row shard [lo, hi) with global column ids (multi-GPU row sharding)."""
+        a, b = int(self.row_ptr[lo]), int(self.row_ptr[hi])
+        return CSRGraph(self.num_vertices, (self.row_ptr[lo:hi + 1] - a).astype(np.int32),
+                        self.col_idx[a:b], self.val[a:b], self.raw[a:b])
+
+
+def build_csr(num_vertices: int, src, dst, weight) -> CSRGraph:
+    src = np.asarray(src, dtype=np.int64)
+    dst = np.asarray(dst, dtype=np.int64)
+    w = np.asarray(weight, dtype=np.float64)
+    if not (src.shape == dst.shape == w.shape):
+        raise ValueError("src, dst, weight must have the same shape")
+    if src.size and (min(src.min(), dst.min()) < 0 or max(src.max(), dst.max()) >= num_vertices):
+        raise ValueError("edge endpoint outside [0, num_vertices)")
+    keep = src != dst                       # HippoRAG.py:1201
+    src, dst, w = src[keep], dst[keep], w[keep]
+    rows = np.concatenate([src, dst])       # both directions of every undirected edge
+    cols = np.concatenate([dst, src])
+    vals = np.concatenate([w, w])
+    key = rows * np.int64(num_vertices) + cols
+    order = np.argsort(key, kind="stable")
+    key, vals = key[order], vals[order]
+    if key.size:
+        first = np.concatenate([[True], key[1:] != key[:-1]])
+        starts = np.flatnonzero(first)
+        merged = np.add.reduceat(vals, starts)          # parallel edges sum
+        ukey = key[starts]
+    else:
+        merged = np.zeros(0)
+        ukey = key
+    urows = ukey // num_vertices
+    ucols = ukey % num_vertices
+    if ukey.size >= 2**31 - 1:
+        raise ValueError("nnz does not fit int32")
+    colsum = np.bincount(ucols, weights=merged, minlength=num_vertices)
+    val = (merged / colsum[ucols]).astype(np.float32) if ukey.size else np.zeros(0, np.float32)
+    counts = np.bincount(urows, minlength=num_vertices)
+    row_ptr = np.zeros(num_vertices + 1, dtype=np.int64)
+    np.cumsum(counts, out=row_ptr[1:])
+    return CSRGraph(int(num_vertices), row_ptr.astype(np.int32), ucols.astype(np.int32), val, merged)
+
+
+def float_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16, returned as uint16 (the wire format of hrag_embed_desc)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    rounded = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)
+    return rounded.astype(np.uint16)
+
+
+def bf16_bits_to_float(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)

@@ -1,0 +1,256 @@
+/*
+ * hrag.h -- C ABI of libhrag.so, the MI355X (gfx950) retrieval hot path of HippoRAG.
+ *
+ * The reference (OSU-NLP-Group/HippoRAG) has no FFI for this path: the seam is a
+ * set of Python methods on class HippoRAG (src/hipporag/HippoRAG.py).  Each entry
+ * point below names the reference method(s) it replaces; INTEGRATION.md shows
+ * the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain C types only: pointers + sizes; no torch / C++ types cross the ABI;
+ *   - every function returns an hrag_status (0 = OK); hrag_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - pointers named *_dev are DEVICE pointers on the engine's device; pointers
+ *     in the *_desc structs used by hrag_engine_create may be host OR device
+ *     (copied with hipMemcpyDefault; the caller may free them right after);
+ *   - every compute entry point takes the HIP stream to enqueue on (pass
+ *     torch.cuda.current_stream().cuda_stream) and returns after enqueueing: no
+ *     device synchronisation, no allocation in the call path (graph-capture safe);
+ *   - bf16 = the upper 16 bits of an IEEE-754 binary32, passed as uint16_t;
+ *   - all index outputs are int32, all score outputs fp32;
+ *   - ranking rule everywhere: score descending, ties -> larger index first
+ *     (== numpy.argsort(x, kind="stable")[::-1]; the reference's np.argsort default
+ *     leaves ties undefined, HippoRAG.py:1500,1688,1746).
+ */
+#ifndef HRAG_H_
+#define HRAG_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HRAG_VERSION_MAJOR 0
+#define HRAG_VERSION_MINOR 1
+
+typedef enum hrag_status {
+    HRAG_OK = 0,
+    HRAG_EINVAL = 1,      /* bad shape / null pointer / unsupported option                    */
+    HRAG_ENOMEM = 2,      /* hipMalloc failed                                                  */
+    HRAG_EHIP = 3,        /* a HIP runtime call failed; text in hrag_last_error()              */
+    HRAG_EZERO_RESET = 4, /* reset vector without positive mass (HippoRAG.py:1644 assert)      */
+    HRAG_ECAPACITY = 5    /* batch / k larger than the engine was created for                  */
+} hrag_status;
+
+typedef struct hrag_engine hrag_engine; /* opaque */
+typedef void *hrag_stream;              /* hipStream_t */
+
+/* Knowledge graph as the PPR consumes it (replaces the igraph object handed to
+ * graph.personalized_pagerank at HippoRAG.py:1736-1743).
+ * CSR over OUTPUT vertices: row i lists the in-neighbours j of i with
+ *   val = A[i][j] / sum_i A[i][j]           (column-stochastic, already normalised)
+ * where A is the symmetric weighted adjacency in which parallel igraph edges are
+ * summed (HippoRAG.py:1189-1223, :906-910).  hipporag_amd.graph.build_csr builds it.
+ * Row sharding (multi-GPU): the engine owns rows [row_offset, row_offset + n_rows)
+ * of a graph with num_vertices columns; single GPU: row_offset = 0, n_rows = V. */
+typedef struct hrag_graph_desc {
+    int64_t num_vertices;          /* V: columns of P == length of the PPR vector            */
+    int64_t row_offset;            /* first global row owned by this engine                  */
+    int64_t n_rows;                /* rows owned                                             */
+    int64_t nnz;                   /* entries in the owned rows                              */
+    const int32_t *row_ptr;        /* [n_rows + 1], row_ptr[0] == 0                          */
+    const int32_t *col_idx;        /* [nnz] global column (source vertex) ids                */
+    const float *val;              /* [nnz]                                                  */
+    int64_t n_passages;            /* Np (global number of passages)                         */
+    const int32_t *passage_vertex; /* [Np] vertex id of passage p (passage_node_idxs, :1333) */
+} hrag_graph_desc;
+
+typedef enum hrag_dtype { HRAG_BF16 = 0 } hrag_dtype;
+
+/* Row-major, L2-normalised embedding matrix (self.fact_embeddings /
+ * self.passage_embeddings, HippoRAG.py:1343-1345), rounded to bf16.
+ * Row sharding: this engine holds rows [row_offset, row_offset + rows). */
+typedef struct hrag_embed_desc {
+    int64_t rows;
+    int64_t row_offset;
+    int32_t dim; /* D, multiple of 32 */
+    hrag_dtype dtype;
+    const void *data;
+} hrag_embed_desc;
+
+/* What graph_search_with_fact_entities needs to turn kept facts into seeds
+ * (HippoRAG.py:1583-1606): the vertex of each fact's subject / object phrase
+ * (-1 when md5("entity-"+phrase) is not a graph node) and, per vertex, the number
+ * of chunks the entity occurs in (len(ent_node_to_chunk_ids[key]); 0 = do not divide). */
+typedef struct hrag_fact_desc {
+    int64_t n_facts;            /* global F                                       */
+    const int32_t *subj_vertex; /* [F]                                            */
+    const int32_t *obj_vertex;  /* [F]                                            */
+    const int32_t *num_chunks;  /* [V]                                            */
+} hrag_fact_desc;
+
+typedef struct hrag_opts {
+    int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */
+    int32_t max_topk;     /* largest k_p (retrieval_top_k); <= 2048                              */
+    int32_t slab_width;   /* PPR state slab width BC in {4,8,16,32,64}; 0 = auto                 */
+    int32_t long_row_nnz; /* rows with more entries go to the block-per-row kernel; 0 = auto     */
+    int32_t device;       /* HIP device ordinal, -1 = current                                    */
+    int32_t reserved[11];
+} hrag_opts;
+
+/* Phase timings of the last hrag_retrieve / hrag_score_facts on an engine, measured
+ * with HIP events on the caller's stream (mirrors the reference's ppr_time /
+ * rerank_time accumulators, HippoRAG.py:184-186).  Milliseconds. */
+typedef struct hrag_timings {
+    float fact_sim_ms;  /* fact GEMM + min/max + top-k           */
+    float pass_sim_ms;  /* passage GEMM + min/max                */
+    float seed_ms;      /* seed + teleport construction          */
+    float ppr_ms;       /* all PPR iterations                    */
+    float rank_ms;      /* normalise + gather + top-k            */
+    float total_ms;
+    int32_t ppr_iters;
+    int32_t n_slabs;
+    int32_t slab_width;
+    int32_t n_long_rows;
+} hrag_timings;
+
+const char *hrag_last_error(void);
+int hrag_version(void); /* major * 1000 + minor */
+
+/* engine_create == prepare_retrieval_objects (HippoRAG.py:1287-1389): stage the graph,
+ * the embedding matrices and the lookup arrays on the device once. `facts` / `fact_desc`
+ * may be NULL for a DPR-only engine (StandardRAG). */
+hrag_status hrag_engine_create(const hrag_graph_desc *graph, const hrag_embed_desc *facts,
+                               const hrag_embed_desc *passages, const hrag_fact_desc *fact_desc,
+                               const hrag_opts *opts, hrag_engine **out);
+hrag_status hrag_engine_destroy(hrag_engine *e);
+
+/* Phase A == get_fact_scores (HippoRAG.py:1427-1465) + the candidate selection of
+ * rerank_facts (:1683-1688) for B queries at once.
+ *   q_fact_dev  bf16 [B, D]  "query_to_fact" embeddings, unit norm
+ *   idx_out_dev int32 [B, k] fact ids (global), best first; -1 beyond min(k, F)
+ *   score_out_dev fp32 [B, k] min-max normalised scores of those facts
+ * The LLM filter (rerank.py:108-131) runs on the host between phase A and B. */
+hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q_fact_dev, int32_t batch, int32_t k,
+                             int32_t *idx_out_dev, float *score_out_dev, hrag_stream stream);
+
+/* Phase B == graph_search_with_fact_entities (:1544-1656) + run_ppr (:1709-1749) +
+ * the DPR fallback of retrieve (:467-469), for B queries at once.
+ *   q_pass_dev       bf16 [B, D]  "query_to_passage" embeddings
+ *   kept_idx_dev     int32 [B, kf] fact ids that survived the filter, in filter order
+ *   kept_score_dev   fp32 [B, kf] their normalised scores (from phase A)
+ *   kept_count_dev   int32 [B]    number of valid entries per row; 0 => DPR ranking
+ *   doc_idx_out_dev  int32 [B, k] passage positions (index into passage_node_keys)
+ *   doc_score_out_dev fp32 [B, k] PPR probability (or normalised DPR score on fallback)
+ *   flags_out_dev    int32 [B]    bit0: DPR fallback used; bit1: reset vector had no mass
+ *                                 bit2: the :1541 assert would fire (kept phrase weight 0)
+ *   ppr_iters: fixed number of power iterations (20 in BASELINE.json). */
+hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass_dev, int32_t batch,
+                          const int32_t *kept_idx_dev, const float *kept_score_dev,
+                          const int32_t *kept_count_dev, int32_t kf, int32_t link_top_k,
+                          float damping, float passage_node_weight, int32_t ppr_iters, int32_t k,
+                          int32_t *doc_idx_out_dev, float *doc_score_out_dev,
+                          int32_t *flags_out_dev, hrag_stream stream);
+
+/* == dense_passage_retrieval (HippoRAG.py:1467-1502, StandardRAG.py:393-429), top-k only. */
+hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass_dev, int32_t batch,
+                                int32_t k, int32_t *doc_idx_out_dev, float *doc_score_out_dev,
+                                hrag_stream stream);
+
+/* ---- lower-level seams (used by the per-method adapters and by the parity tests) ---- */
+
+/* np.dot(embeddings, q.T) (HippoRAG.py:1459 / :1496): raw cosine scores.
+ * which: 0 = facts, 1 = passages.  out_dev fp32 [B, rows] (row stride = rows). */
+hrag_status hrag_sim_scores(hrag_engine *e, int32_t which, const uint16_t *q_dev, int32_t batch,
+                            float *out_dev, hrag_stream stream);
+
+/* run_ppr's numerical core (HippoRAG.py:1735-1743) for B reset vectors:
+ *   reset_dev fp32 [B, V] (NaN / negative entries are zeroed like :1735)
+ *   x_out_dev fp32 [B, V] PPR probabilities (each row sums to 1)
+ *   flags_out_dev int32 [B] bit1 set when a row had no positive mass (may be NULL). */
+hrag_status hrag_ppr(hrag_engine *e, const float *reset_dev, int32_t batch, float damping,
+                     int32_t iters, float *x_out_dev, int32_t *flags_out_dev, hrag_stream stream);
+
+/* Generic row-wise top-k with the library's ranking rule (np.argsort(...)[::-1][:k]) fused with
+ * the row min / max.  scores_dev fp32 [B, ld] (n valid entries per row), 1 <= k <= 2048.
+ *   idx_out_dev int32 [B, k] = position + idx_offset (-1 beyond min(k, n))
+ *   val_out_dev fp32 [B, k]  raw score, or (s - min) / (max - min) when normalize != 0
+ *   min_out_dev / max_out_dev fp32 [B] (may be NULL).  No engine needed. */
+hrag_status hrag_topk_rows(const float *scores_dev, int32_t batch, int64_t n, int64_t ld, int32_t k,
+                           int32_t idx_offset, int32_t normalize, int32_t *idx_out_dev,
+                           float *val_out_dev, float *min_out_dev, float *max_out_dev,
+                           hrag_stream stream);
+
+/* Measurement hook: run `n` PPR SpMM sweeps over the engine's current state buffers for
+ * `batch` right-hand sides (state is whatever the last hrag_retrieve / hrag_ppr left).
+ * flags bit0: main CSR kernel only (skip the long-row and seed kernels). */
+hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damping, int32_t flags,
+                            hrag_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage-level operators.  hrag_retrieve() is exactly the composition of these on engine-owned
+ * buffers; they are exported so that a host can interleave its own exchange steps (the
+ * multi-GPU row-shard mode of hipporag_amd/dist.py all-gathers x between hrag_stage_ppr_step
+ * calls) -- every buffer is caller-owned device memory.
+ *
+ * PPR state layout ("slab layout"): x is [n_slabs][V][bc] fp32; query q lives in slab q / bc,
+ * column q % bc; hrag_ppr_layout() returns (bc, n_slabs) for a batch on this engine.
+ * seed arrays: seed_vtx int32 [B][HRAG_SEED_STRIDE], seed_w fp32 [B][HRAG_SEED_STRIDE], seed_cnt int32 [B].
+ * ------------------------------------------------------------------------------------------ */
+#define HRAG_SEED_STRIDE 32
+
+hrag_status hrag_ppr_layout(hrag_engine *e, int32_t batch, int32_t *slab_width_out,
+                            int32_t *n_slabs_out);
+
+/* min / max of every row (what min_max_normalize reduces, misc_utils.py:131-132). */
+hrag_status hrag_row_minmax(const float *scores_dev, int32_t batch, int64_t n, int64_t ld,
+                            float *min_out_dev, float *max_out_dev, hrag_stream stream);
+
+/* seeds == HippoRAG.py:1574-1623 + :1505-1542 on fact ids (needs the engine's fact_desc).
+ * flags_dev int32 [B] is read-modify-written (bits 0 and 2). */
+hrag_status hrag_stage_seeds(hrag_engine *e, const int32_t *kept_idx_dev, const float *kept_score_dev,
+                             const int32_t *kept_count_dev, int32_t kf, int32_t link_top_k,
+                             int32_t batch, int32_t *seed_vtx_dev, float *seed_w_dev,
+                             int32_t *seed_cnt_dev, int32_t *flags_dev, hrag_stream stream);
+
+/* passage prior == HippoRAG.py:1626-1635: tele[slab][p][c] = minmax(S[q][p]) * passage_node_weight
+ * for ALL Np passages (scores_dev fp32 [B, ld] raw cosine scores in passage order, min/max per
+ * row); rows of queries whose flags bit0 is set (DPR fallback) are zero.
+ * tele_out_dev: [n_slabs][Np][bc]. */
+hrag_status hrag_stage_teleport(hrag_engine *e, const float *scores_dev, int64_t ld,
+                                const float *min_dev, const float *max_dev, float passage_node_weight,
+                                const int32_t *flags_dev, int32_t batch, float *tele_out_dev,
+                                hrag_stream stream);
+
+/* x0 = v on the rows this engine owns (rows [row_offset, row_offset + n_rows) of every slab). */
+hrag_status hrag_stage_ppr_init(hrag_engine *e, const float *tele_dev, const int32_t *seed_vtx_dev,
+                                const float *seed_w_dev, const int32_t *seed_cnt_dev, int32_t batch,
+                                float *x_dev, hrag_stream stream);
+
+/* one sweep y = damping * P x + (1 - damping) * v on the owned rows (reads all of x). */
+hrag_status hrag_stage_ppr_step(hrag_engine *e, const float *tele_dev, const int32_t *seed_vtx_dev,
+                                const float *seed_w_dev, const int32_t *seed_cnt_dev, int32_t batch,
+                                float damping, const float *x_dev, float *y_dev, hrag_stream stream);
+
+/* per-query sum of x over the owned rows -> sums_out_dev double [B] (all-reduce it across shards).
+ * workspace_dev: hrag_colsum_workspace_bytes(e, batch) bytes. */
+hrag_status hrag_stage_colsum(hrag_engine *e, const float *x_dev, int32_t batch, void *workspace_dev,
+                              double *sums_out_dev, hrag_stream stream);
+int64_t hrag_colsum_workspace_bytes(hrag_engine *e, int32_t batch);
+
+/* doc_scores == pagerank_scores[passage_node_idxs] / sum (HippoRAG.py:1745) for ALL Np passages
+ * from a complete x; queries with flags bit0 get minmax(scores_dev) (DPR fallback, :467-469);
+ * sets flags bit1 where sums <= 0 on a non-fallback query.  out_dev fp32 [B, out_ld]. */
+hrag_status hrag_stage_doc_scores(hrag_engine *e, const float *x_dev, const double *sums_dev,
+                                  int32_t batch, const float *scores_dev, int64_t ld,
+                                  const float *min_dev, const float *max_dev, int32_t *flags_dev,
+                                  float *out_dev, int64_t out_ld, hrag_stream stream);
+
+hrag_status hrag_get_timings(hrag_engine *e, hrag_timings *out); /* synchronises the events */
+hrag_status hrag_set_profiling(hrag_engine *e, int32_t enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRAG_H_ */

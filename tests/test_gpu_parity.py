@@ -1,0 +1,295 @@
+"""GPU parity tests: the HIP path (through the C ABI, via hipporag_amd.engine) against the CPU
+oracle on the same seeded inputs.  Bars (BASELINE.json north_star): ranked ids identical (modulo
+documented tie classes), PPR scores within 1e-5 relative."""
+
+import numpy as np
+import pytest
+
+import oracle
+from hipporag_amd.graph import bf16_bits_to_float
+from tests.helpers import make_case, tie_aware_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(x, device, dtype=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(device)
+    return t if dtype is None else t.to(dtype)
+
+
+def _bf16(bits, device):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).to(device).view(torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def case(gpu_device):
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd import synth
+    kg, pass_bits, fact_bits, index = make_case(6000, 60000, 192, seed=21, power_law=True)
+    eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pass_bits, fact_bits, kg.subj_vertex, kg.obj_vertex,
+                         kg.num_chunks, max_batch=80, max_topk=200, long_row_nnz=48)
+    qf_bits, _ = synth.make_queries_np(fact_bits, 70, seed=5)
+    qp_bits, _ = synth.make_queries_np(pass_bits, 70, seed=6)
+    yield dict(kg=kg, index=index, eng=eng, qf_bits=qf_bits, qp_bits=qp_bits,
+               pass_bits=pass_bits, fact_bits=fact_bits)
+    eng.close()
+
+
+# ----------------------------------------------------------------------------- K1 similarity
+@pytest.mark.parametrize("rows,dim,batch", [(1000, 768, 1), (333, 64, 5), (4100, 200, 64), (777, 768, 130),
+                                            (129, 1024, 17)])
+def test_sim_scores_match_fp64_dot(gpu_device, rows, dim, batch):
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd import synth
+    from hipporag_amd.graph import build_csr
+    emb = synth.make_embeddings_np(rows, dim, seed=rows)
+    q = synth.make_embeddings_np(batch, dim, seed=rows + 1)      # asymmetric, unrelated rows
+    g = build_csr(4, [0, 1], [1, 2], [1.0, 1.0])
+    with HippoRAGEngine(g, np.full(rows, 3, np.int32), emb, max_batch=batch) as eng:
+        got = eng.sim_scores("passages", _bf16(q, gpu_device)).cpu().numpy()
+    want = bf16_bits_to_float(q).astype(np.float64) @ bf16_bits_to_float(emb).astype(np.float64).T
+    assert got.shape == (batch, rows)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-6)
+
+
+# ----------------------------------------------------------------------------- K4 top-k
+def _check_topk(gpu_device, scores, k, **kw):
+    from hipporag_amd.engine import topk_rows
+    idx, val, mn, mx = topk_rows(_t(scores, gpu_device), k, want_minmax=True, **kw)
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    n = kw.get("n", scores.shape[1])
+    for r in range(scores.shape[0]):
+        row = scores[r, :n] + np.float32(0.0)
+        want = oracle.topk_desc(row, k)
+        m = len(want)
+        np.testing.assert_array_equal(idx[r, :m], want)
+        np.testing.assert_array_equal(val[r, :m], row[want])
+        assert np.all(idx[r, m:] == -1)
+        assert mn.cpu().numpy()[r] == row.min() and mx.cpu().numpy()[r] == row.max()
+
+
+@pytest.mark.parametrize("n,k", [(3, 5), (100, 5), (5000, 200), (300001, 200), (4099, 2048), (1, 1)])
+def test_topk_rows_exact(gpu_device, n, k):
+    rng = np.random.default_rng(n + k)
+    s = rng.standard_normal((4, n)).astype(np.float32)
+    s[1] = np.round(s[1] * 4) / 4           # heavy ties
+    s[2] = 0.25                             # all equal -> index-descending
+    if n > 2:
+        s[3, :2] = [0.0, -0.0]              # the two zeros tie
+        s[3] = np.sort(s[3])                # ascending input
+    _check_topk(gpu_device, s, k)
+
+
+def test_topk_rows_adversarial_overflow_path(gpu_device):
+    # every large value lives in the slice one thread scans => thread-local maxima give a useless
+    # lower bound => candidate buffer overflows => bisection path must still be exact
+    n, k = 1 << 18, 200
+    rng = np.random.default_rng(0)
+    s = rng.random((2, n)).astype(np.float32)
+    hot = np.arange(0, n, 4096)             # all inside thread 0's float4 stride
+    s[0, hot] += 10.0
+    s[0, hot + 1] += 10.0
+    _check_topk(gpu_device, s, k)
+    _check_topk(gpu_device, s[:, : n - 3], k, n=n - 7)      # unaligned row start / ragged n
+
+
+def test_topk_normalize_matches_min_max(gpu_device):
+    from hipporag_amd.engine import topk_rows
+    rng = np.random.default_rng(1)
+    s = rng.standard_normal((3, 9000)).astype(np.float32)
+    s[2] = 1.5                                              # range 0 -> ones
+    idx, val = topk_rows(_t(s, gpu_device), 5, normalize=True)
+    for r in range(3):
+        norm = oracle.min_max_normalize(s[r])
+        want = oracle.topk_desc(norm, 5) if r < 2 else oracle.topk_desc(s[r], 5)
+        np.testing.assert_array_equal(idx.cpu().numpy()[r], want)
+        np.testing.assert_array_equal(val.cpu().numpy()[r], norm[want])
+
+
+# ----------------------------------------------------------------------------- K3 PPR
+@pytest.mark.parametrize("batch", [1, 3, 7, 33, 70])
+def test_ppr_matches_exact_solution(case, gpu_device, batch):
+    kg, index, eng = case["kg"], case["index"], case["eng"]
+    rng = np.random.default_rng(batch)
+    v = kg.num_vertices
+    reset = np.zeros((batch, v), dtype=np.float32)
+    for b in range(batch):
+        reset[b, kg.passage_vertex] = 0.05 * rng.random(kg.n_passages, dtype=np.float32)
+        seeds = rng.integers(0, kg.n_entities, 5)
+        reset[b, seeds] += rng.random(5, dtype=np.float32)
+    reset[0, 11] = np.nan
+    reset[0, 12] = -3.0                                     # sanitised like HippoRAG.py:1735
+    x, flags = eng.ppr(_t(reset, gpu_device), damping=0.5, iters=30)
+    x = x.cpu().numpy()
+    assert np.all(flags.cpu().numpy() == 0)
+    for b in range(batch):
+        want = oracle.ppr_exact(index.p, reset[b].astype(np.float64), 0.5)
+        assert abs(x[b].sum(dtype=np.float64) - 1.0) < 1e-5
+        big = want > 1e-9
+        rel = np.abs(x[b][big] - want[big]) / want[big]
+        assert rel.max() < 1e-5, (b, rel.max())
+        assert np.all(x[b][~big] <= 2e-9)
+
+
+def test_ppr_twenty_sweeps_and_zero_mass(case, gpu_device):
+    kg, index, eng = case["kg"], case["index"], case["eng"]
+    rng = np.random.default_rng(3)
+    reset = np.zeros((2, kg.num_vertices), dtype=np.float32)
+    reset[0, kg.passage_vertex] = 0.05 * rng.random(kg.n_passages, dtype=np.float32)
+    reset[0, 17] = 1.0
+    x, flags = eng.ppr(_t(reset, gpu_device), damping=0.5, iters=20)
+    assert flags.cpu().numpy().tolist() == [0, 2]           # row 1 has no mass
+    assert np.all(x.cpu().numpy()[1] == 0)
+    want = oracle.ppr_exact(index.p, reset[0].astype(np.float64), 0.5)
+    pv = kg.passage_vertex
+    got = x.cpu().numpy()[0][pv]
+    nz = want[pv] > 0
+    assert (np.abs(got[nz] - want[pv][nz]) / want[pv][nz]).max() < 1e-5
+    # same arithmetic as the oracle's fp32 leaky iteration up to summation order
+    p32 = oracle.ppr_power(index.p, reset[0], 0.5, iters=20, dtype=np.float32)
+    np.testing.assert_allclose(x.cpu().numpy()[0], p32, rtol=2e-5, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------- phase A / B
+def test_score_facts_matches_oracle(case, gpu_device):
+    index, eng = case["index"], case["eng"]
+    qf = bf16_bits_to_float(case["qf_bits"])
+    idx, sc = eng.score_facts(_bf16(case["qf_bits"], gpu_device), k=5)
+    idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
+    for b in range(qf.shape[0]):
+        s = oracle.fact_scores(index.fact_emb, qf[b])
+        want = oracle.topk_desc(s, 5)
+        assert tie_aware_equal(idx[b], want, s[want], abs_gap=2e-6)
+        np.testing.assert_allclose(sc[b], s[idx[b]], rtol=0, atol=2e-6)
+
+
+def _oracle_batch(case, kept_lists):
+    index = case["index"]
+    qf = bf16_bits_to_float(case["qf_bits"])
+    qp = bf16_bits_to_float(case["qp_bits"])
+    out = []
+    for b, kept in enumerate(kept_lists):
+        flt = (lambda cand, kept=kept: kept) if kept is not None else None
+        out.append(oracle.retrieve_one(index, qf[b], qp[b], filter_fn=flt))
+    return out
+
+
+def test_retrieve_end_to_end_identity_filter(case, gpu_device):
+    import torch
+    eng = case["eng"]
+    b = case["qf_bits"].shape[0]
+    idx, sc = eng.score_facts(_bf16(case["qf_bits"], gpu_device), k=5)
+    cnt = torch.full((b,), 5, dtype=torch.int32, device=gpu_device)
+    out = eng.retrieve(_bf16(case["qp_bits"], gpu_device), idx, sc, cnt, ppr_iters=25, k=200)
+    refs = _oracle_batch(case, [None] * b)
+    got_idx, got_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+    assert np.all(out.flags.cpu().numpy() == 0)
+    for q in range(b):
+        ref = refs[q]
+        np.testing.assert_array_equal(idx.cpu().numpy()[q], ref.fact_candidates)
+        want_ids, want_sc = ref.sorted_doc_ids[:200], ref.sorted_doc_scores[:200]
+        assert tie_aware_equal(got_idx[q], want_ids, want_sc, rel_gap=2e-5), q
+        np.testing.assert_allclose(got_sc[q], ref.x[case["kg"].passage_vertex][got_idx[q]], rtol=1e-5, atol=0)
+
+
+def test_retrieve_filter_subsets_and_dpr_fallback(case, gpu_device):
+    import torch
+    eng, index = case["eng"], case["index"]
+    b = 12
+    qf_bits, qp_bits = case["qf_bits"][:b], case["qp_bits"][:b]
+    sub = dict(case, qf_bits=qf_bits, qp_bits=qp_bits)
+    idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
+    idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
+    # the "LLM filter": keep a subset, in its own order; query 3 and 7 keep nothing
+    plans = [[0, 1, 2, 3, 4], [4, 0], [2], [], [1, 3], [0], [3, 2, 1], [], [0, 4], [4, 3, 2, 1, 0], [1], [0, 2]]
+    kept_idx = np.full((b, 5), -1, np.int32)
+    kept_sc = np.zeros((b, 5), np.float32)
+    kept_cnt = np.zeros(b, np.int32)
+    kept_lists = []
+    for q, plan in enumerate(plans):
+        kept_idx[q, :len(plan)] = idx_h[q, plan]
+        kept_sc[q, :len(plan)] = sc_h[q, plan]
+        kept_cnt[q] = len(plan)
+        kept_lists.append(idx_h[q, plan].tolist())
+    out = eng.retrieve(_bf16(qp_bits, gpu_device), _t(kept_idx, gpu_device), _t(kept_sc, gpu_device),
+                       _t(kept_cnt, gpu_device), ppr_iters=25, k=150)
+    refs = _oracle_batch(sub, kept_lists)
+    flags = out.flags.cpu().numpy()
+    for q in range(b):
+        ref = refs[q]
+        assert bool(flags[q] & 1) == ref.used_dpr == (len(plans[q]) == 0)
+        want_ids, want_sc = ref.sorted_doc_ids[:150], ref.sorted_doc_scores[:150]
+        got = out.doc_idx.cpu().numpy()[q]
+        if ref.used_dpr:                     # normalised DPR scores, HippoRAG.py:467-469
+            assert tie_aware_equal(got, want_ids, want_sc, abs_gap=3e-6), q
+            np.testing.assert_allclose(out.doc_score.cpu().numpy()[q], want_sc, rtol=0, atol=3e-6)
+        else:
+            assert tie_aware_equal(got, want_ids, want_sc, rel_gap=2e-5), q
+            np.testing.assert_allclose(out.doc_score.cpu().numpy()[q],
+                                       ref.x[case["kg"].passage_vertex][got], rtol=1e-5, atol=0)
+
+
+def test_dense_retrieve_matches_oracle(case, gpu_device):
+    eng, index = case["eng"], case["index"]
+    qp = bf16_bits_to_float(case["qp_bits"][:9])
+    idx, sc = eng.dense_retrieve(_bf16(case["qp_bits"][:9], gpu_device), k=50)
+    for q in range(9):
+        ids, scores = oracle.retrieve_dpr_one(index, qp[q])
+        assert tie_aware_equal(idx.cpu().numpy()[q], ids[:50], scores[:50], abs_gap=3e-6)
+        np.testing.assert_allclose(sc.cpu().numpy()[q], scores[:50], rtol=0, atol=3e-6)
+
+
+def test_seed_edge_cases(gpu_device):
+    """Phrase shared by several kept facts (mean, HippoRAG.py:1608), num_chunks divisor (:1600),
+    absent phrases (-1), subject == object, and the :1541 assert condition (flag bit 2)."""
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd.graph import build_csr
+    from hipporag_amd import synth
+    v, n_p = 12, 4
+    src = [0, 1, 2, 3, 4, 8, 9, 10, 11, 5]
+    dst = [1, 2, 3, 4, 0, 0, 1, 2, 3, 6]
+    g = build_csr(v, src, dst, np.ones(len(src)))
+    pv = np.array([8, 9, 10, 11], np.int32)
+    subj = np.array([0, 0, 1, 5, 7, 2, 3], np.int32)
+    obj = np.array([1, 2, -1, 5, 0, 3, 4], np.int32)
+    nchunks = np.array([2, 1, 3, 0, 1, 1, 1, 4, 0, 0, 0, 0], np.int32)
+    pe = synth.make_embeddings_np(n_p, 64, 1)
+    fe = synth.make_embeddings_np(len(subj), 64, 2)
+    a = oracle.build_symmetric_csr(v, src, dst, np.ones(len(src)))
+    index = oracle.RefIndex(bf16_bits_to_float(fe), bf16_bits_to_float(pe), subj, obj, nchunks, pv,
+                            oracle.column_normalize(a))
+    scores = np.array([0.9, 0.5, 0.7, 0.3, 0.2, 0.0, 0.6], np.float32)
+    plans = [[0, 1, 2], [3, 4], [5], [0, 1, 2, 4, 6], [2]]
+    b = len(plans)
+    kept_idx = np.full((b, 5), -1, np.int32)
+    kept_sc = np.zeros((b, 5), np.float32)
+    cnt = np.zeros(b, np.int32)
+    for q, p in enumerate(plans):
+        kept_idx[q, :len(p)] = p
+        kept_sc[q, :len(p)] = scores[p]
+        cnt[q] = len(p)
+    qp_bits, _ = synth.make_queries_np(pe, b, 9)
+    with HippoRAGEngine(g, pv, pe, fe, subj, obj, nchunks, max_batch=8, max_topk=4) as eng:
+        out = eng.retrieve(_bf16(qp_bits, gpu_device), _t(kept_idx, gpu_device), _t(kept_sc, gpu_device),
+                           _t(cnt, gpu_device), ppr_iters=40, k=4)
+    flags = out.flags.cpu().numpy()
+    qp = bf16_bits_to_float(qp_bits)
+    for q, p in enumerate(plans):
+        try:
+            ids, w = oracle.seed_weights(index, scores, p)
+            asserted = False
+        except AssertionError:
+            asserted = True
+        assert bool(flags[q] & 4) == asserted, q
+        if asserted:
+            continue
+        dpr_ids, dpr_sc = oracle.dense_passage_scores(index.passage_emb, qp[q])
+        by_p = np.empty_like(dpr_sc)
+        by_p[dpr_ids] = dpr_sc
+        reset = oracle.reset_vector(index, ids, w, by_p)
+        want_ids, want_sc, x = oracle.run_ppr(index, reset)
+        assert tie_aware_equal(out.doc_idx.cpu().numpy()[q], want_ids[:4], want_sc[:4], rel_gap=2e-5)
+        np.testing.assert_allclose(out.doc_score.cpu().numpy()[q], x[pv][out.doc_idx.cpu().numpy()[q]],
+                                   rtol=1e-5)

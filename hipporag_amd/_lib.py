@@ -38,7 +38,8 @@ class FactDesc(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("max_batch", C.c_int32), ("max_topk", C.c_int32), ("slab_width", C.c_int32),
-                ("long_row_nnz", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32 * 11)]
+                ("long_row_nnz", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32),
+                ("segment_nnz", C.c_int32), ("reserved", C.c_int32 * 9)]
 
 
 class Timings(C.Structure):
@@ -91,6 +92,11 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It must
+    # be in the process BEFORE libhrag.so so that libhrag's NEEDED libamdhip64.so.7 binds to the same
+    # runtime instance torch uses; loading libhrag first pulls in /opt/rocm's copy as a second
+    # runtime, which then sees "no ROCm-capable device" (observed on the GPU box).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         if not build_if_missing:
             raise ImportError(f"{LIB_PATH} is missing; run `python -m hipporag_amd.csrc.build`")

@@ -69,8 +69,13 @@ struct SpmmArgs {
     const float *val;         // [nnz]
     const int32_t *row_order; // [n_short] local rows handled by the group-per-row kernel
     int32_t n_short;
-    const int32_t *long_rows; // [n_long] local rows handled by the block-per-row kernel
-    int32_t n_long;
+    // rows above the short-row threshold, cut into segments (one wavefront each)
+    const int32_t *seg_row, *seg_begin, *seg_end, *seg_slot;  // [n_seg]; slot -1: single segment
+    int32_t n_seg;
+    const int32_t *mrow_row, *mrow_first, *mrow_cnt;          // [n_mrow] multi-segment rows
+    int32_t n_mrow;
+    float *partial;           // [n_slabs][n_partial][BC] per-segment partial sums
+    int32_t n_partial;
     int64_t n_rows;           // local rows
     int64_t row_offset;       // global id of local row 0
     int64_t num_vertices;     // V (rows per slab of x / y)
@@ -81,6 +86,7 @@ struct SpmmArgs {
     int64_t tele_rows;
     float alpha;              // damping
     float beta;               // 1 - damping
+    int32_t flags;            // HRAG_OPT_NT_CSR | HRAG_OPT_NT_STORE
 };
 hrag_status launch_ppr_spmm(const SpmmArgs &a, SlabLayout lay, bool main_only, hipStream_t s);
 hrag_status launch_ppr_init(const SpmmArgs &a, SlabLayout lay, hipStream_t s); // y = tele (x unused)

@@ -53,8 +53,12 @@ struct hrag_engine {
     int64_t V = 0, row_offset = 0, n_rows = 0, nnz = 0, n_passages = 0;
     int32_t *d_row_ptr = nullptr, *d_col = nullptr;
     float *d_val = nullptr;
-    int32_t *d_row_order = nullptr, *d_long_rows = nullptr;
-    int32_t n_short = 0, n_long = 0;
+    int32_t *d_row_order = nullptr;
+    int32_t n_short = 0;
+    int32_t *d_seg_row = nullptr, *d_seg_begin = nullptr, *d_seg_end = nullptr, *d_seg_slot = nullptr;
+    int32_t *d_mrow_row = nullptr, *d_mrow_first = nullptr, *d_mrow_cnt = nullptr;
+    int32_t n_seg = 0, n_mrow = 0, n_partial = 0, n_long_rows = 0;
+    float *d_partial = nullptr;
     int32_t *d_passage_vertex = nullptr;  // [Np] global vertex ids
     int32_t *d_row_to_tele = nullptr;     // [n_rows] global passage index of an owned row, or -1
     // embeddings (owned rows)
@@ -63,7 +67,7 @@ struct hrag_engine {
     uint16_t *d_pemb = nullptr, *d_femb = nullptr;
     int32_t *d_subj = nullptr, *d_obj = nullptr, *d_num_chunks = nullptr;
     // options
-    int32_t max_batch = 0, max_topk = 0, slab_cap = 32, long_thresh = 0;
+    int32_t max_batch = 0, max_topk = 0, slab_cap = 32, short_thresh = 0, seg_len = 0, opt_flags = 0;
     // workspace
     int64_t state_elems = 0;  // floats in each of d_x / d_y
     float *d_x = nullptr, *d_y = nullptr, *d_tele = nullptr, *d_tele_dense = nullptr;
@@ -89,10 +93,12 @@ struct hrag_engine {
         SpmmArgs a;
         a.row_ptr = d_row_ptr; a.col_idx = d_col; a.val = d_val;
         a.row_order = d_row_order; a.n_short = n_short;
-        a.long_rows = d_long_rows; a.n_long = n_long;
+        a.seg_row = d_seg_row; a.seg_begin = d_seg_begin; a.seg_end = d_seg_end; a.seg_slot = d_seg_slot;
+        a.n_seg = n_seg; a.mrow_row = d_mrow_row; a.mrow_first = d_mrow_first; a.mrow_cnt = d_mrow_cnt;
+        a.n_mrow = n_mrow; a.partial = d_partial; a.n_partial = n_partial;
         a.n_rows = n_rows; a.row_offset = row_offset; a.num_vertices = V;
         a.x = x; a.y = y; a.row_to_tele = row_to_tele; a.tele = tele; a.tele_rows = tele_rows;
-        a.alpha = damping; a.beta = 1.0f - damping;
+        a.alpha = damping; a.beta = 1.0f - damping; a.flags = opt_flags;
         return a;
     }
 };
@@ -101,7 +107,8 @@ namespace {
 
 void free_engine(hrag_engine *e) {
     if (!e) return;
-    void *ptrs[] = {e->d_row_ptr, e->d_col, e->d_val, e->d_row_order, e->d_long_rows,
+    void *ptrs[] = {e->d_row_ptr, e->d_col, e->d_val, e->d_row_order, e->d_seg_row, e->d_seg_begin,
+                    e->d_seg_end, e->d_seg_slot, e->d_mrow_row, e->d_mrow_first, e->d_mrow_cnt, e->d_partial,
                     e->d_passage_vertex, e->d_row_to_tele, e->d_pemb, e->d_femb, e->d_subj, e->d_obj,
                     e->d_num_chunks, e->d_x, e->d_y, e->d_tele, e->d_tele_dense, e->d_spass,
                     e->d_sfact, e->d_doc, e->d_mn_p, e->d_mx_p, e->d_seed_vtx, e->d_seed_cnt,
@@ -189,7 +196,10 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     e->n_passages = g->n_passages;
     e->max_batch = opts->max_batch; e->max_topk = opts->max_topk;
     e->slab_cap = sw ? sw : 32;
-    e->long_thresh = opts->long_row_nnz > 0 ? opts->long_row_nnz : 1024;
+    // a short row is walked by G lanes in deg/G dependent gather rounds: cap it at 8 rounds
+    e->short_thresh = opts->long_row_nnz > 0 ? opts->long_row_nnz : 8 * (e->slab_cap / 4);
+    e->seg_len = opts->segment_nnz > 0 ? (int)round_up(opts->segment_nnz, 64) : 512;
+    e->opt_flags = opts->flags;
 
     // ---- CSR to the device; row lists on the host (copy row_ptr back if it came from the device)
     std::vector<int32_t> h_row_ptr((size_t)e->n_rows + 1);
@@ -204,24 +214,51 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     E_TRY(dev_upload(&e->d_col, g->col_idx, e->nnz));
     E_TRY(dev_upload(&e->d_val, g->val, e->nnz));
     {
-        // short rows in degree-descending order (stable => deterministic), long rows apart
-        std::vector<int32_t> order, longs;
+        // short rows in degree-descending order (stable => deterministic); longer rows are cut
+        // into segments of <= seg_len entries (one wavefront each)
+        std::vector<int32_t> order, seg_row, seg_begin, seg_end, seg_slot, mrow_row, mrow_first, mrow_cnt;
         order.reserve((size_t)e->n_rows);
+        int32_t n_partial = 0;
         for (int64_t r = 0; r < e->n_rows; ++r) {
-            const int32_t deg = h_row_ptr[(size_t)r + 1] - h_row_ptr[(size_t)r];
-            if (deg > e->long_thresh) longs.push_back((int32_t)r);
-            else if (deg > 0) order.push_back((int32_t)r);
+            const int32_t b0 = h_row_ptr[(size_t)r], e0 = h_row_ptr[(size_t)r + 1];
+            const int32_t deg = e0 - b0;
+            if (deg <= e->short_thresh) {
+                if (deg > 0) order.push_back((int32_t)r);
+                continue;
+            }
+            ++e->n_long_rows;
+            const int32_t nseg = (deg + e->seg_len - 1) / e->seg_len;
+            if (nseg > 1) {
+                mrow_row.push_back((int32_t)r);
+                mrow_first.push_back(n_partial);
+                mrow_cnt.push_back(nseg);
+            }
+            for (int32_t sidx = 0; sidx < nseg; ++sidx) {
+                seg_row.push_back((int32_t)r);
+                seg_begin.push_back(b0 + sidx * e->seg_len);
+                seg_end.push_back(std::min(e0, b0 + (sidx + 1) * e->seg_len));
+                seg_slot.push_back(nseg > 1 ? n_partial++ : -1);
+            }
         }
-        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-            return h_row_ptr[(size_t)a + 1] - h_row_ptr[(size_t)a] > h_row_ptr[(size_t)b + 1] - h_row_ptr[(size_t)b];
-        });
+        if (!(opts->flags & HRAG_OPT_NATURAL_ROW_ORDER))
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+                return h_row_ptr[(size_t)a + 1] - h_row_ptr[(size_t)a] > h_row_ptr[(size_t)b + 1] - h_row_ptr[(size_t)b];
+            });
         // rows without entries still need y = (1-alpha) v written: append them at the end
         for (int64_t r = 0; r < e->n_rows; ++r)
             if (h_row_ptr[(size_t)r + 1] == h_row_ptr[(size_t)r]) order.push_back((int32_t)r);
         e->n_short = (int32_t)order.size();
-        e->n_long = (int32_t)longs.size();
+        e->n_seg = (int32_t)seg_row.size();
+        e->n_mrow = (int32_t)mrow_row.size();
+        e->n_partial = n_partial;
         E_TRY(dev_upload(&e->d_row_order, order.data(), (int64_t)order.size()));
-        E_TRY(dev_upload(&e->d_long_rows, longs.data(), (int64_t)longs.size()));
+        E_TRY(dev_upload(&e->d_seg_row, seg_row.data(), (int64_t)seg_row.size()));
+        E_TRY(dev_upload(&e->d_seg_begin, seg_begin.data(), (int64_t)seg_begin.size()));
+        E_TRY(dev_upload(&e->d_seg_end, seg_end.data(), (int64_t)seg_end.size()));
+        E_TRY(dev_upload(&e->d_seg_slot, seg_slot.data(), (int64_t)seg_slot.size()));
+        E_TRY(dev_upload(&e->d_mrow_row, mrow_row.data(), (int64_t)mrow_row.size()));
+        E_TRY(dev_upload(&e->d_mrow_first, mrow_first.data(), (int64_t)mrow_first.size()));
+        E_TRY(dev_upload(&e->d_mrow_cnt, mrow_cnt.data(), (int64_t)mrow_cnt.size()));
     }
     // ---- passages: vertex map and its inverse on the owned rows
     {
@@ -257,6 +294,7 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     const int B = e->max_batch;
     SlabLayout lay = e->layout(B);
     e->state_elems = (int64_t)lay.n_slabs * e->V * lay.bc;
+    E_TRY(dev_alloc(&e->d_partial, (int64_t)(round_up(B, 4) + 64) * std::max(e->n_partial, 1)));
     E_TRY(dev_alloc(&e->d_x, e->state_elems));
     E_TRY(dev_alloc(&e->d_y, e->state_elems));
     E_TRY(dev_alloc(&e->d_tele, (int64_t)lay.n_slabs * std::max<int64_t>(e->n_passages, 1) * lay.bc));
@@ -315,7 +353,7 @@ hrag_status hrag_get_timings(hrag_engine *e, hrag_timings *out) {
         HRAG_HIP_TRY(hipEventSynchronize(e->ev[EV_FACT1]));
         HRAG_HIP_TRY(hipEventElapsedTime(&t.fact_sim_ms, e->ev[EV_FACT0], e->ev[EV_FACT1]));
     }
-    t.n_long_rows = e->n_long;
+    t.n_long_rows = e->n_long_rows;
     *out = t;
     return HRAG_OK;
 }

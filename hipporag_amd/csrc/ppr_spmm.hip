@@ -14,8 +14,11 @@
 // with ds_swizzle (no LDS storage, no address VGPRs) and issue G independent float4 gathers per
 // step, so a wavefront keeps 64 gathers x 16 B in flight per step.  Rows are visited in
 // degree-descending order (row_order), which makes the trip count uniform inside a wavefront and
-// starts the heaviest rows first.  Rows above the long-row threshold go to a block-per-row kernel
-// with a deterministic LDS tree reduction.  No atomics: results are bit-reproducible.
+// starts the heaviest rows first.  A row's entries are walked serially by its G lanes (one
+// dependent gather round per G entries, ~1 us each), so rows above the short-row threshold
+// (8 rounds) are cut into segments handled one wavefront each (ppr_spmm_seg_kernel) -- otherwise a
+// single hub row (degree 39 512 at cfg 3) would set the duration of the whole sweep.
+// No atomics anywhere: results are bit-reproducible.
 #include "common.h"
 
 namespace hrag {
@@ -52,7 +55,9 @@ struct GatherStep {
     }
 };
 
-template <int G>
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <int G, bool NT_ST = false>
 __device__ __forceinline__ void write_row(const SpmmArgs &a, int slab, int row, int gl,
                                           const float4 &acc) {
     constexpr int BC = 4 * G;
@@ -69,10 +74,26 @@ __device__ __forceinline__ void write_row(const SpmmArgs &a, int slab, int row, 
     out.z = fmaf(a.alpha, acc.z, a.beta * t.z);
     out.w = fmaf(a.alpha, acc.w, a.beta * t.w);
     float4 *yp = reinterpret_cast<float4 *>(a.y + (size_t)slab * a.num_vertices * BC);
-    yp[(size_t)(a.row_offset + row) * G + gl] = out;
+    if constexpr (NT_ST) {
+        f32x4_t o = {out.x, out.y, out.z, out.w};
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t *>(yp + (size_t)(a.row_offset + row) * G + gl));
+    } else {
+        yp[(size_t)(a.row_offset + row) * G + gl] = out;
+    }
 }
 
-template <int G>
+template <bool NT>
+__device__ __forceinline__ int ld_i(const int32_t *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ float ld_f(const float *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+template <int G, bool NT_CSR, bool NT_ST>
 __global__ __launch_bounds__(256) void ppr_spmm_kernel(const SpmmArgs a) {
     constexpr int BC = 4 * G;
     constexpr int RPW = 64 / G;   // rows per wavefront
@@ -95,8 +116,8 @@ __global__ __launch_bounds__(256) void ppr_spmm_kernel(const SpmmArgs a) {
     int c = 0;
     float w = 0.f;
     if (e + gl < end) {
-        c = a.col_idx[e + gl];
-        w = a.val[e + gl];
+        c = ld_i<NT_CSR>(a.col_idx + e + gl);
+        w = ld_f<NT_CSR>(a.val + e + gl);
     }
     while (e < end) {  // trip count is uniform inside a G-lane group
         // prefetch the next G (col, val) pairs before the dependent gathers of this step
@@ -104,8 +125,8 @@ __global__ __launch_bounds__(256) void ppr_spmm_kernel(const SpmmArgs a) {
         float wn = 0.f;
         const int en = e + G + gl;
         if (en < end) {
-            cn = a.col_idx[en];
-            wn = a.val[en];
+            cn = ld_i<NT_CSR>(a.col_idx + en);
+            wn = ld_f<NT_CSR>(a.val + en);
         }
         // tail lanes carry (c = 0, w = 0): they gather row 0 (cache resident) and add 0
         GatherStep<G, 0>::run(acc, c, w, xs, gl);
@@ -113,42 +134,71 @@ __global__ __launch_bounds__(256) void ppr_spmm_kernel(const SpmmArgs a) {
         w = wn;
         e += G;
     }
-    if (active) write_row<G>(a, slab, row, gl, acc);
+    if (active) write_row<G, NT_ST>(a, slab, row, gl, acc);
+}
+
+// Rows longer than the short-row threshold are cut into segments of <= seg_len entries; one
+// wavefront per segment.  The 64 lanes fetch 64 consecutive (col, val) pairs with one coalesced
+// load each; group g (G lanes) then walks pairs g*G .. g*G+G-1 with the same swizzle broadcast as
+// the short-row kernel, so a step is again 64/G row gathers of BC*4 bytes.  The 64/G partial sums
+// are combined with xor-shuffles in a fixed order.  Single-segment rows are finished here;
+// multi-segment rows leave per-segment partials that ppr_spmm_reduce_kernel adds in segment order
+// (deterministic, no atomics).
+template <int G>
+__global__ __launch_bounds__(256) void ppr_spmm_seg_kernel(const SpmmArgs a) {
+    constexpr int BC = 4 * G;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int gl = lane & (G - 1);
+    const int grp = lane / G;
+    const int slab = blockIdx.y;
+    const int seg = blockIdx.x * 4 + wave;
+    if (seg >= a.n_seg) return;  // wave-uniform
+    const int row = a.seg_row[seg];
+    const int e_end = a.seg_end[seg];
+    const int slot = a.seg_slot[seg];
+    const float4 *xs = reinterpret_cast<const float4 *>(a.x + (size_t)slab * a.num_vertices * BC);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = a.seg_begin[seg]; base < e_end; base += 64) {
+        const int idx = base + lane;
+        int c = 0;
+        float w = 0.f;
+        if (idx < e_end) {
+            c = a.col_idx[idx];
+            w = a.val[idx];
+        }
+        GatherStep<G, 0>::run(acc, c, w, xs, gl);
+    }
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o, 64);
+        acc.y += __shfl_xor(acc.y, o, 64);
+        acc.z += __shfl_xor(acc.z, o, 64);
+        acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (grp == 0) {
+        if (slot < 0) {
+            write_row<G>(a, slab, row, gl, acc);
+        } else {
+            reinterpret_cast<float4 *>(a.partial)[((size_t)slab * a.n_partial + slot) * G + gl] = acc;
+        }
+    }
 }
 
 template <int G>
-__global__ __launch_bounds__(256) void ppr_spmm_long_kernel(const SpmmArgs a) {
-    constexpr int BC = 4 * G;
-    constexpr int NG = 256 / G;  // groups per workgroup
-    __shared__ float4 red[256];
-    const int tid = threadIdx.x;
-    const int gl = tid & (G - 1);
-    const int g = tid / G;
+__global__ __launch_bounds__(256) void ppr_spmm_reduce_kernel(const SpmmArgs a) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int m = t / G, gl = t % G;
     const int slab = blockIdx.y;
-    const int row = a.long_rows[blockIdx.x];
-    const int start = a.row_ptr[row];
-    const int end = a.row_ptr[row + 1];
-    const float4 *xs = reinterpret_cast<const float4 *>(a.x + (size_t)slab * a.num_vertices * BC);
+    if (m >= a.n_mrow) return;
+    const int first = a.mrow_first[m], cnt = a.mrow_cnt[m];
+    const float4 *pp = reinterpret_cast<const float4 *>(a.partial) + ((size_t)slab * a.n_partial + first) * G + gl;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int e = start + g; e < end; e += NG) {
-        const int c = a.col_idx[e];
-        const float w = a.val[e];
-        const float4 xv = xs[(size_t)c * G + gl];
-        fma4(acc, w, xv);
+    for (int s = 0; s < cnt; ++s) {
+        const float4 v = pp[(size_t)s * G];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    red[tid] = acc;
-    __syncthreads();
-    for (int s = 128; s >= G; s >>= 1) {  // fixed tree => deterministic
-        if (tid < s) {
-            float4 o = red[tid + s];
-            float4 m = red[tid];
-            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
-            red[tid] = m;
-        }
-        __syncthreads();
-    }
-    if (tid < G) write_row<G>(a, slab, row, gl, red[tid]);
+    write_row<G>(a, slab, a.mrow_row[m], gl, acc);
 }
 
 // x0 = v: owned rows of y <- teleport slot (or 0).
@@ -228,13 +278,22 @@ hrag_status spmm_dispatch(const SpmmArgs &a, SlabLayout lay, bool main_only, hip
     constexpr int RPB = 4 * (64 / G);
     if (a.n_short > 0) {
         dim3 grid((unsigned)ceil_div(a.n_short, RPB), (unsigned)lay.n_slabs);
-        hipLaunchKernelGGL(ppr_spmm_kernel<G>, grid, dim3(256), 0, s, a);
+        const bool nt_csr = (a.flags & HRAG_OPT_NT_CSR) != 0, nt_st = (a.flags & HRAG_OPT_NT_STORE) != 0;
+        if (nt_csr && nt_st) hipLaunchKernelGGL((ppr_spmm_kernel<G, true, true>), grid, dim3(256), 0, s, a);
+        else if (nt_csr) hipLaunchKernelGGL((ppr_spmm_kernel<G, true, false>), grid, dim3(256), 0, s, a);
+        else if (nt_st) hipLaunchKernelGGL((ppr_spmm_kernel<G, false, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((ppr_spmm_kernel<G, false, false>), grid, dim3(256), 0, s, a);
         HRAG_LAUNCH_CHECK();
     }
-    if (!main_only && a.n_long > 0) {
-        dim3 grid((unsigned)a.n_long, (unsigned)lay.n_slabs);
-        hipLaunchKernelGGL(ppr_spmm_long_kernel<G>, grid, dim3(256), 0, s, a);
+    if (!main_only && a.n_seg > 0) {
+        dim3 grid((unsigned)ceil_div(a.n_seg, 4), (unsigned)lay.n_slabs);
+        hipLaunchKernelGGL(ppr_spmm_seg_kernel<G>, grid, dim3(256), 0, s, a);
         HRAG_LAUNCH_CHECK();
+        if (a.n_mrow > 0) {
+            dim3 rgrid((unsigned)ceil_div((int64_t)a.n_mrow * G, 256), (unsigned)lay.n_slabs);
+            hipLaunchKernelGGL(ppr_spmm_reduce_kernel<G>, rgrid, dim3(256), 0, s, a);
+            HRAG_LAUNCH_CHECK();
+        }
     }
     return HRAG_OK;
 }

@@ -82,7 +82,6 @@ __global__ __launch_bounds__(TK_THREADS) void row_topk_kernel(
     __shared__ uint64_t buf[TK_CAP];
     __shared__ float red_mn[TK_THREADS / 64], red_mx[TK_THREADS / 64];
     __shared__ unsigned int s_count;
-    __shared__ uint64_t s_key;
 
     const int tid = threadIdx.x;
     const int row = blockIdx.x;

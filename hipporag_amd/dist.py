@@ -1,0 +1,313 @@
+"""Multi-GPU modes of the retrieval hot path: one process per GPU, torch.distributed over RCCL
+(backend "nccl" on ROCm) / gloo in the CPU tests.  The reference has no distributed code at all
+(zero NCCL / MPI call sites); both modes are MI355X-native additions.
+
+replica   (default for throughput): queries are independent (the reference loop at
+          src/hipporag/HippoRAG.py:459 carries no cross-query state), every rank holds the whole
+          index (cfg 3/4: 1.5 GB embeddings + 0.16 GB CSR of 288 GB HBM) and serves its own slice
+          of the batch with the single-GPU engine.  No data-path collective.
+
+rowshard  (the layout BASELINE.json's north star names): the corpus is sharded row-wise --
+          rank g owns CSR rows [r_g, r_{g+1}) (balanced by nnz), a contiguous slice of the fact
+          and of the passage embedding rows -- and the PPR vector x is replicated.  Exchange steps:
+            * phase A : all-gather of each rank's local top-k fact candidates + all-reduce of the
+                        per-query min / max (2 * B floats);
+            * phase B : all-gather of the raw passage scores [B, Np/N] -> [B, Np]; then per PPR
+                        sweep every rank computes its rows of y = alpha P x + (1-alpha) v and the
+                        new x is re-assembled over xGMI.  Assembling "sum of zero-padded slices"
+                        is an all-reduce (north star wording); since the slices are disjoint the
+                        same result is obtained with 1/2 the wire bytes by an all-gather, realised
+                        as one in-place broadcast per owner so that row shards may be uneven
+                        (collective="allreduce" keeps the literal form for comparison);
+            * final   : all-reduce of the per-query column sums (B doubles).
+          Every output row of y is produced by exactly one rank from the same replicated x, so the
+          result is bit-identical to the single-GPU engine whatever the world size.
+
+The compute itself is behind a small "stages" interface (hipporag_amd.engine.EngineStages = the
+hrag_stage_* C entry points); tests drive the same orchestration with a CPU stand-in over gloo.
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import time
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def _td():
+    import torch
+    import torch.distributed as dist
+    return torch, dist
+
+
+def balanced_row_shards(row_ptr: np.ndarray, world: int) -> List[Tuple[int, int]]:
+    """Contiguous row ranges with ~equal nnz (+ ~equal rows as the tie breaker)."""
+    n_rows = len(row_ptr) - 1
+    cost = np.asarray(row_ptr[1:], dtype=np.int64) + np.arange(1, n_rows + 1, dtype=np.int64)
+    total = int(cost[-1]) if n_rows else 0
+    bounds = [0]
+    for g in range(1, world):
+        bounds.append(int(np.searchsorted(cost, total * g / world, side="left")))
+    bounds.append(n_rows)
+    bounds = np.maximum.accumulate(np.array(bounds))
+    return [(int(bounds[g]), int(bounds[g + 1])) for g in range(world)]
+
+
+def even_shards(n: int, world: int) -> List[Tuple[int, int]]:
+    base, rem = divmod(n, world)
+    out, lo = [], 0
+    for g in range(world):
+        hi = lo + base + (1 if g < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+@dataclass
+class ShardPlan:
+    rows: List[Tuple[int, int]]
+    passages: List[Tuple[int, int]]
+    facts: List[Tuple[int, int]]
+
+
+class RowShardedRetriever:
+    """Orchestrates the row-sharded path on top of a per-rank stages object."""
+
+    def __init__(self, stages, plan: ShardPlan, rank: int, world: int, group=None,
+                 collective: str = "allgather"):
+        self.st, self.plan, self.rank, self.world, self.group = stages, plan, rank, world, group
+        if collective not in ("allgather", "allreduce"):
+            raise ValueError(collective)
+        self.collective = collective
+        self.comm_s = 0.0
+
+    # ---- exchange helpers ------------------------------------------------------------------
+    def _all_gather_cols(self, local, shards: Sequence[Tuple[int, int]]):
+        """[B, n_local] per rank -> [B, n_total] (shards may differ by one column: pad)."""
+        torch, dist = _td()
+        if self.world == 1:
+            return local
+        b = local.shape[0]
+        width = max(hi - lo for lo, hi in shards)
+        send = local.new_zeros((b, width))
+        send[:, : local.shape[1]] = local
+        recv = [torch.empty_like(send) for _ in range(self.world)]
+        dist.all_gather(recv, send, group=self.group)
+        return torch.cat([recv[g][:, : shards[g][1] - shards[g][0]] for g in range(self.world)], dim=1).contiguous()
+
+    def _assemble_x(self, x):
+        """Make every rank's owned rows of x visible everywhere (x: [n_slabs, V, bc])."""
+        torch, dist = _td()
+        if self.world == 1:
+            return
+        if self.collective == "allreduce":
+            lo, hi = self.plan.rows[self.rank]
+            x[:, :lo, :].zero_()
+            x[:, hi:, :].zero_()
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        for g, (lo, hi) in enumerate(self.plan.rows):
+            if hi == lo:
+                continue
+            for s in range(x.shape[0]):
+                dist.broadcast(x[s, lo:hi, :], src=self._global_rank(g), group=self.group)
+
+    def _global_rank(self, g: int) -> int:
+        torch, dist = _td()
+        return g if self.group is None else dist.get_global_rank(self.group, g)
+
+    # ---- phase A ---------------------------------------------------------------------------
+    def score_facts(self, q_fact, k: int = 5):
+        """Global (fact ids int32 [B, k], min-max normalised scores fp32 [B, k]), replicated."""
+        torch, dist = _td()
+        st = self.st
+        f_lo, f_hi = self.plan.facts[self.rank]
+        s_local = st.sim_scores("facts", q_fact)
+        idx, val, mn, mx = st.topk(s_local, k, idx_offset=f_lo)
+        b = idx.shape[0]
+        if self.world > 1:
+            idx_all = [torch.empty_like(idx) for _ in range(self.world)]
+            val_all = [torch.empty_like(val) for _ in range(self.world)]
+            dist.all_gather(idx_all, idx, group=self.group)
+            dist.all_gather(val_all, val, group=self.group)
+            dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        else:
+            idx_all, val_all = [idx], [val]
+        # Each list is sorted (score desc, id desc).  Reversed and concatenated in rank order,
+        # "later position" == "larger (score, id)" among equal scores, so the library's positional
+        # tie rule reproduces the global (score desc, id desc) order exactly.
+        cand_idx = torch.cat([t.flip(1) for t in idx_all], dim=1).contiguous()
+        cand_val = torch.cat([t.flip(1) for t in val_all], dim=1)
+        cand_val = torch.where(cand_idx < 0, torch.full_like(cand_val, float("-inf")), cand_val).contiguous()
+        pos, top_val, _, _ = st.topk(cand_val, k)
+        top_idx = torch.gather(cand_idx, 1, pos.clamp(min=0).long())
+        top_idx = torch.where(pos < 0, torch.full_like(top_idx, -1), top_idx).to(torch.int32)
+        rng = (mx - mn).unsqueeze(1)
+        norm = torch.where(rng == 0, torch.ones_like(top_val), (top_val - mn.unsqueeze(1)) / rng)
+        norm = torch.where(top_idx < 0, torch.zeros_like(norm), norm)
+        return top_idx, norm
+
+    # ---- phase B ---------------------------------------------------------------------------
+    def retrieve(self, q_pass, kept_idx, kept_score, kept_count, *, link_top_k=5, damping=0.5,
+                 passage_node_weight=0.05, ppr_iters=20, k=200):
+        torch, dist = _td()
+        st = self.st
+        b = q_pass.shape[0]
+        s_local = st.sim_scores("passages", q_pass)
+        t0 = time.perf_counter()
+        s_full = self._all_gather_cols(s_local, self.plan.passages)
+        self.comm_s += time.perf_counter() - t0
+        mn, mx = st.row_minmax(s_full)
+        sv, sw, sc, flags = st.seeds(kept_idx, kept_score, kept_count, link_top_k)
+        tele = st.teleport(s_full, mn, mx, passage_node_weight, flags)
+        seeds = (sv, sw, sc)
+        x, y = st.new_state(b), st.new_state(b)
+        st.ppr_init(tele, seeds, b, x)
+        self._assemble_x(x)
+        for _ in range(ppr_iters):
+            st.ppr_step(tele, seeds, b, damping, x, y)
+            self._assemble_x(y)
+            x, y = y, x
+        sums = st.colsum(x, b)
+        if self.world > 1:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        doc = st.doc_scores(x, sums, b, s_full, mn, mx, flags)
+        doc_idx, doc_val, _, _ = st.topk(doc, k)
+        return doc_idx, doc_val, flags
+
+
+def build_sharded_engine(kg, pass_emb, fact_emb, rank: int, world: int, max_batch: int, max_topk: int,
+                         slab_width: int = 0):
+    """Row-shard the index for `rank` and create its engine (embeddings: torch bf16 on device or
+    numpy bf16 bits; full matrices are sliced here)."""
+    from .engine import EngineStages, HippoRAGEngine
+    plan = ShardPlan(balanced_row_shards(kg.csr.row_ptr, world), even_shards(kg.n_passages, world),
+                     even_shards(kg.n_facts, world))
+    r_lo, r_hi = plan.rows[rank]
+    p_lo, p_hi = plan.passages[rank]
+    f_lo, f_hi = plan.facts[rank]
+    eng = HippoRAGEngine(kg.csr.rows(r_lo, r_hi), kg.passage_vertex, pass_emb[p_lo:p_hi], fact_emb[f_lo:f_hi],
+                         kg.subj_vertex, kg.obj_vertex, kg.num_chunks, max_batch=max_batch, max_topk=max_topk,
+                         slab_width=slab_width, row_offset=r_lo, passage_offset=p_lo, fact_offset=f_lo,
+                         n_passages=kg.n_passages, n_facts=kg.n_facts)
+    return eng, EngineStages(eng), plan
+
+
+# --------------------------------------------------------------------------------------------
+# bench.py --gpus N (N > 1)
+# --------------------------------------------------------------------------------------------
+def bench_main(args, configs, rank: int, local_rank: int, world: int) -> int:
+    torch, dist = _td()
+    from . import synth
+    from .engine import HippoRAGEngine
+
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cfg = configs[args.config]
+    V, E, D, seed = cfg["V"], cfg["E"], cfg["D"], cfg["seed"]
+    B = args.batch or cfg["B"]                      # per-GPU batch: weak scaling
+    K_F, K_P, ITERS, DAMP, PW = 5, 200, 20, 0.5, 0.05
+
+    kg = synth.make_kg(V, E, seed)                  # same seed on every rank => identical index
+    pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev)
+    fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev)
+    n_batches = args.steps + args.warmup
+    cnt = torch.full((B,), K_F, dtype=torch.int32, device=dev)
+
+    def barrier_sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(seconds: float) -> float:
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---------------- replica mode: every rank serves its own B queries ----------------------
+    eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pass_emb, fact_emb, kg.subj_vertex, kg.obj_vertex,
+                         kg.num_chunks, max_batch=B, max_topk=K_P, slab_width=args.slab_width)
+    qf = [synth.make_queries_torch(fact_emb, B, seed + 100 + i + 1000 * rank)[0] for i in range(n_batches)]
+    qp = [synth.make_queries_torch(pass_emb, B, seed + 500 + i + 1000 * rank)[0] for i in range(n_batches)]
+
+    def step(i):
+        idx, sc = eng.score_facts(qf[i], k=K_F)
+        return eng.retrieve(qp[i], idx, sc, cnt, link_top_k=K_F, damping=DAMP, passage_node_weight=PW,
+                            ppr_iters=ITERS, k=K_P)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier_sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_batches):
+        step(i)
+    barrier_sync()
+    replica_s = max_over_ranks(time.perf_counter() - t0)
+    replica_qps = world * B * args.steps / replica_s
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+
+    # ---------------- rowshard mode: the global batch (world * B) over the sharded corpus ----
+    rowshard = None
+    try:
+        gb = world * B
+        seng, stages, plan = build_sharded_engine(kg, pass_emb, fact_emb, rank, world, gb, K_P, args.slab_width)
+        rs = RowShardedRetriever(stages, plan, rank, world)
+        gq = torch.Generator(device=dev)
+        rs_steps, rs_warm = max(1, min(args.steps, 3)), 1
+        gqf = [synth.make_queries_torch(fact_emb, gb, seed + 9000 + i)[0] for i in range(rs_steps + rs_warm)]
+        gqp = [synth.make_queries_torch(pass_emb, gb, seed + 9500 + i)[0] for i in range(rs_steps + rs_warm)]
+        gcnt = torch.full((gb,), K_F, dtype=torch.int32, device=dev)
+
+        def rs_step(i):
+            idx, sc = rs.score_facts(gqf[i], k=K_F)
+            return rs.retrieve(gqp[i], idx, sc, gcnt, link_top_k=K_F, damping=DAMP, passage_node_weight=PW,
+                               ppr_iters=ITERS, k=K_P)
+
+        for i in range(rs_warm):
+            rs_step(i)
+        barrier_sync()
+        t0 = time.perf_counter()
+        for i in range(rs_warm, rs_warm + rs_steps):
+            rs_step(i)
+        barrier_sync()
+        rs_s = max_over_ranks(time.perf_counter() - t0)
+        bc, ns = stages.layout(gb)
+        wire = (world - 1) / world * V * gb * 4          # bytes each GPU receives per sweep
+        rowshard = {"value": gb * rs_steps / rs_s, "unit": "queries/s", "global_batch": gb,
+                    "steps": rs_steps, "ms_per_step": rs_s * 1e3 / rs_steps,
+                    "exchange": "per-sweep all-gather of the owned rows of x (broadcast per owner)",
+                    "wire_bytes_per_gpu_per_sweep": wire, "slab_width": bc, "n_slabs": ns,
+                    "row_shards": plan.rows}
+        seng.close()
+    except Exception as exc:  # the measured mode above stays valid; report instead of dying
+        rowshard = {"error": f"{type(exc).__name__}: {exc}"}
+
+    if rank == 0:
+        result = {
+            "metric": "retrieval_queries_per_sec", "value": replica_qps, "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": replica_s * 1e3 / max(args.steps, 1), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["label"], "V": V, "E": E, "nnz": kg.csr.nnz,
+                       "n_passages": kg.n_passages, "n_facts": kg.n_facts, "dim": D,
+                       "global_batch": world * B, "per_gpu_batch": B, "ppr_iters": ITERS,
+                       "linking_top_k": K_F, "retrieval_top_k": K_P,
+                       "parallelism": f"replica x{world} (queries sharded, no data-path collective)"},
+            "rowshard": rowshard,
+        }
+        print(json.dumps(result))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0

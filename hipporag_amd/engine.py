@@ -76,7 +76,7 @@ class HippoRAGEngine:
                  max_topk: int = 200, slab_width: int = 0, long_row_nnz: int = 0,
                  row_offset: int = 0, passage_offset: int = 0, fact_offset: int = 0,
                  n_passages: Optional[int] = None, n_facts: Optional[int] = None,
-                 device: Optional[int] = None):
+                 device: Optional[int] = None, flags: int = 0, segment_nnz: int = 0):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("HippoRAGEngine needs an MI355X-class GPU: no HIP device is visible "
@@ -113,7 +113,7 @@ class HippoRAGEngine:
             fdesc = EmbedDesc(f_rows, fact_offset, dim, 0, _ptr(f_obj))
             fd = FactDesc(self.n_facts, _ptr(sv), _ptr(ov), _ptr(nc))
             keep += [f_obj, sv, ov, nc]
-        opts = Opts(max_batch, max_topk, slab_width, long_row_nnz, self.device.index)
+        opts = Opts(max_batch, max_topk, slab_width, long_row_nnz, self.device.index, flags, segment_nnz)
         with torch.cuda.device(self.device):
             check(self._lib.hrag_engine_create(C.byref(gd), C.byref(fdesc) if fdesc else None,
                                                C.byref(pd), C.byref(fd) if fd else None,
@@ -260,3 +260,97 @@ def topk_rows(scores, k: int, *, n: Optional[int] = None, idx_offset: int = 0, n
     check(lib.hrag_topk_rows(s.data_ptr(), b, n, ld, k, idx_offset, 1 if normalize else 0, idx.data_ptr(),
                              val.data_ptr(), mn.data_ptr(), mx.data_ptr(), _stream()))
     return (idx, val, mn, mx) if want_minmax else (idx, val)
+
+
+def row_minmax(scores, n: Optional[int] = None):
+    """Per-row (min, max) of a device fp32 matrix (hrag_row_minmax)."""
+    torch = _torch()
+    lib = _lib.load()
+    s = scores.contiguous()
+    b, ld = s.shape
+    mn = torch.empty((b,), dtype=torch.float32, device=s.device)
+    mx = torch.empty((b,), dtype=torch.float32, device=s.device)
+    check(lib.hrag_row_minmax(s.data_ptr(), b, ld if n is None else n, ld, mn.data_ptr(), mx.data_ptr(),
+                              _stream()))
+    return mn, mx
+
+
+class EngineStages:
+    """The stage-level operators of include/hrag.h on caller-owned torch buffers -- what
+    hipporag_amd.dist composes with its exchange steps.  One instance per (possibly row-sharded)
+    engine."""
+
+    def __init__(self, engine: HippoRAGEngine):
+        self.e = engine
+        self.lib = engine._lib
+        self.h = engine._handle
+        self.device = engine.device
+
+    # --- metadata
+    def layout(self, batch):
+        return self.e.layout(batch)
+
+    def new_state(self, batch):
+        bc, ns = self.layout(batch)
+        return _torch().zeros((ns, self.e.num_vertices, bc), dtype=_torch().float32, device=self.device)
+
+    # --- similarity / selection
+    def sim_scores(self, which, q):
+        return self.e.sim_scores(which, q)
+
+    def topk(self, scores, k, idx_offset=0):
+        return topk_rows(scores, k, idx_offset=idx_offset, want_minmax=True)
+
+    def row_minmax(self, scores):
+        return row_minmax(scores)
+
+    # --- reset vector
+    def seeds(self, kept_idx, kept_score, kept_count, link_top_k):
+        torch = _torch()
+        b, kf = kept_idx.shape
+        sv = torch.zeros((b, SEED_STRIDE), dtype=torch.int32, device=self.device)
+        sw = torch.zeros((b, SEED_STRIDE), dtype=torch.float32, device=self.device)
+        sc = torch.zeros((b,), dtype=torch.int32, device=self.device)
+        flags = torch.zeros((b,), dtype=torch.int32, device=self.device)
+        check(self.lib.hrag_stage_seeds(self.h, kept_idx.data_ptr(), kept_score.data_ptr(),
+                                        kept_count.data_ptr(), kf, link_top_k, b, sv.data_ptr(),
+                                        sw.data_ptr(), sc.data_ptr(), flags.data_ptr(), _stream()))
+        return sv, sw, sc, flags
+
+    def teleport(self, scores_full, mn, mx, weight, flags):
+        torch = _torch()
+        b, ld = scores_full.shape
+        bc, ns = self.layout(b)
+        tele = torch.empty((ns, self.e.n_passages, bc), dtype=torch.float32, device=self.device)
+        check(self.lib.hrag_stage_teleport(self.h, scores_full.data_ptr(), ld, mn.data_ptr(), mx.data_ptr(),
+                                           weight, flags.data_ptr(), b, tele.data_ptr(), _stream()))
+        return tele
+
+    # --- PPR on the owned rows
+    def ppr_init(self, tele, seeds, batch, x):
+        sv, sw, sc = seeds
+        check(self.lib.hrag_stage_ppr_init(self.h, tele.data_ptr(), sv.data_ptr(), sw.data_ptr(),
+                                           sc.data_ptr(), batch, x.data_ptr(), _stream()))
+
+    def ppr_step(self, tele, seeds, batch, damping, x, y):
+        sv, sw, sc = seeds
+        check(self.lib.hrag_stage_ppr_step(self.h, tele.data_ptr(), sv.data_ptr(), sw.data_ptr(),
+                                           sc.data_ptr(), batch, damping, x.data_ptr(), y.data_ptr(),
+                                           _stream()))
+
+    def colsum(self, x, batch):
+        torch = _torch()
+        nbytes = self.lib.hrag_colsum_workspace_bytes(self.h, batch)
+        ws = torch.empty((max(nbytes, 8) // 8,), dtype=torch.float64, device=self.device)
+        sums = torch.empty((batch,), dtype=torch.float64, device=self.device)
+        check(self.lib.hrag_stage_colsum(self.h, x.data_ptr(), batch, ws.data_ptr(), sums.data_ptr(), _stream()))
+        return sums
+
+    def doc_scores(self, x, sums, batch, scores_full, mn, mx, flags):
+        torch = _torch()
+        out = torch.empty((batch, self.e.n_passages), dtype=torch.float32, device=self.device)
+        check(self.lib.hrag_stage_doc_scores(self.h, x.data_ptr(), sums.data_ptr(), batch,
+                                             scores_full.data_ptr(), scores_full.shape[1], mn.data_ptr(),
+                                             mx.data_ptr(), flags.data_ptr(), out.data_ptr(),
+                                             self.e.n_passages, _stream()))
+        return out

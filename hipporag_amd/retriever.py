@@ -1,0 +1,473 @@
+"""Host-side mirror of the reference's retrieval surface, backed by the MI355X engine.
+
+``HippoRAG`` here keeps the names, argument meaning, return types and error behaviour of the
+reference class for THIS path (reference src/hipporag/HippoRAG.py):
+
+    retrieve(queries, num_to_retrieve=None, gold_docs=None)      :413-499
+    retrieve_dpr(queries, num_to_retrieve=None, gold_docs=None)  :665-732
+    rag_qa(queries, gold_docs=None, gold_answers=None)           :591-663   (QA LLM injected)
+    get_fact_scores / dense_passage_retrieval / rerank_facts / run_ppr / get_query_embeddings /
+    prepare_retrieval_objects / ready_to_retrieve                :1287-1749 (per-method seams)
+
+What is NOT here (out of scope, stays with the reference): OpenIE by LLM, embedding models,
+vector stores, prompts, evaluation.  The index is therefore built from what those produce:
+documents + their extracted triples + an embedding callable (``index_from_openie``), or straight
+from arrays (``from_arrays``).  The graph rules are the reference's (add_fact_edges :867-913,
+add_passage_edges :915-957, add_new_nodes :1159-1187, add_new_edges :1189-1223); synonymy edges
+(:959-1020, needs the index-time KNN) are accepted as an explicit edge list.
+
+Differences to the reference, all deliberate:
+  * all queries of a call are batched through the device instead of the per-query loop (:459);
+  * rankings use the documented tie rule (score desc, index desc) where numpy leaves ties open;
+  * facts are kept in first-occurrence order (the reference uses list(set(...)), i.e. hash order).
+"""
+
+from __future__ import annotations
+
+import logging
+import re
+import time
+from dataclasses import dataclass, field
+from hashlib import md5
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .graph import CSRGraph, build_csr, float_to_bf16_bits
+
+logger = logging.getLogger("hipporag_amd")
+
+
+# ------------------------------------------------------------------ utils/misc_utils.py mirrors
+@dataclass(frozen=True)
+class Chunk:                                            # misc_utils.py:35-40
+    content: str
+    source_id: Optional[str] = None
+    metadata: Dict[str, Any] = field(default_factory=dict)
+
+
+@dataclass
+class RetrievalResult:                                  # misc_utils.py:43-50
+    query: str
+    docs: List[str]
+    scores: np.ndarray
+    doc_metadata: List[Dict[str, Any]] = field(default_factory=list)
+    graph_seeds: List[Tuple] = field(default_factory=list)
+
+
+@dataclass
+class QuerySolution:                                    # misc_utils.py:52-78
+    question: str
+    docs: List[str]
+    doc_scores: np.ndarray = None
+    answer: str = None
+    gold_answers: List[str] = None
+    gold_docs: Optional[List[str]] = None
+    thoughts: Optional[List[str]] = None
+    doc_metadata: Optional[List[Dict[str, Any]]] = None
+    graph_seeds: Optional[List[Tuple]] = None
+
+    def to_dict(self):
+        return {
+            "question": self.question, "answer": self.answer, "gold_answers": self.gold_answers,
+            "docs": self.docs[:5],
+            "doc_scores": [round(v, 4) for v in self.doc_scores.tolist()[:5]] if self.doc_scores is not None else None,
+            "gold_docs": self.gold_docs,
+            "doc_metadata": self.doc_metadata[:5] if self.doc_metadata is not None else None,
+            "graph_seeds": self.graph_seeds,
+            **({"thoughts": self.thoughts} if self.thoughts is not None else {}),
+        }
+
+
+def compute_mdhash_id(content: str, prefix: str = "") -> str:      # misc_utils.py:141-152
+    return prefix + md5(content.encode()).hexdigest()
+
+
+def text_processing(text):                                          # misc_utils.py:80-85
+    if isinstance(text, (list, tuple)):
+        return [text_processing(t) for t in text]
+    if not isinstance(text, str):
+        text = str(text)
+    return re.sub("[^A-Za-z0-9 ]", " ", text.lower()).strip()
+
+
+def min_max_normalize(x):                                           # misc_utils.py:130-139
+    mn, mx = np.min(x), np.max(x)
+    rng = mx - mn
+    if rng == 0:
+        return np.ones_like(x)
+    return (x - mn) / rng
+
+
+@dataclass
+class RetrievalConfig:
+    """The BaseConfig fields this path reads (utils/config_utils.py), same names and defaults."""
+    linking_top_k: int = 5               # :184
+    retrieval_top_k: int = 200           # :188
+    damping: float = 0.5                 # :192
+    passage_node_weight: float = 0.05    # :91
+    qa_top_k: int = 5                    # :203
+    embedding_return_as_normalized: bool = True   # :144
+    is_directed_graph: bool = False      # :176
+    # engine-only knobs (no reference analogue)
+    ppr_iters: int = 20
+    max_batch: int = 256
+    slab_width: int = 0
+
+
+def identity_rerank_filter(query, candidate_items, candidate_indices, len_after_rerank=None):
+    """Stand-in for DSPyFilter.__call__ (rerank.py:108-131): keeps every candidate."""
+    n = len_after_rerank or len(candidate_items)
+    return list(candidate_indices)[:n], list(candidate_items)[:n], {"confidence": None}
+
+
+class HippoRAG:
+    def __init__(self, global_config: Optional[RetrievalConfig] = None, embedding_model=None,
+                 rerank_filter: Optional[Callable] = None, qa_fn: Optional[Callable] = None):
+        """embedding_model: object with batch_encode(texts, instruction=..., norm=True) -> [n, D]
+        (reference embedding_model/base.py); rerank_filter: callable like DSPyFilter (identity by
+        default); qa_fn(query_solutions) -> (solutions, messages, metadata) like HippoRAG.qa (:808)."""
+        self.global_config = global_config or RetrievalConfig()
+        self.embedding_model = embedding_model
+        self.rerank_filter = rerank_filter or identity_rerank_filter
+        self.qa_fn = qa_fn
+        self.ready_to_retrieve = False
+        self.engine = None
+        self.ppr_time = self.rerank_time = self.all_retrieval_time = 0.0      # :184-186
+        self.query_to_embedding: Dict[str, Dict[str, np.ndarray]] = {"triple": {}, "passage": {}}
+        # index state
+        self.passage_node_keys: List[str] = []
+        self.passage_texts: List[str] = []
+        self.chunk_metadata: Dict[str, Dict[str, Any]] = {}
+        self.entity_node_keys: List[str] = []
+        self.entity_texts: List[str] = []
+        self.fact_node_keys: List[str] = []
+        self.facts: List[Tuple[str, str, str]] = []
+        self.node_name_to_vertex_idx: Dict[str, int] = {}
+        self.ent_node_to_chunk_ids: Dict[str, set] = {}
+        self.node_to_node_stats: Dict[Tuple[str, str], float] = {}
+        self._arrays = None
+
+    # ------------------------------------------------------------------ index side
+    def index_from_openie(self, docs: Sequence, chunk_triples: Sequence[Sequence[Sequence[str]]],
+                          synonym_edges: Optional[Sequence[Tuple[str, str, float]]] = None,
+                          passage_embeddings=None, entity_embeddings=None, fact_embeddings=None):
+        """Build the index from documents and their OpenIE triples (what index() has after the LLM
+        steps, HippoRAG.py:307-335).  Embeddings are taken as given or computed with
+        embedding_model.batch_encode(texts) (embedding_store.py:131)."""
+        chunks = [d if isinstance(d, Chunk) else Chunk(content=d) for d in docs]
+        if len(chunks) != len(chunk_triples):
+            raise ValueError("one triple list per document")
+        texts, seen = [], {}
+        triples_by_key: Dict[str, list] = {}
+        for ch, tr in zip(chunks, chunk_triples):          # duplicate docs collapse on their hash
+            key = compute_mdhash_id(ch.content, "chunk-")
+            if key not in seen:
+                seen[key] = len(texts)
+                texts.append(ch.content)
+                triples_by_key[key] = [tuple(text_processing(list(t))) for t in tr if len(t) == 3]
+            meta = dict(ch.metadata)
+            if ch.source_id is not None:
+                meta["source_id"] = ch.source_id
+            self.chunk_metadata[key] = meta
+        self.passage_texts = texts
+        self.passage_node_keys = list(seen.keys())
+        proc = [triples_by_key[k] for k in self.passage_node_keys]
+        # extract_entity_nodes (misc_utils.py:110-121): sorted unique entities
+        ents = sorted({e for tr in proc for t in tr for e in (t[0], t[2])})
+        self.entity_texts = ents
+        self.entity_node_keys = [compute_mdhash_id(e, "entity-") for e in ents]
+        # flatten_facts (:123-128), deterministic first-occurrence order
+        facts, fseen = [], set()
+        for tr in proc:
+            for t in tr:
+                if t not in fseen:
+                    fseen.add(t)
+                    facts.append(t)
+        self.facts = facts
+        self.fact_node_keys = [compute_mdhash_id(str(f), "fact-") for f in facts]
+        # graph bookkeeping: add_fact_edges (:867-913) + add_passage_edges (:915-957)
+        self.node_to_node_stats, self.ent_node_to_chunk_ids = {}, {}
+        for chunk_key, tr in zip(self.passage_node_keys, proc):
+            in_chunk = set()
+            for t in tr:
+                a, b = compute_mdhash_id(t[0], "entity-"), compute_mdhash_id(t[2], "entity-")
+                in_chunk.update((a, b))
+                self.node_to_node_stats[(a, b)] = self.node_to_node_stats.get((a, b), 0.0) + 1
+                self.node_to_node_stats[(b, a)] = self.node_to_node_stats.get((b, a), 0.0) + 1
+            for n in in_chunk:
+                self.ent_node_to_chunk_ids.setdefault(n, set()).add(chunk_key)
+            for e in sorted({e for t in tr for e in (t[0], t[2])}):
+                self.node_to_node_stats[(chunk_key, compute_mdhash_id(e, "entity-"))] = 1.0
+        for a, b, w in (synonym_edges or []):              # add_synonymy_edges result (:1007-1018)
+            ka = compute_mdhash_id(text_processing(a), "entity-")
+            kb = compute_mdhash_id(text_processing(b), "entity-")
+            self.node_to_node_stats[(ka, kb)] = float(w)
+        # vertices: entities, then passages (add_new_nodes :1171-1175)
+        names = self.entity_node_keys + self.passage_node_keys
+        self.node_name_to_vertex_idx = {n: i for i, n in enumerate(names)}
+        src, dst, wts = [], [], []
+        for (a, b), w in self.node_to_node_stats.items():   # add_new_edges :1200-1223
+            if a == b or a not in self.node_name_to_vertex_idx or b not in self.node_name_to_vertex_idx:
+                continue
+            src.append(self.node_name_to_vertex_idx[a])
+            dst.append(self.node_name_to_vertex_idx[b])
+            wts.append(w)
+        csr = build_csr(len(names), src, dst, wts)
+
+        def embed(given, strings):
+            if given is not None:
+                return np.asarray(given, dtype=np.float32)
+            if self.embedding_model is None:
+                raise ValueError("no embeddings given and no embedding_model to compute them")
+            return np.asarray(self.embedding_model.batch_encode(list(strings)), dtype=np.float32)
+
+        pe = embed(passage_embeddings, texts)
+        fe = embed(fact_embeddings, [str(f) for f in facts]) if facts else np.zeros((0, pe.shape[1]), np.float32)
+        self.entity_embeddings = embed(entity_embeddings, ents) if (entity_embeddings is not None or self.embedding_model) and ents else None
+        v = len(names)
+        num_chunks = np.zeros(v, np.int32)
+        for k, s in self.ent_node_to_chunk_ids.items():
+            num_chunks[self.node_name_to_vertex_idx[k]] = len(s)
+
+        def vid(phrase):                                   # HippoRAG.py:1584-1597
+            return self.node_name_to_vertex_idx.get(compute_mdhash_id(phrase.lower(), "entity-"), -1)
+
+        subj = np.array([vid(f[0]) for f in facts], np.int32)
+        obj = np.array([vid(f[2]) for f in facts], np.int32)
+        pv = np.array([self.node_name_to_vertex_idx[k] for k in self.passage_node_keys], np.int32)
+        self._arrays = dict(csr=csr, passage_vertex=pv, passage_emb=float_to_bf16_bits(pe),
+                            fact_emb=float_to_bf16_bits(fe) if len(facts) else None, subj=subj, obj=obj,
+                            num_chunks=num_chunks)
+        self.ready_to_retrieve = False                      # explicit invalidate hook
+        return self
+
+    @classmethod
+    def from_arrays(cls, csr: CSRGraph, passage_vertex, passage_emb_bits, fact_emb_bits, subj, obj, num_chunks,
+                    passage_texts: Optional[List[str]] = None, facts: Optional[List[Tuple]] = None, **kw):
+        self = cls(**kw)
+        n_p = len(passage_vertex)
+        self.passage_texts = passage_texts or [f"passage {i}" for i in range(n_p)]
+        self.passage_node_keys = [compute_mdhash_id(t, "chunk-") for t in self.passage_texts]
+        n_f = 0 if fact_emb_bits is None else fact_emb_bits.shape[0]
+        self.facts = facts or [(f"s{i}", "rel", f"o{i}") for i in range(n_f)]
+        self.fact_node_keys = [compute_mdhash_id(str(f), "fact-") for f in self.facts]
+        self._arrays = dict(csr=csr, passage_vertex=np.asarray(passage_vertex, np.int32),
+                            passage_emb=passage_emb_bits, fact_emb=fact_emb_bits,
+                            subj=np.asarray(subj, np.int32), obj=np.asarray(obj, np.int32),
+                            num_chunks=np.asarray(num_chunks, np.int32))
+        return self
+
+    # ------------------------------------------------------------------ HippoRAG.py:1287-1389
+    def prepare_retrieval_objects(self):
+        from .engine import HippoRAGEngine
+        if self._arrays is None:
+            raise RuntimeError("nothing indexed yet")
+        if self.engine is not None:
+            self.engine.close()
+        a = self._arrays
+        self.query_to_embedding = {"triple": {}, "passage": {}}
+        has_facts = a["fact_emb"] is not None and a["fact_emb"].shape[0] > 0
+        self.engine = HippoRAGEngine(a["csr"], a["passage_vertex"], a["passage_emb"],
+                                     a["fact_emb"] if has_facts else None,
+                                     a["subj"] if has_facts else None, a["obj"] if has_facts else None,
+                                     a["num_chunks"] if has_facts else None,
+                                     max_batch=self.global_config.max_batch,
+                                     max_topk=min(2048, max(self.global_config.retrieval_top_k, 1)),
+                                     slab_width=self.global_config.slab_width)
+        self.passage_node_idxs = a["passage_vertex"].tolist()
+        self.ready_to_retrieve = True
+
+    # ------------------------------------------------------------------ HippoRAG.py:1391-1425
+    def get_query_embeddings(self, queries: List):
+        strings = []
+        for q in queries:
+            s = q.question if isinstance(q, QuerySolution) else q
+            if s not in self.query_to_embedding["triple"] or s not in self.query_to_embedding["passage"]:
+                strings.append(s)
+        if strings:
+            if self.embedding_model is None:
+                raise ValueError("embedding_model is required to encode queries")
+            for kind, instr in (("triple", "query_to_fact"), ("passage", "query_to_passage")):
+                embs = self.embedding_model.batch_encode(strings, instruction=instr, norm=True)
+                for s, e in zip(strings, embs):
+                    self.query_to_embedding[kind][s] = np.asarray(e, dtype=np.float32)
+
+    def _q_tensor(self, queries: List[str], kind: str):
+        import torch
+        m = np.stack([np.asarray(self.query_to_embedding[kind][q], np.float32).reshape(-1) for q in queries])
+        return torch.from_numpy(m).to(self.engine.device).to(torch.bfloat16)
+
+    # ------------------------------------------------------------------ per-method seams (B = 1)
+    def get_fact_scores(self, query: str) -> np.ndarray:                  # :1427-1465
+        self._ensure_ready()
+        if len(self.fact_node_keys) == 0:
+            return np.array([])
+        self.get_query_embeddings([query])
+        s = self.engine.sim_scores("facts", self._q_tensor([query], "triple"))[0].cpu().numpy()
+        return min_max_normalize(s)
+
+    def dense_passage_retrieval(self, query: str) -> Tuple[np.ndarray, np.ndarray]:   # :1467-1502
+        self._ensure_ready()
+        self.get_query_embeddings([query])
+        s = self.engine.sim_scores("passages", self._q_tensor([query], "passage"))[0].cpu().numpy()
+        s = min_max_normalize(s)
+        ids = np.argsort(s, kind="stable")[::-1]
+        return ids, s[ids]
+
+    def run_ppr(self, reset_prob: np.ndarray, damping: float = 0.5) -> Tuple[np.ndarray, np.ndarray]:   # :1709-1749
+        import torch
+        self._ensure_ready()
+        if damping is None:
+            damping = 0.5
+        r = torch.from_numpy(np.asarray(reset_prob, dtype=np.float32).reshape(1, -1))
+        x, flags = self.engine.ppr(r, damping=damping, iters=self.global_config.ppr_iters)
+        if int(flags[0].item()) & 2:
+            raise ValueError("reset vector has no positive entry")     # igraph raises here
+        doc_scores = x[0].cpu().numpy()[self._arrays["passage_vertex"]]
+        ids = np.argsort(doc_scores, kind="stable")[::-1]
+        return ids, doc_scores[ids]
+
+    def rerank_facts(self, query: str, query_fact_scores: np.ndarray):     # :1659-1707
+        k = self.global_config.linking_top_k
+        if len(query_fact_scores) == 0 or len(self.fact_node_keys) == 0:
+            return [], [], {"facts_before_rerank": [], "facts_after_rerank": []}
+        try:
+            cand = np.argsort(query_fact_scores, kind="stable")[::-1][:k].tolist()
+            cand_facts = [self.facts[i] for i in cand]
+            idx, facts, _ = self.rerank_filter(query, cand_facts, cand, len_after_rerank=k)
+            return list(idx), list(facts), {"facts_before_rerank": cand_facts, "facts_after_rerank": list(facts)}
+        except Exception as exc:                                           # :1705-1707
+            logger.error("Error in rerank_facts: %s", exc)
+            return [], [], {"facts_before_rerank": [], "facts_after_rerank": [], "error": str(exc)}
+
+    def _ensure_ready(self):
+        if not self.ready_to_retrieve:
+            self.prepare_retrieval_objects()
+
+    # ------------------------------------------------------------------ retrieve :413-499
+    def retrieve(self, queries: List[str], num_to_retrieve: Optional[int] = None,
+                 gold_docs: Optional[List[List[str]]] = None):
+        import torch
+        t_start = time.time()
+        cfg = self.global_config
+        if num_to_retrieve is None:
+            num_to_retrieve = cfg.retrieval_top_k
+        self._ensure_ready()
+        self.get_query_embeddings(queries)
+        k_f, n_q = cfg.linking_top_k, len(queries)
+        eng = self.engine
+        k_docs = max(1, min(num_to_retrieve, len(self.passage_node_keys), eng.max_topk))
+        results: List[QuerySolution] = []
+        for lo in range(0, n_q, eng.max_batch):
+            qs = queries[lo: lo + eng.max_batch]
+            b = len(qs)
+            kept_idx = np.full((b, max(k_f, 1)), -1, np.int32)
+            kept_sc = np.zeros((b, max(k_f, 1)), np.float32)
+            kept_cnt = np.zeros(b, np.int32)
+            seeds: List[List[Tuple]] = [[] for _ in range(b)]
+            t_r = time.time()
+            if len(self.fact_node_keys) > 0 and k_f > 0:
+                idx, sc = eng.score_facts(self._q_tensor(qs, "triple"), k=k_f)         # phase A
+                idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
+                for i, q in enumerate(qs):                                             # host: LLM filter
+                    cand = [int(j) for j in idx_h[i] if j >= 0]
+                    try:
+                        cand_facts = [self.facts[j] for j in cand]
+                        kidx, kfacts, _ = self.rerank_filter(q, cand_facts, cand, len_after_rerank=k_f)
+                    except Exception as exc:                                           # :1705-1707
+                        logger.error("Error in rerank_facts: %s", exc)
+                        kidx, kfacts = [], []
+                    score_of = {j: sc_h[i][p] for p, j in enumerate(idx_h[i]) if j >= 0}
+                    kidx = [j for j in kidx if j in score_of][:k_f]
+                    kept_idx[i, :len(kidx)] = kidx
+                    kept_sc[i, :len(kidx)] = [score_of[j] for j in kidx]
+                    kept_cnt[i] = len(kidx)
+                    seeds[i] = list(kfacts)
+            self.rerank_time += time.time() - t_r
+            t_p = time.time()
+            out = eng.retrieve(self._q_tensor(qs, "passage"), torch.from_numpy(kept_idx),
+                               torch.from_numpy(kept_sc), torch.from_numpy(kept_cnt),
+                               link_top_k=k_f, damping=cfg.damping, passage_node_weight=cfg.passage_node_weight,
+                               ppr_iters=cfg.ppr_iters, k=k_docs)                      # phase B
+            d_idx, d_sc, flags = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy(), out.flags.cpu().numpy()
+            self.ppr_time += time.time() - t_p
+            for i, q in enumerate(qs):
+                if flags[i] & 4:      # :1541
+                    raise AssertionError("count_nonzero(all_phrase_weights) != len(linking_score_map)")
+                if flags[i] & 2:      # :1644
+                    raise AssertionError(f"No phrases found in the graph for the given facts: {seeds[i]}")
+                if flags[i] & 1:
+                    logger.info("No facts found after reranking, return DPR results")   # :468
+                r = self._build_retrieval_result(q, d_idx[i], d_sc[i], num_to_retrieve, seeds[i])
+                results.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
+                                             doc_metadata=r.doc_metadata, graph_seeds=r.graph_seeds))
+        self.all_retrieval_time += time.time() - t_start
+        logger.info("Total Retrieval Time %.2fs", self.all_retrieval_time)
+        logger.info("Total Recognition Memory Time %.2fs", self.rerank_time)
+        logger.info("Total PPR Time %.2fs", self.ppr_time)
+        if gold_docs is not None:
+            return results, self._recall(gold_docs, [r.docs for r in results])
+        return results
+
+    def _build_retrieval_result(self, query, sorted_doc_ids, sorted_doc_scores, num_to_retrieve, graph_seeds=None):
+        ids = [int(i) for i in sorted_doc_ids[:num_to_retrieve] if i >= 0]                 # :501-507
+        keys = [self.passage_node_keys[i] for i in ids]
+        return RetrievalResult(query=query, docs=[self.passage_texts[i] for i in ids],
+                               scores=np.asarray(sorted_doc_scores[:len(ids)]),
+                               doc_metadata=[dict(self.chunk_metadata.get(k, {})) for k in keys],
+                               graph_seeds=graph_seeds or [])
+
+    # ------------------------------------------------------------------ retrieve_dpr :665-732
+    def retrieve_dpr(self, queries: List[str], num_to_retrieve: Optional[int] = None,
+                     gold_docs: Optional[List[List[str]]] = None):
+        cfg = self.global_config
+        if num_to_retrieve is None:
+            num_to_retrieve = cfg.retrieval_top_k
+        self._ensure_ready()
+        self.get_query_embeddings(queries)
+        eng = self.engine
+        k_docs = max(1, min(num_to_retrieve, len(self.passage_node_keys), eng.max_topk))
+        results = []
+        for lo in range(0, len(queries), eng.max_batch):
+            qs = queries[lo: lo + eng.max_batch]
+            idx, sc = eng.dense_retrieve(self._q_tensor(qs, "passage"), k=k_docs)
+            idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
+            for i, q in enumerate(qs):
+                r = self._build_retrieval_result(q, idx[i], sc[i], num_to_retrieve)
+                results.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
+                                             doc_metadata=r.doc_metadata))
+        if gold_docs is not None:
+            return results, self._recall(gold_docs, [r.docs for r in results])
+        return results
+
+    # ------------------------------------------------------------------ rag_qa :591-663
+    def rag_qa(self, queries, gold_docs: Optional[List[List[str]]] = None,
+               gold_answers: Optional[List[List[str]]] = None):
+        if self.qa_fn is None:
+            raise NotImplementedError("rag_qa needs a qa_fn (the reader LLM is outside this package)")
+        retrieval_metrics = None
+        if not isinstance(queries[0], QuerySolution):
+            out = self.retrieve(queries=queries, gold_docs=gold_docs)
+            queries, retrieval_metrics = out if gold_docs is not None else (out, None)
+        solutions, messages, metadata = self.qa_fn(queries)
+        if gold_answers is not None:
+            for s, g in zip(solutions, gold_answers):
+                s.gold_answers = list(g)
+        if gold_docs is not None:
+            for s, g in zip(solutions, gold_docs):
+                s.gold_docs = g
+            return solutions, messages, metadata, retrieval_metrics, None
+        return solutions, messages, metadata
+
+    @staticmethod
+    def _recall(gold_docs, retrieved_docs, k_list=(1, 2, 5, 10, 20, 30, 50, 100, 150, 200)):
+        """RetrievalRecall.calculate_metric_scores (evaluation/retrieval_eval.py:16-73), pooled only."""
+        out = {}
+        for k in k_list:
+            vals = []
+            for gold, got in zip(gold_docs, retrieved_docs):
+                gold_set = set(gold)
+                vals.append(len(gold_set & set(got[:k])) / len(gold_set) if gold_set else 0.0)
+            out[f"Recall@{k}"] = round(float(np.mean(vals)) if vals else 0.0, 4)
+        return out

@@ -90,13 +90,20 @@ typedef struct hrag_fact_desc {
     const int32_t *num_chunks;  /* [V]                                            */
 } hrag_fact_desc;
 
+#define HRAG_OPT_NATURAL_ROW_ORDER 1 /* keep CSR row order instead of degree-descending          */
+#define HRAG_OPT_NT_CSR 2            /* non-temporal loads for the col_idx / val stream             */
+#define HRAG_OPT_NT_STORE 4          /* non-temporal stores for the new PPR state                   */
+
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */
     int32_t max_topk;     /* largest k_p (retrieval_top_k); <= 2048                              */
     int32_t slab_width;   /* PPR state slab width BC in {4,8,16,32,64}; 0 = auto                 */
-    int32_t long_row_nnz; /* rows with more entries go to the block-per-row kernel; 0 = auto     */
+    int32_t long_row_nnz; /* rows with more entries leave the G-lanes-per-row kernel and are cut  */
+                          /* into wavefront-sized segments; 0 = auto (8 gather rounds)            */
     int32_t device;       /* HIP device ordinal, -1 = current                                    */
-    int32_t reserved[11];
+    int32_t flags;        /* tuning bits, 0 = defaults: HRAG_OPT_*                                  */
+    int32_t segment_nnz;  /* entries per long-row segment (multiple of 64); 0 = auto (512)          */
+    int32_t reserved[9];
 } hrag_opts;
 
 /* Phase timings of the last hrag_retrieve / hrag_score_facts on an engine, measured

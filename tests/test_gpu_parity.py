@@ -29,7 +29,7 @@ def case(gpu_device):
     from hipporag_amd import synth
     kg, pass_bits, fact_bits, index = make_case(6000, 60000, 192, seed=21, power_law=True)
     eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pass_bits, fact_bits, kg.subj_vertex, kg.obj_vertex,
-                         kg.num_chunks, max_batch=80, max_topk=200, long_row_nnz=48)
+                         kg.num_chunks, max_batch=80, max_topk=200, long_row_nnz=16, segment_nnz=64)
     qf_bits, _ = synth.make_queries_np(fact_bits, 70, seed=5)
     qp_bits, _ = synth.make_queries_np(pass_bits, 70, seed=6)
     yield dict(kg=kg, index=index, eng=eng, qf_bits=qf_bits, qp_bits=qp_bits,

@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Small target for the rocprofv3 PMC passes: build the cfg-3 engine, fill the PPR state with one
+real retrieve, then run a few sweeps of the dominant kernel.  Run it once per counter:
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python tools/pmc_target.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python tools/pmc_target.py
+then   python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > profiles/pmc_traffic.json
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+from bench import CONFIGS
+from hipporag_amd import synth
+from hipporag_amd.engine import HippoRAGEngine
+
+cfg = CONFIGS[os.environ.get("HRAG_PMC_CONFIG", "cfg3")]
+V, E, B, seed = cfg["V"], cfg["E"], cfg["B"], cfg["seed"]
+dev = torch.device("cuda", 0)
+kg = synth.make_kg(V, E, seed)
+pemb = synth.make_embeddings_torch(kg.n_passages, 64, 1, dev)
+femb = synth.make_embeddings_torch(kg.n_facts, 64, 2, dev)
+eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pemb, femb, kg.subj_vertex, kg.obj_vertex, kg.num_chunks,
+                     max_batch=B, max_topk=200, slab_width=int(os.environ.get("HRAG_SLAB", "0")),
+                     flags=int(os.environ.get("HRAG_FLAGS", "0")))
+qf, _ = synth.make_queries_torch(femb, B, 7)
+qp, _ = synth.make_queries_torch(pemb, B, 8)
+cnt = torch.full((B,), 5, dtype=torch.int32, device=dev)
+idx, sc = eng.score_facts(qf, k=5)
+eng.retrieve(qp, idx, sc, cnt, ppr_iters=2, k=200)
+eng.ppr_sweeps(B, 4, 0.5, main_only=True)
+torch.cuda.synchronize()
+eng.close()
+print("pmc target done")

@@ -39,9 +39,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 PPR_ITERS, K_F, K_P, DAMPING, PASSAGE_W = 20, 5, 200, 0.5, 0.05
 
 
-def spmm_algorithmic_bytes(nnz, V, Np, B):
-    """CSR once + read x + write y + read the passage-dense teleport term."""
-    return nnz * 8 + (V + 1) * 4 + 2 * V * B * 4 + Np * B * 4
+def spmm_algorithmic_bytes(nnz, V, Np, B, state_bytes=4):
+    """CSR once + read x + write y + read the passage-dense teleport term.
+    state_bytes: 4 for the fp32-state kernel, 2 for the fp16-state kernel of the two-stage scheme
+    (the teleport term stays fp32)."""
+    return nnz * 8 + (V + 1) * 4 + 2 * V * B * state_bytes + Np * B * 4
 
 
 def sim_algorithmic_bytes(F, Np, D, B):
@@ -179,28 +181,32 @@ def main():
     # dominant kernel: ppr_spmm_kernel, average duration over back-to-back launches (HIP events on
     # the launch stream), algorithmic bytes per launch from SURVEY.md 8(d)
     n_l = args.sweep_launches
-    eng.ppr_sweeps(B, 4, DAMPING, main_only=True)
+    f16 = phases["slab_width"] == 64 and B > 32     # hrag_retrieve took the two-stage fp16-state path
+    eng.ppr_sweeps(B, 4, DAMPING, main_only=True, f16=f16)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    eng.ppr_sweeps(B, n_l, DAMPING, main_only=True)
+    eng.ppr_sweeps(B, n_l, DAMPING, main_only=True, f16=f16)
     e1.record()
     torch.cuda.synchronize()
     spmm_ms = e0.elapsed_time(e1) / n_l
     e0.record()
-    eng.ppr_sweeps(B, n_l, DAMPING, main_only=False)
+    eng.ppr_sweeps(B, n_l, DAMPING, main_only=False, f16=f16)
     e1.record()
     torch.cuda.synchronize()
     sweep_ms = e0.elapsed_time(e1) / n_l
     nnz = kg.csr.nnz
-    alg = spmm_algorithmic_bytes(nnz, V, kg.n_passages, B)
+    alg = spmm_algorithmic_bytes(nnz, V, kg.n_passages, B, 2 if f16 else 4)
     achieved = alg / (spmm_ms * 1e-3) / 1e9
     traffic = load_traffic()
-    bc, n_slabs = eng.layout(B)
+    bc, n_slabs = (64, (B + 63) // 64) if f16 else eng.layout(B)
+    kernel = "ppr16_kernel" if f16 else "ppr_spmm_kernel"
     roofline = {
-        "bound": "hbm", "kernel": "ppr_spmm_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": (traffic or {}).get("bytes_per_launch") if traffic else None,
-        "algorithmic_bytes_per_launch": alg, "launch_ms": spmm_ms, "sweep_ms_all_kernels": sweep_ms,
+        "traffic": (traffic or {}).get(kernel, {}).get("bytes_per_launch") if traffic else None,
+        "algorithmic_bytes_per_launch": alg, "state_bytes": 2 if f16 else 4,
+        "gather_bytes_per_launch": nnz * B * (2 if f16 else 4),
+        "launch_ms": spmm_ms, "sweep_ms_all_kernels": sweep_ms,
         "launches_timed": n_l, "slab_width": bc, "n_slabs": n_slabs,
         "frac_of_measured_copy_peak_6290": achieved / 6290.0,
     }
@@ -213,7 +219,9 @@ def main():
         "config": {"workload": cfg["label"], "V": V, "E": E, "nnz": nnz, "n_passages": kg.n_passages,
                    "n_facts": kg.n_facts, "dim": D, "global_batch": B, "ppr_iters": PPR_ITERS,
                    "linking_top_k": K_F, "retrieval_top_k": K_P, "damping": DAMPING,
-                   "embedding_dtype": "bf16", "ppr_state_dtype": "f32", "parallelism": "1gpu"},
+                   "embedding_dtype": "bf16",
+                   "ppr_state_dtype": "f16 hi + f16 correction (fp32 arithmetic)" if f16 else "f32",
+                   "parallelism": "1gpu"},
         "roofline": roofline,
         "phases_ms": {k: phases[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")},
         "sim_algorithmic_bytes": sim_algorithmic_bytes(kg.n_facts, kg.n_passages, D, B),

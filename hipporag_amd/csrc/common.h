@@ -55,6 +55,10 @@ __device__ __forceinline__ uint64_t rank_key(float score, uint32_t idx) {
     return ((uint64_t)f32_to_ordered(score) << 32) | (uint64_t)idx;
 }
 
+// seeds.hip limits
+constexpr int kMaxKeptFacts = 16; // kf upper bound
+constexpr int kMaxSeeds = 32;     // 2 * kMaxKeptFacts
+
 // ---- PPR state layout: [n_slabs][rows][BC] fp32, query q lives in slab q / BC, column q % BC.
 struct SlabLayout {
     int32_t bc;       // slab width (4 * lanes-per-row)
@@ -100,12 +104,48 @@ hrag_status launch_colsum(const float *x, int64_t num_vertices, int64_t row_offs
                           int32_t batch, SlabLayout lay, double *partial, double *sums,
                           hipStream_t s);
 
+// ppr16.hip : two-stage fp16-state PPR (64 queries per 128-byte line), SELL-8 matrix
+enum Ppr16Mode { kPprModeH = 0, kPprModeR = 1, kPprModeC = 2 };
+constexpr int32_t kVrowNone = (int32_t)0x80000000;  // padding virtual row (no output)
+constexpr int kSell8SegLen = 64;                     // rows above this are cut into <= 64 segments
+struct Ppr16Args {
+    const int2 *pairs;         // [total_steps * 64] (col, fp32 bits of val), step-major per chunk
+    const int2 *chunk_meta;    // [n_chunks] (first step, number of steps)
+    const int32_t *vrow;       // [n_chunks * 8] row id >= 0 | -(partial slot + 1) | kVrowNone
+    int32_t n_chunks;
+    const int32_t *lrow_row, *lrow_first, *lrow_cnt;  // [n_lrow] long rows and their partial slots
+    int32_t n_lrow;
+    int32_t n_partial;
+    float *partial;            // [n_slabs][n_partial][64] fp32
+    int64_t num_vertices;
+    const uint16_t *x;         // gather source, fp16 [n_slabs][V][64]
+    uint16_t *y;               // output, same layout
+    const uint16_t *aux;       // mode C: r
+    const int32_t *row_slot;   // [V] teleport row of a vertex (passage or seed row) or -1
+    const float *tele;         // fp32 [n_slabs][tele_rows][64]
+    int64_t tele_rows;
+    float alpha, beta, cscale;
+};
+hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, bool nt_pairs, bool main_only,
+                               hipStream_t s);
+hrag_status launch_ppr16_init(const Ppr16Args &a, int n_slabs, hipStream_t s);  // y = f16(v)
+hrag_status launch_ppr16_combine(const uint16_t *h, const uint16_t *c, float inv_cscale, int64_t elems,
+                                 float *out, hipStream_t s);
+hrag_status launch_ppr16_scale(const float *mn, const float *mx, const float *ssum, int64_t n_passages,
+                               float passage_weight, const float *seed_w, const int32_t *seed_cnt,
+                               const int32_t *flags, int32_t batch, float *qscale, hipStream_t s);
+hrag_status launch_ppr16_seed_rows(const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
+                                   const float *qscale, int32_t batch, int64_t n_passages,
+                                   int64_t num_vertices, int32_t *row_slot, float *tele,
+                                   int64_t tele_rows, hipStream_t s);
+
 // layout.hip : [B, n] row-major  <->  slab layout, with the fused element-wise stages
+// slab_rows: rows per slab of the destination (>= n; 0 means n); qscale: optional per-query factor
 enum ToSlabMode { kSanitize = 0, kMinMaxScale = 1 };
 hrag_status launch_rows_to_slab(const float *rows, int64_t ld, int64_t n, int32_t batch,
                                 ToSlabMode mode, const float *mn, const float *mx, float scale,
                                 const int32_t *skip_flags, float *slab, SlabLayout lay,
-                                hipStream_t s);
+                                hipStream_t s, int64_t slab_rows = 0, const float *qscale = nullptr);
 // out[q][i] = x[slab(q)][gather ? gather[i] : i][col(q)] / sums[q]
 //   alt != nullptr and (flags[q] & 1): out[q][i] = minmax(alt[q][i]) instead (DPR fallback)
 hrag_status launch_slab_to_rows(const float *slab, int64_t slab_rows, const int32_t *gather,
@@ -127,11 +167,9 @@ hrag_status launch_row_topk(const float *scores, int32_t batch, int64_t n, int64
                             int32_t idx_offset, TopkNorm norm, int32_t *idx_out, float *val_out,
                             float *mn_out, float *mx_out, hipStream_t s);
 hrag_status launch_row_minmax(const float *scores, int32_t batch, int64_t n, int64_t ld,
-                              float *mn_out, float *mx_out, hipStream_t s);
+                              float *mn_out, float *mx_out, hipStream_t s, float *sum_out = nullptr);
 
 // seeds.hip
-constexpr int kMaxKeptFacts = 16; // kf upper bound
-constexpr int kMaxSeeds = 32;     // 2 * kMaxKeptFacts
 hrag_status launch_build_seeds(const int32_t *kept_idx, const float *kept_score,
                                const int32_t *kept_count, int32_t kf, int32_t link_top_k,
                                int32_t batch, const int32_t *subj, const int32_t *obj,

@@ -16,6 +16,8 @@ using namespace hrag;
 
 namespace {
 
+constexpr float kPpr16CScale = 64.f;  // correction / residual are stored as f16(c * 64); see ppr16.hip
+
 enum EvId { EV_START = 0, EV_SIM, EV_SEED, EV_PPR, EV_RANK, EV_FACT0, EV_FACT1, EV_COUNT };
 
 template <typename T>
@@ -77,6 +79,19 @@ struct hrag_engine {
     int32_t *d_seed_vtx = nullptr, *d_seed_cnt = nullptr, *d_flags = nullptr;
     float *d_seed_w = nullptr;
     double *d_colsum_partial = nullptr, *d_sums = nullptr;
+    // two-stage fp16 PPR (ppr16.hip): SELL-8 matrix + fp16 state, unsharded engines with max_batch > 32
+    bool f16_ready = false;
+    int2 *d_pairs = nullptr, *d_chunk_meta = nullptr;
+    int32_t *d_vrow = nullptr, *d_lrow_row = nullptr, *d_lrow_first = nullptr, *d_lrow_cnt = nullptr;
+    int32_t n_chunks = 0, n_lrow = 0, n_partial16 = 0;
+    int64_t sell_steps = 0;
+    float *d_partial16 = nullptr;
+    uint16_t *d_h16[4] = {nullptr, nullptr, nullptr, nullptr};  // hA, hB, r, cA
+    int64_t state16_elems = 0;
+    float *d_tele16 = nullptr;      // fp32 [n_slabs64][tele16_rows][64]: passages, then seed rows
+    int64_t tele16_rows = 0;
+    int32_t *d_row_slot = nullptr;  // [V] per-batch copy of d_row_to_tele with the seed rows patched in
+    float *d_qscale = nullptr, *d_ssum = nullptr;
     // timing
     hipEvent_t ev[EV_COUNT] = {};
     bool profiling = false, have_retrieve_ev = false, have_fact_ev = false;
@@ -112,7 +127,10 @@ void free_engine(hrag_engine *e) {
                     e->d_passage_vertex, e->d_row_to_tele, e->d_pemb, e->d_femb, e->d_subj, e->d_obj,
                     e->d_num_chunks, e->d_x, e->d_y, e->d_tele, e->d_tele_dense, e->d_spass,
                     e->d_sfact, e->d_doc, e->d_mn_p, e->d_mx_p, e->d_seed_vtx, e->d_seed_cnt,
-                    e->d_flags, e->d_seed_w, e->d_colsum_partial, e->d_sums};
+                    e->d_flags, e->d_seed_w, e->d_colsum_partial, e->d_sums, e->d_pairs, e->d_chunk_meta,
+                    e->d_vrow, e->d_lrow_row, e->d_lrow_first, e->d_lrow_cnt, e->d_partial16, e->d_h16[0],
+                    e->d_h16[1], e->d_h16[2], e->d_h16[3], e->d_tele16, e->d_row_slot, e->d_qscale,
+                    e->d_ssum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ev : e->ev)
@@ -150,6 +168,114 @@ hrag_status ppr_step(hrag_engine *e, const float *tele, int64_t tele_rows, const
         HRAG_TRY(launch_seed_scatter(y, e->V, e->row_offset, e->n_rows, sv, sw, sc, kMaxSeeds, batch,
                                      1.0f - damping, lay, s));
     return HRAG_OK;
+}
+
+// SELL-8 form of the owned CSR for ppr16.hip (see the header comment there).
+hrag_status build_sell8(hrag_engine *e, const std::vector<int32_t> &row_ptr, const int32_t *col,
+                        const float *val) {
+    struct VRow { int32_t len, begin, target; };
+    std::vector<VRow> vr;
+    vr.reserve((size_t)e->n_rows + 1024);
+    std::vector<int32_t> lrow_row, lrow_first, lrow_cnt;
+    int32_t n_partial = 0;
+    for (int64_t r = 0; r < e->n_rows; ++r) {
+        const int32_t b0 = row_ptr[(size_t)r], deg = row_ptr[(size_t)r + 1] - b0;
+        if (deg <= kSell8SegLen) {
+            vr.push_back({deg, b0, (int32_t)r});
+            continue;
+        }
+        // at most 64 segments per row, each a multiple of 8 entries
+        int32_t nseg = std::min<int32_t>((deg + kSell8SegLen - 1) / kSell8SegLen, 64);
+        const int32_t seg_len = (int32_t)round_up((deg + nseg - 1) / nseg, 8);
+        nseg = (deg + seg_len - 1) / seg_len;
+        lrow_row.push_back((int32_t)r);
+        lrow_first.push_back(n_partial);
+        lrow_cnt.push_back(nseg);
+        for (int32_t i = 0; i < nseg; ++i)
+            vr.push_back({std::min(seg_len, deg - i * seg_len), b0 + i * seg_len, -(n_partial++ + 1)});
+    }
+    // longest first (stable => deterministic); a chunk = 8 consecutive virtual rows
+    std::stable_sort(vr.begin(), vr.end(), [](const VRow &a, const VRow &b) { return a.len > b.len; });
+    const int64_t n_chunks = ceil_div((int64_t)vr.size(), 8);
+    std::vector<int2> meta((size_t)n_chunks);
+    std::vector<int32_t> vrow((size_t)n_chunks * 8, kVrowNone);
+    int64_t steps = 0;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int32_t ns = (int32_t)ceil_div(vr[(size_t)c * 8].len, 8);
+        meta[(size_t)c] = make_int2((int)steps, ns);
+        steps += ns;
+    }
+    HRAG_REQUIRE(steps * 64 < (int64_t)0x7fffffff, "graph too large for the SELL-8 index range");
+    std::vector<int2> pairs((size_t)(steps + 2) * 64, make_int2(0, 0));  // +2 steps: read-ahead padding
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t base = (int64_t)meta[(size_t)c].x * 64;
+        for (int g = 0; g < 8; ++g) {
+            const int64_t vi = c * 8 + g;
+            if (vi >= (int64_t)vr.size()) break;
+            const VRow &v = vr[(size_t)vi];
+            vrow[(size_t)vi] = v.target;
+            for (int32_t i = 0; i < v.len; ++i) {
+                int32_t bits;
+                std::memcpy(&bits, &val[v.begin + i], 4);
+                pairs[(size_t)(base + (int64_t)(i >> 3) * 64 + g * 8 + (i & 7))] = make_int2(col[v.begin + i], bits);
+            }
+        }
+    }
+    e->n_chunks = (int32_t)n_chunks;
+    e->n_lrow = (int32_t)lrow_row.size();
+    e->n_partial16 = n_partial;
+    e->sell_steps = steps;
+    HRAG_TRY(dev_upload(&e->d_pairs, pairs.data(), (int64_t)pairs.size()));
+    HRAG_TRY(dev_upload(&e->d_chunk_meta, meta.data(), (int64_t)meta.size()));
+    HRAG_TRY(dev_upload(&e->d_vrow, vrow.data(), (int64_t)vrow.size()));
+    HRAG_TRY(dev_upload(&e->d_lrow_row, lrow_row.data(), (int64_t)lrow_row.size()));
+    HRAG_TRY(dev_upload(&e->d_lrow_first, lrow_first.data(), (int64_t)lrow_first.size()));
+    HRAG_TRY(dev_upload(&e->d_lrow_cnt, lrow_cnt.data(), (int64_t)lrow_cnt.size()));
+    return HRAG_OK;
+}
+
+inline int n_slabs64(int batch) { return (int)ceil_div(batch, 64); }
+
+Ppr16Args ppr16_args(const hrag_engine *e, const uint16_t *x, uint16_t *y, const uint16_t *aux,
+                     float damping) {
+    Ppr16Args a;
+    a.pairs = e->d_pairs; a.chunk_meta = e->d_chunk_meta; a.vrow = e->d_vrow; a.n_chunks = e->n_chunks;
+    a.lrow_row = e->d_lrow_row; a.lrow_first = e->d_lrow_first; a.lrow_cnt = e->d_lrow_cnt;
+    a.n_lrow = e->n_lrow; a.n_partial = e->n_partial16; a.partial = e->d_partial16;
+    a.num_vertices = e->V; a.x = x; a.y = y; a.aux = aux; a.row_slot = e->d_row_slot;
+    a.tele = e->d_tele16; a.tele_rows = e->tele16_rows;
+    a.alpha = damping; a.beta = 1.0f - damping; a.cscale = kPpr16CScale;
+    return a;
+}
+
+// h_0 = f16(v); K1 sweeps on h; the residual sweep; K2 sweeps on the correction; d_x = h + c / cs.
+// Buffers: d_h16[0], [1] ping-pong for h; [2] = r; the free h buffer and [3] ping-pong for c.
+hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipStream_t s) {
+    const int ns = n_slabs64(batch);
+    const bool nt = (e->opt_flags & HRAG_OPT_NT_PAIRS) != 0;
+    const int k1 = iters / 2, k2 = iters - k1 - 1;
+    uint16_t *h = e->d_h16[0], *hn = e->d_h16[1], *r = e->d_h16[2];
+    HRAG_TRY(launch_ppr16_init(ppr16_args(e, nullptr, h, nullptr, damping), ns, s));
+    for (int it = 0; it < k1; ++it) {
+        HRAG_TRY(launch_ppr16_sweep(ppr16_args(e, h, hn, nullptr, damping), kPprModeH, ns, nt, false, s));
+        std::swap(h, hn);
+    }
+    HRAG_TRY(launch_ppr16_sweep(ppr16_args(e, h, r, nullptr, damping), kPprModeR, ns, nt, false, s));
+    const uint16_t *c = r;            // c_{K1+1} = r
+    uint16_t *cn = hn, *cn2 = e->d_h16[3];
+    for (int it = 0; it < k2; ++it) {
+        HRAG_TRY(launch_ppr16_sweep(ppr16_args(e, c, cn, r, damping), kPprModeC, ns, nt, false, s));
+        c = cn;
+        std::swap(cn, cn2);
+    }
+    HRAG_TRY(launch_ppr16_combine(h, c, 1.0f / kPpr16CScale, (int64_t)ns * e->V * 64, e->d_x, s));
+    if (h != e->d_h16[0]) std::swap(e->d_h16[0], e->d_h16[1]);  // keep h in [0] for hrag_ppr_sweeps
+    return HRAG_OK;
+}
+
+// The fp16 two-stage scheme needs K1 >= 8 sweeps before the residual sweep (error ~ 2^-(11+K1)).
+inline bool use_f16(const hrag_engine *e, int batch, int iters) {
+    return e->f16_ready && batch > 32 && iters >= 16;
 }
 
 }  // namespace
@@ -260,6 +386,18 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         E_TRY(dev_upload(&e->d_mrow_first, mrow_first.data(), (int64_t)mrow_first.size()));
         E_TRY(dev_upload(&e->d_mrow_cnt, mrow_cnt.data(), (int64_t)mrow_cnt.size()));
     }
+    // ---- SELL-8 + fp16 state for the two-stage PPR (unsharded engines, batches > 32)
+    const bool want_f16 = !(opts->flags & HRAG_OPT_F32_STATE) && e->n_rows == e->V && opts->max_batch > 32 &&
+                          e->V * 128 < ((int64_t)1 << 32);
+    if (want_f16) {
+        std::vector<int32_t> h_col((size_t)e->nnz);
+        std::vector<float> h_val((size_t)e->nnz);
+        if (e->nnz) {
+            E_HIP(hipMemcpy(h_col.data(), g->col_idx, h_col.size() * sizeof(int32_t), hipMemcpyDefault));
+            E_HIP(hipMemcpy(h_val.data(), g->val, h_val.size() * sizeof(float), hipMemcpyDefault));
+        }
+        E_TRY(build_sell8(e, h_row_ptr, h_col.data(), h_val.data()));
+    }
     // ---- passages: vertex map and its inverse on the owned rows
     {
         std::vector<int32_t> h_pv((size_t)e->n_passages);
@@ -294,6 +432,22 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     const int B = e->max_batch;
     SlabLayout lay = e->layout(B);
     e->state_elems = (int64_t)lay.n_slabs * e->V * lay.bc;
+    if (want_f16) {
+        const int ns = n_slabs64(B);
+        e->state16_elems = (int64_t)ns * e->V * 64;
+        e->state_elems = std::max(e->state_elems, e->state16_elems);  // d_x also receives h + c
+        for (auto &p : e->d_h16) E_TRY(dev_alloc(&p, e->state16_elems));
+        e->tele16_rows = e->n_passages + (int64_t)B * kMaxSeeds;
+        E_TRY(dev_alloc(&e->d_tele16, (int64_t)ns * e->tele16_rows * 64));
+        E_TRY(dev_alloc(&e->d_partial16, (int64_t)ns * std::max(e->n_partial16, 1) * 64));
+        E_TRY(dev_alloc(&e->d_row_slot, e->V));
+        E_TRY(dev_alloc(&e->d_qscale, B));
+        E_TRY(dev_alloc(&e->d_ssum, B));
+        for (auto &p : e->d_h16) E_HIP(hipMemset(p, 0, (size_t)e->state16_elems * sizeof(uint16_t)));
+        E_HIP(hipMemset(e->d_tele16, 0, (size_t)ns * e->tele16_rows * 64 * sizeof(float)));
+        E_HIP(hipMemcpy(e->d_row_slot, e->d_row_to_tele, (size_t)e->V * sizeof(int32_t), hipMemcpyDeviceToDevice));
+        e->f16_ready = true;
+    }
     E_TRY(dev_alloc(&e->d_partial, (int64_t)(round_up(B, 4) + 64) * std::max(e->n_partial, 1)));
     E_TRY(dev_alloc(&e->d_x, e->state_elems));
     E_TRY(dev_alloc(&e->d_y, e->state_elems));
@@ -490,36 +644,61 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     HRAG_REQUIRE(ppr_iters >= 0, "ppr_iters must be >= 0");
     HRAG_REQUIRE(e->n_passages >= 1, "engine has no passages");
     hipStream_t s = (hipStream_t)stream;
-    const SlabLayout lay = e->layout(batch);
+    const bool f16 = use_f16(e, batch, ppr_iters);
+    SlabLayout lay = e->layout(batch);
+    if (f16) { lay.bc = 64; lay.n_slabs = n_slabs64(batch); }
     const bool prof = e->profiling;
 
     HRAG_HIP_TRY(hipMemsetAsync(e->d_flags, 0, (size_t)batch * sizeof(int32_t), s));
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_START], s));
     // dense_passage_retrieval: raw scores + min / max (HippoRAG.py:1496-1498)
     HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s));
-    HRAG_TRY(launch_row_minmax(e->d_spass, batch, e->n_passages, e->ld_p, e->d_mn_p, e->d_mx_p, s));
+    HRAG_TRY(launch_row_minmax(e->d_spass, batch, e->n_passages, e->ld_p, e->d_mn_p, e->d_mx_p, s,
+                               f16 ? e->d_ssum : nullptr));
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SIM], s));
     // reset vector: entity seeds + passage prior (HippoRAG.py:1574-1638)
     HRAG_TRY(hrag_stage_seeds(e, kept_idx, kept_score, kept_count, kf, link_top_k, batch, e->d_seed_vtx,
                               e->d_seed_w, e->d_seed_cnt, e->d_flags, stream));
-    HRAG_TRY(hrag_stage_teleport(e, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, passage_node_weight,
-                                 e->d_flags, batch, e->d_tele, stream));
+    if (f16) {
+        // v is scaled per query by a power of two so that every iterate fits fp16 (ppr16.hip); the
+        // seeds become extra teleport rows, i.e. v is one array that every sweep reads identically
+        HRAG_TRY(launch_ppr16_scale(e->d_mn_p, e->d_mx_p, e->d_ssum, e->n_passages, passage_node_weight,
+                                    e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, e->d_qscale, s));
+        HRAG_TRY(launch_rows_to_slab(e->d_spass, e->ld_p, e->n_passages, batch, kMinMaxScale, e->d_mn_p,
+                                     e->d_mx_p, passage_node_weight, e->d_flags, e->d_tele16, lay, s,
+                                     e->tele16_rows, e->d_qscale));
+        for (int sl = 0; sl < lay.n_slabs; ++sl)
+            HRAG_HIP_TRY(hipMemsetAsync(e->d_tele16 + ((size_t)sl * e->tele16_rows + (size_t)e->n_passages) * 64,
+                                        0, (size_t)batch * kMaxSeeds * 64 * sizeof(float), s));
+        HRAG_HIP_TRY(hipMemcpyAsync(e->d_row_slot, e->d_row_to_tele, (size_t)e->V * sizeof(int32_t),
+                                    hipMemcpyDeviceToDevice, s));
+        HRAG_TRY(launch_ppr16_seed_rows(e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt, e->d_qscale, batch,
+                                        e->n_passages, e->V, e->d_row_slot, e->d_tele16, e->tele16_rows, s));
+    } else {
+        HRAG_TRY(hrag_stage_teleport(e, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, passage_node_weight,
+                                     e->d_flags, batch, e->d_tele, stream));
+    }
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SEED], s));
     // PPR (HippoRAG.py:1736-1743): fixed-count leaky power iteration
-    float *x = e->d_x, *y = e->d_y;
-    HRAG_TRY(ppr_init(e, e->d_tele, e->n_passages, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w,
-                      e->d_seed_cnt, batch, x, lay, s));
-    for (int it = 0; it < ppr_iters; ++it) {
-        HRAG_TRY(ppr_step(e, e->d_tele, e->n_passages, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w,
-                          e->d_seed_cnt, batch, damping, x, y, lay, false, s));
-        std::swap(x, y);
+    if (f16) {
+        HRAG_TRY(ppr16_run(e, batch, damping, ppr_iters, s));
+    } else {
+        float *x = e->d_x, *y = e->d_y;
+        HRAG_TRY(ppr_init(e, e->d_tele, e->n_passages, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w,
+                          e->d_seed_cnt, batch, x, lay, s));
+        for (int it = 0; it < ppr_iters; ++it) {
+            HRAG_TRY(ppr_step(e, e->d_tele, e->n_passages, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w,
+                              e->d_seed_cnt, batch, damping, x, y, lay, false, s));
+            std::swap(x, y);
+        }
+        if (x != e->d_x) std::swap(e->d_x, e->d_y);  // keep the final state in d_x
     }
-    if (x != e->d_x) std::swap(e->d_x, e->d_y);  // keep the final state in d_x
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_PPR], s));
     // doc scores + ranking (HippoRAG.py:1745-1747, :503)
     HRAG_TRY(launch_colsum(e->d_x, e->V, 0, e->V, batch, lay, e->d_colsum_partial, e->d_sums, s));
-    HRAG_TRY(hrag_stage_doc_scores(e, e->d_x, e->d_sums, batch, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p,
-                                   e->d_flags, e->d_doc, e->ld_p, stream));
+    HRAG_TRY(launch_slab_to_rows(e->d_x, e->V, e->d_passage_vertex, e->n_passages, batch, e->d_sums, e->d_doc,
+                                 e->ld_p, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, e->d_flags, lay, s));
+    HRAG_TRY(launch_flag_zero_mass(e->d_sums, batch, e->d_flags, 2, s));
     HRAG_TRY(launch_row_topk(e->d_doc, batch, e->n_passages, e->ld_p, k, 0, kNormNone, doc_idx_out,
                              doc_score_out, nullptr, nullptr, s));
     if (flags_out)
@@ -579,6 +758,18 @@ hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damp
                             hrag_stream stream) {
     HRAG_TRY(check_batch(e, batch));
     HRAG_REQUIRE(n >= 0, "n must be >= 0");
+    if (flags & 2) {
+        HRAG_REQUIRE(e->f16_ready, "engine has no fp16 PPR state");
+        const bool nt = (e->opt_flags & HRAG_OPT_NT_PAIRS) != 0;
+        uint16_t *h = e->d_h16[0], *hn = e->d_h16[1];
+        for (int it = 0; it < n; ++it) {
+            HRAG_TRY(launch_ppr16_sweep(ppr16_args(e, h, hn, nullptr, damping), kPprModeH, n_slabs64(batch), nt,
+                                        (flags & 1) != 0, (hipStream_t)stream));
+            std::swap(h, hn);
+        }
+        if (h != e->d_h16[0]) std::swap(e->d_h16[0], e->d_h16[1]);
+        return HRAG_OK;
+    }
     const SlabLayout lay = e->layout(batch);
     float *x = e->d_x, *y = e->d_y;
     for (int it = 0; it < n; ++it) {

@@ -25,7 +25,8 @@ template <int G>
 __global__ __launch_bounds__(256) void rows_to_slab_kernel(
     const float *__restrict__ rows, int64_t ld, int64_t n, int32_t batch, int mode,
     const float *__restrict__ mn, const float *__restrict__ mx, float scale,
-    const int32_t *__restrict__ skip_flags, float *__restrict__ slab) {
+    const int32_t *__restrict__ skip_flags, float *__restrict__ slab, int64_t slab_rows,
+    const float *__restrict__ qscale) {
     constexpr int BC = 4 * G;
     __shared__ float tile[BC][TI + 1];
     const int tid = threadIdx.x;
@@ -43,12 +44,13 @@ __global__ __launch_bounds__(256) void rows_to_slab_kernel(
                 v = (v != v || v < 0.f) ? 0.f : v;
             } else {
                 v = minmax_norm(v, mn[q], mx[q]) * scale;
+                if (qscale) v *= qscale[q];  // a power of two: exact
             }
         }
         tile[qq][ii] = v;
     }
     __syncthreads();
-    float4 *out = reinterpret_cast<float4 *>(slab + (size_t)s * n * BC);
+    float4 *out = reinterpret_cast<float4 *>(slab + (size_t)s * slab_rows * BC);
     for (int t = tid; t < TI * G; t += 256) {
         const int ii = t / G, gl = t % G;
         const int64_t i = i0 + ii;
@@ -116,12 +118,13 @@ __global__ void flag_zero_mass_kernel(const double *sums, int32_t batch, int32_t
 hrag_status launch_rows_to_slab(const float *rows, int64_t ld, int64_t n, int32_t batch,
                                 ToSlabMode mode, const float *mn, const float *mx, float scale,
                                 const int32_t *skip_flags, float *slab, SlabLayout lay,
-                                hipStream_t s) {
+                                hipStream_t s, int64_t slab_rows, const float *qscale) {
     if (n == 0) return HRAG_OK;
+    if (slab_rows <= 0) slab_rows = n;
     dim3 grid((unsigned)ceil_div(n, TI), (unsigned)lay.n_slabs);
 #define CALL(G)                                                                                    \
     hipLaunchKernelGGL(rows_to_slab_kernel<G>, grid, dim3(256), 0, s, rows, ld, n, batch, (int)mode, \
-                       mn, mx, scale, skip_flags, slab)
+                       mn, mx, scale, skip_flags, slab, slab_rows, qscale)
     switch (lay.bc) {
         case 4: CALL(1); break;
         case 8: CALL(2); break;

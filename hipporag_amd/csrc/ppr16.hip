@@ -1,0 +1,338 @@
+// K3h -- PPR power iteration with a two-stage fp16 state ("hi + correction"), fp32 arithmetic.
+//
+// Replaces igraph/PRPACK behind HippoRAG.run_ppr (reference src/hipporag/HippoRAG.py:1736-1743)
+// for batches wide enough to fill 128-byte lines with fp16 (B > 32).
+//
+// Why: the sweep  y = alpha P x + (1 - alpha) v  is bound by the random row gathers of x
+// (nnz * B * sizeof(state) bytes per sweep, ~7 TB/s of 128-byte lines whether they come from HBM or
+// the Infinity Cache -- tools/membench.hip), so the only lever is bytes per gathered element.
+// A plain fp16 state cannot meet the 1e-5 parity bar (2^-11 per rounding).  This file keeps the
+// state in fp16 AND follows the fp32 trajectory to ~4e-7 (measured):
+//
+//   sweeps 1..K1      h_{k+1} = f16(alpha P h_k + beta v)                          (mode H)
+//   sweep  K1+1       r       = (alpha P h + beta v) - h   in fp32, stored f16(r * cs)   (mode R)
+//                     -- this IS sweep K1+1 of the iteration started at x_K1 = h: x_{K1+1} = h + r
+//   sweeps K1+2..K    c_{k+1} = f16(alpha P c_k + r),  c_{K1+1} = r               (mode C)
+//   result            x_K     = h + c_K / cs           (fp32, ppr16_combine_kernel)
+//
+// x_k = h + c_k obeys exactly the recurrence of the fp32 iteration from x_K1 = h, so the truncation
+// error after K sweeps is that of K ordinary sweeps; the rounding of h is removed by r (computed
+// in fp32 from the exact fp16 values) and the rounding of c is 2^-11 relative to |c| ~ 2^-K1 |x|.
+// All products are exact (fp16 x fp32 -> v_fma_mix_f32), sums are fp32 in a fixed order.
+//
+// Storage: x is [n_slabs][V][64] fp16 -- one gather = one 128-byte line = 64 queries.
+// Matrix: SELL-8 ("sliced ELLPACK", slice = the 8 rows of one wavefront): rows sorted by length,
+// rows longer than 64 entries cut into <= 64 segments ("virtual rows" whose partial sums are
+// combined by ppr16_reduce_kernel in a fixed order -- no atomics, bit-reproducible), 8 virtual
+// rows per wavefront, entries stored step-major as (col, val) pairs so that a wavefront's CSR
+// read is ONE coalesced 512-byte load per 8-gather step and every fetched byte is used once.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace hrag {
+namespace {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr float kHalfMax = 65504.f;
+
+template <int K>
+__device__ __forceinline__ int bcast8(int v) {
+    // ds_swizzle bit mode inside each 8-lane group: src = (lane & 0x18) | K
+    return __builtin_amdgcn_ds_swizzle(v, (K << 5) | 0x18);
+}
+
+__device__ __forceinline__ void fma8(float (&acc)[8], float w, const half8_t &x) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf((float)x[j], w, acc[j]);
+}
+
+template <int K>
+struct Gather8 {
+    __device__ __forceinline__ static void run(float (&acc)[8], int c, int wbits, const char *xs,
+                                               unsigned lane_off) {
+        const unsigned ck = (unsigned)bcast8<K>(c);
+        const float wk = __int_as_float(bcast8<K>(wbits));
+        // 128 bytes per vertex, 16 per lane; V * 128 < 2^32 is checked at engine creation
+        const half8_t xv = *reinterpret_cast<const half8_t *>(xs + (size_t)(ck * 128u + lane_off));
+        fma8(acc, wk, xv);
+        if constexpr (K + 1 < 8) Gather8<K + 1>::run(acc, c, wbits, xs, lane_off);
+    }
+};
+
+template <bool NT>
+__device__ __forceinline__ int2 ld_pair(const int2 *p) {
+    if constexpr (NT) {
+        const long long v = __builtin_nontemporal_load(reinterpret_cast<const long long *>(p));
+        int2 r;
+        r.x = (int)(v & 0xffffffffll);
+        r.y = (int)(v >> 32);
+        return r;
+    } else {
+        // relaxed wavefront-scope atomic = a plain global_load_dwordx2 that the optimiser may not
+        // move: without it LLVM sinks the read-ahead loads back to their first use (the (col, val)
+        // stream is loop-invariant memory) and every step stalls on its own pair load
+        const long long v = __hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WAVEFRONT);
+        int2 r;
+        r.x = (int)(v & 0xffffffffll);
+        r.y = (int)(v >> 32);
+        return r;
+    }
+}
+
+__device__ __forceinline__ float clamp_half(float v) { return fminf(fmaxf(v, -kHalfMax), kHalfMax); }
+
+// Finish one output row: lane gl of its group owns queries 8*gl .. 8*gl+7 of the slab.
+template <int MODE>
+__device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row, int gl,
+                                           const float (&acc)[8]) {
+    float out[8];
+    const size_t state_off = ((size_t)slab * a.num_vertices + (size_t)row) * 64 + (size_t)gl * 8;
+    if constexpr (MODE == kPprModeH || MODE == kPprModeR) {
+        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int slot = a.row_slot[row];
+        if (slot >= 0) {
+            const f32x4_t *tp = reinterpret_cast<const f32x4_t *>(
+                a.tele + ((size_t)slab * a.tele_rows + (size_t)slot) * 64 + (size_t)gl * 8);
+            const f32x4_t t0 = tp[0], t1 = tp[1];
+            t[0] = t0.x; t[1] = t0.y; t[2] = t0.z; t[3] = t0.w;
+            t[4] = t1.x; t[5] = t1.y; t[6] = t1.z; t[7] = t1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = fmaf(a.alpha, acc[j], a.beta * t[j]);
+        if constexpr (MODE == kPprModeR) {
+            const half8_t h = *reinterpret_cast<const half8_t *>(a.x + state_off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] = (out[j] - (float)h[j]) * a.cscale;
+        }
+    } else {
+        const half8_t r = *reinterpret_cast<const half8_t *>(a.aux + state_off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = fmaf(a.alpha, acc[j], (float)r[j]);
+    }
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)clamp_half(out[j]);
+    *reinterpret_cast<half8_t *>(a.y + state_off) = o;
+}
+
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256) void ppr16_kernel(const Ppr16Args a) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & 7, grp = lane >> 3;
+    const int slab = blockIdx.y;
+    const int chunk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (chunk >= a.n_chunks) return;
+    const int2 meta = a.chunk_meta[chunk];  // (first step, number of steps)
+    const int n_steps = meta.y;
+    const char *xs = reinterpret_cast<const char *>(a.x + (size_t)slab * a.num_vertices * 64);
+    const int2 *pp = a.pairs + (size_t)meta.x * 64 + lane;
+    const unsigned lane_off = (unsigned)gl * 16u;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the pair stream is read two steps ahead, unconditionally (the array carries two steps of
+    // padding), so that the loop body is branch-free and the compiler can wait with vmcnt(N > 0)
+    int2 p0 = ld_pair<NT>(pp);
+    int2 p1 = ld_pair<NT>(pp + 64);
+    for (int s = 0; s < n_steps; ++s) {
+        const int2 p2 = ld_pair<NT>(pp + (size_t)(s + 2) * 64);
+        Gather8<0>::run(acc, p0.x, p0.y, xs, lane_off);
+        p0 = p1;
+        p1 = p2;
+    }
+    const int tgt = a.vrow[chunk * 8 + grp];
+    if (tgt >= 0) {
+        finish_row<MODE>(a, slab, tgt, gl, acc);
+    } else if (tgt != kVrowNone) {
+        f32x4_t *pp4 = reinterpret_cast<f32x4_t *>(
+            a.partial + ((size_t)slab * a.n_partial + (size_t)(-(tgt + 1))) * 64 + (size_t)gl * 8);
+        f32x4_t v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
+        pp4[0] = v0;
+        pp4[1] = v1;
+    }
+}
+
+// One wavefront per long row: the 8 lane groups stride over the row's partial sums, then the 8
+// group totals are added with xor-shuffles -- a fixed summation order.
+template <int MODE>
+__global__ __launch_bounds__(256) void ppr16_reduce_kernel(const Ppr16Args a) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & 7, grp = lane >> 3;
+    const int slab = blockIdx.y;
+    const int m = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (m >= a.n_lrow) return;
+    const int first = a.lrow_first[m], cnt = a.lrow_cnt[m];
+    const float *base = a.partial + ((size_t)slab * a.n_partial + (size_t)first) * 64 + (size_t)gl * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = grp; s < cnt; s += 8) {
+        const f32x4_t *p = reinterpret_cast<const f32x4_t *>(base + (size_t)s * 64);
+        const f32x4_t v0 = p[0], v1 = p[1];
+        acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
+        acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+    if (grp == 0) finish_row<MODE>(a, slab, a.lrow_row[m], gl, acc);
+}
+
+// h_0 = f16(v): every vertex row of every slab
+__global__ __launch_bounds__(256) void ppr16_init_kernel(const Ppr16Args a) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t >> 3;
+    const int gl = (int)(t & 7);
+    const int slab = blockIdx.y;
+    if (row >= a.num_vertices) return;
+    half8_t o = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int slot = a.row_slot[row];
+    if (slot >= 0) {
+        const f32x4_t *tp = reinterpret_cast<const f32x4_t *>(
+            a.tele + ((size_t)slab * a.tele_rows + (size_t)slot) * 64 + (size_t)gl * 8);
+        const f32x4_t t0 = tp[0], t1 = tp[1];
+        o[0] = (_Float16)clamp_half(t0.x); o[1] = (_Float16)clamp_half(t0.y);
+        o[2] = (_Float16)clamp_half(t0.z); o[3] = (_Float16)clamp_half(t0.w);
+        o[4] = (_Float16)clamp_half(t1.x); o[5] = (_Float16)clamp_half(t1.y);
+        o[6] = (_Float16)clamp_half(t1.z); o[7] = (_Float16)clamp_half(t1.w);
+    }
+    *reinterpret_cast<half8_t *>(a.y + ((size_t)slab * a.num_vertices + (size_t)row) * 64 + (size_t)gl * 8) = o;
+}
+
+// x32[slab][v][64] = h + c * inv_cscale   (c may be null: x = h)
+__global__ __launch_bounds__(256) void ppr16_combine_kernel(const _Float16 *h, const _Float16 *c,
+                                                            float inv_cscale, int64_t n8,
+                                                            float *out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n8) return;
+    const half8_t hv = reinterpret_cast<const half8_t *>(h)[t];
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)hv[j];
+    if (c) {
+        const half8_t cv = reinterpret_cast<const half8_t *>(c)[t];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf((float)cv[j], inv_cscale, o[j]);
+    }
+    f32x4_t *op = reinterpret_cast<f32x4_t *>(out) + t * 2;
+    f32x4_t v0 = {o[0], o[1], o[2], o[3]}, v1 = {o[4], o[5], o[6], o[7]};
+    op[0] = v0;
+    op[1] = v1;
+}
+
+// Per-query scale s_q (a power of two) such that sum(v_q) * s_q is in (2^14, 2^15]: every entry of
+// every iterate is then <= 2^15 < 65504 (the leaky iteration never gains mass).
+//   total_q = passage_node_weight * sum_p minmax(score_qp) + sum_j seed_w[q][j]
+__global__ void ppr16_scale_kernel(const float *mn, const float *mx, const float *ssum, int64_t n_passages,
+                                   float passage_weight, const float *seed_w, const int32_t *seed_cnt,
+                                   const int32_t *flags, int32_t batch, float *qscale) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= batch) return;
+    double total = 0.0;
+    if (!(flags[q] & 1)) {
+        const double range = (double)mx[q] - (double)mn[q];
+        const double norm_sum = range == 0.0 ? (double)n_passages
+                                             : ((double)ssum[q] - (double)n_passages * (double)mn[q]) / range;
+        total = (double)passage_weight * fmax(norm_sum, 0.0);
+        for (int j = 0; j < seed_cnt[q]; ++j) total += fmax((double)seed_w[q * kMaxSeeds + j], 0.0);
+    }
+    float s = 1.f;
+    if (total > 0.0 && total < 1e300) {
+        int ex;
+        (void)frexp(32768.0 / total, &ex);   // 32768/total = m * 2^ex, m in [0.5, 1)
+        ex -= 1;                              // floor(log2)
+        ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+        s = ldexpf(1.f, ex);
+    }
+    qscale[q] = s;
+}
+
+// Entity seeds become extra teleport rows: vertex v of query q gets slot n_passages + q*kMaxSeeds+j
+// (first claimant wins; another query seeding the same vertex reuses the winner's row), or, when
+// v is a passage vertex, its weight is added to that passage's teleport row.
+__global__ void ppr16_seed_rows_kernel(const int32_t *seed_vtx, const float *seed_w,
+                                       const int32_t *seed_cnt, const float *qscale, int32_t batch,
+                                       int64_t n_passages, int64_t num_vertices, int32_t *row_slot,
+                                       float *tele, int64_t tele_rows) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = t / kMaxSeeds, j = t % kMaxSeeds;
+    if (q >= batch || j >= seed_cnt[q]) return;
+    const int64_t v = seed_vtx[q * kMaxSeeds + j];
+    if (v < 0 || v >= num_vertices) return;
+    const int mine = (int)n_passages + q * kMaxSeeds + j;
+    const int old = atomicCAS(&row_slot[v], -1, mine);
+    const int slot = old == -1 ? mine : old;
+    const int slab = q >> 6, col = q & 63;
+    // vertices are unique within a query, so (slot, col) has a single writer
+    tele[((size_t)slab * tele_rows + (size_t)slot) * 64 + col] += seed_w[q * kMaxSeeds + j] * qscale[q];
+}
+
+template <int MODE>
+hrag_status sweep_mode(const Ppr16Args &a, int n_slabs, bool nt, bool main_only, hipStream_t s) {
+    if (a.n_chunks > 0) {
+        dim3 grid((unsigned)ceil_div(a.n_chunks, 4), (unsigned)n_slabs);
+        if (nt) hipLaunchKernelGGL((ppr16_kernel<MODE, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((ppr16_kernel<MODE, false>), grid, dim3(256), 0, s, a);
+        HRAG_LAUNCH_CHECK();
+    }
+    if (!main_only && a.n_lrow > 0) {
+        dim3 grid((unsigned)ceil_div(a.n_lrow, 4), (unsigned)n_slabs);
+        hipLaunchKernelGGL(ppr16_reduce_kernel<MODE>, grid, dim3(256), 0, s, a);
+        HRAG_LAUNCH_CHECK();
+    }
+    return HRAG_OK;
+}
+
+}  // namespace
+
+hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, bool nt_pairs, bool main_only,
+                               hipStream_t s) {
+    switch (mode) {
+        case kPprModeH: return sweep_mode<kPprModeH>(a, n_slabs, nt_pairs, main_only, s);
+        case kPprModeR: return sweep_mode<kPprModeR>(a, n_slabs, nt_pairs, main_only, s);
+        case kPprModeC: return sweep_mode<kPprModeC>(a, n_slabs, nt_pairs, main_only, s);
+        default: set_error("bad ppr16 mode %d", mode); return HRAG_EINVAL;
+    }
+}
+
+hrag_status launch_ppr16_init(const Ppr16Args &a, int n_slabs, hipStream_t s) {
+    dim3 grid((unsigned)ceil_div(a.num_vertices * 8, 256), (unsigned)n_slabs);
+    hipLaunchKernelGGL(ppr16_init_kernel, grid, dim3(256), 0, s, a);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr16_combine(const uint16_t *h, const uint16_t *c, float inv_cscale, int64_t elems,
+                                 float *out, hipStream_t s) {
+    const int64_t n8 = elems / 8;
+    if (n8 == 0) return HRAG_OK;
+    hipLaunchKernelGGL(ppr16_combine_kernel, dim3((unsigned)ceil_div(n8, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const _Float16 *>(h), reinterpret_cast<const _Float16 *>(c),
+                       inv_cscale, n8, out);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr16_scale(const float *mn, const float *mx, const float *ssum, int64_t n_passages,
+                               float passage_weight, const float *seed_w, const int32_t *seed_cnt,
+                               const int32_t *flags, int32_t batch, float *qscale, hipStream_t s) {
+    hipLaunchKernelGGL(ppr16_scale_kernel, dim3((unsigned)ceil_div(batch, 64)), dim3(64), 0, s, mn, mx,
+                       ssum, n_passages, passage_weight, seed_w, seed_cnt, flags, batch, qscale);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr16_seed_rows(const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
+                                   const float *qscale, int32_t batch, int64_t n_passages,
+                                   int64_t num_vertices, int32_t *row_slot, float *tele,
+                                   int64_t tele_rows, hipStream_t s) {
+    const int total = batch * kMaxSeeds;
+    hipLaunchKernelGGL(ppr16_seed_rows_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
+                       seed_vtx, seed_w, seed_cnt, qscale, batch, n_passages, num_vertices, row_slot,
+                       tele, tele_rows);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+}  // namespace hrag

@@ -194,8 +194,11 @@ __global__ __launch_bounds__(TK_THREADS) void row_topk_kernel(
 __global__ __launch_bounds__(TK_THREADS) void row_minmax_kernel(const float *__restrict__ scores,
                                                                 int64_t n, int64_t ld,
                                                                 float *__restrict__ mn_out,
-                                                                float *__restrict__ mx_out) {
+                                                                float *__restrict__ mx_out,
+                                                                float *__restrict__ sum_out) {
     __shared__ float red_mn[TK_THREADS / 64], red_mx[TK_THREADS / 64];
+    __shared__ double red_sum[TK_THREADS / 64];
+    double sum = 0.0;  // only used to pick a scale (ppr16): accuracy is irrelevant
     const int tid = threadIdx.x;
     const int row = blockIdx.x;
     const float *s = scores + (size_t)row * ld;
@@ -203,21 +206,26 @@ __global__ __launch_bounds__(TK_THREADS) void row_minmax_kernel(const float *__r
     for_each_in_row(s, n, tid, [&](float v, uint32_t) {
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
+        sum += (double)v;
     });
     mn = wave_min(mn);
     mx = wave_max(mx);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     if ((tid & 63) == 0) {
         red_mn[tid >> 6] = mn;
         red_mx[tid >> 6] = mx;
+        red_sum[tid >> 6] = sum;
     }
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < TK_THREADS / 64; ++w) {
             mn = fminf(mn, red_mn[w]);
             mx = fmaxf(mx, red_mx[w]);
+            sum += red_sum[w];
         }
         mn_out[row] = mn;
         mx_out[row] = mx;
+        if (sum_out) sum_out[row] = (float)sum;
     }
 }
 
@@ -236,10 +244,10 @@ hrag_status launch_row_topk(const float *scores, int32_t batch, int64_t n, int64
 }
 
 hrag_status launch_row_minmax(const float *scores, int32_t batch, int64_t n, int64_t ld,
-                              float *mn_out, float *mx_out, hipStream_t s) {
+                              float *mn_out, float *mx_out, hipStream_t s, float *sum_out) {
     if (batch == 0) return HRAG_OK;
     hipLaunchKernelGGL(row_minmax_kernel, dim3((unsigned)batch), dim3(TK_THREADS), 0, s, scores, n, ld,
-                       mn_out, mx_out);
+                       mn_out, mx_out, sum_out);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

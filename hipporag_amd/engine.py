@@ -239,8 +239,11 @@ class HippoRAGEngine:
                                  flags.data_ptr(), _stream()))
         return x, flags
 
-    def ppr_sweeps(self, batch: int, n: int, damping: float = 0.5, main_only: bool = False):
-        check(self._lib.hrag_ppr_sweeps(self._handle, batch, n, damping, 1 if main_only else 0, _stream()))
+    def ppr_sweeps(self, batch: int, n: int, damping: float = 0.5, main_only: bool = False,
+                   f16: bool = False):
+        """Measurement hook: n sweeps of the fp32 kernel, or (f16=True) of the fp16-state kernel."""
+        flags = (1 if main_only else 0) | (2 if f16 else 0)
+        check(self._lib.hrag_ppr_sweeps(self._handle, batch, n, damping, flags, _stream()))
 
 
 def topk_rows(scores, k: int, *, n: Optional[int] = None, idx_offset: int = 0, normalize: bool = False,

@@ -93,6 +93,9 @@ typedef struct hrag_fact_desc {
 #define HRAG_OPT_NATURAL_ROW_ORDER 1 /* keep CSR row order instead of degree-descending          */
 #define HRAG_OPT_NT_CSR 2            /* non-temporal loads for the col_idx / val stream             */
 #define HRAG_OPT_NT_STORE 4          /* non-temporal stores for the new PPR state                   */
+#define HRAG_OPT_F32_STATE 8         /* never use the two-stage fp16 PPR state (hrag_retrieve uses it  */
+                                     /* for batch > 32 and ppr_iters >= 16; same 1e-5 parity bar)       */
+#define HRAG_OPT_NT_PAIRS 16         /* non-temporal loads for the SELL-8 (col, val) stream            */
 
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */
@@ -191,7 +194,9 @@ hrag_status hrag_topk_rows(const float *scores_dev, int32_t batch, int64_t n, in
 
 /* Measurement hook: run `n` PPR SpMM sweeps over the engine's current state buffers for
  * `batch` right-hand sides (state is whatever the last hrag_retrieve / hrag_ppr left).
- * flags bit0: main CSR kernel only (skip the long-row and seed kernels). */
+ * flags bit0: main CSR kernel only (skip the long-row and seed kernels);
+ * flags bit1: the fp16-state kernel of the two-stage scheme (mode H) instead of the fp32 one
+ *             (HRAG_EINVAL when the engine has no fp16 state: sharded, max_batch <= 32, F32_STATE). */
 hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damping, int32_t flags,
                             hrag_stream stream);
 

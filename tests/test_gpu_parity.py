@@ -293,3 +293,78 @@ def test_seed_edge_cases(gpu_device):
         assert tie_aware_equal(out.doc_idx.cpu().numpy()[q], want_ids[:4], want_sc[:4], rel_gap=2e-5)
         np.testing.assert_allclose(out.doc_score.cpu().numpy()[q], x[pv][out.doc_idx.cpu().numpy()[q]],
                                    rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- two-stage fp16 PPR state
+def test_retrieve_f16_state_path_vs_f32_state_path_and_oracle(case, gpu_device):
+    """hrag_retrieve switches to the two-stage fp16 state (csrc/ppr16.hip) for batch > 32 and
+    ppr_iters >= 16.  Same inputs through (a) that path, (b) an engine created with
+    HRAG_OPT_F32_STATE, (c) the oracle: both device paths must meet the 1e-5 bar, including filter
+    subsets, DPR-fallback rows and queries in different 64-wide slabs seeding the same vertices."""
+    import torch
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd._lib import OPT_F32_STATE
+    kg, eng16 = case["kg"], case["eng"]
+    b = 70
+    qf_bits, qp_bits = case["qf_bits"][:b].copy(), case["qp_bits"][:b].copy()
+    qf_bits[65] = qf_bits[1]            # slab 1 seeds the same entities as slab 0
+    qf_bits[66] = qf_bits[2]
+    sub = dict(case, qf_bits=qf_bits, qp_bits=qp_bits)
+    idx, sc = eng16.score_facts(_bf16(qf_bits, gpu_device), k=5)
+    idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
+    rng = np.random.default_rng(4)
+    kept_idx = np.full((b, 5), -1, np.int32)
+    kept_sc = np.zeros((b, 5), np.float32)
+    kept_cnt = np.zeros(b, np.int32)
+    kept_lists = []
+    for q in range(b):
+        n = 5 if q in (1, 2, 65, 66) else int(rng.integers(0, 6))       # some rows keep nothing
+        plan = rng.permutation(5)[:n].tolist() if q not in (1, 2, 65, 66) else [0, 1, 2, 3, 4]
+        kept_idx[q, :n] = idx_h[q, plan]
+        kept_sc[q, :n] = sc_h[q, plan]
+        kept_cnt[q] = n
+        kept_lists.append(idx_h[q, plan].tolist())
+    refs = _oracle_batch(sub, kept_lists)
+    eng32 = HippoRAGEngine(kg.csr, kg.passage_vertex, case["pass_bits"], case["fact_bits"], kg.subj_vertex,
+                           kg.obj_vertex, kg.num_chunks, max_batch=80, max_topk=200, flags=OPT_F32_STATE)
+    outs = {}
+    for name, eng in (("f16", eng16), ("f32", eng32)):
+        out = eng.retrieve(_bf16(qp_bits, gpu_device), _t(kept_idx, gpu_device), _t(kept_sc, gpu_device),
+                           _t(kept_cnt, gpu_device), ppr_iters=20, k=200)
+        torch.cuda.synchronize()
+        outs[name] = (out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy(), out.flags.cpu().numpy())
+    assert eng16.timings()["slab_width"] == 64 and eng32.timings()["slab_width"] == 32
+    eng32.close()
+    pv = kg.passage_vertex
+    worst = {"f16": 0.0, "f32": 0.0}
+    for name, (got_idx, got_sc, flags) in outs.items():
+        for q in range(b):
+            ref = refs[q]
+            assert bool(flags[q] & 1) == ref.used_dpr == (kept_cnt[q] == 0), (name, q)
+            want_ids, want_sc = ref.sorted_doc_ids[:200], ref.sorted_doc_scores[:200]
+            if ref.used_dpr:
+                assert tie_aware_equal(got_idx[q], want_ids, want_sc, abs_gap=3e-6), (name, q)
+                np.testing.assert_allclose(got_sc[q], want_sc, rtol=0, atol=3e-6)
+            else:
+                assert tie_aware_equal(got_idx[q], want_ids, want_sc, rel_gap=2e-5), (name, q)
+                want = ref.x[pv][got_idx[q]]
+                rel = np.abs(got_sc[q] - want) / want
+                worst[name] = max(worst[name], float(rel.max()))
+                assert rel.max() < 1e-5, (name, q, rel.max())
+    # the fp16-state path follows the fp32 trajectory: its error stays within a small factor
+    assert worst["f16"] < 5e-6, worst
+
+
+def test_ppr_sweeps_hook_f16(case, gpu_device):
+    """Measurement hook on the fp16 kernels runs (bench.py's roofline leg) and leaves no NaN."""
+    import torch
+    eng = case["eng"]
+    b = 70
+    idx, sc = eng.score_facts(_bf16(case["qf_bits"][:b], gpu_device), k=5)
+    cnt = torch.full((b,), 5, dtype=torch.int32, device=gpu_device)
+    ref = eng.retrieve(_bf16(case["qp_bits"][:b], gpu_device), idx, sc, cnt, ppr_iters=20, k=50)
+    eng.ppr_sweeps(b, 3, 0.5, main_only=False, f16=True)
+    eng.ppr_sweeps(b, 2, 0.5, main_only=True, f16=True)
+    out = eng.retrieve(_bf16(case["qp_bits"][:b], gpu_device), idx, sc, cnt, ppr_iters=20, k=50)
+    torch.cuda.synchronize()
+    assert torch.equal(ref.doc_idx, out.doc_idx) and torch.equal(ref.doc_score, out.doc_score)

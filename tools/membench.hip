@@ -1,0 +1,88 @@
+// Memory-system microbenchmarks for the PPR SpMM design (not product code):
+//   stream  : float4 streaming read of a buffer of S bytes
+//   gather  : pseudo-random chunk gathers (chunk = g bytes, g/16 lanes per chunk) from a buffer of S bytes
+// Prints GB/s for each (S, g).  Usage: membench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+__device__ __forceinline__ uint32_t mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+
+__global__ __launch_bounds__(256) void stream_kernel(const float4 *p, size_t n4, float *out) {
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = p[i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = 1.f;
+}
+
+// LPC = lanes per chunk (chunk bytes = 16 * LPC); each lane group performs `iters` x U gathers
+template <int LPC, int U>
+__global__ __launch_bounds__(256) void gather_kernel(const float4 *p, uint32_t n_chunks, int iters, float *out) {
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t grp = tid / LPC, gl = tid % LPC;
+    float4 acc = make_float4(0, 0, 0, 0);
+    uint32_t s = grp * 0x9E3779B9u + 12345u;
+    for (int it = 0; it < iters; ++it) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s = mix(s + u + 1);
+            const uint32_t c = (uint32_t)(((uint64_t)s * n_chunks) >> 32);
+            v[u] = p[(size_t)c * LPC + gl];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = 1.f;
+}
+
+template <int LPC>
+double run_gather(const float4 *buf, size_t bytes, float *out, int blocks, int iters) {
+    const uint32_t n_chunks = (uint32_t)(bytes / (16 * LPC));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((gather_kernel<LPC, 8>), dim3(blocks), dim3(256), 0, 0, buf, n_chunks, iters, out);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 3; ++r)
+        hipLaunchKernelGGL((gather_kernel<LPC, 8>), dim3(blocks), dim3(256), 0, 0, buf, n_chunks, iters, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double total = 3.0 * (double)blocks * 256 * iters * 8 * 16;
+    return total / (ms * 1e-3) / 1e9;
+}
+
+int main() {
+    const size_t maxb = (size_t)4 << 30;
+    float4 *buf; float *out;
+    CK(hipMalloc(&buf, maxb)); CK(hipMalloc(&out, 64));
+    CK(hipMemset(buf, 0, maxb));
+    const size_t sizes[] = {2u << 20, 16u << 20, 64u << 20, 128u << 20, 192u << 20, 256u << 20, 512u << 20, (size_t)1 << 30, (size_t)4 << 30};
+    printf("stream read GB/s\n");
+    for (size_t S : sizes) {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        const int reps = (int)std::max<size_t>(4, ((size_t)8 << 30) / S);
+        hipLaunchKernelGGL(stream_kernel, dim3(256 * 16), dim3(256), 0, 0, buf, S / 16, out);
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(stream_kernel, dim3(256 * 16), dim3(256), 0, 0, buf, S / 16, out);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  S=%6zu MiB  %8.0f\n", S >> 20, (double)S * reps / (ms * 1e-3) / 1e9);
+    }
+    printf("random gather GB/s (useful bytes), columns: chunk 64 128 256 512 1024 B\n");
+    const int blocks = 256 * 32, iters = 32;
+    for (size_t S : sizes) {
+        printf("  S=%6zu MiB ", S >> 20);
+        printf(" %8.0f", run_gather<4>(buf, S, out, blocks, iters));
+        printf(" %8.0f", run_gather<8>(buf, S, out, blocks, iters));
+        printf(" %8.0f", run_gather<16>(buf, S, out, blocks, iters));
+        printf(" %8.0f", run_gather<32>(buf, S, out, blocks, iters));
+        printf(" %8.0f\n", run_gather<64>(buf, S, out, blocks, iters));
+        fflush(stdout);
+    }
+    return 0;
+}

@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep-launches", type=int, default=40)
+    ap.add_argument("--no-rowshard", action="store_true", help="N > 1: skip the secondary row-sharded leg")
+    ap.add_argument("--rowshard-timeout-s", type=float, default=240.0,
+                    help="N > 1: abandon the row-sharded leg after this long (the primary line still prints)")
     args = ap.parse_args()
 
     import torch
@@ -131,7 +134,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("HRAG_FORCE_DIST"):   # env: exercise the N>1 code on 1 GPU
         from hipporag_amd import dist as hdist
         return hdist.bench_main(args, CONFIGS, rank, local_rank, world)
 

@@ -32,8 +32,8 @@ qf, _ = synth.make_queries_torch(femb, B, 7)
 qp, _ = synth.make_queries_torch(pemb, B, 8)
 cnt = torch.full((B,), 5, dtype=torch.int32, device=dev)
 idx, sc = eng.score_facts(qf, k=5)
-eng.retrieve(qp, idx, sc, cnt, ppr_iters=2, k=200)
-eng.ppr_sweeps(B, 4, 0.5, main_only=True)
+eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=200)   # takes the fp16-state path when B > 32
+eng.ppr_sweeps(B, 4, 0.5, main_only=True, f16=B > 32 and not (int(os.environ.get("HRAG_FLAGS", "0")) & 8))
 torch.cuda.synchronize()
 eng.close()
 print("pmc target done")

@@ -13,7 +13,7 @@ HRAG_OK, HRAG_EINVAL, HRAG_ENOMEM, HRAG_EHIP, HRAG_EZERO_RESET, HRAG_ECAPACITY =
 SEED_STRIDE = 32
 FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE = 1, 2, 4
 # hrag_opts.flags (include/hrag.h HRAG_OPT_*)
-OPT_NATURAL_ROW_ORDER, OPT_NT_CSR, OPT_NT_STORE, OPT_F32_STATE, OPT_NT_PAIRS = 1, 2, 4, 8, 16
+OPT_NATURAL_ROW_ORDER, OPT_NT_CSR, OPT_NT_STORE, OPT_F32_STATE, OPT_TEMPORAL16 = 1, 2, 4, 8, 16
 
 
 class HragError(RuntimeError):

@@ -126,7 +126,8 @@ struct Ppr16Args {
     int64_t tele_rows;
     float alpha, beta, cscale;
 };
-hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, bool nt_pairs, bool main_only,
+// nt: bit0 non-temporal (col, val) loads, bit1 non-temporal state stores
+hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, int nt, bool main_only,
                                hipStream_t s);
 hrag_status launch_ppr16_init(const Ppr16Args &a, int n_slabs, hipStream_t s);  // y = f16(v)
 hrag_status launch_ppr16_combine(const uint16_t *h, const uint16_t *c, float inv_cscale, int64_t elems,

@@ -252,7 +252,7 @@ Ppr16Args ppr16_args(const hrag_engine *e, const uint16_t *x, uint16_t *y, const
 // Buffers: d_h16[0], [1] ping-pong for h; [2] = r; the free h buffer and [3] ping-pong for c.
 hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipStream_t s) {
     const int ns = n_slabs64(batch);
-    const bool nt = (e->opt_flags & HRAG_OPT_NT_PAIRS) != 0;
+    const int nt = (e->opt_flags & HRAG_OPT_TEMPORAL16) ? 0 : 3;
     const int k1 = iters / 2, k2 = iters - k1 - 1;
     uint16_t *h = e->d_h16[0], *hn = e->d_h16[1], *r = e->d_h16[2];
     HRAG_TRY(launch_ppr16_init(ppr16_args(e, nullptr, h, nullptr, damping), ns, s));
@@ -760,7 +760,7 @@ hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damp
     HRAG_REQUIRE(n >= 0, "n must be >= 0");
     if (flags & 2) {
         HRAG_REQUIRE(e->f16_ready, "engine has no fp16 PPR state");
-        const bool nt = (e->opt_flags & HRAG_OPT_NT_PAIRS) != 0;
+        const int nt = (e->opt_flags & HRAG_OPT_TEMPORAL16) ? 0 : 3;
         uint16_t *h = e->d_h16[0], *hn = e->d_h16[1];
         for (int it = 0; it < n; ++it) {
             HRAG_TRY(launch_ppr16_sweep(ppr16_args(e, h, hn, nullptr, damping), kPprModeH, n_slabs64(batch), nt,

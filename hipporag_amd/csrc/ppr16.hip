@@ -86,7 +86,7 @@ __device__ __forceinline__ int2 ld_pair(const int2 *p) {
 __device__ __forceinline__ float clamp_half(float v) { return fminf(fmaxf(v, -kHalfMax), kHalfMax); }
 
 // Finish one output row: lane gl of its group owns queries 8*gl .. 8*gl+7 of the slab.
-template <int MODE>
+template <int MODE, bool NT_ST = false>
 __device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row, int gl,
                                            const float (&acc)[8]) {
     float out[8];
@@ -116,10 +116,14 @@ __device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row
     half8_t o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (_Float16)clamp_half(out[j]);
-    *reinterpret_cast<half8_t *>(a.y + state_off) = o;
+    if constexpr (NT_ST) {
+        __builtin_nontemporal_store(o, reinterpret_cast<half8_t *>(a.y + state_off));
+    } else {
+        *reinterpret_cast<half8_t *>(a.y + state_off) = o;
+    }
 }
 
-template <int MODE, bool NT>
+template <int MODE, bool NT, bool NT_ST>
 __global__ __launch_bounds__(256) void ppr16_kernel(const Ppr16Args a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void ppr16_kernel(const Ppr16Args a) {
     }
     const int tgt = a.vrow[chunk * 8 + grp];
     if (tgt >= 0) {
-        finish_row<MODE>(a, slab, tgt, gl, acc);
+        finish_row<MODE, NT_ST>(a, slab, tgt, gl, acc);
     } else if (tgt != kVrowNone) {
         f32x4_t *pp4 = reinterpret_cast<f32x4_t *>(
             a.partial + ((size_t)slab * a.n_partial + (size_t)(-(tgt + 1))) * 64 + (size_t)gl * 8);
@@ -269,11 +273,15 @@ __global__ void ppr16_seed_rows_kernel(const int32_t *seed_vtx, const float *see
 }
 
 template <int MODE>
-hrag_status sweep_mode(const Ppr16Args &a, int n_slabs, bool nt, bool main_only, hipStream_t s) {
+hrag_status sweep_mode(const Ppr16Args &a, int n_slabs, int nt, bool main_only, hipStream_t s) {
     if (a.n_chunks > 0) {
         dim3 grid((unsigned)ceil_div(a.n_chunks, 4), (unsigned)n_slabs);
-        if (nt) hipLaunchKernelGGL((ppr16_kernel<MODE, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((ppr16_kernel<MODE, false>), grid, dim3(256), 0, s, a);
+        switch (nt & 3) {   // bit0: non-temporal pair loads, bit1: non-temporal state stores
+            case 0: hipLaunchKernelGGL((ppr16_kernel<MODE, false, false>), grid, dim3(256), 0, s, a); break;
+            case 1: hipLaunchKernelGGL((ppr16_kernel<MODE, true, false>), grid, dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((ppr16_kernel<MODE, false, true>), grid, dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((ppr16_kernel<MODE, true, true>), grid, dim3(256), 0, s, a); break;
+        }
         HRAG_LAUNCH_CHECK();
     }
     if (!main_only && a.n_lrow > 0) {
@@ -286,7 +294,7 @@ hrag_status sweep_mode(const Ppr16Args &a, int n_slabs, bool nt, bool main_only,
 
 }  // namespace
 
-hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, bool nt_pairs, bool main_only,
+hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, int nt_pairs, bool main_only,
                                hipStream_t s) {
     switch (mode) {
         case kPprModeH: return sweep_mode<kPprModeH>(a, n_slabs, nt_pairs, main_only, s);

@@ -110,6 +110,7 @@ constexpr int32_t kVrowNone = (int32_t)0x80000000;  // padding virtual row (no o
 constexpr int kSell8SegLen = 64;                     // rows above this are cut into <= 64 segments
 struct Ppr16Args {
     const int2 *pairs;         // [total_steps * 64] (col, fp32 bits of val), step-major per chunk
+    uint32_t pairs_bytes;      // size of the pairs array incl. the read-ahead padding (< 2^31)
     const int2 *chunk_meta;    // [n_chunks] (first step, number of steps)
     const int32_t *vrow;       // [n_chunks * 8] row id >= 0 | -(partial slot + 1) | kVrowNone
     int32_t n_chunks;
@@ -135,10 +136,44 @@ hrag_status launch_ppr16_combine(const uint16_t *h, const uint16_t *c, float inv
 hrag_status launch_ppr16_scale(const float *mn, const float *mx, const float *ssum, int64_t n_passages,
                                float passage_weight, const float *seed_w, const int32_t *seed_cnt,
                                const int32_t *flags, int32_t batch, float *qscale, hipStream_t s);
+// bc: columns per teleport row (64 on the fp16 path, BP on the small-batch path); qscale may be null
 hrag_status launch_ppr16_seed_rows(const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
                                    const float *qscale, int32_t batch, int64_t n_passages,
                                    int64_t num_vertices, int32_t *row_slot, float *tele,
-                                   int64_t tele_rows, hipStream_t s);
+                                   int64_t tele_rows, int32_t bc, hipStream_t s);
+
+// ppr_sv.hip : small batches (B <= 8), fp32 state [V][BP], same SELL-8 matrix
+struct PprSvArgs {
+    const int2 *pairs;
+    uint32_t pairs_bytes;
+    const int2 *chunk_meta;
+    const int32_t *vrow;
+    int32_t n_chunks;
+    const int32_t *lrow_row, *lrow_first, *lrow_cnt;
+    int32_t n_lrow;
+    float *partial;            // [n_partial][BP]
+    int64_t num_vertices;
+    const float *x;            // [V][BP]
+    float *y;                  // [V][BP]
+    const int32_t *row_slot;   // [V] or nullptr (slot = vertex)
+    const float *tele;         // [tele_rows][BP]
+    float alpha, beta;
+    int32_t nt;                // non-temporal (col, val) loads
+};
+hrag_status launch_ppr_sv_sweep(const PprSvArgs &a, int bp, bool main_only, hipStream_t s);
+hrag_status launch_ppr_sv_init(const PprSvArgs &a, int bp, hipStream_t s);
+hrag_status launch_ppr_sv_tele(const float *scores, int64_t ld, int64_t n, int32_t batch, const float *mn,
+                               const float *mx, float weight, const int32_t *flags, float *tele, int bp,
+                               hipStream_t s);
+hrag_status launch_ppr_sv_reset(const float *reset, int64_t n, int32_t batch, float *tele, int bp,
+                                hipStream_t s);
+// partial: 256 * bp doubles
+hrag_status launch_ppr_sv_colsum(const float *x, int64_t n, int bp, double *partial, double *sums,
+                                 hipStream_t s);
+hrag_status launch_ppr_sv_rows(const float *x, const int32_t *gather, int64_t n, int32_t batch,
+                               const double *sums, float *out, int64_t ld, const float *alt, int64_t alt_ld,
+                               const float *mn, const float *mx, const int32_t *flags, int bp,
+                               hipStream_t s);
 
 // layout.hip : [B, n] row-major  <->  slab layout, with the fused element-wise stages
 // slab_rows: rows per slab of the destination (>= n; 0 means n); qscale: optional per-query factor

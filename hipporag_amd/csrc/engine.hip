@@ -16,6 +16,7 @@ using namespace hrag;
 
 namespace {
 
+constexpr int kSvMaxBatch = 8;         // batches up to this take the small-batch kernels (ppr_sv.hip)
 constexpr float kPpr16CScale = 64.f;  // correction / residual are stored as f16(c * 64); see ppr16.hip
 
 enum EvId { EV_START = 0, EV_SIM, EV_SEED, EV_PPR, EV_RANK, EV_FACT0, EV_FACT1, EV_COUNT };
@@ -80,7 +81,9 @@ struct hrag_engine {
     float *d_seed_w = nullptr;
     double *d_colsum_partial = nullptr, *d_sums = nullptr;
     // two-stage fp16 PPR (ppr16.hip): SELL-8 matrix + fp16 state, unsharded engines with max_batch > 32
-    bool f16_ready = false;
+    bool f16_ready = false;   // fp16 state buffers present (max_batch > 8)
+    bool sell_ready = false;  // SELL-8 matrix + small-batch buffers present (every unsharded engine)
+    float *d_tele_sv = nullptr, *d_partial_sv = nullptr;   // small-batch path (ppr_sv.hip), BP <= 8
     int2 *d_pairs = nullptr, *d_chunk_meta = nullptr;
     int32_t *d_vrow = nullptr, *d_lrow_row = nullptr, *d_lrow_first = nullptr, *d_lrow_cnt = nullptr;
     int32_t n_chunks = 0, n_lrow = 0, n_partial16 = 0;
@@ -130,7 +133,7 @@ void free_engine(hrag_engine *e) {
                     e->d_flags, e->d_seed_w, e->d_colsum_partial, e->d_sums, e->d_pairs, e->d_chunk_meta,
                     e->d_vrow, e->d_lrow_row, e->d_lrow_first, e->d_lrow_cnt, e->d_partial16, e->d_h16[0],
                     e->d_h16[1], e->d_h16[2], e->d_h16[3], e->d_tele16, e->d_row_slot, e->d_qscale,
-                    e->d_ssum};
+                    e->d_ssum, e->d_tele_sv, e->d_partial_sv};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ev : e->ev)
@@ -205,8 +208,8 @@ hrag_status build_sell8(hrag_engine *e, const std::vector<int32_t> &row_ptr, con
         meta[(size_t)c] = make_int2((int)steps, ns);
         steps += ns;
     }
-    HRAG_REQUIRE(steps * 64 < (int64_t)0x7fffffff, "graph too large for the SELL-8 index range");
-    std::vector<int2> pairs((size_t)(steps + 2) * 64, make_int2(0, 0));  // +2 steps: read-ahead padding
+    HRAG_REQUIRE((steps + 4) * 512 < (int64_t)0x7fffffff, "graph too large for the SELL-8 buffer range (2 GiB)");
+    std::vector<int2> pairs((size_t)(steps + 4) * 64, make_int2(0, 0));  // +4 steps: read-ahead padding
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int64_t base = (int64_t)meta[(size_t)c].x * 64;
         for (int g = 0; g < 8; ++g) {
@@ -239,7 +242,8 @@ inline int n_slabs64(int batch) { return (int)ceil_div(batch, 64); }
 Ppr16Args ppr16_args(const hrag_engine *e, const uint16_t *x, uint16_t *y, const uint16_t *aux,
                      float damping) {
     Ppr16Args a;
-    a.pairs = e->d_pairs; a.chunk_meta = e->d_chunk_meta; a.vrow = e->d_vrow; a.n_chunks = e->n_chunks;
+    a.pairs = e->d_pairs; a.pairs_bytes = (uint32_t)((e->sell_steps + 4) * 512);
+    a.chunk_meta = e->d_chunk_meta; a.vrow = e->d_vrow; a.n_chunks = e->n_chunks;
     a.lrow_row = e->d_lrow_row; a.lrow_first = e->d_lrow_first; a.lrow_cnt = e->d_lrow_cnt;
     a.n_lrow = e->n_lrow; a.n_partial = e->n_partial16; a.partial = e->d_partial16;
     a.num_vertices = e->V; a.x = x; a.y = y; a.aux = aux; a.row_slot = e->d_row_slot;
@@ -275,7 +279,34 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
 
 // The fp16 two-stage scheme needs K1 >= 8 sweeps before the residual sweep (error ~ 2^-(11+K1)).
 inline bool use_f16(const hrag_engine *e, int batch, int iters) {
-    return e->f16_ready && batch > 32 && iters >= 16;
+    return e->f16_ready && batch > kSvMaxBatch && iters >= 16;
+}
+inline bool use_sv(const hrag_engine *e, int batch) { return e->sell_ready && batch <= kSvMaxBatch; }
+inline int sv_width(int batch) { return batch <= 1 ? 1 : batch <= 2 ? 2 : batch <= 4 ? 4 : 8; }
+
+PprSvArgs ppr_sv_args(const hrag_engine *e, const float *x, float *y, const int32_t *row_slot,
+                      const float *tele, float damping) {
+    PprSvArgs a;
+    a.pairs = e->d_pairs; a.pairs_bytes = (uint32_t)((e->sell_steps + 4) * 512); a.chunk_meta = e->d_chunk_meta; a.vrow = e->d_vrow; a.n_chunks = e->n_chunks;
+    a.lrow_row = e->d_lrow_row; a.lrow_first = e->d_lrow_first; a.lrow_cnt = e->d_lrow_cnt;
+    a.n_lrow = e->n_lrow; a.partial = e->d_partial_sv; a.num_vertices = e->V;
+    a.x = x; a.y = y; a.row_slot = row_slot; a.tele = tele;
+    a.alpha = damping; a.beta = 1.0f - damping;
+    a.nt = (e->opt_flags & HRAG_OPT_NT_CSR) ? 1 : 0;   // measured: nt loads are 25 % slower at B = 1
+    return a;
+}
+
+// x_0 = v, `iters` sweeps; the final state ends in e->d_x ([V][bp] fp32)
+hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tele, int bp, float damping,
+                       int iters, hipStream_t s) {
+    float *x = e->d_x, *y = e->d_y;
+    HRAG_TRY(launch_ppr_sv_init(ppr_sv_args(e, nullptr, x, row_slot, tele, damping), bp, s));
+    for (int it = 0; it < iters; ++it) {
+        HRAG_TRY(launch_ppr_sv_sweep(ppr_sv_args(e, x, y, row_slot, tele, damping), bp, false, s));
+        std::swap(x, y);
+    }
+    if (x != e->d_x) std::swap(e->d_x, e->d_y);
+    return HRAG_OK;
 }
 
 }  // namespace
@@ -387,9 +418,10 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         E_TRY(dev_upload(&e->d_mrow_cnt, mrow_cnt.data(), (int64_t)mrow_cnt.size()));
     }
     // ---- SELL-8 + fp16 state for the two-stage PPR (unsharded engines, batches > 32)
-    const bool want_f16 = !(opts->flags & HRAG_OPT_F32_STATE) && e->n_rows == e->V && opts->max_batch > 32 &&
-                          e->V * 128 < ((int64_t)1 << 32);
-    if (want_f16) {
+    const bool want_sell = !(opts->flags & HRAG_OPT_F32_STATE) && e->n_rows == e->V &&
+                           e->V * 128 < ((int64_t)1 << 32);
+    const bool want_f16 = want_sell && opts->max_batch > kSvMaxBatch;
+    if (want_sell) {
         std::vector<int32_t> h_col((size_t)e->nnz);
         std::vector<float> h_val((size_t)e->nnz);
         if (e->nnz) {
@@ -432,6 +464,13 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     const int B = e->max_batch;
     SlabLayout lay = e->layout(B);
     e->state_elems = (int64_t)lay.n_slabs * e->V * lay.bc;
+    if (want_sell) {
+        E_TRY(dev_alloc(&e->d_tele_sv, (e->n_passages + (int64_t)kSvMaxBatch * kMaxSeeds) * kSvMaxBatch));
+        E_TRY(dev_alloc(&e->d_partial_sv, (int64_t)std::max(e->n_partial16, 1) * kSvMaxBatch));
+        E_TRY(dev_alloc(&e->d_row_slot, e->V));
+        E_HIP(hipMemcpy(e->d_row_slot, e->d_row_to_tele, (size_t)e->V * sizeof(int32_t), hipMemcpyDeviceToDevice));
+        e->sell_ready = true;
+    }
     if (want_f16) {
         const int ns = n_slabs64(B);
         e->state16_elems = (int64_t)ns * e->V * 64;
@@ -440,12 +479,10 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         e->tele16_rows = e->n_passages + (int64_t)B * kMaxSeeds;
         E_TRY(dev_alloc(&e->d_tele16, (int64_t)ns * e->tele16_rows * 64));
         E_TRY(dev_alloc(&e->d_partial16, (int64_t)ns * std::max(e->n_partial16, 1) * 64));
-        E_TRY(dev_alloc(&e->d_row_slot, e->V));
         E_TRY(dev_alloc(&e->d_qscale, B));
         E_TRY(dev_alloc(&e->d_ssum, B));
         for (auto &p : e->d_h16) E_HIP(hipMemset(p, 0, (size_t)e->state16_elems * sizeof(uint16_t)));
         E_HIP(hipMemset(e->d_tele16, 0, (size_t)ns * e->tele16_rows * 64 * sizeof(float)));
-        E_HIP(hipMemcpy(e->d_row_slot, e->d_row_to_tele, (size_t)e->V * sizeof(int32_t), hipMemcpyDeviceToDevice));
         e->f16_ready = true;
     }
     E_TRY(dev_alloc(&e->d_partial, (int64_t)(round_up(B, 4) + 64) * std::max(e->n_partial, 1)));
@@ -644,9 +681,12 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     HRAG_REQUIRE(ppr_iters >= 0, "ppr_iters must be >= 0");
     HRAG_REQUIRE(e->n_passages >= 1, "engine has no passages");
     hipStream_t s = (hipStream_t)stream;
-    const bool f16 = use_f16(e, batch, ppr_iters);
+    const bool sv = use_sv(e, batch);
+    const bool f16 = !sv && use_f16(e, batch, ppr_iters);
+    const int bp = sv_width(batch);
     SlabLayout lay = e->layout(batch);
     if (f16) { lay.bc = 64; lay.n_slabs = n_slabs64(batch); }
+    if (sv) { lay.bc = bp; lay.n_slabs = 1; }
     const bool prof = e->profiling;
 
     HRAG_HIP_TRY(hipMemsetAsync(e->d_flags, 0, (size_t)batch * sizeof(int32_t), s));
@@ -673,7 +713,17 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
         HRAG_HIP_TRY(hipMemcpyAsync(e->d_row_slot, e->d_row_to_tele, (size_t)e->V * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, s));
         HRAG_TRY(launch_ppr16_seed_rows(e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt, e->d_qscale, batch,
-                                        e->n_passages, e->V, e->d_row_slot, e->d_tele16, e->tele16_rows, s));
+                                        e->n_passages, e->V, e->d_row_slot, e->d_tele16, e->tele16_rows, 64, s));
+    } else if (sv) {
+        // small batch (ppr_sv.hip): v = [Np + seed rows][bp] fp32, same "seeds are teleport rows" form
+        HRAG_TRY(launch_ppr_sv_tele(e->d_spass, e->ld_p, e->n_passages, batch, e->d_mn_p, e->d_mx_p,
+                                    passage_node_weight, e->d_flags, e->d_tele_sv, bp, s));
+        HRAG_HIP_TRY(hipMemsetAsync(e->d_tele_sv + (size_t)e->n_passages * bp, 0,
+                                    (size_t)batch * kMaxSeeds * bp * sizeof(float), s));
+        HRAG_HIP_TRY(hipMemcpyAsync(e->d_row_slot, e->d_row_to_tele, (size_t)e->V * sizeof(int32_t),
+                                    hipMemcpyDeviceToDevice, s));
+        HRAG_TRY(launch_ppr16_seed_rows(e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt, nullptr, batch,
+                                        e->n_passages, e->V, e->d_row_slot, e->d_tele_sv, 0, bp, s));
     } else {
         HRAG_TRY(hrag_stage_teleport(e, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, passage_node_weight,
                                      e->d_flags, batch, e->d_tele, stream));
@@ -682,6 +732,8 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     // PPR (HippoRAG.py:1736-1743): fixed-count leaky power iteration
     if (f16) {
         HRAG_TRY(ppr16_run(e, batch, damping, ppr_iters, s));
+    } else if (sv) {
+        HRAG_TRY(ppr_sv_run(e, e->d_row_slot, e->d_tele_sv, bp, damping, ppr_iters, s));
     } else {
         float *x = e->d_x, *y = e->d_y;
         HRAG_TRY(ppr_init(e, e->d_tele, e->n_passages, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w,
@@ -695,9 +747,16 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     }
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_PPR], s));
     // doc scores + ranking (HippoRAG.py:1745-1747, :503)
-    HRAG_TRY(launch_colsum(e->d_x, e->V, 0, e->V, batch, lay, e->d_colsum_partial, e->d_sums, s));
-    HRAG_TRY(launch_slab_to_rows(e->d_x, e->V, e->d_passage_vertex, e->n_passages, batch, e->d_sums, e->d_doc,
-                                 e->ld_p, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, e->d_flags, lay, s));
+    if (sv) {
+        HRAG_TRY(launch_ppr_sv_colsum(e->d_x, e->V, bp, e->d_colsum_partial, e->d_sums, s));
+        HRAG_TRY(launch_ppr_sv_rows(e->d_x, e->d_passage_vertex, e->n_passages, batch, e->d_sums, e->d_doc,
+                                    e->ld_p, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, e->d_flags, bp, s));
+    } else {
+        HRAG_TRY(launch_colsum(e->d_x, e->V, 0, e->V, batch, lay, e->d_colsum_partial, e->d_sums, s));
+        HRAG_TRY(launch_slab_to_rows(e->d_x, e->V, e->d_passage_vertex, e->n_passages, batch, e->d_sums,
+                                     e->d_doc, e->ld_p, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, e->d_flags,
+                                     lay, s));
+    }
     HRAG_TRY(launch_flag_zero_mass(e->d_sums, batch, e->d_flags, 2, s));
     HRAG_TRY(launch_row_topk(e->d_doc, batch, e->n_passages, e->ld_p, k, 0, kNormNone, doc_idx_out,
                              doc_score_out, nullptr, nullptr, s));
@@ -733,6 +792,19 @@ hrag_status hrag_ppr(hrag_engine *e, const float *reset, int32_t batch, float da
     HRAG_REQUIRE(e->n_rows == e->V, "hrag_ppr needs an unsharded engine");
     hipStream_t s = (hipStream_t)stream;
     if (!e->d_tele_dense) HRAG_TRY(dev_alloc(&e->d_tele_dense, e->state_elems));  // first use only
+    if (use_sv(e, batch)) {   // run_ppr seam at B = 1 (ppr_sv.hip), v dense over all vertices
+        const int bp = sv_width(batch);
+        HRAG_TRY(launch_ppr_sv_reset(reset, e->V, batch, e->d_tele_dense, bp, s));
+        HRAG_TRY(ppr_sv_run(e, nullptr, e->d_tele_dense, bp, damping, iters, s));
+        HRAG_TRY(launch_ppr_sv_colsum(e->d_x, e->V, bp, e->d_colsum_partial, e->d_sums, s));
+        HRAG_TRY(launch_ppr_sv_rows(e->d_x, nullptr, e->V, batch, e->d_sums, x_out, e->V, nullptr, 0, nullptr,
+                                    nullptr, nullptr, bp, s));
+        if (flags_out) {
+            HRAG_HIP_TRY(hipMemsetAsync(flags_out, 0, (size_t)batch * sizeof(int32_t), s));
+            HRAG_TRY(launch_flag_zero_mass(e->d_sums, batch, flags_out, 2, s));
+        }
+        return HRAG_OK;
+    }
     const SlabLayout lay = e->layout(batch);
     HRAG_TRY(launch_rows_to_slab(reset, e->V, e->V, batch, kSanitize, nullptr, nullptr, 1.f, nullptr,
                                  e->d_tele_dense, lay, s));
@@ -758,6 +830,18 @@ hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damp
                             hrag_stream stream) {
     HRAG_TRY(check_batch(e, batch));
     HRAG_REQUIRE(n >= 0, "n must be >= 0");
+    if (flags & 4) {
+        HRAG_REQUIRE(use_sv(e, batch), "small-batch kernels need an unsharded engine and batch <= 8");
+        const int bp = sv_width(batch);
+        float *x = e->d_x, *y = e->d_y;
+        for (int it = 0; it < n; ++it) {
+            HRAG_TRY(launch_ppr_sv_sweep(ppr_sv_args(e, x, y, e->d_row_slot, e->d_tele_sv, damping), bp,
+                                         (flags & 1) != 0, (hipStream_t)stream));
+            std::swap(x, y);
+        }
+        if (x != e->d_x) std::swap(e->d_x, e->d_y);
+        return HRAG_OK;
+    }
     if (flags & 2) {
         HRAG_REQUIRE(e->f16_ready, "engine has no fp16 PPR state");
         const int nt = (e->opt_flags & HRAG_OPT_TEMPORAL16) ? 0 : 3;

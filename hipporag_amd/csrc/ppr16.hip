@@ -44,9 +44,17 @@ __device__ __forceinline__ int bcast8(int v) {
     return __builtin_amdgcn_ds_swizzle(v, (K << 5) | 0x18);
 }
 
-__device__ __forceinline__ void fma8(float (&acc)[8], float w, const half8_t &x) {
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// acc[j] += float(x[j]) * w with v_fma_mix_f32 (fp16 operand converted inside the FMA: exact product,
+// one rounding).  Written as asm because hipcc otherwise emits 8 v_cvt_f32_f16 + 4 v_pk_fma_f32 per
+// gather, whose temporaries cost a wavefront of occupancy (84 -> 64 VGPRs).
+__device__ __forceinline__ void fma8(float (&acc)[8], float w, const v4i_t &x) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf((float)x[j], w, acc[j]);
+    for (int d = 0; d < 4; ++d) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2 * d]) : "v"(x[d]), "v"(w));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * d + 1]) : "v"(x[d]), "v"(w));
+    }
 }
 
 template <int K>
@@ -56,31 +64,21 @@ struct Gather8 {
         const unsigned ck = (unsigned)bcast8<K>(c);
         const float wk = __int_as_float(bcast8<K>(wbits));
         // 128 bytes per vertex, 16 per lane; V * 128 < 2^32 is checked at engine creation
-        const half8_t xv = *reinterpret_cast<const half8_t *>(xs + (size_t)(ck * 128u + lane_off));
+        const v4i_t xv = *reinterpret_cast<const v4i_t *>(xs + (size_t)(ck * 128u + lane_off));
         fma8(acc, wk, xv);
         if constexpr (K + 1 < 8) Gather8<K + 1>::run(acc, c, wbits, xs, lane_off);
     }
 };
 
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+
+// (col, val) pairs are read through a buffer descriptor: hipcc keeps raw buffer loads where they are
+// written (a plain or __builtin_nontemporal_load of this loop-invariant stream is sunk back to its
+// first use, which turns the read-ahead into a stall per step) and the nt bit rides in `aux`.
 template <bool NT>
-__device__ __forceinline__ int2 ld_pair(const int2 *p) {
-    if constexpr (NT) {
-        const long long v = __builtin_nontemporal_load(reinterpret_cast<const long long *>(p));
-        int2 r;
-        r.x = (int)(v & 0xffffffffll);
-        r.y = (int)(v >> 32);
-        return r;
-    } else {
-        // relaxed wavefront-scope atomic = a plain global_load_dwordx2 that the optimiser may not
-        // move: without it LLVM sinks the read-ahead loads back to their first use (the (col, val)
-        // stream is loop-invariant memory) and every step stalls on its own pair load
-        const long long v = __hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_WAVEFRONT);
-        int2 r;
-        r.x = (int)(v & 0xffffffffll);
-        r.y = (int)(v >> 32);
-        return r;
-    }
+__device__ __forceinline__ int2 ld_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, NT ? 2 : 0);
+    return make_int2(v.x, v.y);
 }
 
 __device__ __forceinline__ float clamp_half(float v) { return fminf(fmaxf(v, -kHalfMax), kHalfMax); }
@@ -124,7 +122,7 @@ __device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row
 }
 
 template <int MODE, bool NT, bool NT_ST>
-__global__ __launch_bounds__(256) void ppr16_kernel(const Ppr16Args a) {
+__global__ __launch_bounds__(256, 6) void ppr16_kernel(const Ppr16Args a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
     const int slab = blockIdx.y;
@@ -133,15 +131,18 @@ __global__ __launch_bounds__(256) void ppr16_kernel(const Ppr16Args a) {
     const int2 meta = a.chunk_meta[chunk];  // (first step, number of steps)
     const int n_steps = meta.y;
     const char *xs = reinterpret_cast<const char *>(a.x + (size_t)slab * a.num_vertices * 64);
-    const int2 *pp = a.pairs + (size_t)meta.x * 64 + lane;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int2 *>(a.pairs), 0, (int)a.pairs_bytes, 0x00020000);
+    const unsigned pbase = (unsigned)meta.x * 512u;   // scalar: first byte of this chunk's pairs
+    const unsigned poff = (unsigned)lane * 8u;
     const unsigned lane_off = (unsigned)gl * 16u;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // the pair stream is read two steps ahead, unconditionally (the array carries two steps of
     // padding), so that the loop body is branch-free and the compiler can wait with vmcnt(N > 0)
-    int2 p0 = ld_pair<NT>(pp);
-    int2 p1 = ld_pair<NT>(pp + 64);
+    int2 p0 = ld_pair<NT>(prs, poff, pbase);
+    int2 p1 = ld_pair<NT>(prs, poff + 512u, pbase);
     for (int s = 0; s < n_steps; ++s) {
-        const int2 p2 = ld_pair<NT>(pp + (size_t)(s + 2) * 64);
+        const int2 p2 = ld_pair<NT>(prs, poff + (unsigned)(s + 2) * 512u, pbase);
         Gather8<0>::run(acc, p0.x, p0.y, xs, lane_off);
         p0 = p1;
         p1 = p2;
@@ -258,7 +259,7 @@ __global__ void ppr16_scale_kernel(const float *mn, const float *mx, const float
 __global__ void ppr16_seed_rows_kernel(const int32_t *seed_vtx, const float *seed_w,
                                        const int32_t *seed_cnt, const float *qscale, int32_t batch,
                                        int64_t n_passages, int64_t num_vertices, int32_t *row_slot,
-                                       float *tele, int64_t tele_rows) {
+                                       float *tele, int64_t tele_rows, int32_t bc) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int q = t / kMaxSeeds, j = t % kMaxSeeds;
     if (q >= batch || j >= seed_cnt[q]) return;
@@ -267,9 +268,9 @@ __global__ void ppr16_seed_rows_kernel(const int32_t *seed_vtx, const float *see
     const int mine = (int)n_passages + q * kMaxSeeds + j;
     const int old = atomicCAS(&row_slot[v], -1, mine);
     const int slot = old == -1 ? mine : old;
-    const int slab = q >> 6, col = q & 63;
+    const int slab = q / bc, col = q % bc;
     // vertices are unique within a query, so (slot, col) has a single writer
-    tele[((size_t)slab * tele_rows + (size_t)slot) * 64 + col] += seed_w[q * kMaxSeeds + j] * qscale[q];
+    tele[((size_t)slab * tele_rows + (size_t)slot) * bc + col] += seed_w[q * kMaxSeeds + j] * (qscale ? qscale[q] : 1.f);
 }
 
 template <int MODE>
@@ -334,11 +335,11 @@ hrag_status launch_ppr16_scale(const float *mn, const float *mx, const float *ss
 hrag_status launch_ppr16_seed_rows(const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
                                    const float *qscale, int32_t batch, int64_t n_passages,
                                    int64_t num_vertices, int32_t *row_slot, float *tele,
-                                   int64_t tele_rows, hipStream_t s) {
+                                   int64_t tele_rows, int32_t bc, hipStream_t s) {
     const int total = batch * kMaxSeeds;
     hipLaunchKernelGGL(ppr16_seed_rows_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
                        seed_vtx, seed_w, seed_cnt, qscale, batch, n_passages, num_vertices, row_slot,
-                       tele, tele_rows);
+                       tele, tele_rows, bc);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -1,0 +1,328 @@
+// K3s -- PPR sweep for latency-bound batches (B <= 8): "sparse matrix x a few vectors".
+//
+// Replaces igraph/PRPACK behind HippoRAG.run_ppr (reference src/hipporag/HippoRAG.py:1736-1743) for
+// the B = 1 callers of the path: the run_ppr seam itself and retrieve_ircot, which calls
+// retrieve([thought]) once per reasoning step (:526,539).
+//
+// At B = 1 the state x is V * 4 bytes (4 MB at 1 M vertices): it lives in every XCD's L2, the
+// random gathers are L2 hits and the sweep is bound by the (col, val) stream -- the textbook SpMV
+// roofline, nnz * 8 + V * 12 bytes.  Layout and matrix format follow that:
+//   * state fp32 [V][BP], BP = batch padded to 1, 2, 4 or 8 (one gather = BP * 4 contiguous bytes);
+//   * the SELL-8 matrix of ppr16.hip, read with ONE coalesced, non-temporal 512-byte load per
+//     wavefront step; here every lane keeps its own (col, val) pair -- lane l of an 8-lane group
+//     walks entries l, l+8, ... of the group's row -- and the 8 partial sums are combined with a
+//     fixed xor-butterfly.  No atomics; bit-reproducible.
+//   * rows longer than 64 entries are the same <= 64 segments as in ppr16.hip (partials + reduce).
+// v (passage prior + seed rows) is one fp32 array [tele_rows][BP] addressed through row_slot, like
+// on the fp16 path; row_slot == nullptr means "dense v" (slot = vertex), used by hrag_ppr.
+#include "common.h"
+
+namespace hrag {
+namespace {
+
+template <int BP>
+struct XVec {
+    float v[BP];
+};
+
+template <int BP>
+__device__ __forceinline__ XVec<BP> ld_x(const float *x, unsigned col) {
+    XVec<BP> r;
+    const float *p = x + (size_t)col * BP;
+    if constexpr (BP == 1) {
+        r.v[0] = *p;
+    } else if constexpr (BP == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        r.v[0] = t.x; r.v[1] = t.y;
+    } else if constexpr (BP == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else {
+        const float4 t0 = reinterpret_cast<const float4 *>(p)[0], t1 = reinterpret_cast<const float4 *>(p)[1];
+        r.v[0] = t0.x; r.v[1] = t0.y; r.v[2] = t0.z; r.v[3] = t0.w;
+        r.v[4] = t1.x; r.v[5] = t1.y; r.v[6] = t1.z; r.v[7] = t1.w;
+    }
+    return r;
+}
+
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+
+// non-temporal buffer load (aux = 2): the stream must not evict x from L2; see ppr16.hip on why a
+// buffer load and not a plain / __builtin_nontemporal_load
+template <bool NT>
+__device__ __forceinline__ int2 ld_pair_nt(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, NT ? 2 : 0);
+    return make_int2(v.x, v.y);
+}
+
+// lane gl (< BP) of the group finishes column gl of the row
+template <int BP>
+__device__ __forceinline__ void sv_finish(const PprSvArgs &a, int row, int gl, float sum) {
+    if (gl >= BP) return;
+    float t = 0.f;
+    const int64_t slot = a.row_slot ? (int64_t)a.row_slot[row] : (int64_t)row;
+    if (slot >= 0) t = a.tele[(size_t)slot * BP + gl];
+    a.y[(size_t)row * BP + gl] = fmaf(a.alpha, sum, a.beta * t);
+}
+
+template <int BP, bool NT>
+__global__ __launch_bounds__(256) void ppr_sv_kernel(const PprSvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & 7, grp = lane >> 3;
+    const int chunk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (chunk >= a.n_chunks) return;
+    const int2 meta = a.chunk_meta[chunk];
+    const int n_steps = meta.y;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int2 *>(a.pairs), 0, (int)a.pairs_bytes, 0x00020000);
+    const unsigned pbase = (unsigned)meta.x * 512u, poff = (unsigned)lane * 8u;
+    float acc[BP];
+#pragma unroll
+    for (int b = 0; b < BP; ++b) acc[b] = 0.f;
+    // pairs are read two steps ahead (the array is padded); two gathers are in flight per lane.
+    // Padding entries are (col 0, val 0): an odd tail step adds 0 * x[0].
+    int2 p0 = ld_pair_nt<NT>(prs, poff, pbase), p1 = ld_pair_nt<NT>(prs, poff + 512u, pbase);
+    for (int s = 0; s < n_steps; s += 2) {
+        const int2 p2 = ld_pair_nt<NT>(prs, poff + (unsigned)(s + 2) * 512u, pbase);
+        const int2 p3 = ld_pair_nt<NT>(prs, poff + (unsigned)(s + 3) * 512u, pbase);
+        const bool tail = s + 1 >= n_steps;      // wave-uniform
+        const XVec<BP> xa = ld_x<BP>(a.x, (unsigned)p0.x);
+        const XVec<BP> xb = ld_x<BP>(a.x, tail ? 0u : (unsigned)p1.x);
+        const float wa = __int_as_float(p0.y), wb = tail ? 0.f : __int_as_float(p1.y);
+#pragma unroll
+        for (int b = 0; b < BP; ++b) acc[b] = fmaf(wa, xa.v[b], acc[b]);
+#pragma unroll
+        for (int b = 0; b < BP; ++b) acc[b] = fmaf(wb, xb.v[b], acc[b]);
+        p0 = p2;
+        p1 = p3;
+    }
+    // fixed-order butterfly over the 8 lanes of the group: every lane ends with the row total
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1)
+#pragma unroll
+        for (int b = 0; b < BP; ++b) acc[b] += __shfl_xor(acc[b], o, 64);
+    float mine = acc[0];
+#pragma unroll
+    for (int b = 1; b < BP; ++b) mine = gl == b ? acc[b] : mine;
+    const int tgt = a.vrow[chunk * 8 + grp];
+    if (tgt >= 0) {
+        sv_finish<BP>(a, tgt, gl, mine);
+    } else if (tgt != kVrowNone && gl < BP) {
+        a.partial[(size_t)(-(tgt + 1)) * BP + gl] = mine;
+    }
+}
+
+// one thread per (long row, column): <= 64 partial sums, added in segment order
+template <int BP>
+__global__ __launch_bounds__(256) void ppr_sv_reduce_kernel(const PprSvArgs a) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int m = t / BP, gl = t % BP;
+    if (m >= a.n_lrow) return;
+    const int first = a.lrow_first[m], cnt = a.lrow_cnt[m];
+    float s = 0.f;
+    for (int i = 0; i < cnt; ++i) s += a.partial[(size_t)(first + i) * BP + gl];
+    sv_finish<BP>(a, a.lrow_row[m], gl, s);
+}
+
+// x_0 = v
+template <int BP>
+__global__ __launch_bounds__(256) void ppr_sv_init_kernel(const PprSvArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t / BP;
+    const int gl = (int)(t % BP);
+    if (row >= a.num_vertices) return;
+    float v = 0.f;
+    const int64_t slot = a.row_slot ? (int64_t)a.row_slot[row] : row;
+    if (slot >= 0) v = a.tele[(size_t)slot * BP + gl];
+    a.y[(size_t)row * BP + gl] = v;
+}
+
+__device__ __forceinline__ float sv_minmax_norm(float s, float mn, float mx) {
+    const float range = mx - mn;
+    return range == 0.f ? 1.f : __fdiv_rn(s - mn, range);   // misc_utils.py:130-139
+}
+
+// passage prior (HippoRAG.py:1626-1635) into tele[p][b]; columns >= batch and DPR-fallback queries are 0
+template <int BP>
+__global__ __launch_bounds__(256) void ppr_sv_tele_kernel(const float *scores, int64_t ld, int64_t n,
+                                                          int32_t batch, const float *mn, const float *mx,
+                                                          float weight, const int32_t *flags, float *tele) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+#pragma unroll
+    for (int b = 0; b < BP; ++b) {
+        float v = 0.f;
+        if (b < batch && !(flags && (flags[b] & 1)))
+            v = sv_minmax_norm(scores[(size_t)b * ld + p], mn[b], mx[b]) * weight;
+        tele[(size_t)p * BP + b] = v;
+    }
+}
+
+// reset_prob rows [B][V] -> v [V][BP] with NaN / negative -> 0 (HippoRAG.py:1735)
+template <int BP>
+__global__ __launch_bounds__(256) void ppr_sv_reset_kernel(const float *reset, int64_t n, int32_t batch,
+                                                           float *tele) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int b = 0; b < BP; ++b) {
+        float v = 0.f;
+        if (b < batch) {
+            v = reset[(size_t)b * n + i];
+            v = (v != v || v < 0.f) ? 0.f : v;
+        }
+        tele[(size_t)i * BP + b] = v;
+    }
+}
+
+constexpr int kSvSumBlocks = 256;
+
+template <int BP>
+__global__ __launch_bounds__(256) void ppr_sv_colsum_kernel(const float *x, int64_t n, double *partial) {
+    __shared__ double red[256];
+    double s[BP];
+#pragma unroll
+    for (int b = 0; b < BP; ++b) s[b] = 0.0;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        const XVec<BP> v = ld_x<BP>(x, (unsigned)r);
+#pragma unroll
+        for (int b = 0; b < BP; ++b) s[b] += (double)v.v[b];
+    }
+#pragma unroll
+    for (int b = 0; b < BP; ++b) {
+        red[threadIdx.x] = s[b];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * BP + b] = red[0];
+        __syncthreads();
+    }
+}
+
+template <int BP>
+__global__ void ppr_sv_colsum_final_kernel(const double *partial, int nblk, double *sums) {
+    const int b = threadIdx.x;
+    if (b >= BP) return;
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += partial[(size_t)i * BP + b];
+    sums[b] = s;
+}
+
+// out[b][i] = x[gather ? gather[i] : i][b] / sums[b]   (or the normalised DPR scores on fallback)
+template <int BP>
+__global__ __launch_bounds__(256) void ppr_sv_rows_kernel(const float *x, const int32_t *gather, int64_t n,
+                                                          int32_t batch, const double *sums, float *out,
+                                                          int64_t ld, const float *alt, int64_t alt_ld,
+                                                          const float *mn, const float *mx,
+                                                          const int32_t *flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const XVec<BP> v = ld_x<BP>(x, (unsigned)(gather ? gather[i] : (int32_t)i));
+#pragma unroll
+    for (int b = 0; b < BP; ++b) {
+        if (b >= batch) break;
+        float r;
+        if (alt && flags && (flags[b] & 1)) {
+            r = sv_minmax_norm(alt[(size_t)b * alt_ld + i], mn[b], mx[b]);
+        } else {
+            const double sm = sums[b];
+            r = sm > 0.0 ? (float)((double)v.v[b] / sm) : 0.f;
+        }
+        out[(size_t)b * ld + i] = r;
+    }
+}
+
+template <int BP>
+hrag_status sv_sweep(const PprSvArgs &a, bool main_only, hipStream_t s) {
+    if (a.n_chunks > 0) {
+        const dim3 grid((unsigned)ceil_div(a.n_chunks, 4));
+        if (a.nt) hipLaunchKernelGGL((ppr_sv_kernel<BP, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((ppr_sv_kernel<BP, false>), grid, dim3(256), 0, s, a);
+        HRAG_LAUNCH_CHECK();
+    }
+    if (!main_only && a.n_lrow > 0) {
+        hipLaunchKernelGGL(ppr_sv_reduce_kernel<BP>, dim3((unsigned)ceil_div((int64_t)a.n_lrow * BP, 256)),
+                           dim3(256), 0, s, a);
+        HRAG_LAUNCH_CHECK();
+    }
+    return HRAG_OK;
+}
+
+}  // namespace
+
+#define HRAG_DISPATCH_BP(bp, CALL)                                   \
+    switch (bp) {                                                    \
+        case 1: CALL(1); break;                                      \
+        case 2: CALL(2); break;                                      \
+        case 4: CALL(4); break;                                      \
+        case 8: CALL(8); break;                                      \
+        default:                                                     \
+            set_error("unsupported small-batch width %d", (int)(bp)); \
+            return HRAG_EINVAL;                                      \
+    }
+
+hrag_status launch_ppr_sv_sweep(const PprSvArgs &a, int bp, bool main_only, hipStream_t s) {
+#define CALL(BP) return sv_sweep<BP>(a, main_only, s)
+    HRAG_DISPATCH_BP(bp, CALL)
+#undef CALL
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr_sv_init(const PprSvArgs &a, int bp, hipStream_t s) {
+    const dim3 grid((unsigned)ceil_div(a.num_vertices * bp, 256));
+#define CALL(BP) hipLaunchKernelGGL(ppr_sv_init_kernel<BP>, grid, dim3(256), 0, s, a)
+    HRAG_DISPATCH_BP(bp, CALL)
+#undef CALL
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr_sv_tele(const float *scores, int64_t ld, int64_t n, int32_t batch, const float *mn,
+                               const float *mx, float weight, const int32_t *flags, float *tele, int bp,
+                               hipStream_t s) {
+    if (n == 0) return HRAG_OK;
+    const dim3 grid((unsigned)ceil_div(n, 256));
+#define CALL(BP) hipLaunchKernelGGL(ppr_sv_tele_kernel<BP>, grid, dim3(256), 0, s, scores, ld, n, batch, mn, mx, weight, flags, tele)
+    HRAG_DISPATCH_BP(bp, CALL)
+#undef CALL
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr_sv_reset(const float *reset, int64_t n, int32_t batch, float *tele, int bp,
+                                hipStream_t s) {
+    const dim3 grid((unsigned)ceil_div(n, 256));
+#define CALL(BP) hipLaunchKernelGGL(ppr_sv_reset_kernel<BP>, grid, dim3(256), 0, s, reset, n, batch, tele)
+    HRAG_DISPATCH_BP(bp, CALL)
+#undef CALL
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr_sv_colsum(const float *x, int64_t n, int bp, double *partial, double *sums,
+                                 hipStream_t s) {
+#define CALL(BP)                                                                                         \
+    hipLaunchKernelGGL(ppr_sv_colsum_kernel<BP>, dim3(kSvSumBlocks), dim3(256), 0, s, x, n, partial);      \
+    hipLaunchKernelGGL(ppr_sv_colsum_final_kernel<BP>, dim3(1), dim3(64), 0, s, partial, kSvSumBlocks, sums)
+    HRAG_DISPATCH_BP(bp, CALL)
+#undef CALL
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr_sv_rows(const float *x, const int32_t *gather, int64_t n, int32_t batch,
+                               const double *sums, float *out, int64_t ld, const float *alt, int64_t alt_ld,
+                               const float *mn, const float *mx, const int32_t *flags, int bp,
+                               hipStream_t s) {
+    if (n == 0) return HRAG_OK;
+    const dim3 grid((unsigned)ceil_div(n, 256));
+#define CALL(BP) hipLaunchKernelGGL(ppr_sv_rows_kernel<BP>, grid, dim3(256), 0, s, x, gather, n, batch, sums, out, ld, alt, alt_ld, mn, mx, flags)
+    HRAG_DISPATCH_BP(bp, CALL)
+#undef CALL
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+}  // namespace hrag

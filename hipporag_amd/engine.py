@@ -240,9 +240,10 @@ class HippoRAGEngine:
         return x, flags
 
     def ppr_sweeps(self, batch: int, n: int, damping: float = 0.5, main_only: bool = False,
-                   f16: bool = False):
-        """Measurement hook: n sweeps of the fp32 kernel, or (f16=True) of the fp16-state kernel."""
-        flags = (1 if main_only else 0) | (2 if f16 else 0)
+                   f16: bool = False, small: bool = False):
+        """Measurement hook: n sweeps of the fp32 slab kernel, of the fp16-state kernel (f16=True) or
+        of the small-batch kernel (small=True, batch <= 8)."""
+        flags = (1 if main_only else 0) | (2 if f16 else 0) | (4 if small else 0)
         check(self._lib.hrag_ppr_sweeps(self._handle, batch, n, damping, flags, _stream()))
 
 

@@ -93,8 +93,9 @@ typedef struct hrag_fact_desc {
 #define HRAG_OPT_NATURAL_ROW_ORDER 1 /* keep CSR row order instead of degree-descending          */
 #define HRAG_OPT_NT_CSR 2            /* fp32-state kernel: non-temporal loads for the col_idx / val stream */
 #define HRAG_OPT_NT_STORE 4          /* fp32-state kernel: non-temporal stores for the new PPR state       */
-#define HRAG_OPT_F32_STATE 8         /* never use the two-stage fp16 PPR state (hrag_retrieve uses it  */
-                                     /* for batch > 32 and ppr_iters >= 16; same 1e-5 parity bar)       */
+#define HRAG_OPT_F32_STATE 8         /* plain CSR + fp32 slab state only: neither the two-stage fp16   */
+                                     /* state (hrag_retrieve: batch > 8, ppr_iters >= 16) nor the       */
+                                     /* small-batch kernels (batch <= 8); same 1e-5 parity bar          */
 #define HRAG_OPT_TEMPORAL16 16       /* fp16-state kernels: plain instead of non-temporal (col, val)   */
                                      /* loads and state stores (non-temporal is 3 % faster at cfg 3)   */
 
@@ -197,7 +198,8 @@ hrag_status hrag_topk_rows(const float *scores_dev, int32_t batch, int64_t n, in
  * `batch` right-hand sides (state is whatever the last hrag_retrieve / hrag_ppr left).
  * flags bit0: main CSR kernel only (skip the long-row and seed kernels);
  * flags bit1: the fp16-state kernel of the two-stage scheme (mode H) instead of the fp32 one
- *             (HRAG_EINVAL when the engine has no fp16 state: sharded, max_batch <= 32, F32_STATE). */
+ *             (HRAG_EINVAL when the engine has no fp16 state: sharded, max_batch <= 8, F32_STATE);
+ * flags bit2: the small-batch kernel (batch <= 8, state fp32 [V][1|2|4|8]). */
 hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damping, int32_t flags,
                             hrag_stream stream);
 

@@ -368,3 +368,102 @@ def test_ppr_sweeps_hook_f16(case, gpu_device):
     out = eng.retrieve(_bf16(case["qp_bits"][:b], gpu_device), idx, sc, cnt, ppr_iters=20, k=50)
     torch.cuda.synchronize()
     assert torch.equal(ref.doc_idx, out.doc_idx) and torch.equal(ref.doc_score, out.doc_score)
+
+
+# ----------------------------------------------------------------------------- full size (BASELINE configs[2])
+def test_full_size_cfg3_properties_and_spot_parity(gpu_device):
+    """1M-node / 10M-edge KG, 1M x 768 bf16 embeddings, batch 256, 20 sweeps (two-stage fp16 state).
+    Size-independent properties over the whole batch + the oracle on a few queries:
+      * every doc-score row is sorted (score desc, index desc), ids are unique and in range;
+      * determinism: a second run is bit-identical (no atomics anywhere on the path);
+      * batch-independence: the same queries as a batch of 64 give the same ids and scores within
+        the tolerance (different slab/column => only the per-query scale can differ);
+      * spot parity: ids identical (tie-class aware) and scores <= 1e-5 relative vs the oracle."""
+    import torch
+    from hipporag_amd import synth
+    from hipporag_amd.engine import HippoRAGEngine
+    V, E, D, B, seed = 1_000_000, 10_000_000, 768, 256, 1237
+    kg = synth.make_kg(V, E, seed)
+    pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, gpu_device)
+    fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, gpu_device)
+    qf = synth.make_queries_torch(fact_emb, B, 11)[0]
+    qp = synth.make_queries_torch(pass_emb, B, 12)[0]
+    cnt = torch.full((B,), 5, dtype=torch.int32, device=gpu_device)
+    with HippoRAGEngine(kg.csr, kg.passage_vertex, pass_emb, fact_emb, kg.subj_vertex, kg.obj_vertex,
+                        kg.num_chunks, max_batch=B, max_topk=200) as eng:
+        idx, sc = eng.score_facts(qf, k=5)
+        out = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=200)
+        out2 = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=200)
+        sub = eng.retrieve(qp[:64], idx[:64], sc[:64], cnt[:64], ppr_iters=20, k=200)
+        torch.cuda.synchronize()
+        assert eng.timings()["slab_width"] == 64
+    ids, scores = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+    assert torch.equal(out.doc_idx, out2.doc_idx) and torch.equal(out.doc_score, out2.doc_score)
+    assert np.all(out.flags.cpu().numpy() == 0)
+    assert ids.min() >= 0 and ids.max() < kg.n_passages
+    for q in range(B):
+        assert len(np.unique(ids[q])) == 200
+        d = np.diff(scores[q])
+        assert np.all(d <= 0)
+        tie = d == 0
+        assert np.all(ids[q][1:][tie] < ids[q][:-1][tie])
+    sub_ids, sub_sc = sub.doc_idx.cpu().numpy(), sub.doc_score.cpu().numpy()
+    for q in range(64):
+        assert tie_aware_equal(sub_ids[q], ids[q], scores[q], rel_gap=2e-6), q
+        full = dict(zip(ids[q].tolist(), scores[q].tolist()))
+        common = [i for i in sub_ids[q].tolist() if i in full]
+        got = np.array([sub_sc[q][list(sub_ids[q]).index(i)] for i in common[:50]])
+        want = np.array([full[i] for i in common[:50]])
+        np.testing.assert_allclose(got, want, rtol=2e-6)
+    # oracle on three queries (PRPACK port: ~0.3 s each + 1.5 s index preparation)
+    a = oracle.build_symmetric_csr(kg.num_vertices, kg.src, kg.dst, kg.weight)
+    index = oracle.RefIndex(fact_emb=fact_emb.float().cpu().numpy(), passage_emb=pass_emb.float().cpu().numpy(),
+                            subj_vertex=kg.subj_vertex, obj_vertex=kg.obj_vertex, num_chunks=kg.num_chunks,
+                            passage_vertex=kg.passage_vertex, p=oracle.column_normalize(a))
+    qf_h, qp_h = qf.float().cpu().numpy(), qp.float().cpu().numpy()
+    for q in (0, 100, 255):
+        ref = oracle.retrieve_one(index, qf_h[q], qp_h[q])
+        assert tie_aware_equal(ids[q], ref.sorted_doc_ids[:200], ref.sorted_doc_scores[:200], rel_gap=2e-5), q
+        want = ref.x[kg.passage_vertex][ids[q]]
+        assert (np.abs(scores[q] - want) / want).max() < 1e-5, q
+
+
+# ----------------------------------------------------------------------------- small-batch kernels (B <= 8)
+@pytest.mark.parametrize("b", [1, 2, 3, 5, 8])
+def test_retrieve_small_batch_path_vs_oracle(case, gpu_device, b):
+    """hrag_retrieve takes the small-batch kernels (csrc/ppr_sv.hip) for B <= 8 -- the IRCoT /
+    per-method-seam shape.  Filter subsets, a DPR-fallback row and shared seeds included."""
+    eng, kg = case["eng"], case["kg"]
+    qf_bits, qp_bits = case["qf_bits"][10:10 + b].copy(), case["qp_bits"][10:10 + b].copy()
+    if b >= 3:
+        qf_bits[2] = qf_bits[0]                       # two queries seed the same entities
+    sub = dict(case, qf_bits=qf_bits, qp_bits=qp_bits)
+    idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
+    idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
+    plans = [[0, 1, 2, 3, 4], [], [0, 1, 2, 3, 4], [3, 1], [2], [4, 0, 1], [0], [1, 2, 3]][:b]
+    if b == 1:
+        plans = [[0, 1, 2, 3, 4]]
+    kept_idx = np.full((b, 5), -1, np.int32)
+    kept_sc = np.zeros((b, 5), np.float32)
+    kept_cnt = np.zeros(b, np.int32)
+    kept_lists = []
+    for q, plan in enumerate(plans):
+        kept_idx[q, :len(plan)] = idx_h[q, plan]
+        kept_sc[q, :len(plan)] = sc_h[q, plan]
+        kept_cnt[q] = len(plan)
+        kept_lists.append(idx_h[q, plan].tolist())
+    out = eng.retrieve(_bf16(qp_bits, gpu_device), _t(kept_idx, gpu_device), _t(kept_sc, gpu_device),
+                       _t(kept_cnt, gpu_device), ppr_iters=20, k=100)
+    got_idx, got_sc, flags = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy(), out.flags.cpu().numpy()
+    assert eng.timings()["slab_width"] == {1: 1, 2: 2, 3: 4, 5: 8, 8: 8}[b]
+    refs = _oracle_batch(sub, kept_lists)
+    for q in range(b):
+        ref = refs[q]
+        assert bool(flags[q] & 1) == ref.used_dpr == (len(plans[q]) == 0)
+        want_ids, want_sc = ref.sorted_doc_ids[:100], ref.sorted_doc_scores[:100]
+        if ref.used_dpr:
+            assert tie_aware_equal(got_idx[q], want_ids, want_sc, abs_gap=3e-6), q
+            np.testing.assert_allclose(got_sc[q], want_sc, rtol=0, atol=3e-6)
+        else:
+            assert tie_aware_equal(got_idx[q], want_ids, want_sc, rel_gap=2e-5), q
+            np.testing.assert_allclose(got_sc[q], ref.x[kg.passage_vertex][got_idx[q]], rtol=1e-5, atol=0)

@@ -20,7 +20,7 @@ from hipporag_amd import synth
 from hipporag_amd.engine import HippoRAGEngine
 
 cfg = CONFIGS[os.environ.get("HRAG_PMC_CONFIG", "cfg3")]
-V, E, B, seed = cfg["V"], cfg["E"], cfg["B"], cfg["seed"]
+V, E, B, seed = cfg["V"], cfg["E"], int(os.environ.get("HRAG_PMC_BATCH", cfg["B"])), cfg["seed"]
 dev = torch.device("cuda", 0)
 kg = synth.make_kg(V, E, seed)
 pemb = synth.make_embeddings_torch(kg.n_passages, 64, 1, dev)
@@ -33,7 +33,8 @@ qp, _ = synth.make_queries_torch(pemb, B, 8)
 cnt = torch.full((B,), 5, dtype=torch.int32, device=dev)
 idx, sc = eng.score_facts(qf, k=5)
 eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=200)   # takes the fp16-state path when B > 32
-eng.ppr_sweeps(B, 4, 0.5, main_only=True, f16=B > 32 and not (int(os.environ.get("HRAG_FLAGS", "0")) & 8))
+f32_only = bool(int(os.environ.get("HRAG_FLAGS", "0")) & 8)
+eng.ppr_sweeps(B, 4, 0.5, main_only=True, f16=B > 8 and not f32_only, small=B <= 8 and not f32_only)
 torch.cuda.synchronize()
 eng.close()
 print("pmc target done")

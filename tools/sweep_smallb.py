@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Small-batch latency of the hot path (B = 1..32): phase timings + per-sweep time of the fp32-state
+PPR kernels.   python tools/sweep_smallb.py --config cfg3"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+from bench import CONFIGS, spmm_algorithmic_bytes
+from hipporag_amd import synth
+from hipporag_amd.engine import HippoRAGEngine
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--batches", default="1,2,4,8,16,32")
+    ap.add_argument("--out", default="gpurun_out/sweep_smallb.json")
+    ap.add_argument("--flags", type=int, default=0)
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    V, E, D, seed = cfg["V"], cfg["E"], cfg["D"], cfg["seed"]
+    dev = torch.device("cuda", 0)
+    kg = synth.make_kg(V, E, seed)
+    pemb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev)
+    femb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    res = {}
+    for B in [int(b) for b in args.batches.split(",")]:
+        eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pemb, femb, kg.subj_vertex, kg.obj_vertex,
+                             kg.num_chunks, max_batch=B, max_topk=200, flags=args.flags)
+        qf, _ = synth.make_queries_torch(femb, B, 7)
+        qp, _ = synth.make_queries_torch(pemb, B, 8)
+        cnt = torch.full((B,), 5, dtype=torch.int32, device=dev)
+
+        def step():
+            idx, sc = eng.score_facts(qf, k=5)
+            return eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=200)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 20
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        lat_ms = (time.perf_counter() - t0) * 1e3 / n
+        eng.set_profiling(True)
+        step()
+        torch.cuda.synchronize()
+        ph = eng.timings()
+        eng.set_profiling(False)
+        kw = dict(small=True) if B <= 8 else dict(f16=True)
+        eng.ppr_sweeps(B, 4, 0.5, **kw)
+        e0.record()
+        eng.ppr_sweeps(B, 40, 0.5, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        sweep_us = e0.elapsed_time(e1) / 40 * 1e3
+        alg = spmm_algorithmic_bytes(kg.csr.nnz, V, kg.n_passages, B, 4 if B <= 8 else 2)
+        res[B] = dict(latency_ms=lat_ms, qps=B / lat_ms * 1e3, sweep_us=sweep_us,
+                      sweep_alg_gbs=alg / (sweep_us * 1e-6) / 1e9,
+                      phases={k: ph[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")},
+                      slab_width=ph["slab_width"])
+        print(B, json.dumps(res[B]), flush=True)
+        eng.close()
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

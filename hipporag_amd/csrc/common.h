@@ -196,12 +196,20 @@ hrag_status launch_flag_zero_mass(const double *sums, int32_t batch, int32_t *fl
 hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
                             int32_t batch, float *out, int64_t ld, hipStream_t s);
 
+// sim_gemv.hip : the same for batch <= 8 (streams E once, queries in registers); false = not handled
+bool launch_sim_gemv(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch,
+                     float *out, int64_t ld, hipStream_t s);
+
 // topk.hip
 constexpr int kTopkMax = 2048;
 enum TopkNorm { kNormNone = 0, kNormMinMax = 1 };
+// ws / ws_bytes: optional workspace (kTopkWsBytes) that lets small batches split every row over
+// several workgroups (two-level selection, same result)
+constexpr size_t kTopkWsBytes = (size_t)64 * 4096 * 8 + (size_t)64 * 64 * 8;
 hrag_status launch_row_topk(const float *scores, int32_t batch, int64_t n, int64_t ld, int32_t k,
                             int32_t idx_offset, TopkNorm norm, int32_t *idx_out, float *val_out,
-                            float *mn_out, float *mx_out, hipStream_t s);
+                            float *mn_out, float *mx_out, hipStream_t s, void *ws = nullptr,
+                            size_t ws_bytes = 0);
 hrag_status launch_row_minmax(const float *scores, int32_t batch, int64_t n, int64_t ld,
                               float *mn_out, float *mx_out, hipStream_t s, float *sum_out = nullptr);
 

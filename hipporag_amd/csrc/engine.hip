@@ -80,6 +80,7 @@ struct hrag_engine {
     int32_t *d_seed_vtx = nullptr, *d_seed_cnt = nullptr, *d_flags = nullptr;
     float *d_seed_w = nullptr;
     double *d_colsum_partial = nullptr, *d_sums = nullptr;
+    void *d_topk_ws = nullptr;   // kTopkWsBytes: lets small batches split a row over several workgroups
     // two-stage fp16 PPR (ppr16.hip): SELL-8 matrix + fp16 state, unsharded engines with max_batch > 32
     bool f16_ready = false;   // fp16 state buffers present (max_batch > 8)
     bool sell_ready = false;  // SELL-8 matrix + small-batch buffers present (every unsharded engine)
@@ -133,7 +134,7 @@ void free_engine(hrag_engine *e) {
                     e->d_flags, e->d_seed_w, e->d_colsum_partial, e->d_sums, e->d_pairs, e->d_chunk_meta,
                     e->d_vrow, e->d_lrow_row, e->d_lrow_first, e->d_lrow_cnt, e->d_partial16, e->d_h16[0],
                     e->d_h16[1], e->d_h16[2], e->d_h16[3], e->d_tele16, e->d_row_slot, e->d_qscale,
-                    e->d_ssum, e->d_tele_sv, e->d_partial_sv};
+                    e->d_ssum, e->d_tele_sv, e->d_partial_sv, e->d_topk_ws};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ev : e->ev)
@@ -503,6 +504,11 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     // colsum partials: worst case is the narrowest slab (most slabs * bc stays ~B, padded)
     E_TRY(dev_alloc(&e->d_colsum_partial, (int64_t)kColsumBlocks * (round_up(B, 4) + 64)));
     E_TRY(dev_alloc(&e->d_sums, B));
+    {
+        char *ws = nullptr;
+        E_TRY(dev_alloc(&ws, (int64_t)kTopkWsBytes));
+        e->d_topk_ws = ws;
+    }
     E_HIP(hipMemset(e->d_x, 0, (size_t)e->state_elems * sizeof(float)));
     E_HIP(hipMemset(e->d_y, 0, (size_t)e->state_elems * sizeof(float)));
     E_HIP(hipMemset(e->d_seed_cnt, 0, (size_t)B * sizeof(int32_t)));
@@ -595,7 +601,7 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q, int32_t batch, i
     HRAG_TRY(launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, e->d_sfact, e->ld_f, s));
     // get_fact_scores' min_max_normalize + rerank_facts' argsort prefix in one kernel
     HRAG_TRY(launch_row_topk(e->d_sfact, batch, e->f_rows, e->ld_f, k, 0, kNormMinMax, idx_out, score_out,
-                             nullptr, nullptr, s));
+                             nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
     if (e->profiling) {
         HRAG_HIP_TRY(hipEventRecord(e->ev[EV_FACT1], s));
         e->have_fact_ev = true;
@@ -759,7 +765,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     }
     HRAG_TRY(launch_flag_zero_mass(e->d_sums, batch, e->d_flags, 2, s));
     HRAG_TRY(launch_row_topk(e->d_doc, batch, e->n_passages, e->ld_p, k, 0, kNormNone, doc_idx_out,
-                             doc_score_out, nullptr, nullptr, s));
+                             doc_score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
     if (flags_out)
         HRAG_HIP_TRY(hipMemcpyAsync(flags_out, e->d_flags, (size_t)batch * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, s));
@@ -782,7 +788,7 @@ hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t 
     hipStream_t s = (hipStream_t)stream;
     HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s));
     return launch_row_topk(e->d_spass, batch, e->n_passages, e->ld_p, k, 0, kNormMinMax, doc_idx_out,
-                           doc_score_out, nullptr, nullptr, s);
+                           doc_score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes);
 }
 
 hrag_status hrag_ppr(hrag_engine *e, const float *reset, int32_t batch, float damping, int32_t iters,

@@ -141,6 +141,12 @@ hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, cons
                             int32_t batch, float *out, int64_t ld, hipStream_t s) {
     HRAG_REQUIRE(dim > 0 && dim % 8 == 0, "embedding dim %d must be a positive multiple of 8", dim);
     if (rows == 0 || batch == 0) return HRAG_OK;
+    // latency path: GEMV.  Measured at F = 875k, D = 768: B = 1 0.27 ms (MFMA kernel 0.70), B = 2 0.31;
+    // from B = 4 the per-lane dot products make it VALU-bound (0.96 ms) and the MFMA kernel wins.
+    if (batch <= 2 && launch_sim_gemv(emb, rows, dim, q, batch, out, ld, s)) {
+        HRAG_LAUNCH_CHECK();
+        return HRAG_OK;
+    }
     const int64_t tiles_m = ceil_div(rows, BM);
     if (batch > 64) {
         const int tn = (int)ceil_div(batch, 128);

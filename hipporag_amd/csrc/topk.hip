@@ -16,6 +16,8 @@
 //           bitonic-sorted descending, and the first k are written out.
 // If an adversarial distribution overflows the buffer the exact k-th key is found by bisection on
 // the key space (counting passes) and pass 2 is repeated; correctness never depends on luck.
+#include <algorithm>
+
 #include "common.h"
 
 namespace hrag {
@@ -75,17 +77,24 @@ __device__ __forceinline__ float minmax_norm(float s, float mn, float mx) {
     return range == 0.f ? 1.f : __fdiv_rn(s - mn, range);  // misc_utils.py:130-139
 }
 
+// parts > 1: workgroup (row_in * parts + part) selects from the slice [part * plen, +plen) of input
+// row row_in and writes its k candidates (global positions, raw values) as output row blockIdx.x;
+// topk_merge_kernel then picks the final k.
 __global__ __launch_bounds__(TK_THREADS) void row_topk_kernel(
-    const float *__restrict__ scores, int64_t n, int64_t ld, int32_t k, int32_t idx_offset,
+    const float *__restrict__ scores, int64_t n_total, int64_t ld, int32_t k, int32_t idx_offset_in,
     int32_t norm, int32_t *__restrict__ idx_out, float *__restrict__ val_out,
-    float *__restrict__ mn_out, float *__restrict__ mx_out) {
+    float *__restrict__ mn_out, float *__restrict__ mx_out, int32_t parts, int64_t plen) {
     __shared__ uint64_t buf[TK_CAP];
     __shared__ float red_mn[TK_THREADS / 64], red_mx[TK_THREADS / 64];
     __shared__ unsigned int s_count;
 
     const int tid = threadIdx.x;
-    const int row = blockIdx.x;
-    const float *s = scores + (size_t)row * ld;
+    const int row = blockIdx.x;          // output row
+    const int row_in = row / parts, part = row % parts;
+    const float *s = scores + (size_t)row_in * ld + (size_t)part * plen;
+    int64_t n = parts > 1 ? n_total - (int64_t)part * plen : n_total;
+    n = n < 0 ? 0 : (parts > 1 && n > plen ? plen : n);
+    const int32_t idx_offset = parts > 1 ? (int32_t)(part * plen) : idx_offset_in;
     const int kk = (int)((int64_t)k < n ? (int64_t)k : n);
 
     // ---- pass 1: thread-local top-2 + min / max
@@ -229,16 +238,84 @@ __global__ __launch_bounds__(TK_THREADS) void row_minmax_kernel(const float *__r
     }
 }
 
+// second level of the split selection: parts * k candidates per row (keys are unique), parts * k <= TK_CAP
+__global__ __launch_bounds__(TK_THREADS) void topk_merge_kernel(
+    const int32_t *__restrict__ cand_idx, const float *__restrict__ cand_val,
+    const float *__restrict__ part_mn, const float *__restrict__ part_mx, int32_t parts, int32_t k,
+    int64_t n_total, int32_t idx_offset, int32_t norm, int32_t *__restrict__ idx_out,
+    float *__restrict__ val_out, float *__restrict__ mn_out, float *__restrict__ mx_out) {
+    __shared__ uint64_t buf[TK_CAP];
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;
+    const int n_cand = parts * k;
+    int p2 = 2;
+    while (p2 < n_cand) p2 <<= 1;
+    for (int j = tid; j < p2; j += TK_THREADS) {
+        uint64_t key = 0;
+        if (j < n_cand) {
+            const int32_t ci = cand_idx[(size_t)row * n_cand + j];
+            if (ci >= 0) key = rank_key(cand_val[(size_t)row * n_cand + j], (uint32_t)ci);
+        }
+        buf[j] = key;
+    }
+    float mn = INFINITY, mx = -INFINITY;
+    for (int p = 0; p < parts; ++p) {
+        mn = fminf(mn, part_mn[(size_t)row * parts + p]);
+        mx = fmaxf(mx, part_mx[(size_t)row * parts + p]);
+    }
+    __syncthreads();
+    bitonic_sort_desc(buf, p2, tid);
+    if (tid == 0) {
+        if (mn_out) mn_out[row] = mn;
+        if (mx_out) mx_out[row] = mx;
+    }
+    const int kk = (int)((int64_t)k < n_total ? (int64_t)k : n_total);
+    for (int j = tid; j < k; j += TK_THREADS) {
+        int32_t idx = -1;
+        float val = 0.f;
+        if (j < kk) {
+            const uint64_t key = buf[j];
+            idx = (int32_t)(uint32_t)key + idx_offset;
+            val = ordered_to_f32((uint32_t)(key >> 32));
+            if (norm == kNormMinMax) val = minmax_norm(val, mn, mx);
+        }
+        idx_out[(size_t)row * k + j] = idx;
+        val_out[(size_t)row * k + j] = val;
+    }
+}
+
 }  // namespace
 
 hrag_status launch_row_topk(const float *scores, int32_t batch, int64_t n, int64_t ld, int32_t k,
                             int32_t idx_offset, TopkNorm norm, int32_t *idx_out, float *val_out,
-                            float *mn_out, float *mx_out, hipStream_t s) {
+                            float *mn_out, float *mx_out, hipStream_t s, void *ws, size_t ws_bytes) {
     HRAG_REQUIRE(k >= 1 && k <= kTopkMax, "top-k k=%d outside [1, %d]", k, kTopkMax);
     HRAG_REQUIRE(n >= 0 && n < (int64_t)0xffffffffll, "row length %lld not supported", (long long)n);
     if (batch == 0) return HRAG_OK;
-    hipLaunchKernelGGL(row_topk_kernel, dim3((unsigned)batch), dim3(TK_THREADS), 0, s, scores, n, ld, k,
-                       idx_offset, (int32_t)norm, idx_out, val_out, mn_out, mx_out);
+    // one workgroup per row leaves the chip idle for a handful of rows: split long rows
+    int parts = 1;
+    if (ws && batch < 64 && n >= 32768) {
+        parts = (int)std::min<int64_t>(std::min<int64_t>(TK_CAP / k, ceil_div(n, 8192)), std::max(1, 256 / batch));
+        parts = std::min(parts, 64);
+        while (parts > 1 && (size_t)batch * parts * ((size_t)k * 8 + 8) > ws_bytes) --parts;
+    }
+    if (parts <= 1) {
+        hipLaunchKernelGGL(row_topk_kernel, dim3((unsigned)batch), dim3(TK_THREADS), 0, s, scores, n, ld, k,
+                           idx_offset, (int32_t)norm, idx_out, val_out, mn_out, mx_out, 1, (int64_t)0);
+        HRAG_LAUNCH_CHECK();
+        return HRAG_OK;
+    }
+    const int64_t plen = round_up(ceil_div(n, parts), 4);
+    const size_t n_cand = (size_t)batch * parts * k;
+    int32_t *c_idx = static_cast<int32_t *>(ws);
+    float *c_val = reinterpret_cast<float *>(c_idx + n_cand);
+    float *p_mn = c_val + n_cand;
+    float *p_mx = p_mn + (size_t)batch * parts;
+    hipLaunchKernelGGL(row_topk_kernel, dim3((unsigned)(batch * parts)), dim3(TK_THREADS), 0, s, scores, n, ld,
+                       k, 0, (int32_t)kNormNone, c_idx, c_val, p_mn, p_mx, parts, plen);
+    HRAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)batch), dim3(TK_THREADS), 0, s, c_idx, c_val, p_mn, p_mx,
+                       parts, k, n, idx_offset, (int32_t)norm, idx_out, val_out, mn_out, mx_out);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -39,7 +39,10 @@ def case(gpu_device):
 
 # ----------------------------------------------------------------------------- K1 similarity
 @pytest.mark.parametrize("rows,dim,batch", [(1000, 768, 1), (333, 64, 5), (4100, 200, 64), (777, 768, 130),
-                                            (129, 1024, 17)])
+                                            (129, 1024, 17),
+                                            # batch <= 2: the GEMV kernel (csrc/sim_gemv.hip), every chunk count
+                                            (1001, 4096, 2), (517, 1536, 2), (5, 8, 2), (2000, 768, 2),
+                                            (900, 512, 1), (64, 2048, 1), (300, 3000, 1), (2000, 768, 8)])
 def test_sim_scores_match_fp64_dot(gpu_device, rows, dim, batch):
     from hipporag_amd.engine import HippoRAGEngine
     from hipporag_amd import synth
@@ -467,3 +470,29 @@ def test_retrieve_small_batch_path_vs_oracle(case, gpu_device, b):
         else:
             assert tie_aware_equal(got_idx[q], want_ids, want_sc, rel_gap=2e-5), q
             np.testing.assert_allclose(got_sc[q], ref.x[kg.passage_vertex][got_idx[q]], rtol=1e-5, atol=0)
+
+
+def test_small_batch_split_topk_and_gemv_at_scale(gpu_device):
+    """B <= 8 on a 300k-vertex index: cosine scores come from the GEMV kernel and every top-k row is
+    split over several workgroups (two-level selection) -- ids and scores must equal the oracle's."""
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd import synth
+    kg, pass_bits, fact_bits, index = make_case(300_000, 1_500_000, 32, seed=5)
+    assert kg.n_facts >= 32768 and kg.n_passages >= 32768
+    with HippoRAGEngine(kg.csr, kg.passage_vertex, pass_bits, fact_bits, kg.subj_vertex, kg.obj_vertex,
+                        kg.num_chunks, max_batch=8, max_topk=200) as eng:
+        for b in (1, 3, 8):
+            qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=40 + b)
+            qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=50 + b)
+            qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+            idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
+            d_idx, d_sc = eng.dense_retrieve(_bf16(qp_bits, gpu_device), k=200)
+            idx, sc, d_idx, d_sc = (t.cpu().numpy() for t in (idx, sc, d_idx, d_sc))
+            for q in range(b):
+                s = oracle.fact_scores(index.fact_emb, qf[q])
+                want = oracle.topk_desc(s, 5)
+                assert tie_aware_equal(idx[q], want, s[want], abs_gap=2e-6), (b, q)
+                np.testing.assert_allclose(sc[q], s[idx[q]], rtol=0, atol=2e-6)
+                ids, scores = oracle.retrieve_dpr_one(index, qp[q])
+                assert tie_aware_equal(d_idx[q], ids[:200], scores[:200], abs_gap=3e-6), (b, q)
+                np.testing.assert_allclose(d_sc[q], scores[:200], rtol=0, atol=3e-6)

@@ -77,6 +77,8 @@ SIGNATURES = {
     "hrag_stage_colsum": (C.c_int, [_P, _P, _I32, _P, _P, _P]),
     "hrag_colsum_workspace_bytes": (C.c_int64, [_P, _I32]),
     "hrag_stage_doc_scores": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _P, _P, _P, _P, _I64, _P]),
+    "hrag_normalize_split_bf16": (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _P]),
+    "hrag_sim_gemm": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P]),
     "hrag_get_timings": (C.c_int, [_P, C.POINTER(Timings)]),
     "hrag_set_profiling": (C.c_int, [_P, _I32]),
 }

@@ -194,7 +194,7 @@ hrag_status launch_flag_zero_mass(const double *sums, int32_t batch, int32_t *fl
 
 // sim_gemm.hip : S[b][m] = sum_k Q[b][k] * E[m][k]   (bf16 in, fp32 out, ld in elements)
 hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
-                            int32_t batch, float *out, int64_t ld, hipStream_t s);
+                            int32_t batch, float *out, int64_t ld, hipStream_t s, int32_t accumulate = 0);
 
 // sim_gemv.hip : the same for batch <= 8 (streams E once, queries in registers); false = not handled
 bool launch_sim_gemv(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch,

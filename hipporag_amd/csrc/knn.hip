@@ -1,0 +1,69 @@
+// Index-time entity KNN: the pieces retrieve_knn needs besides the similarity GEMM and
+// the row top-k that the retrieval path already has.
+//
+// Replaces, in reference src/hipporag/utils/embed_utils.py:6-94 (called by add_synonymy_edges,
+// HippoRAG.py:959-1020):  torch.nn.functional.normalize (:25,28), torch.mm (:53), torch.topk (:55,73).
+// The reference multiplies in fp32.  To stay within ~1e-6 of that on the bf16 matrix cores every vector
+// is split x = hi + lo (both bf16, lo = bf16(x - hi)) and the product is accumulated from three MFMA
+// passes  lo.hi + hi.lo + hi.hi  (the dropped lo.lo term is <= 2^-16 |x||y|); hrag_sim_gemm's
+// `accumulate` flag adds a pass into the fp32 score matrix.
+#include "common.h"
+
+namespace hrag {
+namespace {
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// one wavefront per row: L2-normalise like F.normalize (x / max(||x||, 1e-12)), then split
+__global__ __launch_bounds__(256) void normalize_split_kernel(const float *__restrict__ x, int64_t rows,
+                                                              int32_t dim, int32_t normalize,
+                                                              uint16_t *__restrict__ hi,
+                                                              uint16_t *__restrict__ lo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * dim;
+    float inv = 1.f;
+    if (normalize) {
+        double ss = 0.0;
+        for (int k = lane; k < dim; k += 64) ss += (double)xr[k] * (double)xr[k];
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        inv = 1.f / fmaxf((float)sqrt(ss), 1e-12f);
+    }
+    for (int k = lane; k < dim; k += 64) {
+        const float v = normalize ? xr[k] * inv : xr[k];
+        const uint16_t h = f32_to_bf16_rne(v);
+        hi[(size_t)row * dim + k] = h;
+        if (lo) lo[(size_t)row * dim + k] = f32_to_bf16_rne(v - __uint_as_float((uint32_t)h << 16));
+    }
+}
+
+}  // namespace
+}  // namespace hrag
+
+using namespace hrag;
+
+extern "C" {
+
+hrag_status hrag_normalize_split_bf16(const float *x_dev, int64_t rows, int32_t dim, int32_t normalize,
+                                      uint16_t *hi_dev, uint16_t *lo_dev, hrag_stream stream) {
+    HRAG_REQUIRE(x_dev && hi_dev && rows >= 0 && dim > 0, "bad argument");
+    if (rows == 0) return HRAG_OK;
+    hipLaunchKernelGGL(normalize_split_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0,
+                       (hipStream_t)stream, x_dev, rows, dim, normalize, hi_dev, lo_dev);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status hrag_sim_gemm(const uint16_t *emb_dev, int64_t rows, int32_t dim, const uint16_t *q_dev,
+                          int32_t batch, float *out_dev, int64_t ld, int32_t accumulate, hrag_stream stream) {
+    HRAG_REQUIRE(emb_dev && q_dev && out_dev && rows >= 0 && batch >= 0 && ld >= rows, "bad argument");
+    return launch_sim_gemm(emb_dev, rows, dim, q_dev, batch, out_dev, ld, (hipStream_t)stream, accumulate);
+}
+
+}  // extern "C"

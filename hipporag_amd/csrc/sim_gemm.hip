@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(const uint16_t *__restric
                                                        int64_t rows, int32_t dim,
                                                        const uint16_t *__restrict__ q,
                                                        int32_t batch, float *__restrict__ out,
-                                                       int64_t ld, int32_t n_tiles_n) {
+                                                       int64_t ld, int32_t n_tiles_n, int32_t accumulate) {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     constexpr int MI = BM / (WM * 16);
     constexpr int NJ = BN / (WN * 16);
@@ -124,7 +124,11 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(const uint16_t *__restric
             const int gb = b0 + (wn * NJ + j) * 16 + (lane & 15);
             if (gb >= batch || m >= rows) continue;
             float *dst = out + (size_t)gb * ld + m;
-            const f32x4 v = acc[i][j];
+            f32x4 v = acc[i][j];
+            if (accumulate) {   // multi-pass products (bf16x3 KNN): out += this pass
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < rows) v[r] += dst[r];
+            }
             if (m + 3 < rows && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
                 *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -138,12 +142,12 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(const uint16_t *__restric
 }  // namespace
 
 hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
-                            int32_t batch, float *out, int64_t ld, hipStream_t s) {
+                            int32_t batch, float *out, int64_t ld, hipStream_t s, int32_t accumulate) {
     HRAG_REQUIRE(dim > 0 && dim % 8 == 0, "embedding dim %d must be a positive multiple of 8", dim);
     if (rows == 0 || batch == 0) return HRAG_OK;
     // latency path: GEMV.  Measured at F = 875k, D = 768: B = 1 0.27 ms (MFMA kernel 0.70), B = 2 0.31;
     // from B = 4 the per-lane dot products make it VALU-bound (0.96 ms) and the MFMA kernel wins.
-    if (batch <= 2 && launch_sim_gemv(emb, rows, dim, q, batch, out, ld, s)) {
+    if (batch <= 2 && !accumulate && launch_sim_gemv(emb, rows, dim, q, batch, out, ld, s)) {
         HRAG_LAUNCH_CHECK();
         return HRAG_OK;
     }
@@ -151,14 +155,14 @@ hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, cons
     if (batch > 64) {
         const int tn = (int)ceil_div(batch, 128);
         hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2>), dim3((unsigned)(tiles_m * tn)), dim3(256), 0, s,
-                           emb, rows, dim, q, batch, out, ld, tn);
+                           emb, rows, dim, q, batch, out, ld, tn, accumulate);
     } else if (batch > 16) {
         const int tn = (int)ceil_div(batch, 64);
         hipLaunchKernelGGL((sim_gemm_kernel<64, 4, 1>), dim3((unsigned)(tiles_m * tn)), dim3(256), 0, s,
-                           emb, rows, dim, q, batch, out, ld, tn);
+                           emb, rows, dim, q, batch, out, ld, tn, accumulate);
     } else {
         hipLaunchKernelGGL((sim_gemm_kernel<16, 4, 1>), dim3((unsigned)tiles_m), dim3(256), 0, s, emb,
-                           rows, dim, q, batch, out, ld, 1);
+                           rows, dim, q, batch, out, ld, 1, accumulate);
     }
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;

@@ -194,6 +194,17 @@ hrag_status hrag_topk_rows(const float *scores_dev, int32_t batch, int64_t n, in
                            float *val_out_dev, float *min_out_dev, float *max_out_dev,
                            hrag_stream stream);
 
+/* ---- index-time entity KNN (retrieve_knn, utils/embed_utils.py:6-94; engine-less) ----
+ * hrag_normalize_split_bf16: F.normalize (embed_utils.py:25,28) when normalize != 0, then the split
+ *   x = hi + lo into two bf16 matrices (lo_dev may be NULL: plain bf16 rounding).
+ * hrag_sim_gemm: out[b][m] (+)= sum_k q[b][k] * emb[m][k]  (torch.mm, :53); bf16 in, fp32 out,
+ *   row stride ld; accumulate != 0 adds to out (three passes lo.hi + hi.lo + hi.hi ~ an fp32 product).
+ * The top-k of each score row is hrag_topk_rows (k <= 2048 covers synonymy_edge_topk = 2047). */
+hrag_status hrag_normalize_split_bf16(const float *x_dev, int64_t rows, int32_t dim, int32_t normalize,
+                                      uint16_t *hi_dev, uint16_t *lo_dev, hrag_stream stream);
+hrag_status hrag_sim_gemm(const uint16_t *emb_dev, int64_t rows, int32_t dim, const uint16_t *q_dev,
+                          int32_t batch, float *out_dev, int64_t ld, int32_t accumulate, hrag_stream stream);
+
 /* Measurement hook: run `n` PPR SpMM sweeps over the engine's current state buffers for
  * `batch` right-hand sides (state is whatever the last hrag_retrieve / hrag_ppr left).
  * flags bit0: main CSR kernel only (skip the long-row and seed kernels);

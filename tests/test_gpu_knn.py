@@ -1,0 +1,69 @@
+"""Index-time entity KNN: hipporag_amd.knn.retrieve_knn against an fp64 restatement of
+reference src/hipporag/utils/embed_utils.py:6-94 (normalize -> mm -> topk)."""
+
+import numpy as np
+import pytest
+
+from tests.helpers import tie_aware_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_knn(q, keys, k):
+    qn = q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)
+    kn = keys / np.maximum(np.linalg.norm(keys, axis=1, keepdims=True), 1e-12)
+    s = qn.astype(np.float64) @ kn.astype(np.float64).T
+    order = np.argsort(s, axis=1, kind="stable")[:, ::-1][:, :k]
+    return order, np.take_along_axis(s, order, axis=1)
+
+
+@pytest.mark.parametrize("nq,nk,dim,k,qb", [(37, 3000, 128, 50, 16), (5, 4100, 768, 2047, 1000), (3, 7, 64, 2047, 2),
+                                            (130, 2500, 200, 10, 64)])
+def test_retrieve_knn_matches_fp64(gpu_device, nq, nk, dim, k, qb):
+    from hipporag_amd.knn import retrieve_knn
+    rng = np.random.default_rng(nq + nk)
+    keys = rng.standard_normal((nk, dim)).astype(np.float32) * rng.uniform(0.1, 10, (nk, 1)).astype(np.float32)
+    q = (keys[rng.integers(0, nk, nq)] + 0.3 * rng.standard_normal((nq, dim))).astype(np.float32)
+    idx, sc = retrieve_knn([f"q{i}" for i in range(nq)], [f"k{i}" for i in range(nk)], q, keys, k=k,
+                           query_batch_size=qb, return_arrays=True)
+    want_idx, want_sc = _ref_knn(q, keys, k)
+    assert idx.shape == want_idx.shape
+    for i in range(nq):
+        assert tie_aware_equal(idx[i], want_idx[i], want_sc[i], abs_gap=4e-6), i
+        got_true = _ref_knn(q[i:i + 1], keys, nk)      # true score of the returned ids
+        full = np.empty(nk); full[got_true[0][0]] = got_true[1][0]
+        np.testing.assert_allclose(sc[i], full[idx[i]], rtol=0, atol=3e-6)
+    # dict form, like the reference returns it
+    res = retrieve_knn([f"q{i}" for i in range(2)], [f"k{i}" for i in range(nk)], q[:2], keys, k=min(k, 5),
+                       query_batch_size=qb)
+    ids0, sc0 = res["q0"]
+    assert ids0 == [f"k{j}" for j in idx[0][:len(ids0)]] and np.allclose(sc0, sc[0][:len(sc0)])
+
+
+def test_retrieve_knn_single_pass_bf16_is_coarser(gpu_device):
+    from hipporag_amd.knn import retrieve_knn
+    rng = np.random.default_rng(1)
+    keys = rng.standard_normal((2000, 256)).astype(np.float32)
+    q = rng.standard_normal((8, 256)).astype(np.float32)
+    _, sc3 = retrieve_knn(None, None, q, keys, k=20, return_arrays=True)
+    _, sc1 = retrieve_knn(None, None, q, keys, k=20, precision="bf16", return_arrays=True)
+    _, want = _ref_knn(q, keys, 20)
+    assert np.abs(sc3 - want).max() < 3e-6 < np.abs(sc1 - want).max() < 1e-2
+    assert retrieve_knn([], [], np.zeros((0, 8), np.float32), np.zeros((0, 8), np.float32)) == {}
+
+
+def test_synonymy_candidates_rules(gpu_device):
+    """HippoRAG.py:992-1018: threshold, self-match and short-phrase skips."""
+    from hipporag_amd.knn import synonymy_candidates
+    rng = np.random.default_rng(2)
+    base = rng.standard_normal((6, 64)).astype(np.float32)
+    embs = np.concatenate([base, base[:3] + 0.01 * rng.standard_normal((3, 64)).astype(np.float32)])
+    texts = ["alpha", "beta", "ab", "delta", "epsilon", "zeta", "alpha2", "beta2", "ab2"]
+    keys = [f"entity-{i}" for i in range(9)]
+    edges = synonymy_candidates(keys, texts, embs, topk=8, sim_threshold=0.8)
+    pairs = {(a, b) for a, b, _ in edges}
+    assert ("entity-0", "entity-6") in pairs and ("entity-6", "entity-0") in pairs
+    assert ("entity-1", "entity-7") in pairs
+    assert not any(a == "entity-2" for a, _, _ in edges)          # "ab": <= 2 alphanumerics -> skipped as a query
+    assert ("entity-8", "entity-2") in pairs                       # ... but still a valid neighbour
+    assert all(a != b and s >= 0.8 for a, b, s in edges)

@@ -206,7 +206,9 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": (traffic or {}).get(kernel, {}).get("bytes_per_launch") if traffic else None,
+        # PMC traffic is only meaningful for the workload it was collected on (profiles/pmc_traffic.json)
+        "traffic": ((traffic or {}).get(kernel, {}).get("bytes_per_launch")
+                    if (traffic or {}).get(kernel, {}).get("workload") == f"{args.config}:B{B}" else None),
         "algorithmic_bytes_per_launch": alg, "state_bytes": 2 if f16 else 4,
         "gather_bytes_per_launch": nnz * B * (2 if f16 else 4),
         "launch_ms": spmm_ms, "sweep_ms_all_kernels": sweep_ms,

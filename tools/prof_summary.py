@@ -32,6 +32,7 @@ def short(name: str) -> str:
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
+    workload = sys.argv[3] if len(sys.argv) > 3 else "cfg3:B256"   # what tools/pmc_target.py ran
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
@@ -72,7 +73,7 @@ def main():
             if "bytes_per_launch" in d and base in ("ppr16_kernel", "ppr_spmm_kernel") and n > seen.get(base, 0):
                 seen[base] = n      # the variant with the most launches (mode H for ppr16_kernel)
                 traffic[base] = {"bytes_per_launch": d["bytes_per_launch"], "l2_hit_rate": d.get("l2_hit_rate"),
-                                 "source": os.path.basename(dst) + "_pmc.json"}
+                                 "workload": workload, "source": os.path.basename(dst) + "_pmc.json"}
         if traffic:
             tp = os.path.join(os.path.dirname(dst) or ".", "pmc_traffic.json")
             old = json.load(open(tp)) if os.path.exists(tp) else {}

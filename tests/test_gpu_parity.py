@@ -496,3 +496,66 @@ def test_small_batch_split_topk_and_gemv_at_scale(gpu_device):
                 ids, scores = oracle.retrieve_dpr_one(index, qp[q])
                 assert tie_aware_equal(d_idx[q], ids[:200], scores[:200], abs_gap=3e-6), (b, q)
                 np.testing.assert_allclose(d_sc[q], scores[:200], rtol=0, atol=3e-6)
+
+
+# ----------------------------------------------------------------------------- awkward graphs, all three PPR paths
+@pytest.mark.parametrize("b", [4, 40])
+def test_retrieve_on_graph_with_dangling_hub_and_parallel_edges(gpu_device, b):
+    """Isolated passages (dangling: they keep teleport mass but have no edges, HippoRAG.py:1171-1187
+    adds every stored passage as a vertex), isolated entities -- one of them a seed --, a hub with
+    ~2000 neighbours (long-row segments), duplicated parallel edges (summed, :1189-1223), interleaved
+    passage / entity vertex numbering, V not a multiple of 8, and a fact whose subject vertex is a
+    passage.  B = 4 takes the small-batch kernels, B = 40 the two-stage fp16 kernels; an engine
+    created with HRAG_OPT_F32_STATE runs the fp32 slab kernels on the same input."""
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd.graph import build_csr
+    from hipporag_amd._lib import OPT_F32_STATE
+    from hipporag_amd import synth
+    rng = np.random.default_rng(99)
+    kg0 = synth.make_kg(2997, 20000, seed=3)
+    v = kg0.num_vertices
+    relabel = rng.permutation(v)                                   # mix passage and entity ids
+    src, dst, w = relabel[kg0.src], relabel[kg0.dst], kg0.weight.copy()
+    pv = relabel[kg0.passage_vertex].astype(np.int32)
+    ents = relabel[:kg0.n_entities]
+    iso_p, iso_e = pv[:6], ents[:4]                                # cut every edge of these vertices
+    dead = np.isin(src, np.concatenate([iso_p, iso_e])) | np.isin(dst, np.concatenate([iso_p, iso_e]))
+    src, dst, w = src[~dead], dst[~dead], w[~dead]
+    hub = ents[10]
+    nb = rng.choice(ents[20:], 2000, replace=False)
+    src = np.concatenate([src, np.full(2000, hub), src[:500]])     # hub row + 500 parallel duplicates
+    dst = np.concatenate([dst, nb, dst[:500]])
+    w = np.concatenate([w, rng.uniform(0.5, 3.0, 2000), w[:500]])
+    csr = build_csr(v, src, dst, w)
+    subj, obj = relabel[kg0.subj_vertex].astype(np.int32), relabel[kg0.obj_vertex].astype(np.int32)
+    subj[0], obj[0] = iso_e[0], hub                                # fact 0 seeds an isolated entity + the hub
+    subj[1] = pv[20]                                               # a "phrase" that is a passage vertex
+    obj[2] = -1                                                    # phrase absent from the graph
+    nchunks = np.zeros(v, np.int32)
+    nchunks[relabel] = kg0.num_chunks
+    pass_bits = synth.make_embeddings_np(kg0.n_passages, 64, 7)
+    fact_bits = synth.make_embeddings_np(kg0.n_facts, 64, 8)
+    a = oracle.build_symmetric_csr(v, src, dst, w)
+    index = oracle.RefIndex(bf16_bits_to_float(fact_bits), bf16_bits_to_float(pass_bits), subj, obj, nchunks, pv,
+                            oracle.column_normalize(a))
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=1)
+    qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=2)
+    qf_bits[:3] = fact_bits[:3]                                    # queries 0..2 retrieve facts 0..2 first
+    qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+    refs = [oracle.retrieve_one(index, qf[q], qp[q]) for q in range(b)]
+    assert refs[0].fact_candidates[0] == 0 and refs[1].fact_candidates[0] == 1
+    for flags in (0, OPT_F32_STATE):
+        with HippoRAGEngine(csr, pv, pass_bits, fact_bits, subj, obj, nchunks, max_batch=b, max_topk=100,
+                            flags=flags) as eng:
+            idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
+            cnt = _t(np.full(b, 5, np.int32), gpu_device)
+            out = eng.retrieve(_bf16(qp_bits, gpu_device), idx, sc, cnt, ppr_iters=30, k=100)
+            got_idx, got_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+            assert np.all(out.flags.cpu().numpy() == 0)
+            width = eng.timings()["slab_width"]
+            assert width == ({4: 4, 40: 64}[b] if flags == 0 else {4: 4, 40: 32}[b])
+        for q in range(b):
+            ref = refs[q]
+            assert tie_aware_equal(got_idx[q], ref.sorted_doc_ids[:100], ref.sorted_doc_scores[:100], rel_gap=2e-5), (flags, q)
+            want = ref.x[pv][got_idx[q]]
+            assert (np.abs(got_sc[q] - want) / want).max() < 1e-5, (flags, q)

@@ -59,14 +59,13 @@ def _solution_types():
         return QuerySolution, RetrievalResult
 
 
-def build_engine_from_reference(rag, *, max_batch: int = 256, ppr_iters: int = 20):
-    """Device index from the reference object's host state (prepare_retrieval_objects must have run)."""
-    from .engine import HippoRAGEngine
+def index_arrays_from_reference(rag) -> dict:
+    """The integer / float arrays the engine needs, read off an indexed reference object
+    (prepare_retrieval_objects must have run).  Also what tests/golden/make_ref_golden.py stores."""
     g = rag.graph
     v = int(g.vcount())
     es = np.asarray(g.get_edgelist(), dtype=np.int64).reshape(-1, 2)
     w = np.asarray(g.es["weight"], dtype=np.float64) if es.shape[0] else np.zeros(0)
-    csr = build_csr(v, es[:, 0], es[:, 1], w)                 # edge rules of HippoRAG.py:1189-1223
     key2v = rag.node_name_to_vertex_idx
     fact_keys = list(rag.fact_node_keys)
     rows = rag.fact_embedding_store.get_rows(fact_keys) if fact_keys else {}
@@ -77,14 +76,27 @@ def build_engine_from_reference(rag, *, max_batch: int = 256, ppr_iters: int = 2
     for k, s in (rag.ent_node_to_chunk_ids or {}).items():   # divisor of :1600-1601
         if k in key2v:
             nchunks[key2v[k]] = len(s)
-    pv = np.asarray(rag.passage_node_idxs, np.int32)
-    pe = np.asarray(rag.passage_embeddings, np.float32)
     has_facts = len(facts) > 0
-    fe = np.asarray(rag.fact_embeddings, np.float32) if has_facts else None
+    return {"num_vertices": v, "edge_src": es[:, 0].copy(), "edge_dst": es[:, 1].copy(), "edge_w": w,
+            "passage_vertex": np.asarray(rag.passage_node_idxs, np.int32),
+            "passage_emb": np.asarray(rag.passage_embeddings, np.float32),
+            "fact_emb": np.asarray(rag.fact_embeddings, np.float32) if has_facts else None,
+            "subj_vertex": subj, "obj_vertex": obj, "num_chunks": nchunks, "facts": facts}
+
+
+def build_engine_from_reference(rag, *, max_batch: int = 256, ppr_iters: int = 20):
+    """Device index from the reference object's host state (prepare_retrieval_objects must have run)."""
+    from .engine import HippoRAGEngine
+    a = index_arrays_from_reference(rag)
+    facts = a["facts"]
+    csr = build_csr(a["num_vertices"], a["edge_src"], a["edge_dst"], a["edge_w"])   # edge rules of HippoRAG.py:1189-1223
+    pv = a["passage_vertex"]
+    has_facts = len(facts) > 0
     cfg = rag.global_config
-    eng = HippoRAGEngine(csr, pv, float_to_bf16_bits(pe), float_to_bf16_bits(fe) if has_facts else None,
-                         subj if has_facts else None, obj if has_facts else None,
-                         nchunks if has_facts else None, max_batch=max_batch,
+    eng = HippoRAGEngine(csr, pv, float_to_bf16_bits(a["passage_emb"]),
+                         float_to_bf16_bits(a["fact_emb"]) if has_facts else None,
+                         a["subj_vertex"] if has_facts else None, a["obj_vertex"] if has_facts else None,
+                         a["num_chunks"] if has_facts else None, max_batch=max_batch,
                          max_topk=int(min(2048, max(1, min(cfg.retrieval_top_k, len(pv))))))
     return eng, facts
 

@@ -1,0 +1,298 @@
+"""Fixtures produced by the REFERENCE'S OWN CODE (tests/golden/ref_*.npz, generated in the authoring
+container by tests/golden/make_ref_golden.py, which imports /root/reference/src/hipporag with igraph / LLM /
+embedding model substituted -- see tests/golden/ref_harness.py for exactly what is real).
+
+CPU: the oracle reproduces every stage the reference recorded (this is what pins the oracle).
+GPU: the HIP path reproduces the same vectors through the C ABI.
+The fixtures travel; /root/reference does not, so only ``test_fixtures_are_reproducible`` touches it
+(and skips where it is absent).
+"""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.helpers import tie_aware_equal
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["toy", "synth"]
+
+
+def load(case):
+    return np.load(os.path.join(GOLD, f"ref_{case}.npz"))
+
+
+def ref_index(t) -> oracle.RefIndex:
+    p = oracle.column_normalize(oracle.build_symmetric_csr(int(t["num_vertices"]), t["edge_src"], t["edge_dst"], t["edge_w"]))
+    return oracle.RefIndex(t["fact_emb"], t["passage_emb"], t["subj_vertex"], t["obj_vertex"], t["num_chunks"],
+                           t["passage_vertex"], p, linking_top_k=int(t["linking_top_k"]),
+                           passage_node_weight=float(t["passage_node_weight"]), damping=float(t["damping"]),
+                           retrieval_top_k=int(t["retrieval_top_k"]))
+
+
+def kept_list(t, q):
+    return [int(i) for i in t["kept_fact_idx"][q][: int(t["kept_count"][q])]]
+
+
+def seed_cut_is_tied(index, fact_scores, kept, k):
+    """True when the link_top_k cut of get_top_k_weights falls inside a run of equal phrase weights --
+    there the reference's pick depends on set/dict order (HippoRAG.py:1528,1581), i.e. on string hashes."""
+    ids, w = oracle.seed_weights(index, fact_scores, kept, link_top_k=10 ** 6)
+    return len(w) > k and w[k - 1] == w[k]
+
+
+# ------------------------------------------------------------------------------------------ CPU
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_similarity_matches_reference(case):
+    t = load(case)
+    for q in range(len(t["qf"])):
+        s = oracle.fact_scores(t["fact_emb"], t["qf"][q], exact=False)        # literal fp32 np.dot like :1459
+        np.testing.assert_allclose(s, t["fact_scores"][q], rtol=0, atol=2e-6)
+        s64 = oracle.fact_scores(t["fact_emb"], t["qf"][q], exact=True)        # the device path's parity target
+        np.testing.assert_allclose(s64, t["fact_scores"][q], rtol=0, atol=2e-6)
+        ids, sc = oracle.dense_passage_scores(t["passage_emb"], t["qp"][q], exact=False)
+        np.testing.assert_allclose(sc, t["dpr_scores"][q], rtol=0, atol=2e-6)
+        assert tie_aware_equal(ids, t["dpr_ids"][q], t["dpr_scores"][q], abs_gap=4e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_fact_candidates_match_reference(case):
+    t = load(case)
+    k = int(t["linking_top_k"])
+    for q in range(len(t["qf"])):
+        cand, _ = oracle.rerank_facts(t["fact_scores"][q], k)
+        want = [int(i) for i in t["cand_fact_idx"][q] if i >= 0]
+        assert tie_aware_equal(cand, want, t["fact_scores"][q][want], abs_gap=0.0), (q, cand, want)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_reset_vector_matches_reference(case):
+    """graph_search_with_fact_entities up to the run_ppr call (:1574-1638), fed with the reference's own
+    fact scores, kept facts and DPR scores: the reset vector must agree to the last bit."""
+    t = load(case)
+    index = ref_index(t)
+    k = int(t["linking_top_k"])
+    checked = tied = 0
+    for q in range(len(t["qf"])):
+        if t["used_dpr"][q]:
+            continue
+        kept = kept_list(t, q)
+        ids, w = oracle.seed_weights(index, t["fact_scores"][q], kept)
+        by_passage = np.empty(len(t["passage_vertex"]), np.float32)
+        by_passage[t["dpr_ids"][q]] = t["dpr_scores"][q]
+        reset = oracle.reset_vector(index, ids, w, by_passage)
+        if seed_cut_is_tied(index, t["fact_scores"][q], kept, k):
+            tied += 1                                                   # hash-order pick: compare the rest only
+            pv = t["passage_vertex"]
+            np.testing.assert_array_equal(reset[pv], t["reset"][q][pv])
+            assert np.isclose(np.sort(reset)[::-1][:k + 1].sum(), np.sort(t["reset"][q])[::-1][:k + 1].sum())
+            continue
+        np.testing.assert_array_equal(reset, t["reset"][q])
+        checked += 1
+    assert checked >= 2, (checked, tied)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_ppr_matches_reference_run_ppr(case):
+    """run_ppr (:1709-1749) on the reference's own reset vectors.  The solver behind the reference's
+    igraph stand-in is oracle/prpack_port.c, so this pins the igraph call convention (undirected, parallel
+    edges summed, weights, reset as teleport + dangling distribution, gather, ranking) -- and compares
+    the PRPACK port (tol 1e-10) with the exact solve."""
+    t = load(case)
+    index = ref_index(t)
+    for q in range(len(t["qf"])):
+        if t["used_dpr"][q]:
+            continue
+        ids, sc, x = oracle.run_ppr(index, t["reset"][q], float(t["damping"]))
+        np.testing.assert_allclose(sc, t["ppr_scores"][q], rtol=2e-8, atol=1e-13)
+        assert tie_aware_equal(ids, t["ppr_ids"][q], t["ppr_scores"][q], rel_gap=1e-7)
+        ids20, sc20, _ = oracle.run_ppr(index, t["reset"][q], float(t["damping"]), mode="power", iters=20)
+        by_pos = np.empty(len(sc20)); by_pos[ids20] = sc20
+        ref_by_pos = np.empty(len(sc20)); ref_by_pos[t["ppr_ids"][q]] = t["ppr_scores"][q]
+        nz = ref_by_pos > 0
+        assert np.max(np.abs(by_pos[nz] - ref_by_pos[nz]) / ref_by_pos[nz]) < 1e-5      # what 20 sweeps leave
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_end_to_end_matches_reference_retrieve(case):
+    """retrieve() (:413-499) from query embeddings to ranked passages, incl. the filter's subset/reorder
+    and the DPR fallback (:467-469)."""
+    t = load(case)
+    index = ref_index(t)
+    k_out = t["final_ids"].shape[1]
+    n_fallback = 0
+    for q in range(len(t["qf"])):
+        kept = kept_list(t, q)
+        r = oracle.retrieve_one(index, t["qf"][q], t["qp"][q], filter_fn=lambda cand, kept=kept: kept, exact_dot=False)
+        assert r.used_dpr == bool(t["used_dpr"][q])
+        n_fallback += r.used_dpr
+        if not r.used_dpr and seed_cut_is_tied(index, t["fact_scores"][q], kept, int(t["linking_top_k"])):
+            continue
+        want_ids, want_sc = t["final_ids"][q], t["final_scores"][q]
+        n = int((want_ids >= 0).sum())
+        assert n == min(k_out, len(t["passage_vertex"]))
+        np.testing.assert_allclose(r.sorted_doc_scores[:n], want_sc[:n], rtol=3e-6, atol=1e-9)
+        assert tie_aware_equal(r.sorted_doc_ids[:n], want_ids[:n], want_sc[:n], rel_gap=1e-5, abs_gap=1e-12)
+    if case == "synth":
+        assert n_fallback == 3
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_retrieve_dpr_matches_reference(case):
+    t = load(case)
+    for q in range(len(t["qp"])):
+        ids, sc = oracle.retrieve_dpr_one(ref_index(t), t["qp"][q], exact_dot=False)
+        n = int((t["retrieve_dpr_ids"][q] >= 0).sum())
+        np.testing.assert_allclose(sc[:n], t["retrieve_dpr_scores"][q][:n], atol=2e-6)
+        assert tie_aware_equal(ids[:n], t["retrieve_dpr_ids"][q][:n], t["retrieve_dpr_scores"][q][:n], abs_gap=4e-6)
+
+
+def test_product_graph_builder_matches_reference_graph():
+    """hipporag_amd.graph.build_csr on the reference's igraph edge list == the oracle's rules, and the
+    mirror's index_from_openie (strings -> graph) is the reference graph up to vertex renumbering."""
+    from hipporag_amd import HippoRAG
+    from hipporag_amd.graph import build_csr
+    from tests.golden.make_golden import DOCS, TRIPLES, MockEmbeddingModel
+    t = load("toy")
+    v = int(t["num_vertices"])
+    csr = build_csr(v, t["edge_src"], t["edge_dst"], t["edge_w"])
+    p = ref_index(t).p
+    np.testing.assert_array_equal(csr.col_idx, p.indices)
+    np.testing.assert_allclose(csr.val, p.data, rtol=1e-7)
+    # no synonymy edges in the mirror run (they are an explicit input there): compare degrees of passages
+    rag = HippoRAG(embedding_model=MockEmbeddingModel()).index_from_openie(DOCS, TRIPLES)
+    mine = rag._arrays["csr"]
+    assert mine.num_vertices == v
+    deg_ref = np.diff(p.indptr)[t["passage_vertex"]]
+    deg_mine = np.diff(mine.row_ptr)[rag._arrays["passage_vertex"]]
+    by_text_ref = dict(zip(t["passage_texts"].tolist(), deg_ref.tolist()))
+    assert [by_text_ref[d] for d in DOCS] == deg_mine.tolist()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/hipporag"), reason="reference sources not present")
+def test_fixtures_are_reproducible(tmp_path):
+    """Re-runs the reference in a subprocess (PYTHONHASHSEED=0) and compares with the committed fixtures."""
+    code = (
+        "import sys, os, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(GOLD)!r} + '/..'); sys.path.insert(0, {GOLD!r})\n"
+        "import make_ref_golden as m\n"
+        f"m.HERE = {str(tmp_path)!r}\n"
+        "m.main()\n")
+    env = dict(os.environ, PYTHONHASHSEED="0")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, cwd=str(tmp_path),
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    for case in CASES:
+        new = np.load(os.path.join(str(tmp_path), f"ref_{case}.npz"))
+        old = load(case)
+        for key in old.files:
+            if old[key].dtype.kind in "fc":
+                np.testing.assert_allclose(new[key], old[key], rtol=1e-12, atol=0, err_msg=key)
+            else:
+                np.testing.assert_array_equal(new[key], old[key], err_msg=key)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _engine(t, max_batch):
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd.graph import build_csr, float_to_bf16_bits, bf16_bits_to_float
+    csr = build_csr(int(t["num_vertices"]), t["edge_src"], t["edge_dst"], t["edge_w"])
+    fb, pb = float_to_bf16_bits(t["fact_emb"]), float_to_bf16_bits(t["passage_emb"])
+    # the harness' mock model emits bf16-representable vectors: nothing is lost at the boundary
+    assert np.array_equal(bf16_bits_to_float(fb), t["fact_emb"]) and np.array_equal(bf16_bits_to_float(pb), t["passage_emb"])
+    return HippoRAGEngine(csr, t["passage_vertex"], pb, fb, t["subj_vertex"], t["obj_vertex"], t["num_chunks"],
+                          max_batch=max_batch, max_topk=min(200, len(t["passage_vertex"])))
+
+
+def _batches(nq, batching):
+    """Query index lists per device call: everything at once (fp32 slab path), one by one (B = 1
+    latency kernels), or replicated to 40 rows (two-stage fp16-state path, B > 32)."""
+    if batching == "all":
+        return [list(range(nq))]
+    if batching == "one":
+        return [[q] for q in range(nq)]
+    return [[i % nq for i in range(40)]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batching", ["all", "one", "padded40"])
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_retrieve_matches_reference_vectors(gpu_device, case, batching):
+    """hrag_score_facts -> (the reference's filter decisions) -> hrag_retrieve against what the reference's
+    own retrieve() produced: candidate facts, ranked passages, PPR scores, DPR fallback."""
+    import torch
+    t = load(case)
+    nq, k_f = len(t["qf"]), int(t["linking_top_k"])
+    n_p = len(t["passage_vertex"])
+    k_out = min(int((t["final_ids"][0] >= 0).sum()), n_p)
+
+    def bf16(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device).to(torch.bfloat16)
+
+    with _engine(t, 40) as eng:
+        for qs in _batches(nq, batching):
+            b = len(qs)
+            idx, sc = eng.score_facts(bf16(t["qf"][qs]), k=k_f)
+            idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
+            kept_idx = np.full((b, k_f), -1, np.int32); kept_sc = np.zeros((b, k_f), np.float32); kept_n = np.zeros(b, np.int32)
+            for i, q in enumerate(qs):
+                want = [int(j) for j in t["cand_fact_idx"][q] if j >= 0]
+                assert tie_aware_equal(idx_h[i][:len(want)], want, t["fact_scores"][q][want], abs_gap=4e-6), (q, idx_h[i], want)
+                np.testing.assert_allclose(sc_h[i][:len(want)], t["fact_scores"][q][idx_h[i][:len(want)]], atol=3e-6)
+                kept = kept_list(t, q)                      # the reference filter's decision (subset, its order)
+                score_of = {int(j): sc_h[i][p] for p, j in enumerate(idx_h[i]) if j >= 0}
+                kept_idx[i, :len(kept)] = kept
+                kept_sc[i, :len(kept)] = [score_of[j] for j in kept]
+                kept_n[i] = len(kept)
+            out = eng.retrieve(bf16(t["qp"][qs]), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc),
+                               torch.from_numpy(kept_n), link_top_k=k_f, damping=float(t["damping"]),
+                               passage_node_weight=float(t["passage_node_weight"]), ppr_iters=20, k=k_out)
+            d_idx, d_sc, flags = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy(), out.flags.cpu().numpy()
+            for i, q in enumerate(qs):
+                assert bool(flags[i] & 1) == bool(t["used_dpr"][q]) and not (flags[i] & ~1), (q, flags[i])
+                want_ids, want_sc = t["final_ids"][q][:k_out], t["final_scores"][q][:k_out]
+                if t["used_dpr"][q]:
+                    np.testing.assert_allclose(d_sc[i], want_sc, atol=3e-6)
+                    assert tie_aware_equal(d_idx[i], want_ids, want_sc, abs_gap=6e-6), q
+                else:
+                    ref_by_pos = np.empty(n_p); ref_by_pos[t["ppr_ids"][q]] = t["ppr_scores"][q]
+                    want = ref_by_pos[d_idx[i]]
+                    nz = want > 0
+                    assert np.max(np.abs(d_sc[i][nz] - want[nz]) / want[nz]) < 1e-5, q
+                    assert np.all(d_sc[i][~nz] < 1e-12)
+                    assert tie_aware_equal(d_idx[i], want_ids, want_sc, rel_gap=2e-5, abs_gap=1e-12), (q, d_idx[i][:8], want_ids[:8])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_seams_match_reference_vectors(gpu_device, case):
+    """The per-method seams: run_ppr on the reference's reset vectors (hrag_ppr), get_fact_scores /
+    dense_passage_retrieval raw scores (hrag_sim_scores), retrieve_dpr (hrag_dense_retrieve)."""
+    import torch
+    t = load(case)
+    nq, n_p = len(t["qf"]), len(t["passage_vertex"])
+    ppr_q = [q for q in range(nq) if not t["used_dpr"][q]]
+    with _engine(t, 16) as eng:
+        x, flags = eng.ppr(torch.from_numpy(t["reset"][ppr_q].astype(np.float32)), float(t["damping"]), 20)
+        x = x.cpu().numpy()
+        assert np.all(flags.cpu().numpy() == 0)
+        for i, q in enumerate(ppr_q):
+            ref_by_pos = np.empty(n_p); ref_by_pos[t["ppr_ids"][q]] = t["ppr_scores"][q]
+            got = x[i][t["passage_vertex"]]
+            nz = ref_by_pos > 0
+            assert np.max(np.abs(got[nz] - ref_by_pos[nz]) / ref_by_pos[nz]) < 1e-5, q
+            assert tie_aware_equal(np.argsort(got, kind="stable")[::-1], t["ppr_ids"][q], t["ppr_scores"][q], rel_gap=2e-5, abs_gap=1e-12)
+        qf = torch.from_numpy(t["qf"]).to(gpu_device).to(torch.bfloat16)
+        qp = torch.from_numpy(t["qp"]).to(gpu_device).to(torch.bfloat16)
+        fs = eng.sim_scores("facts", qf).cpu().numpy()
+        for q in range(nq):
+            np.testing.assert_allclose(oracle.min_max_normalize(fs[q]), t["fact_scores"][q], atol=3e-6)
+        k = int((t["retrieve_dpr_ids"][0] >= 0).sum())
+        d_idx, d_sc = eng.dense_retrieve(qp, k=k)
+        d_idx, d_sc = d_idx.cpu().numpy(), d_sc.cpu().numpy()
+        for q in range(nq):
+            np.testing.assert_allclose(d_sc[q], t["retrieve_dpr_scores"][q][:k], atol=3e-6)
+            assert tie_aware_equal(d_idx[q], t["retrieve_dpr_ids"][q][:k], t["retrieve_dpr_scores"][q][:k], abs_gap=6e-6)

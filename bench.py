@@ -40,9 +40,10 @@ PPR_ITERS, K_F, K_P, DAMPING, PASSAGE_W = 20, 5, 200, 0.5, 0.05
 
 
 def spmm_algorithmic_bytes(nnz, V, Np, B, state_bytes=4):
-    """CSR once + read x + write y + read the passage-dense teleport term.
-    state_bytes: 4 for the fp32-state kernel, 2 for the fp16-state kernel of the two-stage scheme
-    (the teleport term stays fp32)."""
+    """SURVEY.md 8(d), per sweep of a batch of B vectors: CSR once + read x + write y + read the
+    passage-dense teleport term, `index 4 B, value 4 B, state 4 B`.  That figure (state_bytes=4) is
+    what one PPR iteration of the reference algorithm has to move and is what `roofline.achieved`
+    prices; state_bytes=2 / 1 give the same formula at the width the fp16 / fp8 kernels store."""
     return nnz * 8 + (V + 1) * 4 + 2 * V * B * state_bytes + Np * B * 4
 
 
@@ -184,34 +185,43 @@ def main():
     # dominant kernel: ppr_spmm_kernel, average duration over back-to-back launches (HIP events on
     # the launch stream), algorithmic bytes per launch from SURVEY.md 8(d)
     n_l = args.sweep_launches
-    f16 = phases["slab_width"] == 64 and B > 32     # hrag_retrieve took the two-stage fp16-state path
-    eng.ppr_sweeps(B, 4, DAMPING, main_only=True, f16=f16)
+    f8 = phases["slab_width"] == 128                # hrag_retrieve took the staged fp8-state path
+    f16 = phases["slab_width"] == 64 and B > 32     # ... the two-stage fp16-state path
+    eng.ppr_sweeps(B, 4, DAMPING, main_only=True, f16=f16, f8=f8)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    eng.ppr_sweeps(B, n_l, DAMPING, main_only=True, f16=f16)
+    eng.ppr_sweeps(B, n_l, DAMPING, main_only=True, f16=f16, f8=f8)
     e1.record()
     torch.cuda.synchronize()
     spmm_ms = e0.elapsed_time(e1) / n_l
     e0.record()
-    eng.ppr_sweeps(B, n_l, DAMPING, main_only=False, f16=f16)
+    eng.ppr_sweeps(B, n_l, DAMPING, main_only=False, f16=f16, f8=f8)
     e1.record()
     torch.cuda.synchronize()
     sweep_ms = e0.elapsed_time(e1) / n_l
     nnz = kg.csr.nnz
-    alg = spmm_algorithmic_bytes(nnz, V, kg.n_passages, B, 2 if f16 else 4)
+    sb = 1 if f8 else 2 if f16 else 4
+    # one launch = one sweep (PPR iteration) of the whole batch: SURVEY.md 8(d)'s per-iteration bytes
+    alg = spmm_algorithmic_bytes(nnz, V, kg.n_passages, B, 4)
+    alg_stored = spmm_algorithmic_bytes(nnz, V, kg.n_passages, B, sb)
     achieved = alg / (spmm_ms * 1e-3) / 1e9
     traffic = load_traffic()
-    bc, n_slabs = (64, (B + 63) // 64) if f16 else eng.layout(B)
-    kernel = "ppr16_kernel" if f16 else "ppr_spmm_kernel"
+    bc, n_slabs = (128, (B + 127) // 128) if f8 else (64, (B + 63) // 64) if f16 else eng.layout(B)
+    kernel = "ppr8_kernel" if f8 else "ppr16_kernel" if f16 else "ppr_spmm_kernel"
+    ppr_iter_ms = phases["ppr_ms"] / PPR_ITERS      # all kernels of the PPR stage (boundary sweeps, reduce)
     roofline = {
         "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         # PMC traffic is only meaningful for the workload it was collected on (profiles/pmc_traffic.json)
         "traffic": ((traffic or {}).get(kernel, {}).get("bytes_per_launch")
                     if (traffic or {}).get(kernel, {}).get("workload") == f"{args.config}:B{B}" else None),
-        "algorithmic_bytes_per_launch": alg, "state_bytes": 2 if f16 else 4,
-        "gather_bytes_per_launch": nnz * B * (2 if f16 else 4),
+        "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_definition": "SURVEY 8(d): nnz*8 + (V+1)*4 + 2*V*B*4 + Np*B*4 per PPR iteration",
+        "state_bytes_stored": sb, "algorithmic_bytes_at_stored_state_width": alg_stored,
+        "frac_at_stored_state_width": alg_stored / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "gather_bytes_per_launch": nnz * B * sb,
         "launch_ms": spmm_ms, "sweep_ms_all_kernels": sweep_ms,
+        "ppr_stage_ms_per_iteration": ppr_iter_ms,
+        "frac_whole_ppr_stage": alg / (ppr_iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "launches_timed": n_l, "slab_width": bc, "n_slabs": n_slabs,
         "frac_of_measured_copy_peak_6290": achieved / 6290.0,
     }
@@ -225,7 +235,8 @@ def main():
                    "n_facts": kg.n_facts, "dim": D, "global_batch": B, "ppr_iters": PPR_ITERS,
                    "linking_top_k": K_F, "retrieval_top_k": K_P, "damping": DAMPING,
                    "embedding_dtype": "bf16",
-                   "ppr_state_dtype": "f16 hi + f16 correction (fp32 arithmetic)" if f16 else "f32",
+                   "ppr_state_dtype": ("e4m3 staged corrections + fp32 true residual (fp32 arithmetic)" if f8 else
+                                       "f16 hi + f16 correction (fp32 arithmetic)" if f16 else "f32"),
                    "parallelism": "1gpu"},
         "roofline": roofline,
         "phases_ms": {k: phases[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")},

@@ -13,7 +13,7 @@ HRAG_OK, HRAG_EINVAL, HRAG_ENOMEM, HRAG_EHIP, HRAG_EZERO_RESET, HRAG_ECAPACITY =
 SEED_STRIDE = 32
 FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE = 1, 2, 4
 # hrag_opts.flags (include/hrag.h HRAG_OPT_*)
-OPT_NATURAL_ROW_ORDER, OPT_NT_CSR, OPT_NT_STORE, OPT_F32_STATE, OPT_TEMPORAL16 = 1, 2, 4, 8, 16
+OPT_NATURAL_ROW_ORDER, OPT_NT_CSR, OPT_NT_STORE, OPT_F32_STATE, OPT_TEMPORAL16, OPT_NO_FP8 = 1, 2, 4, 8, 16, 32
 
 
 class HragError(RuntimeError):
@@ -25,7 +25,8 @@ class HragError(RuntimeError):
 class GraphDesc(C.Structure):
     _fields_ = [("num_vertices", C.c_int64), ("row_offset", C.c_int64), ("n_rows", C.c_int64),
                 ("nnz", C.c_int64), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p),
-                ("val", C.c_void_p), ("n_passages", C.c_int64), ("passage_vertex", C.c_void_p)]
+                ("val", C.c_void_p), ("n_passages", C.c_int64), ("passage_vertex", C.c_void_p),
+                ("col_sum", C.c_void_p)]
 
 
 class EmbedDesc(C.Structure):

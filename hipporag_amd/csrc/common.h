@@ -142,6 +142,45 @@ hrag_status launch_ppr16_seed_rows(const int32_t *seed_vtx, const float *seed_w,
                                    int64_t num_vertices, int32_t *row_slot, float *tele,
                                    int64_t tele_rows, int32_t bc, hipStream_t s);
 
+// ppr8.hip : staged fp8 (e4m3) state + fp32 true residual, 128 queries per 128-byte line, same
+// SELL-8 structure with the row-normalised values At = D^-1 A
+enum Ppr8Mode { kP8ModeC = 0, kP8ModeB = 1, kP8ModeF = 2 };
+constexpr int kP8MaxStages = 12;      // stage lengths 1,2,2,2,2,3,3,... => ppr_iters <= 30
+constexpr float kP8C0Scale = 128.f;   // c_0 = Q(v/d * 2^7),  max(v/d) in (1/2, 1]
+struct Ppr8Args {
+    const int2 *pairs;         // (col, fp32 bits of at_ij), step-major per chunk (ppr16.hip layout)
+    uint32_t pairs_bytes;
+    const int2 *chunk_meta;
+    const int32_t *vrow;
+    int32_t n_chunks;
+    const int32_t *lrow_row, *lrow_first, *lrow_cnt;
+    int32_t n_lrow;
+    int32_t n_partial;
+    float *partial;            // [n_slabs][n_partial][128] fp32
+    int64_t num_vertices;
+    const uint8_t *x;          // gather source: e4m3 [n_slabs][V][128]
+    uint8_t *y;                // mode C: the new iterate; mode B: rt of the next stage
+    const uint8_t *rt;         // mode C: the stage's quantised right-hand side
+    float *R;                  // mode B / F: true residual, fp32 [n_slabs][V][128] (B rewrites it)
+    float alpha, inv_cs, cs_next;
+    // mode F
+    const uint8_t *stage[kP8MaxStages];   // final iterate of every stage (incl. the one in x)
+    float stage_inv[kP8MaxStages];
+    int32_t n_stage;
+    const float *deg;          // [V] weighted degree (1 for isolated vertices)
+    float *out;                // fp32 [n_slabs64][V][64]: x = d z
+    int32_t n_slabs64;
+};
+hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, int n_slabs, bool main_only, hipStream_t s);
+hrag_status launch_ppr8_init(const float *tele, int64_t tele_rows, const int32_t *row_slot, const float *deg,
+                             int64_t num_vertices, int n_slabs, int n_slabs64, float beta, float c0_scale,
+                             float *R, uint8_t *c0, hipStream_t s);
+hrag_status launch_ppr8_scale(const float *scores, int64_t ld, int64_t n_passages, const float *mn,
+                              const float *mx, float passage_weight, const float *pinvdeg,
+                              const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
+                              const float *deg, int64_t num_vertices, const int32_t *flags, int32_t batch,
+                              float *qscale, hipStream_t s);
+
 // ppr_sv.hip : small batches (B <= 8), fp32 state [V][BP], same SELL-8 matrix
 struct PprSvArgs {
     const int2 *pairs;

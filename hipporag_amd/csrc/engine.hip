@@ -5,6 +5,7 @@
 // (reference src/hipporag/HippoRAG.py:1287-1389) into device memory once; every compute call
 // afterwards only enqueues kernels on the caller's stream (no allocation, no synchronisation).
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -96,6 +97,14 @@ struct hrag_engine {
     int64_t tele16_rows = 0;
     int32_t *d_row_slot = nullptr;  // [V] per-batch copy of d_row_to_tele with the seed rows patched in
     float *d_qscale = nullptr, *d_ssum = nullptr;
+    // staged fp8 PPR (ppr8.hip): SELL-8 matrix with the row-normalised values, fp32 residual, a pool of
+    // e4m3 state buffers; needs hrag_graph_desc.col_sum, max_batch > 64
+    bool f8_ready = false;
+    int2 *d_pairs8 = nullptr;
+    float *d_deg = nullptr, *d_pinvdeg = nullptr, *d_R8 = nullptr, *d_partial8 = nullptr;
+    static constexpr int kP8Pool = kP8MaxStages + 3;
+    uint8_t *d_pool8[kP8Pool] = {};
+    int64_t state8_bytes = 0;
     // timing
     hipEvent_t ev[EV_COUNT] = {};
     bool profiling = false, have_retrieve_ev = false, have_fact_ev = false;
@@ -134,8 +143,11 @@ void free_engine(hrag_engine *e) {
                     e->d_flags, e->d_seed_w, e->d_colsum_partial, e->d_sums, e->d_pairs, e->d_chunk_meta,
                     e->d_vrow, e->d_lrow_row, e->d_lrow_first, e->d_lrow_cnt, e->d_partial16, e->d_h16[0],
                     e->d_h16[1], e->d_h16[2], e->d_h16[3], e->d_tele16, e->d_row_slot, e->d_qscale,
-                    e->d_ssum, e->d_tele_sv, e->d_partial_sv, e->d_topk_ws};
+                    e->d_ssum, e->d_tele_sv, e->d_partial_sv, e->d_topk_ws, e->d_pairs8, e->d_deg,
+                    e->d_pinvdeg, e->d_R8, e->d_partial8};
     for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (void *p : e->d_pool8)
         if (p) (void)hipFree(p);
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -175,9 +187,11 @@ hrag_status ppr_step(hrag_engine *e, const float *tele, int64_t tele_rows, const
 }
 
 // SELL-8 form of the owned CSR for ppr16.hip (see the header comment there).
+// deg (may be null): weighted degrees; when given, a second pairs array with the row-normalised
+// values at_ij = p_ij d_j / d_i (the degree-scaled iteration of ppr8.hip) is built as well.
 hrag_status build_sell8(hrag_engine *e, const std::vector<int32_t> &row_ptr, const int32_t *col,
-                        const float *val) {
-    struct VRow { int32_t len, begin, target; };
+                        const float *val, const double *deg) {
+    struct VRow { int32_t len, begin, target, row; };
     std::vector<VRow> vr;
     vr.reserve((size_t)e->n_rows + 1024);
     std::vector<int32_t> lrow_row, lrow_first, lrow_cnt;
@@ -185,7 +199,7 @@ hrag_status build_sell8(hrag_engine *e, const std::vector<int32_t> &row_ptr, con
     for (int64_t r = 0; r < e->n_rows; ++r) {
         const int32_t b0 = row_ptr[(size_t)r], deg = row_ptr[(size_t)r + 1] - b0;
         if (deg <= kSell8SegLen) {
-            vr.push_back({deg, b0, (int32_t)r});
+            vr.push_back({deg, b0, (int32_t)r, (int32_t)r});
             continue;
         }
         // at most 64 segments per row, each a multiple of 8 entries
@@ -196,7 +210,7 @@ hrag_status build_sell8(hrag_engine *e, const std::vector<int32_t> &row_ptr, con
         lrow_first.push_back(n_partial);
         lrow_cnt.push_back(nseg);
         for (int32_t i = 0; i < nseg; ++i)
-            vr.push_back({std::min(seg_len, deg - i * seg_len), b0 + i * seg_len, -(n_partial++ + 1)});
+            vr.push_back({std::min(seg_len, deg - i * seg_len), b0 + i * seg_len, -(n_partial++ + 1), (int32_t)r});
     }
     // longest first (stable => deterministic); a chunk = 8 consecutive virtual rows
     std::stable_sort(vr.begin(), vr.end(), [](const VRow &a, const VRow &b) { return a.len > b.len; });
@@ -211,6 +225,7 @@ hrag_status build_sell8(hrag_engine *e, const std::vector<int32_t> &row_ptr, con
     }
     HRAG_REQUIRE((steps + 4) * 512 < (int64_t)0x7fffffff, "graph too large for the SELL-8 buffer range (2 GiB)");
     std::vector<int2> pairs((size_t)(steps + 4) * 64, make_int2(0, 0));  // +4 steps: read-ahead padding
+    std::vector<int2> pairs8(deg ? pairs.size() : 0, make_int2(0, 0));
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int64_t base = (int64_t)meta[(size_t)c].x * 64;
         for (int g = 0; g < 8; ++g) {
@@ -221,7 +236,13 @@ hrag_status build_sell8(hrag_engine *e, const std::vector<int32_t> &row_ptr, con
             for (int32_t i = 0; i < v.len; ++i) {
                 int32_t bits;
                 std::memcpy(&bits, &val[v.begin + i], 4);
-                pairs[(size_t)(base + (int64_t)(i >> 3) * 64 + g * 8 + (i & 7))] = make_int2(col[v.begin + i], bits);
+                const size_t at = (size_t)(base + (int64_t)(i >> 3) * 64 + g * 8 + (i & 7));
+                pairs[at] = make_int2(col[v.begin + i], bits);
+                if (deg) {
+                    const float atv = (float)((double)val[v.begin + i] * deg[col[v.begin + i]] / deg[v.row]);
+                    std::memcpy(&bits, &atv, 4);
+                    pairs8[at] = make_int2(col[v.begin + i], bits);
+                }
             }
         }
     }
@@ -230,6 +251,7 @@ hrag_status build_sell8(hrag_engine *e, const std::vector<int32_t> &row_ptr, con
     e->n_partial16 = n_partial;
     e->sell_steps = steps;
     HRAG_TRY(dev_upload(&e->d_pairs, pairs.data(), (int64_t)pairs.size()));
+    if (deg) HRAG_TRY(dev_upload(&e->d_pairs8, pairs8.data(), (int64_t)pairs8.size()));
     HRAG_TRY(dev_upload(&e->d_chunk_meta, meta.data(), (int64_t)meta.size()));
     HRAG_TRY(dev_upload(&e->d_vrow, vrow.data(), (int64_t)vrow.size()));
     HRAG_TRY(dev_upload(&e->d_lrow_row, lrow_row.data(), (int64_t)lrow_row.size()));
@@ -282,6 +304,79 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
 inline bool use_f16(const hrag_engine *e, int batch, int iters) {
     return e->f16_ready && batch > kSvMaxBatch && iters >= 16;
 }
+inline int n_slabs128(int batch) { return (int)ceil_div(batch, 128); }
+
+// Stage lengths of the fp8 scheme (ppr8.hip): 1 (the quantised start), then 2, 2, 2, 2, 3, 3, ...
+inline int ppr8_plan(int iters, int *plan) {
+    int n = 0, left = iters;
+    plan[n++] = 1; left -= 1;
+    for (int i = 0; i < 4 && left >= 2; ++i) { plan[n++] = 2; left -= 2; }
+    while (left > 0) { const int m = std::min(3, left); plan[n++] = m; left -= m; }
+    return n;
+}
+inline bool use_f8(const hrag_engine *e, int batch, int iters) {
+    return e->f8_ready && batch > 64 && iters >= 16 && iters <= 30;   // <= kP8MaxStages stages
+}
+
+Ppr8Args ppr8_args(const hrag_engine *e, float damping) {
+    Ppr8Args a = {};
+    a.pairs = e->d_pairs8; a.pairs_bytes = (uint32_t)((e->sell_steps + 4) * 512);
+    a.chunk_meta = e->d_chunk_meta; a.vrow = e->d_vrow; a.n_chunks = e->n_chunks;
+    a.lrow_row = e->d_lrow_row; a.lrow_first = e->d_lrow_first; a.lrow_cnt = e->d_lrow_cnt;
+    a.n_lrow = e->n_lrow; a.n_partial = e->n_partial16; a.partial = e->d_partial8;
+    a.num_vertices = e->V; a.R = e->d_R8; a.alpha = damping; a.deg = e->d_deg;
+    return a;
+}
+
+// The staged iteration of ppr8.hip; v comes from d_tele16 / d_row_slot (scaled so that max v/d is in
+// (1/2, 1]); the result x = d z lands in d_x as [n_slabs64][V][64] fp32.
+hrag_status ppr8_run(hrag_engine *e, int batch, float damping, int iters, hipStream_t s) {
+    const int ns = n_slabs128(batch), ns64 = n_slabs64(batch);
+    int plan[kP8MaxStages + 4];
+    const int n_stage = ppr8_plan(iters, plan);
+    HRAG_REQUIRE(n_stage <= kP8MaxStages, "ppr_iters=%d needs %d fp8 stages (max %d)", iters, n_stage, kP8MaxStages);
+    std::vector<uint8_t *> pool(e->d_pool8, e->d_pool8 + hrag_engine::kP8Pool);
+    auto take = [&]() { uint8_t *p = pool.back(); pool.pop_back(); return p; };
+    const uint8_t *stage_buf[kP8MaxStages];
+    float stage_inv[kP8MaxStages];
+    uint8_t *c = take();   // c_0 = Q(v/d * 2^7)
+    HRAG_TRY(launch_ppr8_init(e->d_tele16, e->tele16_rows, e->d_row_slot, e->d_deg, e->V, ns, ns64,
+                              1.0f - damping, kP8C0Scale, e->d_R8, c, s));
+    float cs = kP8C0Scale, cs_next = 2.0f * kP8C0Scale;   // |R_0| <= 0.57 max(v/d): 2^8 maps it to <= 146
+    uint8_t *rt = nullptr;
+    for (int si = 0; si < n_stage; ++si) {
+        const int m = plan[si];
+        if (si > 0) {
+            cs = cs_next;
+            c = rt;
+            for (int j = 1; j < m; ++j) {
+                uint8_t *dst = take();
+                Ppr8Args a = ppr8_args(e, damping);
+                a.x = c; a.y = dst; a.rt = rt;
+                HRAG_TRY(launch_ppr8_sweep(a, kP8ModeC, ns, false, s));
+                if (c != rt) pool.push_back(c);
+                c = dst;
+            }
+            if (c != rt) pool.push_back(rt);
+            cs_next = cs * (float)(1 << m);
+        }
+        stage_buf[si] = c;
+        stage_inv[si] = 1.0f / cs;
+        Ppr8Args a = ppr8_args(e, damping);
+        a.x = c; a.inv_cs = 1.0f / cs; a.cs_next = cs_next;
+        if (si + 1 < n_stage) {
+            rt = take();
+            a.y = rt;
+            HRAG_TRY(launch_ppr8_sweep(a, kP8ModeB, ns, false, s));
+        } else {
+            for (int k = 0; k <= si; ++k) { a.stage[k] = stage_buf[k]; a.stage_inv[k] = stage_inv[k]; }
+            a.n_stage = si + 1; a.out = e->d_x; a.n_slabs64 = ns64;
+            HRAG_TRY(launch_ppr8_sweep(a, kP8ModeF, ns, false, s));
+        }
+    }
+    return HRAG_OK;
+}
+
 inline bool use_sv(const hrag_engine *e, int batch) { return e->sell_ready && batch <= kSvMaxBatch; }
 inline int sv_width(int batch) { return batch <= 1 ? 1 : batch <= 2 ? 2 : batch <= 4 ? 4 : 8; }
 
@@ -429,7 +524,53 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
             E_HIP(hipMemcpy(h_col.data(), g->col_idx, h_col.size() * sizeof(int32_t), hipMemcpyDefault));
             E_HIP(hipMemcpy(h_val.data(), g->val, h_val.size() * sizeof(float), hipMemcpyDefault));
         }
-        E_TRY(build_sell8(e, h_row_ptr, h_col.data(), h_val.data()));
+        // staged fp8 path (ppr8.hip): needs the weighted degrees the caller normalised P with
+        std::vector<double> h_deg;
+        const bool want_f8 = want_f16 && opts->max_batch > 64 && g->col_sum && !(opts->flags & HRAG_OPT_NO_FP8);
+        if (want_f8) {
+            h_deg.resize((size_t)e->V);
+            E_HIP(hipMemcpy(h_deg.data(), g->col_sum, h_deg.size() * sizeof(double), hipMemcpyDefault));
+            for (auto &d : h_deg) {
+                if (!(d >= 0.0) || !(d < 1e300)) {
+                    set_error("col_sum must be finite and >= 0");
+                    free_engine(e);
+                    return HRAG_EINVAL;
+                }
+                if (d == 0.0) d = 1.0;   // isolated vertex: no entries, z = x
+            }
+            // P d = d must hold (P = A D^-1 with A symmetric): it makes At = D^-1 P D row-stochastic,
+            // which is what keeps the static fp8 scales of ppr8.hip valid
+            double worst = 0.0;
+            for (int64_t r = 0; r < e->n_rows; ++r) {
+                double acc = 0.0;
+                for (int32_t k = h_row_ptr[(size_t)r]; k < h_row_ptr[(size_t)r + 1]; ++k)
+                    acc += (double)h_val[(size_t)k] * h_deg[(size_t)h_col[(size_t)k]];
+                if (h_row_ptr[(size_t)r + 1] > h_row_ptr[(size_t)r])
+                    worst = std::max(worst, std::fabs(acc / h_deg[(size_t)r] - 1.0));
+            }
+            if (worst > 1e-3) {
+                set_error("col_sum is not the weighted degree of a symmetric adjacency: max |sum_j P_ij d_j / d_i - 1| = %.3g",
+                          worst);
+                free_engine(e);
+                return HRAG_EINVAL;
+            }
+        }
+        E_TRY(build_sell8(e, h_row_ptr, h_col.data(), h_val.data(), want_f8 ? h_deg.data() : nullptr));
+        if (want_f8) {
+            std::vector<float> f_deg((size_t)e->V);
+            for (int64_t i = 0; i < e->V; ++i) f_deg[(size_t)i] = (float)h_deg[(size_t)i];
+            E_TRY(dev_upload(&e->d_deg, f_deg.data(), e->V));
+            std::vector<int32_t> h_pv((size_t)e->n_passages);
+            if (e->n_passages)
+                E_HIP(hipMemcpy(h_pv.data(), g->passage_vertex, h_pv.size() * sizeof(int32_t), hipMemcpyDefault));
+            std::vector<float> pinv((size_t)e->n_passages);
+            for (int64_t q = 0; q < e->n_passages; ++q) {
+                const int64_t v = h_pv[(size_t)q];
+                pinv[(size_t)q] = (v >= 0 && v < e->V) ? 1.0f / f_deg[(size_t)v] : 0.f;
+            }
+            E_TRY(dev_upload(&e->d_pinvdeg, pinv.data(), e->n_passages));
+            e->f8_ready = true;   // buffers follow with the workspace
+        }
     }
     // ---- passages: vertex map and its inverse on the owned rows
     {
@@ -485,6 +626,16 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         for (auto &p : e->d_h16) E_HIP(hipMemset(p, 0, (size_t)e->state16_elems * sizeof(uint16_t)));
         E_HIP(hipMemset(e->d_tele16, 0, (size_t)ns * e->tele16_rows * 64 * sizeof(float)));
         e->f16_ready = true;
+    }
+    if (e->f8_ready) {
+        const int ns = n_slabs128(B);
+        e->state8_bytes = (int64_t)ns * e->V * 128;
+        for (auto &p : e->d_pool8) {
+            E_TRY(dev_alloc(&p, e->state8_bytes));
+            E_HIP(hipMemset(p, 0, (size_t)e->state8_bytes));
+        }
+        E_TRY(dev_alloc(&e->d_R8, e->state8_bytes));
+        E_TRY(dev_alloc(&e->d_partial8, (int64_t)ns * std::max(e->n_partial16, 1) * 128));
     }
     E_TRY(dev_alloc(&e->d_partial, (int64_t)(round_up(B, 4) + 64) * std::max(e->n_partial, 1)));
     E_TRY(dev_alloc(&e->d_x, e->state_elems));
@@ -688,10 +839,11 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     HRAG_REQUIRE(e->n_passages >= 1, "engine has no passages");
     hipStream_t s = (hipStream_t)stream;
     const bool sv = use_sv(e, batch);
-    const bool f16 = !sv && use_f16(e, batch, ppr_iters);
+    const bool f8 = !sv && use_f8(e, batch, ppr_iters);
+    const bool f16 = !sv && !f8 && use_f16(e, batch, ppr_iters);
     const int bp = sv_width(batch);
     SlabLayout lay = e->layout(batch);
-    if (f16) { lay.bc = 64; lay.n_slabs = n_slabs64(batch); }
+    if (f16 || f8) { lay.bc = 64; lay.n_slabs = n_slabs64(batch); }
     if (sv) { lay.bc = bp; lay.n_slabs = 1; }
     const bool prof = e->profiling;
 
@@ -700,16 +852,22 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     // dense_passage_retrieval: raw scores + min / max (HippoRAG.py:1496-1498)
     HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s));
     HRAG_TRY(launch_row_minmax(e->d_spass, batch, e->n_passages, e->ld_p, e->d_mn_p, e->d_mx_p, s,
-                               f16 ? e->d_ssum : nullptr));
+                               (f16 || f8) ? e->d_ssum : nullptr));
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SIM], s));
     // reset vector: entity seeds + passage prior (HippoRAG.py:1574-1638)
     HRAG_TRY(hrag_stage_seeds(e, kept_idx, kept_score, kept_count, kf, link_top_k, batch, e->d_seed_vtx,
                               e->d_seed_w, e->d_seed_cnt, e->d_flags, stream));
-    if (f16) {
-        // v is scaled per query by a power of two so that every iterate fits fp16 (ppr16.hip); the
-        // seeds become extra teleport rows, i.e. v is one array that every sweep reads identically
-        HRAG_TRY(launch_ppr16_scale(e->d_mn_p, e->d_mx_p, e->d_ssum, e->n_passages, passage_node_weight,
-                                    e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, e->d_qscale, s));
+    if (f16 || f8) {
+        // v is scaled per query by a power of two -- so that every iterate fits fp16 (ppr16.hip), or so
+        // that max v/d is in (1/2, 1] (ppr8.hip); the seeds become extra teleport rows, i.e. v is one
+        // array that every sweep (ppr16) / the init kernel (ppr8) reads identically
+        if (f8)
+            HRAG_TRY(launch_ppr8_scale(e->d_spass, e->ld_p, e->n_passages, e->d_mn_p, e->d_mx_p,
+                                       passage_node_weight, e->d_pinvdeg, e->d_seed_vtx, e->d_seed_w,
+                                       e->d_seed_cnt, e->d_deg, e->V, e->d_flags, batch, e->d_qscale, s));
+        else
+            HRAG_TRY(launch_ppr16_scale(e->d_mn_p, e->d_mx_p, e->d_ssum, e->n_passages, passage_node_weight,
+                                        e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, e->d_qscale, s));
         HRAG_TRY(launch_rows_to_slab(e->d_spass, e->ld_p, e->n_passages, batch, kMinMaxScale, e->d_mn_p,
                                      e->d_mx_p, passage_node_weight, e->d_flags, e->d_tele16, lay, s,
                                      e->tele16_rows, e->d_qscale));
@@ -736,7 +894,9 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     }
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SEED], s));
     // PPR (HippoRAG.py:1736-1743): fixed-count leaky power iteration
-    if (f16) {
+    if (f8) {
+        HRAG_TRY(ppr8_run(e, batch, damping, ppr_iters, s));
+    } else if (f16) {
         HRAG_TRY(ppr16_run(e, batch, damping, ppr_iters, s));
     } else if (sv) {
         HRAG_TRY(ppr_sv_run(e, e->d_row_slot, e->d_tele_sv, bp, damping, ppr_iters, s));
@@ -775,7 +935,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     }
     e->last.ppr_iters = ppr_iters;
     e->last.n_slabs = lay.n_slabs;
-    e->last.slab_width = lay.bc;
+    e->last.slab_width = f8 ? 128 : lay.bc;
     return HRAG_OK;
 }
 
@@ -846,6 +1006,17 @@ hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damp
             std::swap(x, y);
         }
         if (x != e->d_x) std::swap(e->d_x, e->d_y);
+        return HRAG_OK;
+    }
+    if (flags & 8) {   // fp8 mode-C sweeps over the pool buffers left by the last hrag_retrieve
+        HRAG_REQUIRE(e->f8_ready && batch > 64, "engine has no fp8 PPR state (needs col_sum, max_batch > 64)");
+        uint8_t *c = e->d_pool8[0], *cn = e->d_pool8[1];
+        for (int it = 0; it < n; ++it) {
+            Ppr8Args a = ppr8_args(e, damping);
+            a.x = c; a.y = cn; a.rt = e->d_pool8[2];
+            HRAG_TRY(launch_ppr8_sweep(a, kP8ModeC, n_slabs128(batch), (flags & 1) != 0, (hipStream_t)stream));
+            std::swap(c, cn);
+        }
         return HRAG_OK;
     }
     if (flags & 2) {

@@ -92,11 +92,18 @@ class HippoRAGEngine:
         col_idx = np.ascontiguousarray(graph.col_idx, dtype=np.int32)
         val = np.ascontiguousarray(graph.val, dtype=np.float32)
         n_rows = row_ptr.shape[0] - 1
+        # weighted degrees (optional): enable the fp8-state PPR for batches > 64 (csrc/ppr8.hip)
+        col_sum = getattr(graph, "col_sum", None)
+        if col_sum is not None:
+            col_sum = np.ascontiguousarray(col_sum, dtype=np.float64)
+            if col_sum.shape[0] != graph.num_vertices:
+                raise ValueError("col_sum must have one entry per vertex")
         gd = GraphDesc(graph.num_vertices, row_offset, n_rows, col_idx.shape[0], _ptr(row_ptr),
-                       _ptr(col_idx), _ptr(val), self.n_passages, _ptr(pv))
+                       _ptr(col_idx), _ptr(val), self.n_passages, _ptr(pv),
+                       _ptr(col_sum) if col_sum is not None else None)
         pd = EmbedDesc(p_rows, passage_offset, dim, 0, _ptr(p_obj))
         fdesc = fd = None
-        keep = [pv, p_obj, row_ptr, col_idx, val]
+        keep = [pv, p_obj, row_ptr, col_idx, val, col_sum]
         self.n_facts = 0
         if fact_emb is not None:
             f_obj, f_rows, f_dim = _as_bf16_bits(fact_emb)
@@ -240,10 +247,10 @@ class HippoRAGEngine:
         return x, flags
 
     def ppr_sweeps(self, batch: int, n: int, damping: float = 0.5, main_only: bool = False,
-                   f16: bool = False, small: bool = False):
-        """Measurement hook: n sweeps of the fp32 slab kernel, of the fp16-state kernel (f16=True) or
-        of the small-batch kernel (small=True, batch <= 8)."""
-        flags = (1 if main_only else 0) | (2 if f16 else 0) | (4 if small else 0)
+                   f16: bool = False, small: bool = False, f8: bool = False):
+        """Measurement hook: n sweeps of the fp32 slab kernel, of the fp16-state kernel (f16=True), of
+        the small-batch kernel (small=True, batch <= 8) or of the fp8-state kernel (f8=True, mode C)."""
+        flags = (1 if main_only else 0) | (2 if f16 else 0) | (4 if small else 0) | (8 if f8 else 0)
         check(self._lib.hrag_ppr_sweeps(self._handle, batch, n, damping, flags, _stream()))
 
 

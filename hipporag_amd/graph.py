@@ -29,6 +29,7 @@ class CSRGraph:
     col_idx: np.ndarray   # int32 [nnz]
     val: np.ndarray       # fp32  [nnz]  column-normalised
     raw: np.ndarray       # fp64  [nnz]  summed adjacency weights A[i,j] (before normalisation)
+    col_sum: "np.ndarray | None" = None   # fp64 [V] weighted degree sum_i A[i,j] (hrag_graph_desc.col_sum)
 
     @property
     def nnz(self) -> int:
@@ -38,7 +39,7 @@ class CSRGraph:
         """Row shard [lo, hi) with global column ids (multi-GPU row sharding)."""
         a, b = int(self.row_ptr[lo]), int(self.row_ptr[hi])
         return CSRGraph(self.num_vertices, (self.row_ptr[lo:hi + 1] - a).astype(np.int32),
-                        self.col_idx[a:b], self.val[a:b], self.raw[a:b])
+                        self.col_idx[a:b], self.val[a:b], self.raw[a:b], self.col_sum)
 
 
 def build_csr(num_vertices: int, src, dst, weight) -> CSRGraph:
@@ -74,7 +75,8 @@ def build_csr(num_vertices: int, src, dst, weight) -> CSRGraph:
     counts = np.bincount(urows, minlength=num_vertices)
     row_ptr = np.zeros(num_vertices + 1, dtype=np.int64)
     np.cumsum(counts, out=row_ptr[1:])
-    return CSRGraph(int(num_vertices), row_ptr.astype(np.int32), ucols.astype(np.int32), val, merged)
+    return CSRGraph(int(num_vertices), row_ptr.astype(np.int32), ucols.astype(np.int32), val, merged,
+                    colsum.astype(np.float64))
 
 
 def float_to_bf16_bits(x: np.ndarray) -> np.ndarray:

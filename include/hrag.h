@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define HRAG_VERSION_MAJOR 0
-#define HRAG_VERSION_MINOR 1
+#define HRAG_VERSION_MINOR 2
 
 typedef enum hrag_status {
     HRAG_OK = 0,
@@ -64,6 +64,10 @@ typedef struct hrag_graph_desc {
     const float *val;              /* [nnz]                                                  */
     int64_t n_passages;            /* Np (global number of passages)                         */
     const int32_t *passage_vertex; /* [Np] vertex id of passage p (passage_node_idxs, :1333) */
+    const double *col_sum;         /* [V] optional (may be NULL): sum_i A[i][j], the weighted degree   */
+                                   /* each column was normalised with (0 for a vertex without edges). */
+                                   /* Enables the fp8-state PPR for batches > 64 (csrc/ppr8.hip), which */
+                                   /* iterates in the degree-scaled variable x / col_sum.             */
 } hrag_graph_desc;
 
 typedef enum hrag_dtype { HRAG_BF16 = 0 } hrag_dtype;
@@ -98,6 +102,9 @@ typedef struct hrag_fact_desc {
                                      /* small-batch kernels (batch <= 8); same 1e-5 parity bar          */
 #define HRAG_OPT_TEMPORAL16 16       /* fp16-state kernels: plain instead of non-temporal (col, val)   */
                                      /* loads and state stores (non-temporal is 3 % faster at cfg 3)   */
+
+#define HRAG_OPT_NO_FP8 32           /* never take the fp8-state PPR (batch > 64, 16 <= ppr_iters <= 30,  */
+                                     /* col_sum given); the fp16 two-stage path serves those batches    */
 
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */
@@ -210,7 +217,9 @@ hrag_status hrag_sim_gemm(const uint16_t *emb_dev, int64_t rows, int32_t dim, co
  * flags bit0: main CSR kernel only (skip the long-row and seed kernels);
  * flags bit1: the fp16-state kernel of the two-stage scheme (mode H) instead of the fp32 one
  *             (HRAG_EINVAL when the engine has no fp16 state: sharded, max_batch <= 8, F32_STATE);
- * flags bit2: the small-batch kernel (batch <= 8, state fp32 [V][1|2|4|8]). */
+ * flags bit2: the small-batch kernel (batch <= 8, state fp32 [V][1|2|4|8]);
+ * flags bit3: the fp8-state kernel (mode C) over the buffers of the last hrag_retrieve
+ *             (HRAG_EINVAL without col_sum / max_batch <= 64 / batch <= 64). */
 hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damping, int32_t flags,
                             hrag_stream stream);
 

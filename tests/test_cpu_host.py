@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hrag_version() == 1            # 0 * 1000 + 1
+    assert lib.hrag_version() == 2            # 0 * 1000 + 2 (hrag_graph_desc.col_sum)
 
 
 def test_product_csr_builder_matches_oracle():
@@ -37,6 +37,7 @@ def test_product_csr_builder_matches_oracle():
     np.testing.assert_array_equal(g.col_idx, p.indices)
     np.testing.assert_allclose(g.val, p.data, rtol=1e-7)
     np.testing.assert_allclose(g.raw, a.data, rtol=1e-14)
+    np.testing.assert_allclose(g.col_sum, np.asarray(a.sum(axis=0)).ravel(), rtol=1e-13)   # weighted degrees
     # column-stochastic (dangling columns aside)
     colsum = np.bincount(g.col_idx, weights=g.val.astype(np.float64), minlength=g.num_vertices)
     assert np.allclose(colsum[colsum > 0], 1.0, atol=1e-5)

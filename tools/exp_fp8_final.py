@@ -1,0 +1,89 @@
+"""Numerics experiment (CPU, not product code): the staged fp8 (e4m3) PPR exactly as csrc/ppr8.hip
+runs it -- degree-scaled space, stage 0 = quantised v/d (mass-matched start), static power-of-two
+scales, fp32 true residual, final flush -- against the exact fp64 solution.
+
+    python tools/exp_fp8_final.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import oracle  # noqa: E402
+from exp_fp8_zspace import graphs, q8  # noqa: E402
+
+
+def plan_for(iters):
+    """stage lengths: [1] + four 2-sweep stages + 3-sweep stages (remainder last)"""
+    plan, left = [1], iters - 1
+    for _ in range(4):
+        if left >= 2:
+            plan.append(2); left -= 2
+    while left > 0:
+        m = min(3, left)
+        plan.append(m); left -= m
+    return plan
+
+
+def ppr8(at32, d1, v, alpha, plan):
+    al, be = np.float32(alpha), np.float32(1 - alpha)
+    zv = (v / d1[:, None])
+    s0 = zv.max(axis=0)
+    qs = np.exp2(-np.ceil(np.log2(np.maximum(s0, 1e-300))))
+    zv = (zv * qs).astype(np.float32)                      # max in (0.5, 1]
+    R = be * zv
+    c = q8(zv * np.float32(128.0)); inv = np.float32(1 / 128.0)
+    X = np.zeros_like(zv, dtype=np.float64)
+    cs_next = np.float32(256.0)
+    for si, m in enumerate(plan):
+        if si > 0:
+            cs = cs_next
+            inv = np.float32(1.0) / cs
+            rt = q8(R * cs)
+            c = rt
+            for _ in range(m - 1):
+                c = q8(al * (at32 @ c) + rt)
+            cs_next = cs * np.float32(2.0 ** m)
+        R = (R + (al * (at32 @ c) - c) * inv).astype(np.float32)
+        X = X + c.astype(np.float64) * inv
+    z = X + R
+    x = z * d1[:, None]
+    return x / x.sum(0)
+
+
+def main():
+    rng = np.random.default_rng(5)
+    B = 16
+    for name, (a, pv) in graphs().items():
+        a = a.tocsr().astype(np.float64)
+        n = a.shape[0]
+        d = np.asarray(a.sum(axis=0)).ravel()
+        d1 = np.where(d > 0, d, 1.0)
+        p = oracle.column_normalize(a)
+        at32 = (sp.diags(1.0 / d1) @ a).tocsr().astype(np.float32)
+        v = np.zeros((n, B))
+        for q in range(B):
+            pr = rng.standard_normal(len(pv)).astype(np.float32)
+            pr = (pr - pr.min()) / (pr.max() - pr.min())
+            v[pv, q] = pr * np.float32(0.05)
+            seeds = rng.choice(n, 5, replace=False)
+            v[seeds, q] += rng.random(5) * (1.0 if q % 2 == 0 else 1e-3)
+        xe = np.stack([oracle.ppr_exact(p, v[:, q], 0.5) for q in range(B)], 1)
+        line = f"{name:22s}"
+        for iters in (16, 20, 24):
+            xp = np.stack([oracle.ppr_power(p, v[:, q], 0.5, iters) for q in range(B)], 1)
+            x8 = ppr8(at32, d1, v, 0.5, plan_for(iters))
+            line += f" | K={iters} power {np.abs(xp[pv] / xe[pv] - 1).max():.1e} fp8 {np.abs(x8[pv] / xe[pv] - 1).max():.1e}"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()

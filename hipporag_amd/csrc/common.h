@@ -145,7 +145,7 @@ hrag_status launch_ppr16_seed_rows(const int32_t *seed_vtx, const float *seed_w,
 // ppr8.hip : staged fp8 (e4m3) state + fp32 true residual, 128 queries per 128-byte line, same
 // SELL-8 structure with the row-normalised values At = D^-1 A
 enum Ppr8Mode { kP8ModeC = 0, kP8ModeB = 1, kP8ModeF = 2 };
-constexpr int kP8MaxStages = 12;      // stage lengths 1,2,2,2,2,3,3,... => ppr_iters <= 30
+constexpr int kP8MaxStages = 12;      // stage lengths 1,2,2,3,3,3,... => 12 stages cover ppr_iters <= 32
 constexpr float kP8C0Scale = 128.f;   // c_0 = Q(v/d * 2^7),  max(v/d) in (1/2, 1]
 struct Ppr8Args {
     const int2 *pairs;         // (col, fp32 bits of at_ij), step-major per chunk (ppr16.hip layout)
@@ -179,7 +179,7 @@ hrag_status launch_ppr8_scale(const float *scores, int64_t ld, int64_t n_passage
                               const float *mx, float passage_weight, const float *pinvdeg,
                               const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
                               const float *deg, int64_t num_vertices, const int32_t *flags, int32_t batch,
-                              float *qscale, hipStream_t s);
+                              int32_t *zmax_bits, float *qscale, hipStream_t s);
 
 // ppr_sv.hip : small batches (B <= 8), fp32 state [V][BP], same SELL-8 matrix
 struct PprSvArgs {

@@ -306,11 +306,12 @@ inline bool use_f16(const hrag_engine *e, int batch, int iters) {
 }
 inline int n_slabs128(int batch) { return (int)ceil_div(batch, 128); }
 
-// Stage lengths of the fp8 scheme (ppr8.hip): 1 (the quantised start), then 2, 2, 2, 2, 3, 3, ...
+// Stage lengths of the fp8 scheme (ppr8.hip): 1 (the quantised start), then 2, 2, 3, 3, 3, ...
+// (tools/exp_fp8_final.py: as accurate as 1,2,2,2,2,3,3,3,2 with one boundary sweep fewer at 20)
 inline int ppr8_plan(int iters, int *plan) {
     int n = 0, left = iters;
     plan[n++] = 1; left -= 1;
-    for (int i = 0; i < 4 && left >= 2; ++i) { plan[n++] = 2; left -= 2; }
+    for (int i = 0; i < 2 && left >= 2; ++i) { plan[n++] = 2; left -= 2; }
     while (left > 0) { const int m = std::min(3, left); plan[n++] = m; left -= m; }
     return n;
 }
@@ -342,7 +343,19 @@ hrag_status ppr8_run(hrag_engine *e, int batch, float damping, int iters, hipStr
     uint8_t *c = take();   // c_0 = Q(v/d * 2^7)
     HRAG_TRY(launch_ppr8_init(e->d_tele16, e->tele16_rows, e->d_row_slot, e->d_deg, e->V, ns, ns64,
                               1.0f - damping, kP8C0Scale, e->d_R8, c, s));
-    float cs = kP8C0Scale, cs_next = 2.0f * kP8C0Scale;   // |R_0| <= 0.57 max(v/d): 2^8 maps it to <= 146
+    // static scales: the max-norm of the true residual contracts by `damping` per sweep (At is row-
+    // stochastic), |R_0| <= max(a, 1 - a) max(v/d) + the rounding of c_0; a stage of m sweeps grows its
+    // iterate by at most (1 - a^m) / (1 - a).  cs = the power of two that maps that bound to <= 224
+    // (half the e4m3 range: the bound ignores rounding noise, and the conversion saturates anyway).
+    const double al = (double)damping;
+    double bound = std::max(al, 1.0 - al) + 0.07;
+    auto scale_for = [&](int m) {
+        const double growth = al < 1.0 ? (1.0 - std::pow(al, m)) / (1.0 - al) : (double)m;
+        int ex = (int)std::floor(std::log2(224.0 / (bound * std::max(growth, 1.0))));
+        ex = std::min(std::max(ex, -60), 60);
+        return std::ldexp(1.0f, ex);
+    };
+    float cs = kP8C0Scale, cs_next = n_stage > 1 ? scale_for(plan[1]) : 1.0f;
     uint8_t *rt = nullptr;
     for (int si = 0; si < n_stage; ++si) {
         const int m = plan[si];
@@ -358,7 +371,8 @@ hrag_status ppr8_run(hrag_engine *e, int batch, float damping, int iters, hipStr
                 c = dst;
             }
             if (c != rt) pool.push_back(rt);
-            cs_next = cs * (float)(1 << m);
+            bound *= std::pow(al, m);
+            cs_next = si + 1 < n_stage ? scale_for(plan[si + 1]) : 1.0f;
         }
         stage_buf[si] = c;
         stage_inv[si] = 1.0f / cs;
@@ -852,7 +866,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     // dense_passage_retrieval: raw scores + min / max (HippoRAG.py:1496-1498)
     HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s));
     HRAG_TRY(launch_row_minmax(e->d_spass, batch, e->n_passages, e->ld_p, e->d_mn_p, e->d_mx_p, s,
-                               (f16 || f8) ? e->d_ssum : nullptr));
+                               f16 ? e->d_ssum : nullptr));   // fp8 path: d_ssum is the z-max scratch
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SIM], s));
     // reset vector: entity seeds + passage prior (HippoRAG.py:1574-1638)
     HRAG_TRY(hrag_stage_seeds(e, kept_idx, kept_score, kept_count, kf, link_top_k, batch, e->d_seed_vtx,
@@ -864,7 +878,8 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
         if (f8)
             HRAG_TRY(launch_ppr8_scale(e->d_spass, e->ld_p, e->n_passages, e->d_mn_p, e->d_mx_p,
                                        passage_node_weight, e->d_pinvdeg, e->d_seed_vtx, e->d_seed_w,
-                                       e->d_seed_cnt, e->d_deg, e->V, e->d_flags, batch, e->d_qscale, s));
+                                       e->d_seed_cnt, e->d_deg, e->V, e->d_flags, batch,
+                                       reinterpret_cast<int32_t *>(e->d_ssum), e->d_qscale, s));
         else
             HRAG_TRY(launch_ppr16_scale(e->d_mn_p, e->d_mx_p, e->d_ssum, e->n_passages, passage_node_weight,
                                         e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, e->d_qscale, s));

@@ -28,7 +28,7 @@
 // Every gather sweep is one of the `ppr_iters` iterations: X_0 = v/d costs none, stage s of m_s
 // sweeps advances the exact iteration by m_s applications of (a At . + b v/d) up to the fp8
 // rounding of that stage, which the NEXT boundary measures exactly and hands to the next stage.
-// Stages: 1, 2, 2, 2, 2, 3, 3, ... (short first: that is where the residual is large).  Measured
+// Stages: 1, 2, 2, 3, 3, 3, ... (short first: that is where the residual is large).  Measured
 // (tools/exp_fp8_final.py): max relative error over all passages 2.6e-7 at 20 sweeps on the
 // benchmark graph -- the level of the fp32 iteration -- and within 3x of the plain 20-sweep
 // iteration on slowly mixing graphs (ring, stars) whose own truncation error is the larger term.
@@ -310,23 +310,22 @@ __global__ __launch_bounds__(256) void ppr8_init_kernel(const float *__restrict_
 
 // Per-query power-of-two scale s_q with  max_i v_i / d_i * s_q  in (1/2, 1]:
 //   bound_q = passage_weight * max_p minmax(score_qp) / d_p  +  max_j seed_w / d(seed_j)
-// (the sum of the two maxima covers a seed that is also a passage vertex).  One workgroup per query.
-__global__ __launch_bounds__(256) void ppr8_scale_kernel(const float *__restrict__ scores, int64_t ld,
-                                                         int64_t n_passages, const float *__restrict__ mn,
-                                                         const float *__restrict__ mx, float passage_weight,
-                                                         const float *__restrict__ pinvdeg,
-                                                         const int32_t *__restrict__ seed_vtx,
-                                                         const float *__restrict__ seed_w,
-                                                         const int32_t *__restrict__ seed_cnt,
-                                                         const float *__restrict__ deg, int64_t num_vertices,
-                                                         const int32_t *__restrict__ flags, float *qscale) {
+// (the sum of the two maxima covers a seed that is also a passage vertex).
+// Pass 1: grid (kScaleSplit, B) partial maxima, combined with an integer atomicMax on the bits of the
+// non-negative floats (order-preserving, so the result does not depend on the arrival order).
+constexpr int kScaleSplit = 16;
+__global__ __launch_bounds__(256) void ppr8_zmax_kernel(const float *__restrict__ scores, int64_t ld,
+                                                        int64_t n_passages, const float *__restrict__ mn,
+                                                        const float *__restrict__ mx,
+                                                        const float *__restrict__ pinvdeg,
+                                                        const int32_t *__restrict__ flags, int32_t *zmax_bits) {
     __shared__ float red[256];
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int q = blockIdx.y, tid = threadIdx.x;
     float best = 0.f;
     if (!(flags[q] & 1)) {
         const float lo = mn[q], range = mx[q] - mn[q];
         const float *row = scores + (size_t)q * ld;
-        for (int64_t p = tid; p < n_passages; p += 256) {
+        for (int64_t p = (int64_t)blockIdx.x * 256 + tid; p < n_passages; p += (int64_t)kScaleSplit * 256) {
             const float nrm = range == 0.f ? 1.f : __fdiv_rn(row[p] - lo, range);
             best = fmaxf(best, nrm * pinvdeg[p]);
         }
@@ -337,27 +336,35 @@ __global__ __launch_bounds__(256) void ppr8_scale_kernel(const float *__restrict
         if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
         __syncthreads();
     }
-    if (tid == 0) {
-        float bound = 0.f;
-        if (!(flags[q] & 1)) {
-            bound = fmaxf(passage_weight, 0.f) * red[0];
-            float sb = 0.f;
-            for (int j = 0; j < seed_cnt[q]; ++j) {
-                const int64_t v = seed_vtx[q * kMaxSeeds + j];
-                if (v >= 0 && v < num_vertices) sb = fmaxf(sb, __fdiv_rn(fmaxf(seed_w[q * kMaxSeeds + j], 0.f), deg[v]));
-            }
-            bound += sb;
+    if (tid == 0) atomicMax(&zmax_bits[q], __float_as_int(fmaxf(red[0], 0.f)));
+}
+
+__global__ void ppr8_scale_kernel(const int32_t *__restrict__ zmax_bits, float passage_weight,
+                                  const int32_t *__restrict__ seed_vtx, const float *__restrict__ seed_w,
+                                  const int32_t *__restrict__ seed_cnt, const float *__restrict__ deg,
+                                  int64_t num_vertices, const int32_t *__restrict__ flags, int32_t batch,
+                                  float *qscale) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= batch) return;
+    float bound = 0.f;
+    if (!(flags[q] & 1)) {
+        bound = fmaxf(passage_weight, 0.f) * __int_as_float(zmax_bits[q]);
+        float sb = 0.f;
+        for (int j = 0; j < seed_cnt[q]; ++j) {
+            const int64_t v = seed_vtx[q * kMaxSeeds + j];
+            if (v >= 0 && v < num_vertices) sb = fmaxf(sb, __fdiv_rn(fmaxf(seed_w[q * kMaxSeeds + j], 0.f), deg[v]));
         }
-        float s = 1.f;
-        if (bound > 0.f && bound < 3e38f) {
-            int ex;
-            const float m = frexpf(bound, &ex);    // bound = m * 2^ex, m in [0.5, 1)
-            if (m == 0.5f) ex -= 1;                // exact power of two: bound * 2^-(ex-1) = 1
-            ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
-            s = ldexpf(1.f, -ex);
-        }
-        qscale[q] = s;
+        bound += sb;
     }
+    float s = 1.f;
+    if (bound > 0.f && bound < 3e38f) {
+        int ex;
+        const float m = frexpf(bound, &ex);    // bound = m * 2^ex, m in [0.5, 1)
+        if (m == 0.5f) ex -= 1;                // exact power of two: bound * 2^-(ex-1) = 1
+        ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+        s = ldexpf(1.f, -ex);
+    }
+    qscale[q] = s;
 }
 
 template <int MODE>
@@ -400,9 +407,15 @@ hrag_status launch_ppr8_scale(const float *scores, int64_t ld, int64_t n_passage
                               const float *mx, float passage_weight, const float *pinvdeg,
                               const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
                               const float *deg, int64_t num_vertices, const int32_t *flags, int32_t batch,
-                              float *qscale, hipStream_t s) {
-    hipLaunchKernelGGL(ppr8_scale_kernel, dim3((unsigned)batch), dim3(256), 0, s, scores, ld, n_passages, mn,
-                       mx, passage_weight, pinvdeg, seed_vtx, seed_w, seed_cnt, deg, num_vertices, flags, qscale);
+                              int32_t *zmax_bits, float *qscale, hipStream_t s) {
+    HRAG_HIP_TRY(hipMemsetAsync(zmax_bits, 0, (size_t)batch * sizeof(int32_t), s));
+    if (n_passages > 0) {
+        hipLaunchKernelGGL(ppr8_zmax_kernel, dim3(kScaleSplit, (unsigned)batch), dim3(256), 0, s, scores, ld,
+                           n_passages, mn, mx, pinvdeg, flags, zmax_bits);
+        HRAG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(ppr8_scale_kernel, dim3((unsigned)ceil_div(batch, 64)), dim3(64), 0, s, zmax_bits,
+                       passage_weight, seed_vtx, seed_w, seed_cnt, deg, num_vertices, flags, batch, qscale);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -22,9 +22,9 @@ from exp_fp8_zspace import graphs, q8  # noqa: E402
 
 
 def plan_for(iters):
-    """stage lengths: [1] + four 2-sweep stages + 3-sweep stages (remainder last)"""
+    """stage lengths: [1] + two 2-sweep stages + 3-sweep stages (remainder last) -- ppr8_plan in engine.hip"""
     plan, left = [1], iters - 1
-    for _ in range(4):
+    for _ in range(2):
         if left >= 2:
             plan.append(2); left -= 2
     while left > 0:

@@ -32,9 +32,9 @@ qf, _ = synth.make_queries_torch(femb, B, 7)
 qp, _ = synth.make_queries_torch(pemb, B, 8)
 cnt = torch.full((B,), 5, dtype=torch.int32, device=dev)
 idx, sc = eng.score_facts(qf, k=5)
-eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=200)   # takes the fp16-state path when B > 32
-f32_only = bool(int(os.environ.get("HRAG_FLAGS", "0")) & 8)
-eng.ppr_sweeps(B, 4, 0.5, main_only=True, f16=B > 8 and not f32_only, small=B <= 8 and not f32_only)
+eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=200)   # fp8 state for B > 64, fp16 for B > 8, small-batch below
+width = eng.timings()["slab_width"]
+eng.ppr_sweeps(B, 4, 0.5, main_only=True, f8=width == 128, f16=width == 64 and B > 8, small=B <= 8 and width <= 8)
 torch.cuda.synchronize()
 eng.close()
 print("pmc target done")

@@ -70,8 +70,8 @@ def main():
         for k, d in out.items():
             base = k.split("::")[-1].split("<")[0]
             n = d["launches"].get("FETCH_SIZE", 0)
-            if "bytes_per_launch" in d and base in ("ppr16_kernel", "ppr_spmm_kernel") and n > seen.get(base, 0):
-                seen[base] = n      # the variant with the most launches (mode H for ppr16_kernel)
+            if "bytes_per_launch" in d and base in ("ppr8_kernel", "ppr16_kernel", "ppr_spmm_kernel") and n > seen.get(base, 0):
+                seen[base] = n      # the variant with the most launches (mode H for ppr16_kernel, C for ppr8_kernel)
                 traffic[base] = {"bytes_per_launch": d["bytes_per_launch"], "l2_hit_rate": d.get("l2_hit_rate"),
                                  "workload": workload, "source": os.path.basename(dst) + "_pmc.json"}
         if traffic:

@@ -14,15 +14,24 @@ Who may import this package: ``tests/``, ``__graft_entry__.smoke()`` and the
 the thing measured or shipped.  ``hipporag_amd`` (the product) must never
 import it; the product path fails loudly when the HIP library is missing.
 
-PARITY UNPINNED.  The reference has no test, golden vector or known-answer
-fixture for any function on this path, and its PPR
-arithmetic lives in ``python_igraph==0.11.8`` (PRPACK), which is not
-installable in the authoring container.  The oracle is therefore pinned
-against independent formulations instead (``networkx.pagerank`` -- networkx
-3.4.2 is the version the reference pins -- and a sparse direct solve of
-(I - alpha P) x = v), see ``tests/test_oracle_ppr.py``; fixtures under
-``tests/golden/`` were generated by this oracle and cross-checked that way
-(``tests/golden/make_golden.py``).
+PARITY STATUS.  The reference has no test, golden vector or known-answer fixture for
+any function on this path.  What pins this oracle instead:
+
+  * PINNED against the reference's own code, run in the authoring container: the fixtures
+    ``tests/golden/ref_*.npz`` were produced by importing ``/root/reference/src/hipporag``
+    (``tests/golden/ref_harness.py`` / ``make_ref_golden.py``; real: index(), the edge rules,
+    prepare_retrieval_objects, get_fact_scores, rerank_facts, graph_search_with_fact_entities,
+    get_top_k_weights, dense_passage_retrieval, run_ppr's wrapper, retrieve, retrieve_dpr;
+    substituted: igraph, the LLM calls, the embedding model).  ``tests/test_ref_golden.py``
+    checks every stage of this oracle against those recordings (fact scores, candidate
+    facts, seed weights, reset vectors bit-for-bit, DPR ranking, final ranking).
+  * UNPINNED: the PPR arithmetic itself.  It lives in ``python_igraph==0.11.8`` (PRPACK),
+    which is neither vendored in /root/reference nor installable here, so the stand-in
+    igraph of the harness solves with this oracle's own PRPACK restatement.  That part is
+    cross-checked against independent formulations instead (``networkx.pagerank`` --
+    networkx 3.4.2 is the version the reference pins --, a sparse direct solve of
+    (I - alpha P) x = v, and the C port on both sides of PRPACK's 128-vertex solver switch),
+    see ``tests/test_oracle_ppr.py``.
 """
 
 from .hipporag_ref import (  # noqa: F401

@@ -1,7 +1,8 @@
 """Oracle: array-level restatement of ``HippoRAG.retrieve()``'s per-query path.
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED (no
-reference test pins this path; igraph absent).
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Pinned against recordings of the
+reference's own code (tests/golden/ref_*.npz, tests/test_ref_golden.py) for every stage
+except the PPR arithmetic, which is PARITY UNPINNED (igraph absent; oracle/ppr.py).
 
 The reference works on strings (fact triples, md5 node keys) and an igraph
 object; this restatement works on the integer arrays those resolve to:

@@ -235,6 +235,14 @@ hrag_status launch_flag_zero_mass(const double *sums, int32_t batch, int32_t *fl
 hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
                             int32_t batch, float *out, int64_t ld, hipStream_t s, int32_t accumulate = 0);
 
+// fused similarity + top-k for k <= 16 (no [B, rows] score matrix; bit-identical to the two-step path)
+//   ws: 2 * sim_fused_tiles(rows) * batch floats; sel: batch * 16 ints; mn / mx: batch floats
+int64_t sim_fused_tiles(int64_t rows);
+hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
+                                  int32_t batch, int32_t k, int32_t idx_offset, int32_t normalize,
+                                  float *ws, int32_t *sel, float *mn, float *mx, int32_t *idx_out,
+                                  float *val_out, hipStream_t s);
+
 // sim_gemv.hip : the same for batch <= 8 (streams E once, queries in registers); false = not handled
 bool launch_sim_gemv(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch,
                      float *out, int64_t ld, hipStream_t s);

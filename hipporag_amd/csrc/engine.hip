@@ -82,6 +82,9 @@ struct hrag_engine {
     float *d_seed_w = nullptr;
     double *d_colsum_partial = nullptr, *d_sums = nullptr;
     void *d_topk_ws = nullptr;   // kTopkWsBytes: lets small batches split a row over several workgroups
+    // fused fact top-k (sim_gemm.hip): tile max / min, selected tiles, global min / max per query
+    float *d_fused_ws = nullptr, *d_mn_f = nullptr, *d_mx_f = nullptr;
+    int32_t *d_fused_sel = nullptr;
     // two-stage fp16 PPR (ppr16.hip): SELL-8 matrix + fp16 state, unsharded engines with max_batch > 32
     bool f16_ready = false;   // fp16 state buffers present (max_batch > 8)
     bool sell_ready = false;  // SELL-8 matrix + small-batch buffers present (every unsharded engine)
@@ -144,7 +147,7 @@ void free_engine(hrag_engine *e) {
                     e->d_vrow, e->d_lrow_row, e->d_lrow_first, e->d_lrow_cnt, e->d_partial16, e->d_h16[0],
                     e->d_h16[1], e->d_h16[2], e->d_h16[3], e->d_tele16, e->d_row_slot, e->d_qscale,
                     e->d_ssum, e->d_tele_sv, e->d_partial_sv, e->d_topk_ws, e->d_pairs8, e->d_deg,
-                    e->d_pinvdeg, e->d_R8, e->d_partial8};
+                    e->d_pinvdeg, e->d_R8, e->d_partial8, e->d_fused_ws, e->d_mn_f, e->d_mx_f, e->d_fused_sel};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : e->d_pool8)
@@ -660,6 +663,12 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     E_TRY(dev_alloc(&e->d_spass, (int64_t)B * e->ld_p));
     E_TRY(dev_alloc(&e->d_doc, (int64_t)B * e->ld_p));
     if (facts) E_TRY(dev_alloc(&e->d_sfact, (int64_t)B * e->ld_f));
+    if (facts && B > 64) {
+        E_TRY(dev_alloc(&e->d_fused_ws, 2 * sim_fused_tiles(std::max<int64_t>(e->f_rows, 1)) * B));
+        E_TRY(dev_alloc(&e->d_fused_sel, (int64_t)B * 16));
+        E_TRY(dev_alloc(&e->d_mn_f, B));
+        E_TRY(dev_alloc(&e->d_mx_f, B));
+    }
     E_TRY(dev_alloc(&e->d_mn_p, B));
     E_TRY(dev_alloc(&e->d_mx_p, B));
     E_TRY(dev_alloc(&e->d_seed_vtx, (int64_t)B * kMaxSeeds));
@@ -763,10 +772,17 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q, int32_t batch, i
                  "engine goes through hrag_sim_scores + hrag_topk_rows + an all-gather");
     hipStream_t s = (hipStream_t)stream;
     if (e->profiling) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_FACT0], s));
-    HRAG_TRY(launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, e->d_sfact, e->ld_f, s));
-    // get_fact_scores' min_max_normalize + rerank_facts' argsort prefix in one kernel
-    HRAG_TRY(launch_row_topk(e->d_sfact, batch, e->f_rows, e->ld_f, k, 0, kNormMinMax, idx_out, score_out,
-                             nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
+    if (batch > 64 && k <= 16 && e->f_rows > 0 && e->d_fused_ws) {
+        // no [B, F] score matrix: tile maxima -> k tiles per query -> exact top-k of k * 128 recomputed
+        // scores (bit-identical to the two-step path below; sim_gemm.hip)
+        HRAG_TRY(launch_sim_topk_fused(e->d_femb, e->f_rows, e->dim, q, batch, k, 0, 1, e->d_fused_ws,
+                                       e->d_fused_sel, e->d_mn_f, e->d_mx_f, idx_out, score_out, s));
+    } else {
+        HRAG_TRY(launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, e->d_sfact, e->ld_f, s));
+        // get_fact_scores' min_max_normalize + rerank_facts' argsort prefix in one kernel
+        HRAG_TRY(launch_row_topk(e->d_sfact, batch, e->f_rows, e->ld_f, k, 0, kNormMinMax, idx_out, score_out,
+                                 nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
+    }
     if (e->profiling) {
         HRAG_HIP_TRY(hipEventRecord(e->ev[EV_FACT1], s));
         e->have_fact_ev = true;

@@ -28,12 +28,16 @@ constexpr int BM = 128;
 constexpr int BK = 64;
 constexpr int LDS_LD = BK + 8;  // bf16 elements per LDS row (144 bytes)
 
-template <int BN, int WM, int WN>
+// TILEMAX: instead of the scores, write per (row tile, query) the max and min score of the tile
+// (tmax / tmin: [n_tiles_m][batch]) -- pass 1 of the fused fact top-k below.
+template <int BN, int WM, int WN, bool TILEMAX = false>
 __global__ __launch_bounds__(256) void sim_gemm_kernel(const uint16_t *__restrict__ emb,
                                                        int64_t rows, int32_t dim,
                                                        const uint16_t *__restrict__ q,
                                                        int32_t batch, float *__restrict__ out,
-                                                       int64_t ld, int32_t n_tiles_n, int32_t accumulate) {
+                                                       int64_t ld, int32_t n_tiles_n, int32_t accumulate,
+                                                       float *__restrict__ tmax = nullptr,
+                                                       float *__restrict__ tmin = nullptr) {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     constexpr int MI = BM / (WM * 16);
     constexpr int NJ = BN / (WN * 16);
@@ -115,6 +119,45 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(const uint16_t *__restric
         __syncthreads();
     }
 
+    if constexpr (TILEMAX) {
+        // lane: 4 * MI rows of NJ queries; lanes l, l+16, l+32, l+48 share a query; the WM wavefronts
+        // with the same wn share it too (LDS).  Rows beyond `rows` (zero-filled) are excluded.
+        __shared__ float red_mx[WM][BN], red_mn[WM][BN];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int64_t m = m0 + (wm * MI + i) * 16 + 4 * (lane >> 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < rows) {
+                        mx = fmaxf(mx, acc[i][j][r]);
+                        mn = fminf(mn, acc[i][j][r]);
+                    }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mn = fminf(mn, __shfl_xor(mn, 16, 64));
+            mn = fminf(mn, __shfl_xor(mn, 32, 64));
+            if (lane < 16) {
+                red_mx[wm][(wn * NJ + j) * 16 + lane] = mx;
+                red_mn[wm][(wn * NJ + j) * 16 + lane] = mn;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && b0 + tid < batch) {
+            float mx = red_mx[0][tid], mn = red_mn[0][tid];
+#pragma unroll
+            for (int w = 1; w < WM; ++w) {
+                mx = fmaxf(mx, red_mx[w][tid]);
+                mn = fminf(mn, red_mn[w][tid]);
+            }
+            tmax[(size_t)mt * batch + b0 + tid] = mx;
+            tmin[(size_t)mt * batch + b0 + tid] = mn;
+        }
+        return;
+    }
     // epilogue: lane owns rows m..m+3 of query gb for every (i, j) fragment
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -139,6 +182,170 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(const uint16_t *__restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused fact top-k (get_fact_scores + rerank_facts' argsort prefix, HippoRAG.py:1427-1465, :1683-1688)
+// without materialising the [B, F] score matrix:
+//   pass 1  sim_gemm_kernel<.., TILEMAX>: max / min score of every 128-row tile, per query;
+//   pass 2  tile_select_kernel: the k tiles with the largest maxima (key = score desc, tile desc).
+//           The k largest scores of a row live in those tiles: the k best tile maxima are k distinct
+//           scores >= the k-th best maximum t_k, hence the k-th largest score is >= t_k, and any
+//           score >= t_k sits in a tile whose maximum is >= t_k.  Ties follow the ranking rule
+//           (larger index first = larger tile first).
+//   pass 3  tile_rescore_kernel: recompute the k x 128 scores of those tiles with the SAME MFMA
+//           fragments in the SAME k order as pass 1 (bit-identical values), exact top-k of them,
+//           min-max normalisation with the global min / max from pass 1.
+// Output is bit-identical to launch_sim_gemm + launch_row_topk (tests/test_gpu_parity.py).
+constexpr int kFusedMaxK = 16;
+
+__device__ __forceinline__ uint64_t block_max_u64(uint64_t v, uint64_t *red, int tid) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t u = __shfl_xor((unsigned long long)v, o, 64);
+        v = u > v ? u : v;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    uint64_t r = red[0];
+    for (int w = 1; w < 4; ++w) r = red[w] > r ? red[w] : r;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void tile_select_kernel(const float *__restrict__ tmax,
+                                                          const float *__restrict__ tmin, int32_t n_tiles,
+                                                          int32_t batch, int32_t k, int32_t *__restrict__ sel,
+                                                          float *__restrict__ mn_out, float *__restrict__ mx_out) {
+    __shared__ uint64_t red[4];
+    __shared__ float redf[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float mn = INFINITY;
+    for (int t = tid; t < n_tiles; t += 256) mn = fminf(mn, tmin[(size_t)t * batch + b]);
+    for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
+    if ((tid & 63) == 0) redf[tid >> 6] = mn;
+    __syncthreads();
+    mn = fminf(fminf(redf[0], redf[1]), fminf(redf[2], redf[3]));
+    uint64_t prev = ~0ull;
+    for (int r = 0; r < k; ++r) {
+        uint64_t best = 0;   // keys are > 0: ordered(x) of any non-NaN float is >= 0x00800000
+        for (int t = tid; t < n_tiles; t += 256) {
+            const uint64_t key = rank_key(tmax[(size_t)t * batch + b], (uint32_t)t);
+            if (key < prev && key > best) best = key;
+        }
+        best = block_max_u64(best, red, tid);
+        if (tid == 0) {
+            sel[b * kFusedMaxK + r] = best ? (int32_t)(uint32_t)best : -1;
+            if (r == 0) {
+                mx_out[b] = best ? ordered_to_f32((uint32_t)(best >> 32)) : -INFINITY;
+                mn_out[b] = mn;
+            }
+        }
+        prev = best ? best : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_rescore_kernel(const uint16_t *__restrict__ emb, int64_t rows,
+                                                           int32_t dim, const uint16_t *__restrict__ q,
+                                                           const int32_t *__restrict__ sel,
+                                                           const float *__restrict__ mn_in,
+                                                           const float *__restrict__ mx_in, int32_t k,
+                                                           int32_t idx_offset, int32_t normalize,
+                                                           int32_t *__restrict__ idx_out,
+                                                           float *__restrict__ val_out) {
+    __shared__ uint64_t cand[kFusedMaxK * BM];
+    __shared__ uint64_t red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint16_t *qrow = q + (size_t)b * dim;
+    int n_cand = 0;
+    for (int r = 0; r < k; ++r) {
+        const int t = sel[b * kFusedMaxK + r];
+        if (t < 0) break;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int64_t row0 = (int64_t)t * BM + wave * 32 + f * 16;
+            const int64_t arow = row0 + (lane & 15);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // the k order of sim_gemm_kernel: BK = 64 steps, two 32-wide MFMAs each, 8-element zero fill
+            for (int k0 = 0; k0 < dim; k0 += BK) {
+#pragma unroll
+                for (int s = 0; s < BK / 32; ++s) {
+                    const int kcol = k0 + s * 32 + 8 * (lane >> 4);
+                    uint4 ua = make_uint4(0, 0, 0, 0), ub = make_uint4(0, 0, 0, 0);
+                    if (kcol < dim) {
+                        ub = *reinterpret_cast<const uint4 *>(qrow + kcol);
+                        if (arow < rows) ua = *reinterpret_cast<const uint4 *>(emb + (size_t)arow * dim + kcol);
+                    }
+                    bf16x8 a, bb;
+                    __builtin_memcpy(&a, &ua, 16);
+                    __builtin_memcpy(&bb, &ub, 16);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc, 0, 0, 0);
+                }
+            }
+            if ((lane & 15) == 0) {   // every column holds the same query: take column 0
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int64_t m = row0 + 4 * (lane >> 4) + reg;
+                    cand[r * BM + wave * 32 + f * 16 + 4 * (lane >> 4) + reg] =
+                        m < rows ? rank_key(acc[reg], (uint32_t)m) : 0ull;
+                }
+            }
+        }
+        n_cand += BM;
+    }
+    __syncthreads();
+    const float mn = mn_in[b], mx = mx_in[b];
+    uint64_t prev = ~0ull;
+    for (int r = 0; r < k; ++r) {
+        uint64_t best = 0;
+        for (int i = tid; i < n_cand; i += 256) {
+            const uint64_t key = cand[i];
+            if (key < prev && key > best) best = key;
+        }
+        best = block_max_u64(best, red, tid);
+        if (tid == 0) {
+            int32_t idx = -1;
+            float val = 0.f;
+            if (best) {
+                idx = (int32_t)(uint32_t)best + idx_offset;
+                val = ordered_to_f32((uint32_t)(best >> 32));
+                if (normalize) {
+                    const float range = mx - mn;
+                    val = range == 0.f ? 1.f : __fdiv_rn(val - mn, range);   // misc_utils.py:130-139
+                }
+            }
+            idx_out[(size_t)b * k + r] = idx;
+            val_out[(size_t)b * k + r] = val;
+        }
+        prev = best ? best : 0;
+    }
+}
+
+}  // namespace
+
+int64_t sim_fused_tiles(int64_t rows) { return ceil_div(rows, BM); }
+
+// ws: 2 * tiles * batch floats (tile max / min) ; sel: batch * 16 ints ; mn / mx: batch floats
+hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
+                                  int32_t batch, int32_t k, int32_t idx_offset, int32_t normalize,
+                                  float *ws, int32_t *sel, float *mn, float *mx, int32_t *idx_out,
+                                  float *val_out, hipStream_t s) {
+    HRAG_REQUIRE(dim > 0 && dim % 8 == 0, "embedding dim %d must be a positive multiple of 8", dim);
+    HRAG_REQUIRE(k >= 1 && k <= kFusedMaxK && rows >= 1 && batch >= 1, "fused top-k: bad k / rows / batch");
+    const int64_t tiles_m = ceil_div(rows, BM);
+    const int tn = (int)ceil_div(batch, 128);
+    float *tmax = ws, *tmin = ws + (size_t)tiles_m * batch;
+    hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2, true>), dim3((unsigned)(tiles_m * tn)), dim3(256), 0, s, emb,
+                       rows, dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);
+    HRAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tile_select_kernel, dim3((unsigned)batch), dim3(256), 0, s, tmax, tmin, (int32_t)tiles_m,
+                       batch, k, sel, mn, mx);
+    HRAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tile_rescore_kernel, dim3((unsigned)batch), dim3(256), 0, s, emb, rows, dim, q, sel, mn, mx,
+                       k, idx_offset, normalize, idx_out, val_out);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+namespace {
 }  // namespace
 
 hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,

@@ -168,6 +168,36 @@ def test_score_facts_matches_oracle(case, gpu_device):
         np.testing.assert_allclose(sc[b], s[idx[b]], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("rows,dim,b,k", [(6000, 192, 70, 5), (1000, 768, 130, 16), (129, 72, 65, 5), (100, 64, 200, 16),
+                                          (40000, 256, 256, 5), (7, 64, 66, 5)])
+def test_score_facts_fused_is_bit_identical_to_gemm_plus_topk(gpu_device, rows, dim, b, k):
+    """Batches > 64 take the fused path (tile maxima -> k tiles -> recomputed scores, csrc/sim_gemm.hip)
+    without the [B, F] score matrix: ids and normalised scores must equal the two-step path
+    (hrag_sim_scores + hrag_topk_rows) bit for bit, including duplicated rows (ties -> larger index),
+    a last partial tile and fewer rows than k."""
+    import torch
+    from hipporag_amd.engine import HippoRAGEngine, topk_rows
+    from hipporag_amd.graph import build_csr
+    from hipporag_amd import synth
+    emb = synth.make_embeddings_np(rows, dim, seed=rows + 3)
+    if rows > 300:
+        emb[200:260] = emb[100:160]                      # exact ties across two tiles
+        emb[-1] = emb[5]
+    q, _ = synth.make_queries_np(emb, b, seed=9)
+    g = build_csr(4, [0, 1], [1, 2], [1.0, 1.0])
+    zeros = np.zeros(rows, np.int32)
+    with HippoRAGEngine(g, np.array([3], np.int32), emb[:1], emb, zeros, zeros, np.zeros(4, np.int32),
+                        max_batch=b, max_topk=16) as eng:
+        idx, sc = eng.score_facts(_bf16(q, gpu_device), k=k)
+        raw = eng.sim_scores("facts", _bf16(q, gpu_device))
+        idx2, sc2 = topk_rows(raw, k, normalize=True)
+        torch.cuda.synchronize()
+    assert torch.equal(idx, idx2)
+    assert torch.equal(sc, sc2)
+    if rows < k:
+        assert (idx[:, rows:] == -1).all()
+
+
 def _oracle_batch(case, kept_lists):
     index = case["index"]
     qf = bf16_bits_to_float(case["qf_bits"])

@@ -168,10 +168,16 @@ struct Ppr8Args {
     float stage_inv[kP8MaxStages];
     int32_t n_stage;
     const float *deg;          // [V] weighted degree (1 for isolated vertices)
-    float *out;                // fp32 [n_slabs64][V][64]: x = d z
+    const int32_t *row_slot;   // [V] teleport slot of a vertex: slot < n_passages <=> passage number
+    int64_t n_passages;
+    float *out;                // x = d z at the passage vertices, fp32 [n_slabs64][Np][64] (passage order)
     int32_t n_slabs64;
+    float *csum;               // [n_slabs][n_csum][128] fp32: column sums of x per chunk / long row
+    int32_t n_csum;            // n_chunks + n_lrow
 };
 hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, int n_slabs, bool main_only, hipStream_t s);
+hrag_status launch_ppr8_colsum(const float *csum, int32_t n_csum, int n_slabs, int32_t batch, double *partial,
+                               double *sums, hipStream_t s);
 hrag_status launch_ppr8_init(const float *tele, int64_t tele_rows, const int32_t *row_slot, const float *deg,
                              int64_t num_vertices, int n_slabs, int n_slabs64, float beta, float c0_scale,
                              float *R, uint8_t *c0, hipStream_t s);

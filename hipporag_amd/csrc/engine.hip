@@ -105,6 +105,7 @@ struct hrag_engine {
     bool f8_ready = false;
     int2 *d_pairs8 = nullptr;
     float *d_deg = nullptr, *d_pinvdeg = nullptr, *d_R8 = nullptr, *d_partial8 = nullptr;
+    float *d_csum8 = nullptr, *d_xp8 = nullptr;   // mode F outputs: column-sum partial rows, x at the passages
     static constexpr int kP8Pool = kP8MaxStages + 3;
     uint8_t *d_pool8[kP8Pool] = {};
     int64_t state8_bytes = 0;
@@ -147,7 +148,7 @@ void free_engine(hrag_engine *e) {
                     e->d_vrow, e->d_lrow_row, e->d_lrow_first, e->d_lrow_cnt, e->d_partial16, e->d_h16[0],
                     e->d_h16[1], e->d_h16[2], e->d_h16[3], e->d_tele16, e->d_row_slot, e->d_qscale,
                     e->d_ssum, e->d_tele_sv, e->d_partial_sv, e->d_topk_ws, e->d_pairs8, e->d_deg,
-                    e->d_pinvdeg, e->d_R8, e->d_partial8, e->d_fused_ws, e->d_mn_f, e->d_mx_f, e->d_fused_sel};
+                    e->d_pinvdeg, e->d_R8, e->d_partial8, e->d_fused_ws, e->d_mn_f, e->d_mx_f, e->d_fused_sel, e->d_csum8, e->d_xp8};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : e->d_pool8)
@@ -333,7 +334,8 @@ Ppr8Args ppr8_args(const hrag_engine *e, float damping) {
 }
 
 // The staged iteration of ppr8.hip; v comes from d_tele16 / d_row_slot (scaled so that max v/d is in
-// (1/2, 1]); the result x = d z lands in d_x as [n_slabs64][V][64] fp32.
+// (1/2, 1]); the result x = d z lands in d_xp8 ([n_slabs64][Np][64] fp32, passage rows only) and its
+// column sums over ALL vertices as partial rows in d_csum8 (launch_ppr8_colsum adds them up).
 hrag_status ppr8_run(hrag_engine *e, int batch, float damping, int iters, hipStream_t s) {
     const int ns = n_slabs128(batch), ns64 = n_slabs64(batch);
     int plan[kP8MaxStages + 4];
@@ -387,7 +389,9 @@ hrag_status ppr8_run(hrag_engine *e, int batch, float damping, int iters, hipStr
             HRAG_TRY(launch_ppr8_sweep(a, kP8ModeB, ns, false, s));
         } else {
             for (int k = 0; k <= si; ++k) { a.stage[k] = stage_buf[k]; a.stage_inv[k] = stage_inv[k]; }
-            a.n_stage = si + 1; a.out = e->d_x; a.n_slabs64 = ns64;
+            a.n_stage = si + 1; a.out = e->d_xp8; a.n_slabs64 = ns64;
+            a.row_slot = e->d_row_slot; a.n_passages = e->n_passages;
+            a.csum = e->d_csum8; a.n_csum = e->n_chunks + e->n_lrow;
             HRAG_TRY(launch_ppr8_sweep(a, kP8ModeF, ns, false, s));
         }
     }
@@ -653,6 +657,8 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         }
         E_TRY(dev_alloc(&e->d_R8, e->state8_bytes));
         E_TRY(dev_alloc(&e->d_partial8, (int64_t)ns * std::max(e->n_partial16, 1) * 128));
+        E_TRY(dev_alloc(&e->d_csum8, (int64_t)ns * std::max(e->n_chunks + e->n_lrow, 1) * 128));
+        E_TRY(dev_alloc(&e->d_xp8, (int64_t)n_slabs64(B) * std::max<int64_t>(e->n_passages, 1) * 64));
     }
     E_TRY(dev_alloc(&e->d_partial, (int64_t)(round_up(B, 4) + 64) * std::max(e->n_partial, 1)));
     E_TRY(dev_alloc(&e->d_x, e->state_elems));
@@ -948,6 +954,12 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
         HRAG_TRY(launch_ppr_sv_colsum(e->d_x, e->V, bp, e->d_colsum_partial, e->d_sums, s));
         HRAG_TRY(launch_ppr_sv_rows(e->d_x, e->d_passage_vertex, e->n_passages, batch, e->d_sums, e->d_doc,
                                     e->ld_p, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, e->d_flags, bp, s));
+    } else if (f8) {
+        HRAG_TRY(launch_ppr8_colsum(e->d_csum8, e->n_chunks + e->n_lrow, n_slabs128(batch), batch,
+                                    e->d_colsum_partial, e->d_sums, s));
+        HRAG_TRY(launch_slab_to_rows(e->d_xp8, e->n_passages, nullptr, e->n_passages, batch, e->d_sums,
+                                     e->d_doc, e->ld_p, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, e->d_flags,
+                                     lay, s));
     } else {
         HRAG_TRY(launch_colsum(e->d_x, e->V, 0, e->V, batch, lay, e->d_colsum_partial, e->d_sums, s));
         HRAG_TRY(launch_slab_to_rows(e->d_x, e->V, e->d_passage_vertex, e->n_passages, batch, e->d_sums,

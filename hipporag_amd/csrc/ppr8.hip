@@ -154,9 +154,10 @@ __device__ __forceinline__ void st16f(float *p, const f32x2_t (&f)[8]) {
 }
 
 // Finish one output row: lane gl of its group owns queries 16*gl .. 16*gl+15 of the 128-wide slab.
+// Mode F returns the row's x (16 queries of this lane) in xs for the caller's column sums.
 template <int MODE>
 __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int row, int gl,
-                                           const f32x2_t (&acc)[8]) {
+                                           const f32x2_t (&acc)[8], f32x2_t (&xs)[8]) {
     const size_t off = ((size_t)slab * a.num_vertices + (size_t)row) * 128 + (size_t)gl * 16;
     f32x2_t out[8];
     if constexpr (MODE == kP8ModeC) {
@@ -195,11 +196,13 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int row,
             }
             const float dg = a.deg[row];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = (z[j] + out[j]) * dg;
-            // caller-facing state layout: [n_slabs64][V][64] fp32 (layout.hip / colsum consume it)
+            for (int j = 0; j < 8; ++j) xs[j] = (z[j] + out[j]) * dg;
+            // only the passage rows are needed downstream (HippoRAG.py:1745), in passage order:
+            // xp is [n_slabs64][Np][64] fp32, the layout slab_to_rows reads without a gather
+            const int slot = a.row_slot[row];
             const int slab64 = 2 * slab + (gl >> 2);
-            if (slab64 < a.n_slabs64)
-                st16f(a.out + ((size_t)slab64 * a.num_vertices + (size_t)row) * 64 + (size_t)(gl & 3) * 16, z);
+            if (slot >= 0 && slot < a.n_passages && slab64 < a.n_slabs64)
+                st16f(a.out + ((size_t)slab64 * a.n_passages + (size_t)slot) * 64 + (size_t)(gl & 3) * 16, xs);
         }
     }
 }
@@ -232,10 +235,25 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
         p1 = p2;
     }
     const int tgt = a.vrow[chunk * 8 + grp];
+    f32x2_t xr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xr[j] = f32x2_t{0.f, 0.f};
     if (tgt >= 0) {
-        finish_row<MODE>(a, slab, tgt, gl, acc);
+        finish_row<MODE>(a, slab, tgt, gl, acc, xr);
     } else if (tgt != kVrowNone) {
         st16i(a.partial + ((size_t)slab * a.n_partial + (size_t)(-(tgt + 1))) * 128, gl, acc);
+    }
+    if constexpr (MODE == kP8ModeF) {
+        // column sums of x over this wavefront's 8 rows (fixed order), one partial row per chunk;
+        // ppr8_colsum_kernel adds the partial rows up in double
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xr[j].x += __shfl_xor(xr[j].x, o, 64);
+                xr[j].y += __shfl_xor(xr[j].y, o, 64);
+            }
+        if (grp == 0) st16i(a.csum + ((size_t)slab * a.n_csum + (size_t)chunk) * 128, gl, xr);
     }
 }
 
@@ -266,7 +284,46 @@ __global__ __launch_bounds__(256) void ppr8_reduce_kernel(const Ppr8Args a) {
             acc[j].x += __shfl_xor(acc[j].x, o, 64);
             acc[j].y += __shfl_xor(acc[j].y, o, 64);
         }
-    if (grp == 0) finish_row<MODE>(a, slab, a.lrow_row[m], gl, acc);
+    if (grp == 0) {
+        f32x2_t xs[8];
+        finish_row<MODE>(a, slab, a.lrow_row[m], gl, acc, xs);
+        if constexpr (MODE == kP8ModeF)   // a long row is its own partial row (after the chunk rows)
+            st16i(a.csum + ((size_t)slab * a.n_csum + (size_t)a.n_chunks + (size_t)m) * 128, gl, xs);
+    }
+}
+
+// Column sums of x = d z from the partial rows mode F wrote (lane-interleaved 128-float rows):
+// pass 1 (grid kP8ColsumBlocks x n_slabs): block b sums rows b, b + kP8ColsumBlocks, ... in double;
+// pass 2: sums[q] = sum over blocks, q -> (slab, interleaved position).  Fixed order, no atomics.
+constexpr int kP8ColsumBlocks = 128;
+__global__ __launch_bounds__(256) void ppr8_colsum_kernel(const float *__restrict__ csum, int32_t n_csum,
+                                                          double *__restrict__ partial) {
+    __shared__ double red[8][128];
+    const int tid = threadIdx.x, f4 = tid & 31, rl = tid >> 5;   // 32 float4 per row, 8 rows per pass
+    const int slab = blockIdx.y;
+    const f32x4_t *base = reinterpret_cast<const f32x4_t *>(csum + (size_t)slab * n_csum * 128);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int64_t r = (int64_t)blockIdx.x * 8 + rl; r < n_csum; r += (int64_t)kP8ColsumBlocks * 8) {
+        const f32x4_t v = base[r * 32 + f4];
+        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+    red[rl][f4 * 4 + 0] = s0; red[rl][f4 * 4 + 1] = s1; red[rl][f4 * 4 + 2] = s2; red[rl][f4 * 4 + 3] = s3;
+    __syncthreads();
+    if (tid < 128) {
+        double t = 0;
+        for (int i = 0; i < 8; ++i) t += red[i][tid];
+        partial[((size_t)slab * kP8ColsumBlocks + blockIdx.x) * 128 + tid] = t;
+    }
+}
+__global__ void ppr8_colsum_final_kernel(const double *__restrict__ partial, int32_t batch, double *sums) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= batch) return;
+    const int slab = q >> 7, qq = q & 127;
+    const int gl = qq >> 4, i = (qq >> 2) & 3, k = qq & 3;   // query qq sits in float4 8 i + gl, component k
+    const int phys = (8 * i + gl) * 4 + k;
+    double s = 0;
+    for (int b = 0; b < kP8ColsumBlocks; ++b) s += partial[((size_t)slab * kP8ColsumBlocks + b) * 128 + phys];
+    sums[q] = s;
 }
 
 // R = b v/d (fp32) and c_0 = Q(v/d * c0_scale) for every vertex row of every slab; v comes from the
@@ -391,6 +448,18 @@ hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, int n_slabs, bool mai
         case kP8ModeF: return sweep_mode<kP8ModeF>(a, n_slabs, main_only, s);
         default: set_error("bad ppr8 mode %d", mode); return HRAG_EINVAL;
     }
+}
+
+// partial: n_slabs * 128 * 128 doubles
+hrag_status launch_ppr8_colsum(const float *csum, int32_t n_csum, int n_slabs, int32_t batch, double *partial,
+                               double *sums, hipStream_t s) {
+    hipLaunchKernelGGL(ppr8_colsum_kernel, dim3(kP8ColsumBlocks, (unsigned)n_slabs), dim3(256), 0, s, csum,
+                       n_csum, partial);
+    HRAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ppr8_colsum_final_kernel, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, s, partial,
+                       batch, sums);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
 }
 
 hrag_status launch_ppr8_init(const float *tele, int64_t tele_rows, const int32_t *row_slot, const float *deg,

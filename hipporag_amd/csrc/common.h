@@ -107,7 +107,10 @@ hrag_status launch_colsum(const float *x, int64_t num_vertices, int64_t row_offs
 // ppr16.hip : two-stage fp16-state PPR (64 queries per 128-byte line), SELL-8 matrix
 enum Ppr16Mode { kPprModeH = 0, kPprModeR = 1, kPprModeC = 2 };
 constexpr int32_t kVrowNone = (int32_t)0x80000000;  // padding virtual row (no output)
-constexpr int kSell8SegLen = 64;                     // rows above this are cut into <= 64 segments
+// rows above this are cut into <= 64 segments.  Rows are sorted by length, so the 8 rows of a wavefront
+// have similar trip counts and the longest start first: only real hubs need cutting (at 64 the reduce
+// kernels of cfg 3 handled 13.6k rows and cost 0.4 ms per batch).
+constexpr int kSell8SegLen = 512;
 struct Ppr16Args {
     const int2 *pairs;         // [total_steps * 64] (col, fp32 bits of val), step-major per chunk
     uint32_t pairs_bytes;      // size of the pairs array incl. the read-ahead padding (< 2^31)
@@ -144,7 +147,7 @@ hrag_status launch_ppr16_seed_rows(const int32_t *seed_vtx, const float *seed_w,
 
 // ppr8.hip : staged fp8 (e4m3) state + fp32 true residual, 128 queries per 128-byte line, same
 // SELL-8 structure with the row-normalised values At = D^-1 A
-enum Ppr8Mode { kP8ModeC = 0, kP8ModeB = 1, kP8ModeF = 2 };
+enum Ppr8Mode { kP8ModeC = 0, kP8ModeB = 1, kP8ModeF = 2, kP8ModeB0 = 3 };   // B0: first boundary, R_in = b v/d
 constexpr int kP8MaxStages = 12;      // stage lengths 1,2,2,3,3,3,... => 12 stages cover ppr_iters <= 32
 constexpr float kP8C0Scale = 128.f;   // c_0 = Q(v/d * 2^7),  max(v/d) in (1/2, 1]
 struct Ppr8Args {
@@ -162,7 +165,9 @@ struct Ppr8Args {
     uint8_t *y;                // mode C: the new iterate; mode B: rt of the next stage
     const uint8_t *rt;         // mode C: the stage's quantised right-hand side
     float *R;                  // mode B / F: true residual, fp32 [n_slabs][V][128] (B rewrites it)
-    float alpha, inv_cs, cs_next;
+    float alpha, beta, inv_cs, cs_next;
+    const float *tele;         // mode B0: teleport rows fp32 [n_slabs64][tele_rows][64] (v, scaled per query)
+    int64_t tele_rows;
     // mode F
     const uint8_t *stage[kP8MaxStages];   // final iterate of every stage (incl. the one in x)
     float stage_inv[kP8MaxStages];
@@ -179,8 +184,8 @@ hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, int n_slabs, bool mai
 hrag_status launch_ppr8_colsum(const float *csum, int32_t n_csum, int n_slabs, int32_t batch, double *partial,
                                double *sums, hipStream_t s);
 hrag_status launch_ppr8_init(const float *tele, int64_t tele_rows, const int32_t *row_slot, const float *deg,
-                             int64_t num_vertices, int n_slabs, int n_slabs64, float beta, float c0_scale,
-                             float *R, uint8_t *c0, hipStream_t s);
+                             int64_t num_vertices, int n_slabs, int n_slabs64, float c0_scale, uint8_t *c0,
+                             hipStream_t s);
 hrag_status launch_ppr8_scale(const float *scores, int64_t ld, int64_t n_passages, const float *mn,
                               const float *mx, float passage_weight, const float *pinvdeg,
                               const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,

@@ -329,7 +329,9 @@ Ppr8Args ppr8_args(const hrag_engine *e, float damping) {
     a.chunk_meta = e->d_chunk_meta; a.vrow = e->d_vrow; a.n_chunks = e->n_chunks;
     a.lrow_row = e->d_lrow_row; a.lrow_first = e->d_lrow_first; a.lrow_cnt = e->d_lrow_cnt;
     a.n_lrow = e->n_lrow; a.n_partial = e->n_partial16; a.partial = e->d_partial8;
-    a.num_vertices = e->V; a.R = e->d_R8; a.alpha = damping; a.deg = e->d_deg;
+    a.num_vertices = e->V; a.R = e->d_R8; a.alpha = damping; a.beta = 1.0f - damping; a.deg = e->d_deg;
+    a.tele = e->d_tele16; a.tele_rows = e->tele16_rows; a.row_slot = e->d_row_slot;
+    a.n_passages = e->n_passages; a.n_slabs64 = n_slabs64(e->max_batch);
     return a;
 }
 
@@ -346,8 +348,8 @@ hrag_status ppr8_run(hrag_engine *e, int batch, float damping, int iters, hipStr
     const uint8_t *stage_buf[kP8MaxStages];
     float stage_inv[kP8MaxStages];
     uint8_t *c = take();   // c_0 = Q(v/d * 2^7)
-    HRAG_TRY(launch_ppr8_init(e->d_tele16, e->tele16_rows, e->d_row_slot, e->d_deg, e->V, ns, ns64,
-                              1.0f - damping, kP8C0Scale, e->d_R8, c, s));
+    HRAG_TRY(launch_ppr8_init(e->d_tele16, e->tele16_rows, e->d_row_slot, e->d_deg, e->V, ns, ns64, kP8C0Scale,
+                              c, s));
     // static scales: the max-norm of the true residual contracts by `damping` per sweep (At is row-
     // stochastic), |R_0| <= max(a, 1 - a) max(v/d) + the rounding of c_0; a stage of m sweeps grows its
     // iterate by at most (1 - a^m) / (1 - a).  cs = the power of two that maps that bound to <= 224
@@ -386,7 +388,8 @@ hrag_status ppr8_run(hrag_engine *e, int batch, float damping, int iters, hipStr
         if (si + 1 < n_stage) {
             rt = take();
             a.y = rt;
-            HRAG_TRY(launch_ppr8_sweep(a, kP8ModeB, ns, false, s));
+            a.n_slabs64 = ns64;
+            HRAG_TRY(launch_ppr8_sweep(a, si == 0 ? kP8ModeB0 : kP8ModeB, ns, false, s));
         } else {
             for (int k = 0; k <= si; ++k) { a.stage[k] = stage_buf[k]; a.stage_inv[k] = stage_inv[k]; }
             a.n_stage = si + 1; a.out = e->d_xp8; a.n_slabs64 = ns64;

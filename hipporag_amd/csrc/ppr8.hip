@@ -16,7 +16,7 @@
 // dynamic range an 8-bit float needs: the diffuse part of a PPR vector on an undirected graph is
 // proportional to the degree, i.e. flat in z.
 //
-//   init       R = b v/d  (fp32),  c_0 = Q(v/d * 2^7)        X_0 = c_0 / 2^7 ~ v/d: the start of
+//   init       c_0 = Q(v/d * 2^7),  R_0 = b v/d (fp32, on the fly)  X_0 = c_0 / 2^7 ~ v/d: the start of
 //                                                            the reference iteration (x_0 = v), mass
 //                                                            matched per connected component
 //   boundary   R <- R + (a At c - c) / cs    = true residual of X + c / cs;   X += c / cs   (mode B)
@@ -153,6 +153,28 @@ __device__ __forceinline__ void st16f(float *p, const f32x2_t (&f)[8]) {
     }
 }
 
+// z_v = v / d for one vertex row: v comes from the teleport rows of the fp16 path's layout
+// (fp32 [n_slabs64][tele_rows][64] + row_slot), already scaled per query.
+__device__ __forceinline__ void load_zv(const float *__restrict__ tele, int64_t tele_rows,
+                                        const int32_t *__restrict__ row_slot, const float *__restrict__ deg,
+                                        int32_t n_slabs64, int slab, int64_t row, int gl, f32x2_t (&z)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = f32x2_t{0.f, 0.f};
+    const int slot = row_slot[row];
+    const int slab64 = 2 * slab + (gl >> 2);
+    if (slot >= 0 && slab64 < n_slabs64) {
+        const f32x4_t *tp = reinterpret_cast<const f32x4_t *>(
+            tele + ((size_t)slab64 * tele_rows + (size_t)slot) * 64 + (size_t)(gl & 3) * 16);
+        const float invd = __fdiv_rn(1.0f, deg[row]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4_t v = tp[i];
+            z[2 * i] = f32x2_t{v.x, v.y} * invd;
+            z[2 * i + 1] = f32x2_t{v.z, v.w} * invd;
+        }
+    }
+}
+
 // Finish one output row: lane gl of its group owns queries 16*gl .. 16*gl+15 of the 128-wide slab.
 // Mode F returns the row's x (16 queries of this lane) in xs for the caller's column sums.
 template <int MODE>
@@ -170,14 +192,20 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int row,
         f32x2_t c[8], rin[8];
         decode16(__builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(a.x + off)), c);
         float *rrow = a.R + ((size_t)slab * a.num_vertices + (size_t)row) * 128;
-        ld16i(rrow, gl, rin);
+        if constexpr (MODE == kP8ModeB0) {
+            load_zv(a.tele, a.tele_rows, a.row_slot, a.deg, a.n_slabs64, slab, row, gl, rin);   // R_in = b v/d
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rin[j] *= a.beta;
+        } else {
+            ld16i(rrow, gl, rin);
+        }
         const f32x2_t al = {a.alpha, a.alpha}, inv = {a.inv_cs, a.inv_cs};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const f32x2_t t = __builtin_elementwise_fma(acc[j], al, -c[j]);   // a (At c) - c, one rounding
             out[j] = __builtin_elementwise_fma(t, inv, rin[j]);              // inv is a power of two: exact
         }
-        if constexpr (MODE == kP8ModeB) {
+        if constexpr (MODE == kP8ModeB || MODE == kP8ModeB0) {
             st16i(rrow, gl, out);
             f32x2_t q[8];
 #pragma unroll
@@ -326,42 +354,23 @@ __global__ void ppr8_colsum_final_kernel(const double *__restrict__ partial, int
     sums[q] = s;
 }
 
-// R = b v/d (fp32) and c_0 = Q(v/d * c0_scale) for every vertex row of every slab; v comes from the
-// teleport rows of the fp16 path's layout: fp32 [n_slabs64][tele_rows][64] + row_slot.
+// c_0 = Q(v/d * c0_scale) for every vertex row of every slab (R_0 = b v/d is formed on the fly by the
+// first boundary sweep, mode B0).
 __global__ __launch_bounds__(256) void ppr8_init_kernel(const float *__restrict__ tele, int64_t tele_rows,
                                                         const int32_t *__restrict__ row_slot,
                                                         const float *__restrict__ deg, int64_t num_vertices,
-                                                        int32_t n_slabs64, float beta, float c0_scale,
-                                                        float *__restrict__ R, uint8_t *__restrict__ c0) {
+                                                        int32_t n_slabs64, float c0_scale,
+                                                        uint8_t *__restrict__ c0) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = t >> 3;
     const int gl = (int)(t & 7);
     const int slab = blockIdx.y;
     if (row >= num_vertices) return;
-    f32x2_t z[8];
+    f32x2_t z[8], q[8];
+    load_zv(tele, tele_rows, row_slot, deg, n_slabs64, slab, row, gl, z);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) z[j] = f32x2_t{0.f, 0.f};
-    const int slot = row_slot[row];
-    const int slab64 = 2 * slab + (gl >> 2);
-    if (slot >= 0 && slab64 < n_slabs64) {
-        const f32x4_t *tp = reinterpret_cast<const f32x4_t *>(
-            tele + ((size_t)slab64 * tele_rows + (size_t)slot) * 64 + (size_t)(gl & 3) * 16);
-        const float invd = __fdiv_rn(1.0f, deg[row]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4_t v = tp[i];
-            z[2 * i] = f32x2_t{v.x, v.y} * invd;
-            z[2 * i + 1] = f32x2_t{v.z, v.w} * invd;
-        }
-    }
+    for (int j = 0; j < 8; ++j) q[j] = z[j] * c0_scale;
     const size_t off = ((size_t)slab * num_vertices + (size_t)row) * 128 + (size_t)gl * 16;
-    f32x2_t r[8], q[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        r[j] = z[j] * beta;
-        q[j] = z[j] * c0_scale;
-    }
-    st16i(R + ((size_t)slab * num_vertices + (size_t)row) * 128, gl, r);
     *reinterpret_cast<v4i_t *>(c0 + off) = encode16(q);
 }
 
@@ -445,6 +454,7 @@ hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, int n_slabs, bool mai
     switch (mode) {
         case kP8ModeC: return sweep_mode<kP8ModeC>(a, n_slabs, main_only, s);
         case kP8ModeB: return sweep_mode<kP8ModeB>(a, n_slabs, main_only, s);
+        case kP8ModeB0: return sweep_mode<kP8ModeB0>(a, n_slabs, main_only, s);
         case kP8ModeF: return sweep_mode<kP8ModeF>(a, n_slabs, main_only, s);
         default: set_error("bad ppr8 mode %d", mode); return HRAG_EINVAL;
     }
@@ -463,11 +473,11 @@ hrag_status launch_ppr8_colsum(const float *csum, int32_t n_csum, int n_slabs, i
 }
 
 hrag_status launch_ppr8_init(const float *tele, int64_t tele_rows, const int32_t *row_slot, const float *deg,
-                             int64_t num_vertices, int n_slabs, int n_slabs64, float beta, float c0_scale,
-                             float *R, uint8_t *c0, hipStream_t s) {
+                             int64_t num_vertices, int n_slabs, int n_slabs64, float c0_scale, uint8_t *c0,
+                             hipStream_t s) {
     dim3 grid((unsigned)ceil_div(num_vertices * 8, 256), (unsigned)n_slabs);
     hipLaunchKernelGGL(ppr8_init_kernel, grid, dim3(256), 0, s, tele, tele_rows, row_slot, deg, num_vertices,
-                       n_slabs64, beta, c0_scale, R, c0);
+                       n_slabs64, c0_scale, c0);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -62,6 +62,55 @@ def load_traffic():
     return None
 
 
+def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
+    """Dominant kernel (the PPR sweep): average duration over n_l back-to-back launches (HIP events on
+    the launch stream) against SURVEY.md 8(d)'s algorithmic bytes per PPR iteration.  Returns
+    (roofline dict, f8, f16)."""
+    import torch
+    f8 = phases["slab_width"] == 128                # hrag_retrieve took the staged fp8-state path
+    f16 = phases["slab_width"] == 64 and B > 32     # ... the two-stage fp16-state path
+    eng.ppr_sweeps(B, 4, DAMPING, main_only=True, f16=f16, f8=f8)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    eng.ppr_sweeps(B, n_l, DAMPING, main_only=True, f16=f16, f8=f8)
+    e1.record()
+    torch.cuda.synchronize()
+    spmm_ms = e0.elapsed_time(e1) / n_l
+    e0.record()
+    eng.ppr_sweeps(B, n_l, DAMPING, main_only=False, f16=f16, f8=f8)
+    e1.record()
+    torch.cuda.synchronize()
+    sweep_ms = e0.elapsed_time(e1) / n_l
+    nnz = kg.csr.nnz
+    sb = 1 if f8 else 2 if f16 else 4
+    # one launch = one sweep (PPR iteration) of the whole batch: SURVEY.md 8(d)'s per-iteration bytes
+    alg = spmm_algorithmic_bytes(nnz, V, kg.n_passages, B, 4)
+    alg_stored = spmm_algorithmic_bytes(nnz, V, kg.n_passages, B, sb)
+    achieved = alg / (spmm_ms * 1e-3) / 1e9
+    traffic = load_traffic()
+    bc, n_slabs = (128, (B + 127) // 128) if f8 else (64, (B + 63) // 64) if f16 else eng.layout(B)
+    kernel = "ppr8_kernel" if f8 else "ppr16_kernel" if f16 else "ppr_spmm_kernel"
+    ppr_iter_ms = phases["ppr_ms"] / PPR_ITERS      # all kernels of the PPR stage (boundary sweeps, reduce)
+    roofline = {
+        "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        # PMC traffic is only meaningful for the workload it was collected on (profiles/pmc_traffic.json)
+        "traffic": ((traffic or {}).get(kernel, {}).get("bytes_per_launch")
+                    if (traffic or {}).get(kernel, {}).get("workload") == f"{config_name}:B{B}" else None),
+        "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_definition": "SURVEY 8(d): nnz*8 + (V+1)*4 + 2*V*B*4 + Np*B*4 per PPR iteration",
+        "state_bytes_stored": sb, "algorithmic_bytes_at_stored_state_width": alg_stored,
+        "frac_at_stored_state_width": alg_stored / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "gather_bytes_per_launch": nnz * B * sb,
+        "launch_ms": spmm_ms, "sweep_ms_all_kernels": sweep_ms,
+        "ppr_stage_ms_per_iteration": ppr_iter_ms,
+        "frac_whole_ppr_stage": alg / (ppr_iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "launches_timed": n_l, "slab_width": bc, "n_slabs": n_slabs,
+        "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+    }
+
+    return roofline, f8, f16
+
+
 def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, budget_s, max_queries):
     """Reference-style CPU loop on a bounded sample (rank 0 only) + parity spot check."""
     import oracle
@@ -137,7 +186,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1 or os.environ.get("HRAG_FORCE_DIST"):   # env: exercise the N>1 code on 1 GPU
         from hipporag_amd import dist as hdist
-        return hdist.bench_main(args, CONFIGS, rank, local_rank, world)
+        return hdist.bench_main(args, CONFIGS, rank, local_rank, world, roofline_fn=measure_roofline)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback on this path)")
@@ -182,50 +231,8 @@ def main():
     phases = eng.timings()
     eng.set_profiling(False)
 
-    # dominant kernel: ppr_spmm_kernel, average duration over back-to-back launches (HIP events on
-    # the launch stream), algorithmic bytes per launch from SURVEY.md 8(d)
-    n_l = args.sweep_launches
-    f8 = phases["slab_width"] == 128                # hrag_retrieve took the staged fp8-state path
-    f16 = phases["slab_width"] == 64 and B > 32     # ... the two-stage fp16-state path
-    eng.ppr_sweeps(B, 4, DAMPING, main_only=True, f16=f16, f8=f8)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    eng.ppr_sweeps(B, n_l, DAMPING, main_only=True, f16=f16, f8=f8)
-    e1.record()
-    torch.cuda.synchronize()
-    spmm_ms = e0.elapsed_time(e1) / n_l
-    e0.record()
-    eng.ppr_sweeps(B, n_l, DAMPING, main_only=False, f16=f16, f8=f8)
-    e1.record()
-    torch.cuda.synchronize()
-    sweep_ms = e0.elapsed_time(e1) / n_l
+    roofline, f8, f16 = measure_roofline(eng, kg, V, B, phases, args.config, args.sweep_launches)
     nnz = kg.csr.nnz
-    sb = 1 if f8 else 2 if f16 else 4
-    # one launch = one sweep (PPR iteration) of the whole batch: SURVEY.md 8(d)'s per-iteration bytes
-    alg = spmm_algorithmic_bytes(nnz, V, kg.n_passages, B, 4)
-    alg_stored = spmm_algorithmic_bytes(nnz, V, kg.n_passages, B, sb)
-    achieved = alg / (spmm_ms * 1e-3) / 1e9
-    traffic = load_traffic()
-    bc, n_slabs = (128, (B + 127) // 128) if f8 else (64, (B + 63) // 64) if f16 else eng.layout(B)
-    kernel = "ppr8_kernel" if f8 else "ppr16_kernel" if f16 else "ppr_spmm_kernel"
-    ppr_iter_ms = phases["ppr_ms"] / PPR_ITERS      # all kernels of the PPR stage (boundary sweeps, reduce)
-    roofline = {
-        "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        # PMC traffic is only meaningful for the workload it was collected on (profiles/pmc_traffic.json)
-        "traffic": ((traffic or {}).get(kernel, {}).get("bytes_per_launch")
-                    if (traffic or {}).get(kernel, {}).get("workload") == f"{args.config}:B{B}" else None),
-        "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_definition": "SURVEY 8(d): nnz*8 + (V+1)*4 + 2*V*B*4 + Np*B*4 per PPR iteration",
-        "state_bytes_stored": sb, "algorithmic_bytes_at_stored_state_width": alg_stored,
-        "frac_at_stored_state_width": alg_stored / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "gather_bytes_per_launch": nnz * B * sb,
-        "launch_ms": spmm_ms, "sweep_ms_all_kernels": sweep_ms,
-        "ppr_stage_ms_per_iteration": ppr_iter_ms,
-        "frac_whole_ppr_stage": alg / (ppr_iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "launches_timed": n_l, "slab_width": bc, "n_slabs": n_slabs,
-        "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-    }
-
     result = {
         "metric": "retrieval_queries_per_sec", "value": qps, "unit": "queries/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -201,7 +201,7 @@ def build_sharded_engine(kg, pass_emb, fact_emb, rank: int, world: int, max_batc
 # --------------------------------------------------------------------------------------------
 # bench.py --gpus N (N > 1)
 # --------------------------------------------------------------------------------------------
-def bench_main(args, configs, rank: int, local_rank: int, world: int) -> int:
+def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_fn=None) -> int:
     torch, dist = _td()
     from . import synth
     from .engine import HippoRAGEngine
@@ -254,6 +254,17 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int) -> int:
     barrier_sync()
     replica_s = max_over_ranks(time.perf_counter() - t0)
     replica_qps = world * B * args.steps / replica_s
+    # phase breakdown + the dominant kernel's roofline, measured on this rank's engine (every rank runs
+    # it so that the ranks stay in step; rank 0 reports)
+    roofline = phases = None
+    if roofline_fn is not None:
+        eng.set_profiling(True)
+        step(n_batches - 1)
+        torch.cuda.synchronize()
+        phases = eng.timings()
+        eng.set_profiling(False)
+        roofline, _, _ = roofline_fn(eng, kg, V, B, phases, args.config, getattr(args, "sweep_launches", 40))
+        barrier_sync()
     eng.close()
     del eng
     torch.cuda.empty_cache()
@@ -268,6 +279,9 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int) -> int:
                    "global_batch": world * B, "per_gpu_batch": B, "ppr_iters": ITERS,
                    "linking_top_k": K_F, "retrieval_top_k": K_P,
                    "parallelism": f"replica x{world} (queries sharded, no data-path collective)"},
+        "roofline": roofline,
+        "phases_ms": ({k: phases[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")}
+                      if phases else None),
         "rowshard": None,
     }
 

@@ -34,6 +34,8 @@ def plan_for(iters):
 
 
 def ppr8(at32, d1, v, alpha, plan):
+    """Mirror of ppr8_run (csrc/engine.hip) + the kernels of csrc/ppr8.hip, fp32 arithmetic."""
+    import math
     al, be = np.float32(alpha), np.float32(1 - alpha)
     zv = (v / d1[:, None])
     s0 = zv.max(axis=0)
@@ -42,16 +44,21 @@ def ppr8(at32, d1, v, alpha, plan):
     R = be * zv
     c = q8(zv * np.float32(128.0)); inv = np.float32(1 / 128.0)
     X = np.zeros_like(zv, dtype=np.float64)
-    cs_next = np.float32(256.0)
+    bound = max(alpha, 1 - alpha) + 0.07                   # |R_0| <= bound * max(v/d)
+
+    def scale_for(m):                                      # static power-of-two scale of a stage of m sweeps
+        growth = (1 - alpha ** m) / (1 - alpha) if alpha < 1 else m
+        return np.float32(2.0 ** math.floor(math.log2(224.0 / (bound * max(growth, 1.0)))))
+
     for si, m in enumerate(plan):
         if si > 0:
-            cs = cs_next
+            cs = scale_for(m)
             inv = np.float32(1.0) / cs
             rt = q8(R * cs)
             c = rt
             for _ in range(m - 1):
                 c = q8(al * (at32 @ c) + rt)
-            cs_next = cs * np.float32(2.0 ** m)
+            bound *= alpha ** m
         R = (R + (al * (at32 @ c) - c) * inv).astype(np.float32)
         X = X + c.astype(np.float64) * inv
     z = X + R

@@ -243,8 +243,10 @@ hrag_status launch_flag_zero_mass(const double *sums, int32_t batch, int32_t *fl
                                   hipStream_t s);
 
 // sim_gemm.hip : S[b][m] = sum_k Q[b][k] * E[m][k]   (bf16 in, fp32 out, ld in elements)
+// dtype: HRAG_BF16 | HRAG_FP16 element type of emb AND q (16-bit patterns)
 hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
-                            int32_t batch, float *out, int64_t ld, hipStream_t s, int32_t accumulate = 0);
+                            int32_t batch, float *out, int64_t ld, hipStream_t s, int32_t accumulate = 0,
+                            int32_t dtype = HRAG_BF16);
 
 // fused similarity + top-k for k <= 16 (no [B, rows] score matrix; bit-identical to the two-step path)
 //   ws: 2 * sim_fused_tiles(rows) * batch floats; sel: batch * 16 ints; mn / mx: batch floats
@@ -252,11 +254,11 @@ int64_t sim_fused_tiles(int64_t rows);
 hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
                                   int32_t batch, int32_t k, int32_t idx_offset, int32_t normalize,
                                   float *ws, int32_t *sel, float *mn, float *mx, int32_t *idx_out,
-                                  float *val_out, hipStream_t s);
+                                  float *val_out, hipStream_t s, int32_t dtype = HRAG_BF16);
 
 // sim_gemv.hip : the same for batch <= 8 (streams E once, queries in registers); false = not handled
 bool launch_sim_gemv(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch,
-                     float *out, int64_t ld, hipStream_t s);
+                     float *out, int64_t ld, hipStream_t s, int32_t dtype = HRAG_BF16);
 
 // topk.hip
 constexpr int kTopkMax = 2048;

@@ -66,7 +66,7 @@ struct hrag_engine {
     int32_t *d_passage_vertex = nullptr;  // [Np] global vertex ids
     int32_t *d_row_to_tele = nullptr;     // [n_rows] global passage index of an owned row, or -1
     // embeddings (owned rows)
-    int32_t dim = 0;
+    int32_t dim = 0, emb_dtype = HRAG_BF16;
     int64_t p_rows = 0, p_offset = 0, f_rows = 0, f_offset = 0, n_facts = 0;
     uint16_t *d_pemb = nullptr, *d_femb = nullptr;
     int32_t *d_subj = nullptr, *d_obj = nullptr, *d_num_chunks = nullptr;
@@ -445,7 +445,8 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     HRAG_REQUIRE(g->nnz >= 0 && g->nnz < (int64_t)0x7fffffff, "nnz must fit int32");
     HRAG_REQUIRE(g->row_ptr && (g->nnz == 0 || (g->col_idx && g->val)), "CSR arrays missing");
     HRAG_REQUIRE(g->n_passages >= 0 && (g->n_passages == 0 || g->passage_vertex), "passage_vertex missing");
-    HRAG_REQUIRE(passages->dtype == HRAG_BF16 && (!facts || facts->dtype == HRAG_BF16), "only bf16 embeddings");
+    HRAG_REQUIRE(passages->dtype == HRAG_BF16 || passages->dtype == HRAG_FP16, "embeddings must be bf16 or fp16");
+    HRAG_REQUIRE(!facts || facts->dtype == passages->dtype, "fact / passage embedding dtypes differ");
     HRAG_REQUIRE(passages->dim > 0 && passages->dim % 8 == 0, "embedding dim must be a multiple of 8");
     HRAG_REQUIRE(!facts || facts->dim == passages->dim, "fact / passage dims differ");
     HRAG_REQUIRE((facts == nullptr) == (fd == nullptr), "facts and fact_desc go together");
@@ -617,6 +618,7 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     }
     // ---- embeddings + fact lookup arrays
     e->dim = passages->dim;
+    e->emb_dtype = passages->dtype;
     e->p_rows = passages->rows; e->p_offset = passages->row_offset;
     E_TRY(dev_upload(&e->d_pemb, static_cast<const uint16_t *>(passages->data), e->p_rows * e->dim));
     if (facts) {
@@ -753,9 +755,9 @@ hrag_status hrag_sim_scores(hrag_engine *e, int32_t which, const uint16_t *q, in
     HRAG_REQUIRE(which == 0 || which == 1, "which must be 0 (facts) or 1 (passages)");
     if (which == 0) {
         HRAG_REQUIRE(e->d_femb != nullptr || e->f_rows == 0, "engine has no fact embeddings");
-        return launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, out, e->f_rows, (hipStream_t)stream);
+        return launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, out, e->f_rows, (hipStream_t)stream, 0, e->emb_dtype);
     }
-    return launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q, batch, out, e->p_rows, (hipStream_t)stream);
+    return launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q, batch, out, e->p_rows, (hipStream_t)stream, 0, e->emb_dtype);
 }
 
 hrag_status hrag_row_minmax(const float *scores, int32_t batch, int64_t n, int64_t ld, float *mn,
@@ -785,9 +787,9 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q, int32_t batch, i
         // no [B, F] score matrix: tile maxima -> k tiles per query -> exact top-k of k * 128 recomputed
         // scores (bit-identical to the two-step path below; sim_gemm.hip)
         HRAG_TRY(launch_sim_topk_fused(e->d_femb, e->f_rows, e->dim, q, batch, k, 0, 1, e->d_fused_ws,
-                                       e->d_fused_sel, e->d_mn_f, e->d_mx_f, idx_out, score_out, s));
+                                       e->d_fused_sel, e->d_mn_f, e->d_mx_f, idx_out, score_out, s, e->emb_dtype));
     } else {
-        HRAG_TRY(launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, e->d_sfact, e->ld_f, s));
+        HRAG_TRY(launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, e->d_sfact, e->ld_f, s, 0, e->emb_dtype));
         // get_fact_scores' min_max_normalize + rerank_facts' argsort prefix in one kernel
         HRAG_TRY(launch_row_topk(e->d_sfact, batch, e->f_rows, e->ld_f, k, 0, kNormMinMax, idx_out, score_out,
                                  nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
@@ -889,7 +891,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     HRAG_HIP_TRY(hipMemsetAsync(e->d_flags, 0, (size_t)batch * sizeof(int32_t), s));
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_START], s));
     // dense_passage_retrieval: raw scores + min / max (HippoRAG.py:1496-1498)
-    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s));
+    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
     HRAG_TRY(launch_row_minmax(e->d_spass, batch, e->n_passages, e->ld_p, e->d_mn_p, e->d_mx_p, s,
                                f16 ? e->d_ssum : nullptr));   // fp8 path: d_ssum is the z-max scratch
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SIM], s));
@@ -992,7 +994,7 @@ hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t 
     HRAG_REQUIRE(e->p_rows == e->n_passages, "hrag_dense_retrieve needs the whole passage matrix");
     HRAG_REQUIRE(k >= 1 && k <= e->max_topk, "k=%d outside [1, max_topk=%d]", k, e->max_topk);
     hipStream_t s = (hipStream_t)stream;
-    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s));
+    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
     return launch_row_topk(e->d_spass, batch, e->n_passages, e->ld_p, k, 0, kNormMinMax, doc_idx_out,
                            doc_score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes);
 }

@@ -1,4 +1,5 @@
-// K1 -- cosine-similarity scores S[b][m] = sum_k Q[b][k] * E[m][k] on the bf16 matrix cores.
+// K1 -- cosine-similarity scores S[b][m] = sum_k Q[b][k] * E[m][k] on the matrix cores (bf16, or IEEE
+// fp16 for BASELINE configs[4]: `fp16 embeddings`; same kernel, v_mfma_f32_16x16x32_f16).
 //
 // Replaces np.dot(self.fact_embeddings, q.T) / np.dot(self.passage_embeddings, q.T)
 // (reference src/hipporag/HippoRAG.py:1459, :1496; StandardRAG.py:422) for a batch of B queries.
@@ -22,7 +23,24 @@ namespace hrag {
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// one 16x16x32 MFMA on 16-byte fragments of bf16 (F16 = false) or IEEE fp16 (F16 = true) elements
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma32(const uint4 &ua, const uint4 &ub, f32x4 acc) {
+    if constexpr (F16) {
+        f16x8 a, b;
+        __builtin_memcpy(&a, &ua, 16);
+        __builtin_memcpy(&b, &ub, 16);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+    } else {
+        bf16x8 a, b;
+        __builtin_memcpy(&a, &ua, 16);
+        __builtin_memcpy(&b, &ub, 16);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    }
+}
 
 constexpr int BM = 128;
 constexpr int BK = 64;
@@ -30,7 +48,7 @@ constexpr int LDS_LD = BK + 8;  // bf16 elements per LDS row (144 bytes)
 
 // TILEMAX: instead of the scores, write per (row tile, query) the max and min score of the tile
 // (tmax / tmin: [n_tiles_m][batch]) -- pass 1 of the fused fact top-k below.
-template <int BN, int WM, int WN, bool TILEMAX = false>
+template <int BN, int WM, int WN, bool TILEMAX = false, bool F16 = false>
 __global__ __launch_bounds__(256) void sim_gemm_kernel(const uint16_t *__restrict__ emb,
                                                        int64_t rows, int32_t dim,
                                                        const uint16_t *__restrict__ q,
@@ -102,19 +120,18 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(const uint16_t *__restric
         if (k0 + BK < dim) load_tile(k0 + BK);  // in flight while the MFMAs below run
 #pragma unroll
         for (int s = 0; s < BK / 32; ++s) {
-            bf16x8 a[MI], b[NJ];
+            uint4 a[MI], b[NJ];
             const int kcol = s * 32 + 8 * (lane >> 4);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                a[i] = *reinterpret_cast<const bf16x8 *>(&As[(wm * MI + i) * 16 + (lane & 15)][kcol]);
+                a[i] = *reinterpret_cast<const uint4 *>(&As[(wm * MI + i) * 16 + (lane & 15)][kcol]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                b[j] = *reinterpret_cast<const bf16x8 *>(&Bs[(wn * NJ + j) * 16 + (lane & 15)][kcol]);
+                b[j] = *reinterpret_cast<const uint4 *>(&Bs[(wn * NJ + j) * 16 + (lane & 15)][kcol]);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<F16>(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
@@ -243,6 +260,7 @@ __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restric
     }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void tile_rescore_kernel(const uint16_t *__restrict__ emb, int64_t rows,
                                                            int32_t dim, const uint16_t *__restrict__ q,
                                                            const int32_t *__restrict__ sel,
@@ -274,10 +292,7 @@ __global__ __launch_bounds__(256) void tile_rescore_kernel(const uint16_t *__res
                         ub = *reinterpret_cast<const uint4 *>(qrow + kcol);
                         if (arow < rows) ua = *reinterpret_cast<const uint4 *>(emb + (size_t)arow * dim + kcol);
                     }
-                    bf16x8 a, bb;
-                    __builtin_memcpy(&a, &ua, 16);
-                    __builtin_memcpy(&bb, &ub, 16);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc, 0, 0, 0);
+                    acc = mfma32<F16>(ua, ub, acc);
                 }
             }
             if ((lane & 15) == 0) {   // every column holds the same query: take column 0
@@ -327,20 +342,28 @@ int64_t sim_fused_tiles(int64_t rows) { return ceil_div(rows, BM); }
 hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
                                   int32_t batch, int32_t k, int32_t idx_offset, int32_t normalize,
                                   float *ws, int32_t *sel, float *mn, float *mx, int32_t *idx_out,
-                                  float *val_out, hipStream_t s) {
+                                  float *val_out, hipStream_t s, int32_t dtype) {
     HRAG_REQUIRE(dim > 0 && dim % 8 == 0, "embedding dim %d must be a positive multiple of 8", dim);
     HRAG_REQUIRE(k >= 1 && k <= kFusedMaxK && rows >= 1 && batch >= 1, "fused top-k: bad k / rows / batch");
     const int64_t tiles_m = ceil_div(rows, BM);
     const int tn = (int)ceil_div(batch, 128);
     float *tmax = ws, *tmin = ws + (size_t)tiles_m * batch;
-    hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2, true>), dim3((unsigned)(tiles_m * tn)), dim3(256), 0, s, emb,
-                       rows, dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);
+    if (dtype == HRAG_FP16)
+        hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2, true, true>), dim3((unsigned)(tiles_m * tn)), dim3(256), 0,
+                           s, emb, rows, dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);
+    else
+        hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2, true, false>), dim3((unsigned)(tiles_m * tn)), dim3(256), 0,
+                           s, emb, rows, dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);
     HRAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(tile_select_kernel, dim3((unsigned)batch), dim3(256), 0, s, tmax, tmin, (int32_t)tiles_m,
                        batch, k, sel, mn, mx);
     HRAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tile_rescore_kernel, dim3((unsigned)batch), dim3(256), 0, s, emb, rows, dim, q, sel, mn, mx,
-                       k, idx_offset, normalize, idx_out, val_out);
+    if (dtype == HRAG_FP16)
+        hipLaunchKernelGGL(tile_rescore_kernel<true>, dim3((unsigned)batch), dim3(256), 0, s, emb, rows, dim, q, sel,
+                           mn, mx, k, idx_offset, normalize, idx_out, val_out);
+    else
+        hipLaunchKernelGGL(tile_rescore_kernel<false>, dim3((unsigned)batch), dim3(256), 0, s, emb, rows, dim, q, sel,
+                           mn, mx, k, idx_offset, normalize, idx_out, val_out);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }
@@ -349,28 +372,37 @@ namespace {
 }  // namespace
 
 hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
-                            int32_t batch, float *out, int64_t ld, hipStream_t s, int32_t accumulate) {
+                            int32_t batch, float *out, int64_t ld, hipStream_t s, int32_t accumulate,
+                            int32_t dtype) {
     HRAG_REQUIRE(dim > 0 && dim % 8 == 0, "embedding dim %d must be a positive multiple of 8", dim);
     if (rows == 0 || batch == 0) return HRAG_OK;
     // latency path: GEMV.  Measured at F = 875k, D = 768: B = 1 0.27 ms (MFMA kernel 0.70), B = 2 0.31;
     // from B = 4 the per-lane dot products make it VALU-bound (0.96 ms) and the MFMA kernel wins.
-    if (batch <= 2 && !accumulate && launch_sim_gemv(emb, rows, dim, q, batch, out, ld, s)) {
+    if (batch <= 2 && !accumulate && launch_sim_gemv(emb, rows, dim, q, batch, out, ld, s, dtype)) {
         HRAG_LAUNCH_CHECK();
         return HRAG_OK;
     }
     const int64_t tiles_m = ceil_div(rows, BM);
+    const bool f16 = dtype == HRAG_FP16;
+#define LAUNCH(BN_, WM_, WN_, GRID, TN)                                                                       \
+    do {                                                                                                      \
+        if (f16)                                                                                              \
+            hipLaunchKernelGGL((sim_gemm_kernel<BN_, WM_, WN_, false, true>), dim3((unsigned)(GRID)), dim3(256), \
+                               0, s, emb, rows, dim, q, batch, out, ld, TN, accumulate);                     \
+        else                                                                                                  \
+            hipLaunchKernelGGL((sim_gemm_kernel<BN_, WM_, WN_, false, false>), dim3((unsigned)(GRID)), dim3(256), \
+                               0, s, emb, rows, dim, q, batch, out, ld, TN, accumulate);                     \
+    } while (0)
     if (batch > 64) {
         const int tn = (int)ceil_div(batch, 128);
-        hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2>), dim3((unsigned)(tiles_m * tn)), dim3(256), 0, s,
-                           emb, rows, dim, q, batch, out, ld, tn, accumulate);
+        LAUNCH(128, 2, 2, tiles_m * tn, tn);
     } else if (batch > 16) {
         const int tn = (int)ceil_div(batch, 64);
-        hipLaunchKernelGGL((sim_gemm_kernel<64, 4, 1>), dim3((unsigned)(tiles_m * tn)), dim3(256), 0, s,
-                           emb, rows, dim, q, batch, out, ld, tn, accumulate);
+        LAUNCH(64, 4, 1, tiles_m * tn, tn);
     } else {
-        hipLaunchKernelGGL((sim_gemm_kernel<16, 4, 1>), dim3((unsigned)tiles_m), dim3(256), 0, s, emb,
-                           rows, dim, q, batch, out, ld, 1, accumulate);
+        LAUNCH(16, 4, 1, tiles_m, 1);
     }
+#undef LAUNCH
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

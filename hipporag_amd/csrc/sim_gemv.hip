@@ -7,7 +7,7 @@
 //   * the queries live in registers (8 bf16 per lane per 512-element chunk of D);
 //   * a wavefront streams R rows at a time, one 16-byte load per lane per chunk (a row of D = 768
 //     is two fully coalesced 1-KiB / 512-B loads), all R*CH loads issued before the first use;
-//   * products and sums by v_dot2c_f32_bf16 (fp32 accumulate);
+//   * products and sums by v_dot2c_f32_bf16 / v_dot2c_f32_f16 (fp32 accumulate);
 //   * the R*BQ partial sums of a lane are reduced across the 64 lanes with a halving butterfly:
 //     each step a lane hands half of its values to the lane `offset` away and keeps the other half
 //     (31 shuffles for 32 values instead of 6 per value), then lanes write distinct outputs.
@@ -20,13 +20,20 @@ namespace hrag {
 namespace {
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
+template <bool F16>
+__device__ __forceinline__ float dot2(unsigned int e, unsigned int q, float acc) {
+    if constexpr (F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, e), __builtin_bit_cast(f16x2_t, q), acc, false);
+    else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, e), __builtin_bit_cast(bf16x2_t, q), acc, false);
+}
+template <bool F16>
 __device__ __forceinline__ float dot8(const uint4 &e, const uint4 &q, float acc) {
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, e.x), __builtin_bit_cast(bf16x2_t, q.x), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, e.y), __builtin_bit_cast(bf16x2_t, q.y), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, e.z), __builtin_bit_cast(bf16x2_t, q.z), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, e.w), __builtin_bit_cast(bf16x2_t, q.w), acc, false);
+    acc = dot2<F16>(e.x, q.x, acc);
+    acc = dot2<F16>(e.y, q.y, acc);
+    acc = dot2<F16>(e.z, q.z, acc);
+    acc = dot2<F16>(e.w, q.w, acc);
     return acc;
 }
 
@@ -60,7 +67,7 @@ __device__ __forceinline__ void halving_reduce(float (&vals)[N], int lane) {
     for (int offset = 32 >> LG; offset > 0; offset >>= 1) vals[0] += __shfl_xor(vals[0], offset, 64);
 }
 
-template <int BQ, int CH, int R>
+template <int BQ, int CH, int R, bool F16>
 __global__ __launch_bounds__(256) void sim_gemv_kernel(const uint16_t *__restrict__ emb, int64_t rows,
                                                        int32_t dim, const uint16_t *__restrict__ q,
                                                        int32_t batch, float *__restrict__ out, int64_t ld) {
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void sim_gemv_kernel(const uint16_t *__restric
             for (int b = 0; b < BQ; ++b) {
                 float a = 0.f;
 #pragma unroll
-                for (int c = 0; c < CH; ++c) a = dot8(e[r][c], qr[b][c], a);
+                for (int c = 0; c < CH; ++c) a = dot8<F16>(e[r][c], qr[b][c], a);
                 vals[r * BQ + b] = a;
             }
         halving_reduce<N>(vals, lane);
@@ -117,24 +124,29 @@ __global__ __launch_bounds__(256) void sim_gemv_kernel(const uint16_t *__restric
 
 template <int BQ, int CH, int R>
 void launch_one(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch, float *out,
-                int64_t ld, hipStream_t s) {
+                int64_t ld, hipStream_t s, bool f16) {
     const int64_t groups = ceil_div(rows, R);
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(groups, 4), 256 * 8);
-    hipLaunchKernelGGL((sim_gemv_kernel<BQ, CH, R>), dim3(blocks), dim3(256), 0, s, emb, rows, dim, q, batch,
-                       out, ld);
+    if (f16)
+        hipLaunchKernelGGL((sim_gemv_kernel<BQ, CH, R, true>), dim3(blocks), dim3(256), 0, s, emb, rows, dim, q,
+                           batch, out, ld);
+    else
+        hipLaunchKernelGGL((sim_gemv_kernel<BQ, CH, R, false>), dim3(blocks), dim3(256), 0, s, emb, rows, dim, q,
+                           batch, out, ld);
 }
 
 }  // namespace
 
 // returns false when no instantiation fits (the caller falls back to the MFMA kernel)
 bool launch_sim_gemv(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch,
-                     float *out, int64_t ld, hipStream_t s) {
+                     float *out, int64_t ld, hipStream_t s, int32_t dtype) {
+    const bool f16 = dtype == HRAG_FP16;
     if (batch < 1 || batch > 8 || dim % 8 != 0 || dim > 4096) return false;
     const int bq = batch <= 1 ? 1 : batch <= 2 ? 2 : batch <= 4 ? 4 : 8;
     const int ch = dim <= 512 ? 1 : dim <= 1024 ? 2 : dim <= 2048 ? 4 : 8;
 #define GO(BQ, CH, R)                                                  \
     do {                                                               \
-        launch_one<BQ, CH, R>(emb, rows, dim, q, batch, out, ld, s);   \
+        launch_one<BQ, CH, R>(emb, rows, dim, q, batch, out, ld, s, f16); \
         return true;                                                   \
     } while (0)
     if (ch == 1) {

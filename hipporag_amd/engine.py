@@ -41,19 +41,23 @@ def _stream() -> int:
     return _torch().cuda.current_stream().cuda_stream
 
 
-def _as_bf16_bits(emb):
-    """Accept a torch bf16 tensor, or uint16 bit patterns (numpy / torch); return (obj, rows, dim)."""
+def _as_16bit(emb):
+    """Accept a torch bf16 / fp16 tensor, a numpy float16 array, or uint16 bf16 bit patterns (numpy /
+    torch); return (obj, rows, dim, dtype) with dtype 0 = bf16, 1 = fp16 (hrag_dtype)."""
     torch = _torch()
     if isinstance(emb, np.ndarray):
+        if emb.dtype == np.float16:
+            emb = np.ascontiguousarray(emb)
+            return emb, emb.shape[0], emb.shape[1], 1
         if emb.dtype != np.uint16:
-            raise TypeError("numpy embeddings must be uint16 bf16 bit patterns "
+            raise TypeError("numpy embeddings must be float16, or uint16 bf16 bit patterns "
                             "(hipporag_amd.graph.float_to_bf16_bits)")
         emb = np.ascontiguousarray(emb)
-        return emb, emb.shape[0], emb.shape[1]
-    if emb.dtype not in (torch.bfloat16, torch.uint16, torch.int16):
-        raise TypeError("tensor embeddings must be torch.bfloat16 (or raw 16-bit patterns)")
+        return emb, emb.shape[0], emb.shape[1], 0
+    if emb.dtype not in (torch.bfloat16, torch.float16, torch.uint16, torch.int16):
+        raise TypeError("tensor embeddings must be torch.bfloat16 or torch.float16 (or raw bf16 bit patterns)")
     emb = emb.contiguous()
-    return emb, emb.shape[0], emb.shape[1]
+    return emb, emb.shape[0], emb.shape[1], 1 if emb.dtype == torch.float16 else 0
 
 
 @dataclass
@@ -87,7 +91,8 @@ class HippoRAGEngine:
 
         pv = np.ascontiguousarray(passage_vertex, dtype=np.int32)
         self.n_passages = int(pv.shape[0]) if n_passages is None else int(n_passages)
-        p_obj, p_rows, dim = _as_bf16_bits(passage_emb)
+        p_obj, p_rows, dim, dt = _as_16bit(passage_emb)
+        self.emb_dtype = torch.float16 if dt == 1 else torch.bfloat16
         row_ptr = np.ascontiguousarray(graph.row_ptr, dtype=np.int32)
         col_idx = np.ascontiguousarray(graph.col_idx, dtype=np.int32)
         val = np.ascontiguousarray(graph.val, dtype=np.float32)
@@ -101,14 +106,14 @@ class HippoRAGEngine:
         gd = GraphDesc(graph.num_vertices, row_offset, n_rows, col_idx.shape[0], _ptr(row_ptr),
                        _ptr(col_idx), _ptr(val), self.n_passages, _ptr(pv),
                        _ptr(col_sum) if col_sum is not None else None)
-        pd = EmbedDesc(p_rows, passage_offset, dim, 0, _ptr(p_obj))
+        pd = EmbedDesc(p_rows, passage_offset, dim, dt, _ptr(p_obj))
         fdesc = fd = None
         keep = [pv, p_obj, row_ptr, col_idx, val, col_sum]
         self.n_facts = 0
         if fact_emb is not None:
-            f_obj, f_rows, f_dim = _as_bf16_bits(fact_emb)
-            if f_dim != dim:
-                raise ValueError("fact / passage embedding dims differ")
+            f_obj, f_rows, f_dim, f_dt = _as_16bit(fact_emb)
+            if f_dim != dim or f_dt != dt:
+                raise ValueError("fact / passage embedding dims or dtypes differ")
             sv = np.ascontiguousarray(subj_vertex, dtype=np.int32)
             ov = np.ascontiguousarray(obj_vertex, dtype=np.int32)
             nc = np.ascontiguousarray(num_chunks, dtype=np.int32)
@@ -117,7 +122,7 @@ class HippoRAGEngine:
             self.n_facts = int(sv.shape[0]) if n_facts is None else int(n_facts)
             if sv.shape[0] != self.n_facts or ov.shape[0] != self.n_facts:
                 raise ValueError("subj_vertex / obj_vertex must cover all (global) facts")
-            fdesc = EmbedDesc(f_rows, fact_offset, dim, 0, _ptr(f_obj))
+            fdesc = EmbedDesc(f_rows, fact_offset, dim, dt, _ptr(f_obj))
             fd = FactDesc(self.n_facts, _ptr(sv), _ptr(ov), _ptr(nc))
             keep += [f_obj, sv, ov, nc]
         opts = Opts(max_batch, max_topk, slab_width, long_row_nnz, self.device.index, flags, segment_nnz)
@@ -155,8 +160,8 @@ class HippoRAGEngine:
     # ------------------------------------------------------------------ helpers
     def _q(self, q):
         torch = _torch()
-        if q.dtype != torch.bfloat16:
-            q = q.to(torch.bfloat16)
+        if q.dtype != self.emb_dtype:      # queries travel in the engine's embedding dtype (bf16 / fp16)
+            q = q.to(self.emb_dtype)
         q = q.to(self.device).contiguous()
         if q.dim() != 2 or q.shape[1] != self.dim:
             raise ValueError(f"queries must be [B, {self.dim}]")

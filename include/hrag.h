@@ -16,7 +16,8 @@
  *   - every compute entry point takes the HIP stream to enqueue on (pass
  *     torch.cuda.current_stream().cuda_stream) and returns after enqueueing: no
  *     device synchronisation, no allocation in the call path (graph-capture safe);
- *   - bf16 = the upper 16 bits of an IEEE-754 binary32, passed as uint16_t;
+ *   - bf16 = the upper 16 bits of an IEEE-754 binary32, passed as uint16_t (fp16 engines:
+ *     IEEE binary16 bit patterns in the same uint16_t slots);
  *   - all index outputs are int32, all score outputs fp32;
  *   - ranking rule everywhere: score descending, ties -> larger index first
  *     (== numpy.argsort(x, kind="stable")[::-1]; the reference's np.argsort default
@@ -70,10 +71,11 @@ typedef struct hrag_graph_desc {
                                    /* iterates in the degree-scaled variable x / col_sum.             */
 } hrag_graph_desc;
 
-typedef enum hrag_dtype { HRAG_BF16 = 0 } hrag_dtype;
+typedef enum hrag_dtype { HRAG_BF16 = 0, HRAG_FP16 = 1 } hrag_dtype; /* IEEE binary16 = BASELINE configs[4] */
 
 /* Row-major, L2-normalised embedding matrix (self.fact_embeddings /
- * self.passage_embeddings, HippoRAG.py:1343-1345), rounded to bf16.
+ * self.passage_embeddings, HippoRAG.py:1343-1345), rounded to bf16 or fp16 (facts and
+ * passages use the same dtype; every q_*_dev query pointer then carries that dtype too).
  * Row sharding: this engine holds rows [row_offset, row_offset + rows). */
 typedef struct hrag_embed_desc {
     int64_t rows;

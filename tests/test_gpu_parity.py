@@ -198,6 +198,41 @@ def test_score_facts_fused_is_bit_identical_to_gemm_plus_topk(gpu_device, rows, 
         assert (idx[:, rows:] == -1).all()
 
 
+@pytest.mark.parametrize("b", [2, 12, 40, 70])
+def test_fp16_embeddings_end_to_end(gpu_device, b):
+    """BASELINE configs[4] names fp16 embeddings: the same kernels on IEEE binary16 elements
+    (v_mfma_f32_16x16x32_f16 / v_dot2c_f32_f16).  Raw scores against an fp64 dot of the fp16-rounded
+    inputs, then phase A + B against the oracle built from those inputs: B = 2 takes the GEMV,
+    12 / 40 the MFMA GEMM tiles of 16 / 64 queries, 70 the fused top-k + the fp8-state PPR."""
+    import torch
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd import synth
+    kg, pass_bits, fact_bits, index = make_case(5000, 50000, 96, seed=61)
+    pass16 = bf16_bits_to_float(pass_bits).astype(np.float16)
+    fact16 = bf16_bits_to_float(fact_bits).astype(np.float16)
+    index.passage_emb, index.fact_emb = pass16.astype(np.float32), fact16.astype(np.float32)
+    rng = np.random.default_rng(b)
+    qf = (fact16[rng.integers(0, len(fact16), b)].astype(np.float32) + 0.05 * rng.standard_normal((b, 96))).astype(np.float16)
+    qp = (pass16[rng.integers(0, len(pass16), b)].astype(np.float32) + 0.05 * rng.standard_normal((b, 96))).astype(np.float16)
+    with HippoRAGEngine(kg.csr, kg.passage_vertex, pass16, fact16, kg.subj_vertex, kg.obj_vertex, kg.num_chunks,
+                        max_batch=b, max_topk=50) as eng:
+        tq = torch.from_numpy(qf).to(gpu_device)
+        raw = eng.sim_scores("facts", tq).cpu().numpy()
+        idx, sc = eng.score_facts(tq, k=5)
+        cnt = _t(np.full(b, 5, np.int32), gpu_device)
+        out = eng.retrieve(torch.from_numpy(qp).to(gpu_device), idx, sc, cnt, ppr_iters=20, k=50)
+        got_idx, got_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+        idx_h = idx.cpu().numpy()
+    want = qf.astype(np.float64) @ fact16.astype(np.float64).T
+    np.testing.assert_allclose(raw, want, rtol=0, atol=3e-6)
+    for q in range(b):
+        ref = oracle.retrieve_one(index, qf[q].astype(np.float32), qp[q].astype(np.float32))
+        assert tie_aware_equal(idx_h[q], np.array(ref.fact_candidates), ref.fact_candidate_scores, abs_gap=2e-6), q
+        assert tie_aware_equal(got_idx[q], ref.sorted_doc_ids[:50], ref.sorted_doc_scores[:50], rel_gap=2e-5), q
+        w = ref.x[kg.passage_vertex][got_idx[q]]
+        assert (np.abs(got_sc[q] - w) / w).max() < 1e-5, q
+
+
 def _oracle_batch(case, kept_lists):
     index = case["index"]
     qf = bf16_bits_to_float(case["qf_bits"])

@@ -33,6 +33,9 @@ CONFIGS = {
                  label="configs[1]: synthetic 100k-node/1M-edge KG, 100k x 768 bf16, batch 64"),
     "cfg3": dict(V=1_000_000, E=10_000_000, D=768, B=256, seed=1237,
                  label="configs[2]: synthetic 1M-node/10M-edge KG, 1M x 768 bf16, batch 256"),
+    # one GPU's share of configs[4] (10M-node power-law KG, 10M x 1024 fp16 embeddings, 4096 / 8 queries)
+    "cfg5gpu": dict(V=10_000_000, E=100_000_000, D=1024, B=512, seed=1239, power_law=True, fp16=True,
+                    label="configs[4] per-GPU share: synthetic 10M-node/100M-edge power-law KG, 10M x 1024 fp16, batch 512"),
     "tiny": dict(V=20_000, E=200_000, D=256, B=32, seed=1235, label="tiny smoke workload"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -196,9 +199,10 @@ def main():
     V, E, D, B, seed = cfg["V"], cfg["E"], cfg["D"], args.batch or cfg["B"], cfg["seed"]
 
     t_setup = time.perf_counter()
-    kg = synth.make_kg(V, E, seed)
-    pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev)
-    fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev)
+    kg = synth.make_kg(V, E, seed, power_law=bool(cfg.get("power_law")))
+    emb_dtype = torch.float16 if cfg.get("fp16") else torch.bfloat16
+    pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev, dtype=emb_dtype)
+    fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev, dtype=emb_dtype)
     eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pass_emb, fact_emb, kg.subj_vertex, kg.obj_vertex,
                          kg.num_chunks, max_batch=B, max_topk=K_P, slab_width=args.slab_width)
     n_batches = args.steps + args.warmup
@@ -241,7 +245,7 @@ def main():
         "config": {"workload": cfg["label"], "V": V, "E": E, "nnz": nnz, "n_passages": kg.n_passages,
                    "n_facts": kg.n_facts, "dim": D, "global_batch": B, "ppr_iters": PPR_ITERS,
                    "linking_top_k": K_F, "retrieval_top_k": K_P, "damping": DAMPING,
-                   "embedding_dtype": "bf16",
+                   "embedding_dtype": "fp16" if cfg.get("fp16") else "bf16",
                    "ppr_state_dtype": ("e4m3 staged corrections + fp32 true residual (fp32 arithmetic)" if f8 else
                                        "f16 hi + f16 correction (fp32 arithmetic)" if f16 else "f32"),
                    "parallelism": "1gpu"},

@@ -87,6 +87,7 @@ struct hrag_engine {
     int32_t *d_fused_sel = nullptr;
     // two-stage fp16 PPR (ppr16.hip): SELL-8 matrix + fp16 state, unsharded engines with max_batch > 32
     bool f16_ready = false;   // fp16 state buffers present (max_batch > 8)
+    int32_t f16_max_batch = 0;  // ... sized for this many queries (64 when the fp8 path serves the larger batches)
     bool sell_ready = false;  // SELL-8 matrix + small-batch buffers present (every unsharded engine)
     float *d_tele_sv = nullptr, *d_partial_sv = nullptr;   // small-batch path (ppr_sv.hip), BP <= 8
     int2 *d_pairs = nullptr, *d_chunk_meta = nullptr;
@@ -306,7 +307,7 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
 
 // The fp16 two-stage scheme needs K1 >= 8 sweeps before the residual sweep (error ~ 2^-(11+K1)).
 inline bool use_f16(const hrag_engine *e, int batch, int iters) {
-    return e->f16_ready && batch > kSvMaxBatch && iters >= 16;
+    return e->f16_ready && batch > kSvMaxBatch && batch <= e->f16_max_batch && iters >= 16;
 }
 inline int n_slabs128(int batch) { return (int)ceil_div(batch, 128); }
 
@@ -641,7 +642,10 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     }
     if (want_f16) {
         const int ns = n_slabs64(B);
-        e->state16_elems = (int64_t)ns * e->V * 64;
+        // the fp16 STATE only has to hold the batches the fp8 path does not take (<= 64 queries); the
+        // teleport rows below are shared with the fp8 path and stay sized for max_batch
+        e->f16_max_batch = e->f8_ready ? std::min(B, 64) : B;
+        e->state16_elems = (int64_t)n_slabs64(e->f16_max_batch) * e->V * 64;
         e->state_elems = std::max(e->state_elems, e->state16_elems);  // d_x also receives h + c
         for (auto &p : e->d_h16) E_TRY(dev_alloc(&p, e->state16_elems));
         e->tele16_rows = e->n_passages + (int64_t)B * kMaxSeeds;
@@ -1068,7 +1072,7 @@ hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damp
         return HRAG_OK;
     }
     if (flags & 2) {
-        HRAG_REQUIRE(e->f16_ready, "engine has no fp16 PPR state");
+        HRAG_REQUIRE(e->f16_ready && batch <= e->f16_max_batch, "engine has no fp16 PPR state for batch %d", batch);
         const int nt = (e->opt_flags & HRAG_OPT_TEMPORAL16) ? 0 : 3;
         uint16_t *h = e->d_h16[0], *hn = e->d_h16[1];
         for (int it = 0; it < n; ++it) {

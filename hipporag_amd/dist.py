@@ -218,9 +218,10 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
     B = args.batch or cfg["B"]                      # per-GPU batch: weak scaling
     K_F, K_P, ITERS, DAMP, PW = 5, 200, 20, 0.5, 0.05
 
-    kg = synth.make_kg(V, E, seed)                  # same seed on every rank => identical index
-    pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev)
-    fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev)
+    kg = synth.make_kg(V, E, seed, power_law=bool(cfg.get("power_law")))   # same seed on every rank => identical index
+    emb_dtype = torch.float16 if cfg.get("fp16") else torch.bfloat16
+    pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev, dtype=emb_dtype)
+    fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev, dtype=emb_dtype)
     n_batches = args.steps + args.warmup
     cnt = torch.full((B,), K_F, dtype=torch.int32, device=dev)
 

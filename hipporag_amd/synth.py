@@ -141,17 +141,18 @@ def make_queries_np(emb_bits: np.ndarray, batch: int, seed: int, noise: float = 
     return float_to_bf16_bits(q), pick
 
 
-def make_embeddings_torch(rows: int, dim: int, seed: int, device, chunk: int = 1 << 18):
-    """Same recipe generated on the device (bench-scale matrices): bf16 tensor [rows, dim]."""
+def make_embeddings_torch(rows: int, dim: int, seed: int, device, chunk: int = 1 << 18, dtype=None):
+    """Same recipe generated on the device (bench-scale matrices): bf16 (default) or fp16 tensor [rows, dim]."""
     import torch
+    dtype = dtype or torch.bfloat16
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    out = torch.empty((rows, dim), dtype=torch.bfloat16, device=device)
+    out = torch.empty((rows, dim), dtype=dtype, device=device)
     for r0 in range(0, rows, chunk):
         r1 = min(rows, r0 + chunk)
         x = torch.randn((r1 - r0, dim), generator=g, device=device, dtype=torch.float32)
         x /= x.norm(dim=1, keepdim=True)
-        out[r0:r1] = x.to(torch.bfloat16)
+        out[r0:r1] = x.to(dtype)
     return out
 
 
@@ -165,4 +166,4 @@ def make_queries_torch(emb, batch: int, seed: int, noise: float = 0.5):
     nz /= nz.norm(dim=1, keepdim=True)
     q = base + noise * nz
     q /= q.norm(dim=1, keepdim=True)
-    return q.to(torch.bfloat16), pick
+    return q.to(emb.dtype if emb.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16), pick

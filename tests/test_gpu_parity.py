@@ -464,8 +464,8 @@ def test_ppr_sweeps_hook_f16(case, gpu_device):
     idx, sc = eng.score_facts(_bf16(case["qf_bits"][:b], gpu_device), k=5)
     cnt = torch.full((b,), 5, dtype=torch.int32, device=gpu_device)
     ref = eng.retrieve(_bf16(case["qp_bits"][:b], gpu_device), idx, sc, cnt, ppr_iters=20, k=50)
-    eng.ppr_sweeps(b, 3, 0.5, main_only=False, f16=True)
-    eng.ppr_sweeps(b, 2, 0.5, main_only=True, f16=True)
+    eng.ppr_sweeps(64, 3, 0.5, main_only=False, f16=True)     # fp16 state: batches <= 64 on an fp8-ready engine
+    eng.ppr_sweeps(64, 2, 0.5, main_only=True, f16=True)
     eng.ppr_sweeps(b, 3, 0.5, main_only=False, f8=True)
     eng.ppr_sweeps(b, 2, 0.5, main_only=True, f8=True)
     out = eng.retrieve(_bf16(case["qp_bits"][:b], gpu_device), idx, sc, cnt, ppr_iters=20, k=50)

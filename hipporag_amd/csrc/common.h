@@ -179,6 +179,7 @@ struct Ppr8Args {
     int32_t n_slabs64;
     float *csum;               // [n_slabs][n_csum][128] fp32: column sums of x per chunk / long row
     int32_t n_csum;            // n_chunks + n_lrow
+    int32_t n_slabs;           // 128-query slabs of this launch (set by launch_ppr8_sweep)
 };
 hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, int n_slabs, bool main_only, hipStream_t s);
 hrag_status launch_ppr8_colsum(const float *csum, int32_t n_csum, int n_slabs, int32_t batch, double *partial,

@@ -228,6 +228,10 @@ __device__ __forceinline__ uint64_t block_max_u64(uint64_t v, uint64_t *red, int
     return r;
 }
 
+// One workgroup per query.  tmax is [tile][batch], so a query's maxima are a strided column: they are
+// read ONCE into registers (kSelRegs per thread covers 8192 tiles = 1M rows; beyond that the rounds
+// re-read memory) and the k selection rounds run on the registers.
+constexpr int kSelRegs = 32;
 __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restrict__ tmax,
                                                           const float *__restrict__ tmin, int32_t n_tiles,
                                                           int32_t batch, int32_t k, int32_t *__restrict__ sel,
@@ -235,8 +239,20 @@ __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restric
     __shared__ uint64_t red[4];
     __shared__ float redf[4];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const bool in_regs = n_tiles <= 256 * kSelRegs;
+    uint64_t keys[kSelRegs];
     float mn = INFINITY;
-    for (int t = tid; t < n_tiles; t += 256) mn = fminf(mn, tmin[(size_t)t * batch + b]);
+#pragma unroll
+    for (int i = 0; i < kSelRegs; ++i) {
+        const int t = tid + 256 * i;
+        keys[i] = 0;
+        if (in_regs && t < n_tiles) {
+            keys[i] = rank_key(tmax[(size_t)t * batch + b], (uint32_t)t);
+            mn = fminf(mn, tmin[(size_t)t * batch + b]);
+        }
+    }
+    if (!in_regs)
+        for (int t = tid; t < n_tiles; t += 256) mn = fminf(mn, tmin[(size_t)t * batch + b]);
     for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
     if ((tid & 63) == 0) redf[tid >> 6] = mn;
     __syncthreads();
@@ -244,9 +260,15 @@ __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restric
     uint64_t prev = ~0ull;
     for (int r = 0; r < k; ++r) {
         uint64_t best = 0;   // keys are > 0: ordered(x) of any non-NaN float is >= 0x00800000
-        for (int t = tid; t < n_tiles; t += 256) {
-            const uint64_t key = rank_key(tmax[(size_t)t * batch + b], (uint32_t)t);
-            if (key < prev && key > best) best = key;
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < kSelRegs; ++i)
+                if (keys[i] < prev && keys[i] > best) best = keys[i];
+        } else {
+            for (int t = tid; t < n_tiles; t += 256) {
+                const uint64_t key = rank_key(tmax[(size_t)t * batch + b], (uint32_t)t);
+                if (key < prev && key > best) best = key;
+            }
         }
         best = block_max_u64(best, red, tid);
         if (tid == 0) {

@@ -295,6 +295,11 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
         if rank == 0 and not printed.is_set():
             printed.set()
             result["rowshard"] = rowshard
+            try:   # RCCL's version banner sits in the C stdio buffer: emit it first so that the JSON is the last line
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
             print(json.dumps(result), flush=True)
 
     def watchdog(limit_s, why):

@@ -209,16 +209,17 @@ def _engine(t, max_batch):
 
 def _batches(nq, batching):
     """Query index lists per device call: everything at once (fp32 slab path), one by one (B = 1
-    latency kernels), or replicated to 40 rows (two-stage fp16-state path, B > 32)."""
+    latency kernels), replicated to 40 rows (two-stage fp16-state path, 8 < B <= 64) or to 70 rows (fused
+    fact top-k + staged fp8-state path, B > 64)."""
     if batching == "all":
         return [list(range(nq))]
     if batching == "one":
         return [[q] for q in range(nq)]
-    return [[i % nq for i in range(40)]]
+    return [[i % nq for i in range(70 if batching == "padded70" else 40)]]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batching", ["all", "one", "padded40"])
+@pytest.mark.parametrize("batching", ["all", "one", "padded40", "padded70"])
 @pytest.mark.parametrize("case", CASES)
 def test_gpu_retrieve_matches_reference_vectors(gpu_device, case, batching):
     """hrag_score_facts -> (the reference's filter decisions) -> hrag_retrieve against what the reference's
@@ -232,7 +233,7 @@ def test_gpu_retrieve_matches_reference_vectors(gpu_device, case, batching):
     def bf16(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device).to(torch.bfloat16)
 
-    with _engine(t, 40) as eng:
+    with _engine(t, 80) as eng:
         for qs in _batches(nq, batching):
             b = len(qs)
             idx, sc = eng.score_facts(bf16(t["qf"][qs]), k=k_f)
@@ -251,6 +252,8 @@ def test_gpu_retrieve_matches_reference_vectors(gpu_device, case, batching):
                                torch.from_numpy(kept_n), link_top_k=k_f, damping=float(t["damping"]),
                                passage_node_weight=float(t["passage_node_weight"]), ppr_iters=20, k=k_out)
             d_idx, d_sc, flags = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy(), out.flags.cpu().numpy()
+            if batching.startswith("padded"):          # the PPR path this batching is meant to exercise
+                assert eng.timings()["slab_width"] == (128 if batching == "padded70" else 64)
             for i, q in enumerate(qs):
                 assert bool(flags[i] & 1) == bool(t["used_dpr"][q]) and not (flags[i] & ~1), (q, flags[i])
                 want_ids, want_sc = t["final_ids"][q][:k_out], t["final_scores"][q][:k_out]

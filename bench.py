@@ -172,7 +172,7 @@ def main():
     ap.add_argument("--mode", default="rowshard", choices=["rowshard", "replica"],
                     help="multi-GPU mode (N > 1)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    ap.add_argument("--cpu-queries", type=int, default=4)
+    ap.add_argument("--cpu-queries", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep-launches", type=int, default=40)
     ap.add_argument("--no-rowshard", action="store_true", help="N > 1: skip the secondary row-sharded leg")

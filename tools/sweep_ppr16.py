@@ -41,7 +41,7 @@ def main():
         for B in batches:
             for fl in [int(f) for f in args.flags.split(",")]:
                 eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pemb, femb, kg.subj_vertex, kg.obj_vertex,
-                                     kg.num_chunks, max_batch=B, max_topk=200, flags=fl)
+                                     kg.num_chunks, max_batch=B, max_topk=200, flags=fl | 32)   # 32 = HRAG_OPT_NO_FP8: this tool measures the fp16 path
                 qf, _ = synth.make_queries_torch(femb, B, 7)
                 qp, _ = synth.make_queries_torch(pemb, B, 8)
                 cnt = torch.full((B,), 5, dtype=torch.int32, device=dev)

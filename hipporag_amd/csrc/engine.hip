@@ -359,7 +359,7 @@ hrag_status ppr8_run(hrag_engine *e, int batch, float damping, int iters, hipStr
     double bound = std::max(al, 1.0 - al) + 0.07;
     auto scale_for = [&](int m) {
         const double growth = al < 1.0 ? (1.0 - std::pow(al, m)) / (1.0 - al) : (double)m;
-        int ex = (int)std::floor(std::log2(224.0 / (bound * std::max(growth, 1.0))));
+        int ex = (int)std::floor(std::log2(224.0 / std::max(bound * std::max(growth, 1.0), 1e-18)));   // damping ~ 0: bound -> 0
         ex = std::min(std::max(ex, -60), 60);
         return std::ldexp(1.0f, ex);
     };
@@ -881,6 +881,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
                  "hrag_retrieve needs an unsharded engine; sharded engines use the hrag_stage_* operators");
     HRAG_REQUIRE(k >= 1 && k <= e->max_topk, "k=%d outside [1, max_topk=%d]", k, e->max_topk);
     HRAG_REQUIRE(ppr_iters >= 0, "ppr_iters must be >= 0");
+    HRAG_REQUIRE(damping >= 0.f && damping < 1.f, "damping %g outside [0, 1)", (double)damping);
     HRAG_REQUIRE(e->n_passages >= 1, "engine has no passages");
     hipStream_t s = (hipStream_t)stream;
     const bool sv = use_sv(e, batch);
@@ -1007,6 +1008,7 @@ hrag_status hrag_ppr(hrag_engine *e, const float *reset, int32_t batch, float da
                      float *x_out, int32_t *flags_out, hrag_stream stream) {
     HRAG_TRY(check_batch(e, batch));
     HRAG_REQUIRE(reset && x_out && iters >= 0, "bad argument");
+    HRAG_REQUIRE(damping >= 0.f && damping < 1.f, "damping %g outside [0, 1)", (double)damping);
     HRAG_REQUIRE(e->n_rows == e->V, "hrag_ppr needs an unsharded engine");
     hipStream_t s = (hipStream_t)stream;
     if (!e->d_tele_dense) HRAG_TRY(dev_alloc(&e->d_tele_dense, e->state_elems));  // first use only

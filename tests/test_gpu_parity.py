@@ -474,6 +474,26 @@ def test_ppr_sweeps_hook_f16(case, gpu_device):
     assert torch.equal(ref.doc_idx, out.doc_idx) and torch.equal(ref.doc_score, out.doc_score)
 
 
+@pytest.mark.parametrize("iters", [8, 40])
+def test_retrieve_wide_batch_outside_the_fp8_iteration_range_takes_the_fp32_slabs(case, gpu_device, iters):
+    """B > 64 with ppr_iters outside [16, 30] (fp8 stage plan) and no fp16 state for that width: the
+    fp32 slab kernels serve the call; 8 sweeps are compared with the oracle's 8-sweep power iteration
+    (same start x0 = v), 40 sweeps with the exact solution."""
+    eng, kg, index = case["eng"], case["kg"], case["index"]
+    b = 70
+    idx, sc = eng.score_facts(_bf16(case["qf_bits"][:b], gpu_device), k=5)
+    cnt = _t(np.full(b, 5, np.int32), gpu_device)
+    out = eng.retrieve(_bf16(case["qp_bits"][:b], gpu_device), idx, sc, cnt, ppr_iters=iters, k=100)
+    got_idx, got_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+    assert eng.timings()["slab_width"] == 32
+    qf, qp = bf16_bits_to_float(case["qf_bits"]), bf16_bits_to_float(case["qp_bits"])
+    for q in range(0, b, 9):
+        ref = oracle.retrieve_one(index, qf[q], qp[q], ppr_mode="power" if iters == 8 else "exact", ppr_iters=iters)
+        want = ref.x[kg.passage_vertex][got_idx[q]]
+        assert (np.abs(got_sc[q] - want) / want).max() < 1e-5, q
+        assert tie_aware_equal(got_idx[q], ref.sorted_doc_ids[:100], ref.sorted_doc_scores[:100], rel_gap=2e-5), q
+
+
 # ----------------------------------------------------------------------------- full size (BASELINE configs[2])
 def test_full_size_cfg3_properties_and_spot_parity(gpu_device):
     """1M-node / 10M-edge KG, 1M x 768 bf16 embeddings, batch 256, 20 sweeps (staged fp8 state; the

@@ -105,7 +105,7 @@ typedef struct hrag_fact_desc {
 #define HRAG_OPT_TEMPORAL16 16       /* fp16-state kernels: plain instead of non-temporal (col, val)   */
                                      /* loads and state stores (non-temporal is 3 % faster at cfg 3)   */
 
-#define HRAG_OPT_NO_FP8 32           /* never take the fp8-state PPR (batch > 64, 16 <= ppr_iters <= 30,  */
+#define HRAG_OPT_NO_FP8 32           /* never take the fp8-state PPR (batch > 64, 16 <= ppr_iters <= 30, damping <= 0.7,  */
                                      /* col_sum given); the fp16 two-stage path serves those batches    */
 
 typedef struct hrag_opts {

@@ -474,6 +474,44 @@ def test_ppr_sweeps_hook_f16(case, gpu_device):
     assert torch.equal(ref.doc_idx, out.doc_idx) and torch.equal(ref.doc_score, out.doc_score)
 
 
+@pytest.mark.parametrize("damping,iters", [(0.3, 20), (0.7, 30), (0.85, 30)])
+def test_retrieve_f8_state_other_damping_factors(gpu_device, damping, iters):
+    """The fp8 stage scales follow the damping factor (residual contraction a per sweep, iterate growth
+    (1 - a^m) / (1 - a) per stage) up to 0.7, where the stage rounding starts to cost accuracy (still
+    inside the 1e-5 bar); above that hrag_retrieve takes the fp32 slabs."""
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd._lib import OPT_F32_STATE
+    from hipporag_amd import synth
+    import dataclasses
+    b = 96
+    kg, pass_bits, fact_bits, index = make_case(7000, 70000, 64, seed=77)
+    index = dataclasses.replace(index, damping=damping)
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=13)
+    qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=14)
+    qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+    errs = {}
+    for name, flags, width in (("f8", 0, 128 if damping <= 0.7 else 32), ("f32", OPT_F32_STATE, 32)):
+        with HippoRAGEngine(kg.csr, kg.passage_vertex, pass_bits, fact_bits, kg.subj_vertex, kg.obj_vertex,
+                            kg.num_chunks, max_batch=b, max_topk=100, flags=flags) as eng:
+            idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
+            cnt = _t(np.full(b, 5, np.int32), gpu_device)
+            out = eng.retrieve(_bf16(qp_bits, gpu_device), idx, sc, cnt, damping=damping, ppr_iters=iters, k=100)
+            got_idx, got_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+            assert eng.timings()["slab_width"] == width
+        worst = 0.0
+        for q in range(0, b, 11):
+            ref = oracle.retrieve_one(index, qf[q], qp[q])
+            want = ref.x[kg.passage_vertex][got_idx[q]]
+            worst = max(worst, float((np.abs(got_sc[q] - want) / want).max()))
+        errs[name] = worst
+    if damping <= 0.5:
+        assert errs["f8"] < 3e-6, errs
+    elif damping <= 0.7:
+        assert errs["f8"] < 1e-5, errs
+    else:
+        assert errs["f8"] == errs["f32"], errs          # the same kernels served both engines
+
+
 @pytest.mark.parametrize("iters", [8, 40])
 def test_retrieve_wide_batch_outside_the_fp8_iteration_range_takes_the_fp32_slabs(case, gpu_device, iters):
     """B > 64 with ppr_iters outside [16, 30] (fp8 stage plan) and no fp16 state for that width: the

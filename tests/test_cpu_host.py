@@ -27,6 +27,36 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.hrag_version() == 2            # 0 * 1000 + 2 (hrag_graph_desc.col_sum)
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The ctypes mirrors in hipporag_amd/_lib.py against include/hrag.h as gcc lays it out (sizes and
+    the offset of every field): a drift here would corrupt hrag_engine_create's inputs silently."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    structs = {"hrag_graph_desc": _lib.GraphDesc, "hrag_embed_desc": _lib.EmbedDesc,
+               "hrag_fact_desc": _lib.FactDesc, "hrag_opts": _lib.Opts, "hrag_timings": _lib.Timings}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "hrag.h"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        cname, fname, val = ln.split()
+        got[(cname, fname)] = int(val)
+    for cname, cls in structs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
 def test_product_csr_builder_matches_oracle():
     kg = synth.make_kg(3000, 30000, seed=5, power_law=True)
     a = oracle.build_symmetric_csr(kg.num_vertices, kg.src, kg.dst, kg.weight)

@@ -346,8 +346,11 @@ hrag_status ppr8_run(hrag_engine *e, int batch, float damping, int iters, hipStr
     const int ns = n_slabs128(batch), ns64 = n_slabs64(batch);
     int plan[kP8MaxStages + 4];
     const int n_stage = ppr8_plan(iters, plan);
-    HRAG_REQUIRE(n_stage <= kP8MaxStages, "ppr_iters=%d needs %d fp8 stages (max %d)", iters, n_stage, kP8MaxStages);
+    HRAG_REQUIRE(n_stage >= 2 && n_stage <= kP8MaxStages, "ppr_iters=%d needs %d fp8 stages (2..%d)", iters, n_stage,
+                 kP8MaxStages);
+    static_assert(hrag_engine::kP8Pool >= kP8MaxStages + 3, "fp8 buffer pool too small for the stage plan");
     std::vector<uint8_t *> pool(e->d_pool8, e->d_pool8 + hrag_engine::kP8Pool);
+    // <= kP8MaxStages stage results + the stage's right-hand side + one iterate in flight <= kP8Pool
     auto take = [&]() { uint8_t *p = pool.back(); pool.pop_back(); return p; };
     const uint8_t *stage_buf[kP8MaxStages];
     float stage_inv[kP8MaxStages];

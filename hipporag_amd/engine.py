@@ -259,6 +259,47 @@ class HippoRAGEngine:
         check(self._lib.hrag_ppr_sweeps(self._handle, batch, n, damping, flags, _stream()))
 
 
+class CapturedPipeline:
+    """Phase A + identity filter + phase B of one fixed batch size captured into a HIP graph.
+
+    The C ABI only enqueues kernels (no allocation, no synchronisation), so the ~35 launches of a
+    single-query retrieval (``retrieve_ircot`` issues one per reasoning step, HippoRAG.py:526,539)
+    collapse into one graph launch.  ``__call__`` copies the new queries into the graph's static input
+    buffers, replays, and returns views of the static outputs (valid until the next call):
+
+        pipe = CapturedPipeline(engine, batch=1, k=200)
+        fact_idx, fact_score, doc_idx, doc_score, flags = pipe(q_fact, q_pass)
+
+    A host-side LLM filter cannot sit inside a graph: use score_facts / retrieve directly for that.
+    """
+
+    def __init__(self, engine: "HippoRAGEngine", batch: int, *, k_f: int = 5, k: int = 200, **retrieve_kw):
+        torch = _torch()
+        self.engine, self.batch = engine, int(batch)
+        dev, dt = engine.device, engine.emb_dtype
+        self._qf = torch.zeros((batch, engine.dim), dtype=dt, device=dev)
+        self._qp = torch.zeros((batch, engine.dim), dtype=dt, device=dev)
+        self._cnt = torch.full((batch,), k_f, dtype=torch.int32, device=dev)
+
+        def run():
+            idx, sc = engine.score_facts(self._qf, k=k_f)
+            out = engine.retrieve(self._qp, idx, sc, self._cnt, link_top_k=k_f, k=k, **retrieve_kw)
+            return idx, sc, out.doc_idx, out.doc_score, out.flags
+
+        with torch.cuda.device(dev):
+            run()                                    # warm-up (lazy module loads) outside the capture
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._out = run()
+
+    def __call__(self, q_fact, q_pass):
+        self._qf.copy_(q_fact)
+        self._qp.copy_(q_pass)
+        self.graph.replay()
+        return self._out
+
+
 def topk_rows(scores, k: int, *, n: Optional[int] = None, idx_offset: int = 0, normalize: bool = False,
               want_minmax: bool = False):
     """Row-wise top-k of a device fp32 matrix with the library ranking rule (hrag_topk_rows)."""

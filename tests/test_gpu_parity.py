@@ -474,6 +474,28 @@ def test_ppr_sweeps_hook_f16(case, gpu_device):
     assert torch.equal(ref.doc_idx, out.doc_idx) and torch.equal(ref.doc_score, out.doc_score)
 
 
+@pytest.mark.parametrize("b", [1, 40, 70])
+def test_hot_path_is_graph_capturable(case, gpu_device, b):
+    """include/hrag.h promises that the compute entry points only enqueue work (no allocation, no
+    synchronisation): phase A + B are captured into a HIP graph once and replayed on new query contents;
+    every replay must reproduce the eager result bit for bit (B = 1 small-batch kernels, 40 fp16 state,
+    70 fused top-k + fp8 state)."""
+    import torch
+    from hipporag_amd.engine import CapturedPipeline
+    eng = case["eng"]
+    qf_all, qp_all = _bf16(case["qf_bits"], gpu_device), _bf16(case["qp_bits"], gpu_device)
+    cnt = torch.full((b,), 5, dtype=torch.int32, device=gpu_device)
+    pipe = CapturedPipeline(eng, b, k_f=5, k=50, ppr_iters=20)
+    for lo in (0, 7, 20):                                      # three different query sets through the same graph
+        qf, qp = torch.roll(qf_all, lo, 0)[:b].contiguous(), torch.roll(qp_all, lo, 0)[:b].contiguous()
+        got = [t.clone() for t in pipe(qf, qp)]
+        idx, sc = eng.score_facts(qf, k=5)
+        out = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50)
+        torch.cuda.synchronize()
+        for a_, w_ in zip(got, (idx, sc, out.doc_idx, out.doc_score, out.flags)):
+            assert torch.equal(a_, w_)
+
+
 @pytest.mark.parametrize("damping,iters", [(0.3, 20), (0.7, 30), (0.85, 30)])
 def test_retrieve_f8_state_other_damping_factors(gpu_device, damping, iters):
     """The fp8 stage scales follow the damping factor (residual contraction a per sweep, iterate growth

@@ -14,7 +14,7 @@ import torch
 
 from bench import CONFIGS, spmm_algorithmic_bytes
 from hipporag_amd import synth
-from hipporag_amd.engine import HippoRAGEngine
+from hipporag_amd.engine import CapturedPipeline, HippoRAGEngine
 
 
 def main():
@@ -51,6 +51,21 @@ def main():
             step()
         torch.cuda.synchronize()
         lat_ms = (time.perf_counter() - t0) * 1e3 / n
+        # true per-call latency (synchronise after every call): eager launches vs one HIP-graph replay
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+            torch.cuda.synchronize()
+        eager_sync_ms = (time.perf_counter() - t0) * 1e3 / n
+        pipe = CapturedPipeline(eng, B, k_f=5, k=200, ppr_iters=20)
+        for _ in range(3):
+            pipe(qf, qp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            pipe(qf, qp)
+            torch.cuda.synchronize()
+        graph_sync_ms = (time.perf_counter() - t0) * 1e3 / n
         eng.set_profiling(True)
         step()
         torch.cuda.synchronize()
@@ -64,7 +79,8 @@ def main():
         torch.cuda.synchronize()
         sweep_us = e0.elapsed_time(e1) / 40 * 1e3
         alg = spmm_algorithmic_bytes(kg.csr.nnz, V, kg.n_passages, B, 4 if B <= 8 else 2)
-        res[B] = dict(latency_ms=lat_ms, qps=B / lat_ms * 1e3, sweep_us=sweep_us,
+        res[B] = dict(latency_ms=lat_ms, eager_sync_ms=eager_sync_ms, graph_sync_ms=graph_sync_ms,
+                      qps=B / lat_ms * 1e3, sweep_us=sweep_us,
                       sweep_alg_gbs=alg / (sweep_us * 1e-6) / 1e9,
                       phases={k: ph[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")},
                       slab_width=ph["slab_width"])

@@ -85,7 +85,7 @@ struct hrag_engine {
     // fused fact top-k (sim_gemm.hip): tile max / min, selected tiles, global min / max per query
     float *d_fused_ws = nullptr, *d_mn_f = nullptr, *d_mx_f = nullptr;
     int32_t *d_fused_sel = nullptr;
-    // two-stage fp16 PPR (ppr16.hip): SELL-8 matrix + fp16 state, unsharded engines with max_batch > 32
+    // two-stage fp16 PPR (ppr16.hip): SELL-8 matrix + fp16 state, unsharded engines with max_batch > 8
     bool f16_ready = false;   // fp16 state buffers present (max_batch > 8)
     int32_t f16_max_batch = 0;  // ... sized for this many queries (64 when the fp8 path serves the larger batches)
     bool sell_ready = false;  // SELL-8 matrix + small-batch buffers present (every unsharded engine)

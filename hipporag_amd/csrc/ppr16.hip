@@ -1,7 +1,7 @@
 // K3h -- PPR power iteration with a two-stage fp16 state ("hi + correction"), fp32 arithmetic.
 //
 // Replaces igraph/PRPACK behind HippoRAG.run_ppr (reference src/hipporag/HippoRAG.py:1736-1743)
-// for batches wide enough to fill 128-byte lines with fp16 (B > 32).
+// for batches of 9..64 queries (and wider ones when the fp8 path of ppr8.hip is unavailable).
 //
 // Why: the sweep  y = alpha P x + (1 - alpha) v  is bound by the random row gathers of x
 // (nnz * B * sizeof(state) bytes per sweep, ~7 TB/s of 128-byte lines whether they come from HBM or
@@ -22,7 +22,7 @@
 //
 // Storage: x is [n_slabs][V][64] fp16 -- one gather = one 128-byte line = 64 queries.
 // Matrix: SELL-8 ("sliced ELLPACK", slice = the 8 rows of one wavefront): rows sorted by length,
-// rows longer than 64 entries cut into <= 64 segments ("virtual rows" whose partial sums are
+// rows longer than kSell8SegLen (512) entries cut into <= 64 segments ("virtual rows" whose partial sums are
 // combined by ppr16_reduce_kernel in a fixed order -- no atomics, bit-reproducible), 8 virtual
 // rows per wavefront, entries stored step-major as (col, val) pairs so that a wavefront's CSR
 // read is ONE coalesced 512-byte load per 8-gather step and every fetched byte is used once.

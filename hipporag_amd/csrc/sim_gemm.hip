@@ -68,9 +68,15 @@ __global__ __launch_bounds__(256) void sim_gemm_kernel(const uint16_t *__restric
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin, so ids 8 apart run back to
+    // back on one XCD; they get the n_tiles_n query tiles of the SAME row tile, whose embedding rows the
+    // later ones then find in that XCD's L2 (PMC: the fact GEMM fetched 2.7 GB for a 1.34 GB matrix
+    // when the two query tiles of a row tile sat on neighbouring XCDs).
     const int64_t tile = blockIdx.x;
-    const int nt = (int)(tile % n_tiles_n);
-    const int64_t mt = tile / n_tiles_n;
+    const int64_t jj = tile >> 3;
+    const int nt = (int)(jj % n_tiles_n);
+    const int64_t mt = (jj / n_tiles_n) * 8 + (tile & 7);
+    if (mt * BM >= rows) return;     // the grid is padded to a multiple of 8 row tiles
     const int64_t m0 = mt * BM;
     const int b0 = nt * BN;
 
@@ -371,10 +377,10 @@ hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim
     const int tn = (int)ceil_div(batch, 128);
     float *tmax = ws, *tmin = ws + (size_t)tiles_m * batch;
     if (dtype == HRAG_FP16)
-        hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2, true, true>), dim3((unsigned)(tiles_m * tn)), dim3(256), 0,
+        hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2, true, true>), dim3((unsigned)(round_up(tiles_m, 8) * tn)), dim3(256), 0,
                            s, emb, rows, dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);
     else
-        hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2, true, false>), dim3((unsigned)(tiles_m * tn)), dim3(256), 0,
+        hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2, true, false>), dim3((unsigned)(round_up(tiles_m, 8) * tn)), dim3(256), 0,
                            s, emb, rows, dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);
     HRAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(tile_select_kernel, dim3((unsigned)batch), dim3(256), 0, s, tmax, tmin, (int32_t)tiles_m,
@@ -417,12 +423,12 @@ hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, cons
     } while (0)
     if (batch > 64) {
         const int tn = (int)ceil_div(batch, 128);
-        LAUNCH(128, 2, 2, tiles_m * tn, tn);
+        LAUNCH(128, 2, 2, round_up(tiles_m, 8) * tn, tn);
     } else if (batch > 16) {
         const int tn = (int)ceil_div(batch, 64);
-        LAUNCH(64, 4, 1, tiles_m * tn, tn);
+        LAUNCH(64, 4, 1, round_up(tiles_m, 8) * tn, tn);
     } else {
-        LAUNCH(16, 4, 1, tiles_m, 1);
+        LAUNCH(16, 4, 1, round_up(tiles_m, 8), 1);
     }
 #undef LAUNCH
     HRAG_LAUNCH_CHECK();

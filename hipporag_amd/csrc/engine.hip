@@ -684,7 +684,7 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     E_TRY(dev_alloc(&e->d_spass, (int64_t)B * e->ld_p));
     E_TRY(dev_alloc(&e->d_doc, (int64_t)B * e->ld_p));
     if (facts) E_TRY(dev_alloc(&e->d_sfact, (int64_t)B * e->ld_f));
-    if (facts && B > 64) {
+    if (facts && B > 16) {
         E_TRY(dev_alloc(&e->d_fused_ws, 2 * sim_fused_tiles(std::max<int64_t>(e->f_rows, 1)) * B));
         E_TRY(dev_alloc(&e->d_fused_sel, (int64_t)B * 16));
         E_TRY(dev_alloc(&e->d_mn_f, B));
@@ -793,7 +793,7 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q, int32_t batch, i
                  "engine goes through hrag_sim_scores + hrag_topk_rows + an all-gather");
     hipStream_t s = (hipStream_t)stream;
     if (e->profiling) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_FACT0], s));
-    if (batch > 64 && k <= 16 && e->f_rows > 0 && e->d_fused_ws) {
+    if (batch > 16 && k <= 16 && e->f_rows > 0 && e->d_fused_ws) {
         // no [B, F] score matrix: tile maxima -> k tiles per query -> exact top-k of k * 128 recomputed
         // scores (bit-identical to the two-step path below; sim_gemm.hip)
         HRAG_TRY(launch_sim_topk_fused(e->d_femb, e->f_rows, e->dim, q, batch, k, 0, 1, e->d_fused_ws,

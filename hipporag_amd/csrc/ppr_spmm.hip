@@ -263,14 +263,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *x, int
     }
 }
 
-__global__ void colsum_final_kernel(const double *partial, int32_t batch, int32_t bc, int32_t nblk,
-                                    double *sums) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per query: lane l adds blocks l, l + 64, ... in that order, then a fixed xor-butterfly
+// (a single thread walking all kColsumBlocks partials took 62 us -- 4 % of a cfg-2 batch)
+__global__ __launch_bounds__(64) void colsum_final_kernel(const double *partial, int32_t batch, int32_t bc,
+                                                          int32_t nblk, double *sums) {
+    const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= batch) return;
     const int slab = q / bc, col = q % bc;
     double s = 0;
-    for (int b = 0; b < nblk; ++b) s += partial[((size_t)slab * nblk + b) * bc + col];
-    sums[q] = s;
+    for (int b = lane; b < nblk; b += 64) s += partial[((size_t)slab * nblk + b) * bc + col];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) sums[q] = s;
 }
 
 template <int G>
@@ -364,8 +367,8 @@ hrag_status launch_colsum(const float *x, int64_t num_vertices, int64_t row_offs
     st = [&]() -> hrag_status { HRAG_DISPATCH_G(lay, CALL) }();
 #undef CALL
     if (st != HRAG_OK) return st;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, s,
-                       partial, batch, lay.bc, kColsumBlocks, sums);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)batch), dim3(64), 0, s, partial, batch, lay.bc,
+                       kColsumBlocks, sums);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -374,14 +374,24 @@ hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim
     HRAG_REQUIRE(dim > 0 && dim % 8 == 0, "embedding dim %d must be a positive multiple of 8", dim);
     HRAG_REQUIRE(k >= 1 && k <= kFusedMaxK && rows >= 1 && batch >= 1, "fused top-k: bad k / rows / batch");
     const int64_t tiles_m = ceil_div(rows, BM);
-    const int tn = (int)ceil_div(batch, 128);
     float *tmax = ws, *tmin = ws + (size_t)tiles_m * batch;
-    if (dtype == HRAG_FP16)
-        hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2, true, true>), dim3((unsigned)(round_up(tiles_m, 8) * tn)), dim3(256), 0,
-                           s, emb, rows, dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);
-    else
-        hipLaunchKernelGGL((sim_gemm_kernel<128, 2, 2, true, false>), dim3((unsigned)(round_up(tiles_m, 8) * tn)), dim3(256), 0,
-                           s, emb, rows, dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);
+    const bool f16 = dtype == HRAG_FP16;
+    // the same tile shapes as launch_sim_gemm (the scores do not depend on the shape: every element is
+    // the same chain of 16x16x32 MFMAs in ascending k)
+#define LAUNCH_TM(BN_, WM_, WN_)                                                                              \
+    do {                                                                                                      \
+        const int tn = (int)ceil_div(batch, BN_);                                                             \
+        const dim3 grid((unsigned)(round_up(tiles_m, 8) * tn));                                               \
+        if (f16)                                                                                              \
+            hipLaunchKernelGGL((sim_gemm_kernel<BN_, WM_, WN_, true, true>), grid, dim3(256), 0, s, emb, rows, \
+                               dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);                                 \
+        else                                                                                                  \
+            hipLaunchKernelGGL((sim_gemm_kernel<BN_, WM_, WN_, true, false>), grid, dim3(256), 0, s, emb, rows, \
+                               dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);                                 \
+    } while (0)
+    if (batch > 64) LAUNCH_TM(128, 2, 2);
+    else LAUNCH_TM(64, 4, 1);
+#undef LAUNCH_TM
     HRAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(tile_select_kernel, dim3((unsigned)batch), dim3(256), 0, s, tmax, tmin, (int32_t)tiles_m,
                        batch, k, sel, mn, mx);

@@ -29,6 +29,10 @@ if ROOT not in sys.path:
 
 CONFIGS = {
     # name: (V, E, D, B, seed)   -- SURVEY.md section 8 table; seed = 1234 + cfg number
+    # configs[0] is the MuSiQue 1k-passage corpus (no dataset here, no network): SURVEY.md 8(d)'s synthetic
+    # substitute of the same shape -- 1 000 passages, ~8k vertices -- labelled as such
+    "cfg1s": dict(V=8_000, E=80_000, D=768, B=64, seed=1235,
+                  label="configs[0] SUBSTITUTE: synthetic 1 000-passage / 8k-node / 80k-edge KG, 8k x 768 bf16, batch 64"),
     "cfg2": dict(V=100_000, E=1_000_000, D=768, B=64, seed=1236,
                  label="configs[1]: synthetic 100k-node/1M-edge KG, 100k x 768 bf16, batch 64"),
     "cfg3": dict(V=1_000_000, E=10_000_000, D=768, B=256, seed=1237,
@@ -36,6 +40,10 @@ CONFIGS = {
     # one GPU's share of configs[4] (10M-node power-law KG, 10M x 1024 fp16 embeddings, 4096 / 8 queries)
     "cfg5gpu": dict(V=10_000_000, E=100_000_000, D=1024, B=512, seed=1239, power_law=True, fp16=True,
                     label="configs[4] per-GPU share: synthetic 10M-node/100M-edge power-law KG, 10M x 1024 fp16, batch 512"),
+    # one GPU's share of configs[3]: shard 0 of the 8-way row shard of the 1M-node KG with the GLOBAL batch of
+    # 1024 queries (compute of one GPU; the exchanges need the other 7 GPUs and are not performed)
+    "cfg4gpu": dict(V=1_000_000, E=10_000_000, D=768, B=1024, seed=1237, shard_of=8,
+                    label="configs[3] per-GPU share: shard 0 of 8 row shards of the 1M-node/10M-edge KG, global batch 1024"),
     "tiny": dict(V=20_000, E=200_000, D=256, B=32, seed=1235, label="tiny smoke workload"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -65,25 +73,45 @@ def load_traffic():
     return None
 
 
-def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
-    """Dominant kernel (the PPR sweep): average duration over n_l back-to-back launches (HIP events on
-    the launch stream) against SURVEY.md 8(d)'s algorithmic bytes per PPR iteration.  Returns
-    (roofline dict, f8, f16)."""
+def _time_launches(fn, n_l):
     import torch
-    f8 = phases["slab_width"] == 128                # hrag_retrieve took the staged fp8-state path
-    f16 = phases["slab_width"] == 64 and B > 32     # ... the two-stage fp16-state path
-    eng.ppr_sweeps(B, 4, DAMPING, main_only=True, f16=f16, f8=f8)
+    fn(4)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    eng.ppr_sweeps(B, n_l, DAMPING, main_only=True, f16=f16, f8=f8)
+    fn(n_l)
     e1.record()
     torch.cuda.synchronize()
-    spmm_ms = e0.elapsed_time(e1) / n_l
-    e0.record()
-    eng.ppr_sweeps(B, n_l, DAMPING, main_only=False, f16=f16, f8=f8)
-    e1.record()
-    torch.cuda.synchronize()
-    sweep_ms = e0.elapsed_time(e1) / n_l
+    return e0.elapsed_time(e1) / n_l
+
+
+def fp8_mode_counts(iters):
+    """(C, B, B0, F) launches of one retrieve: ppr8_plan in csrc/shard.hip (1, 2, 3.., 4..)."""
+    r = iters - 3
+    b4, a3 = r % 3, (r - 4 * (r % 3)) // 3
+    if a3 >= 4:
+        a3, b4 = a3 - 4, b4 + 3
+    stages = [1, 2] + [3] * a3 + [4] * b4
+    return {"C": sum(m - 1 for m in stages[1:]), "B": len(stages) - 2, "B0": 1, "F": 1}
+
+
+def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
+    """Dominant kernel (the PPR sweep): average launch duration (HIP events on the launch stream, n_l
+    back-to-back launches per kernel instantiation) against SURVEY.md 8(d)'s algorithmic bytes per PPR
+    iteration.  On the fp8 path one retrieve launches ppr8_kernel in four instantiations (C stage sweep,
+    B boundary, B0 first boundary, F final): `achieved` / `frac` price the AVERAGE launch of a retrieve
+    (counts from the stage plan), the C-only figure is kept beside it.  Returns (roofline dict, f8, f16)."""
+    f8 = phases["slab_width"] == 128                # hrag_retrieve took the staged fp8-state path
+    f16 = phases["slab_width"] == 64 and B > 32     # ... the two-stage fp16-state path
+    per_mode = None
+    if f8:
+        per_mode = {m: _time_launches(lambda n, m=m: eng.ppr_sweeps(B, n, DAMPING, f8=True, f8_mode=m), n_l)
+                    for m in ("C", "B", "B0", "F")}
+        counts = fp8_mode_counts(PPR_ITERS)
+        spmm_ms = sum(counts[m] * per_mode[m] for m in counts) / PPR_ITERS
+        main_ms = _time_launches(lambda n: eng.ppr_sweeps(B, n, DAMPING, main_only=True, f8=True), n_l)
+    else:
+        main_ms = _time_launches(lambda n: eng.ppr_sweeps(B, n, DAMPING, main_only=True, f16=f16), n_l)
+        spmm_ms = _time_launches(lambda n: eng.ppr_sweeps(B, n, DAMPING, main_only=False, f16=f16), n_l)
     nnz = kg.csr.nnz
     sb = 1 if f8 else 2 if f16 else 4
     # one launch = one sweep (PPR iteration) of the whole batch: SURVEY.md 8(d)'s per-iteration bytes
@@ -93,28 +121,34 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
     traffic = load_traffic()
     bc, n_slabs = (128, (B + 127) // 128) if f8 else (64, (B + 63) // 64) if f16 else eng.layout(B)
     kernel = "ppr8_kernel" if f8 else "ppr16_kernel" if f16 else "ppr_spmm_kernel"
-    ppr_iter_ms = phases["ppr_ms"] / PPR_ITERS      # all kernels of the PPR stage (boundary sweeps, reduce)
+    ppr_iter_ms = phases["ppr_ms"] / PPR_ITERS      # every kernel of the PPR stage (init, reduce) / iterations
+    tr = (traffic or {}).get(kernel, {})
     roofline = {
         "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "frac_definition": ("average launch of one retrieve over the kernel's instantiations (stage plan counts)"
+                            if f8 else "average launch of the sweep kernel (+ its long-row reduce)"),
         # PMC traffic is only meaningful for the workload it was collected on (profiles/pmc_traffic.json)
-        "traffic": ((traffic or {}).get(kernel, {}).get("bytes_per_launch")
-                    if (traffic or {}).get(kernel, {}).get("workload") == f"{config_name}:B{B}" else None),
+        "traffic": tr.get("bytes_per_launch") if tr.get("workload") == f"{config_name}:B{B}" else None,
+        "traffic_source": "replayed from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, "
+                          "FETCH_SIZE x2-corrected + WRITE_SIZE); not measured in this run",
         "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_definition": "SURVEY 8(d): nnz*8 + (V+1)*4 + 2*V*B*4 + Np*B*4 per PPR iteration",
         "state_bytes_stored": sb, "algorithmic_bytes_at_stored_state_width": alg_stored,
         "frac_at_stored_state_width": alg_stored / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "gather_bytes_per_launch": nnz * B * sb,
-        "launch_ms": spmm_ms, "sweep_ms_all_kernels": sweep_ms,
+        "launch_ms": spmm_ms, "launch_ms_main_kernel_only": main_ms,
+        "launch_ms_by_mode": per_mode, "launches_by_mode": fp8_mode_counts(PPR_ITERS) if f8 else None,
+        "frac_mode_c": (alg / (per_mode["C"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if f8 else None,
         "ppr_stage_ms_per_iteration": ppr_iter_ms,
         "frac_whole_ppr_stage": alg / (ppr_iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "launches_timed": n_l, "slab_width": bc, "n_slabs": n_slabs,
         "frac_of_measured_copy_peak_6290": achieved / 6290.0,
     }
-
     return roofline, f8, f16
 
 
-def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, budget_s, max_queries):
+def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, budget_s, max_queries,
+                 vec_queries=32, nx_budget_s=6.0):
     """Reference-style CPU loop on a bounded sample (rank 0 only) + parity spot check."""
     import oracle
     from oracle.cpu_baseline import ReferenceStyleRetriever
@@ -151,14 +185,144 @@ def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, bu
         if time.perf_counter() - t0 > budget_s:
             break
     el = time.perf_counter() - t0
-    return {
+    base = {
         "value": n_done / el, "unit": "queries/s", "cores": int(blas_threads), "kind": "port",
         "sample": f"{n_done} queries of the same workload, reference-style per-query loop "
                   f"(fp32 np.dot on {blas_threads} BLAS threads, Python seed loops, single-thread "
                   f"PRPACK Gauss-Seidel port tol 1e-10); {el:.1f} s (+{prep_s:.1f} s index prep)",
         "sim_s_per_query": ref.sim_time / max(n_done, 1), "ppr_s_per_query": ref.ppr_time / max(n_done, 1),
-        "host_cpus": os.cpu_count(),
-    }, {"queries_checked": n_done, "topk_ids_equal": bool(ids_equal), "max_rel_score_err": max_rel}
+        "host_cpus": os.cpu_count(), "cpu_model": _cpu_model(),
+    }
+    parity = {"queries_checked": n_done, "topk_ids_equal": bool(ids_equal), "max_rel_score_err": max_rel}
+    # ---- "vectorised" leg: batched sgemm + argpartition + OpenMP SpMM over all host cores, the
+    # same algorithm and sweep count as the GPU path -- the ratio against THIS number is the one free of the
+    # reference's Python overhead
+    try:
+        from oracle.cpu_baseline import VectorisedRetriever
+        vb = int(min(vec_queries, qf.shape[0], VectorisedRetriever.MAX_B))
+        vr = VectorisedRetriever(index)
+        vr.retrieve(qf[:2], qp[:2], iters=2)                       # touch the library / BLAS once
+        vr.sim_time = vr.seed_time = vr.ppr_time = vr.rank_time = 0.0
+        t1 = time.perf_counter()
+        v_ids, v_sc = vr.retrieve(qf[:vb], qp[:vb], iters=PPR_ITERS, k=gpu_idx.shape[1])
+        v_el = time.perf_counter() - t1
+        v_rel = np.abs(v_sc[:vb] - gpu_scores[:vb]) / np.maximum(gpu_scores[:vb], 1e-300)
+        base["vectorised"] = {
+            "value": vb / v_el, "unit": "queries/s", "cores": int(os.cpu_count() or 1), "blas_threads": int(blas_threads),
+            "sample": f"one batch of {vb} queries of the same workload: fp32 sgemm (all BLAS threads), argpartition, "
+                      f"numpy seeds, {PPR_ITERS}-sweep fp32 power iteration as an OpenMP SpMM on all cores; {v_el:.2f} s",
+            "sim_s": vr.sim_time, "seed_s": vr.seed_time, "ppr_s": vr.ppr_time, "rank_s": vr.rank_time,
+            "ids_equal_to_gpu_fraction": float((v_ids[:vb] == gpu_idx[:vb]).mean()),
+            "max_rel_score_diff_to_gpu_at_same_rank": float(v_rel.max()),
+        }
+    except Exception as exc:   # a missing gcc / OpenMP must not cost the line
+        base["vectorised"] = {"error": f"{type(exc).__name__}: {exc}"}
+    # ---- networkx.pagerank(tol=1e-10) leg for the PPR step (the small configurations only: building a
+    # 10M-edge networkx graph takes minutes and ~10 GB)
+    if kg.num_vertices <= 200_000 and nx_budget_s > 0:
+        try:
+            from oracle.cpu_baseline import networkx_pagerank_leg
+            resets = []
+            for q in range(min(3, n_done)):
+                r = oracle.retrieve_one(index, qf[q], qp[q])
+                if r.reset is not None:
+                    resets.append(r.reset)
+            if resets:
+                base["networkx_pagerank"] = networkx_pagerank_leg(index, np.array(resets), nx_budget_s)
+        except Exception as exc:
+            base["networkx_pagerank"] = {"error": f"{type(exc).__name__}: {exc}"}
+    else:
+        base["networkx_pagerank"] = {"skipped": "graph too large for a networkx build inside the bench budget"}
+    return base, parity
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+class _NoPeers:
+    """Stand-in for the exchange steps when only ONE shard of `world` runs (per-GPU share measurement):
+    reductions see this shard's contribution only, gathers return `world` copies of it (so that the
+    candidate merge does the full-size work), state exchanges are skipped."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def all_reduce(self, t, op):
+        return t
+
+    def all_gather(self, t):
+        return [t] * self.world
+
+    def exchange(self, buf, lay, g):
+        return None
+
+    def wait(self, handle):
+        pass
+
+
+def bench_shard_share(args, cfg, dev):
+    """One GPU's compute share of a row-sharded configuration: shard 0 of `shard_of` with the global batch.
+    The other shards' rows never arrive, so the scores are meaningless; the kernels, their sizes and the
+    memory traffic are exactly those of one GPU of the sharded job (no collective is timed)."""
+    import torch
+    from hipporag_amd import dist as hd, synth
+    from hipporag_amd.engine import ShardStages
+    world, V, E, D, B, seed = cfg["shard_of"], cfg["V"], cfg["E"], cfg["D"], args.batch or cfg["B"], cfg["seed"]
+    kg = synth.make_kg(V, E, seed)
+    pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev)
+    fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev)
+    sidx = hd.shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+    eng = hd.build_shard_engine(sidx, pass_emb, fact_emb, 0, B, K_P)
+    rs = hd.ShardedRetriever(ShardStages(eng), _NoPeers(0, world), groups=args.exchange_groups)
+    n = args.steps + args.warmup
+    qf = [synth.make_queries_torch(fact_emb, B, seed + 100 + i)[0] for i in range(n)]
+    qp = [synth.make_queries_torch(pass_emb, B, seed + 500 + i)[0] for i in range(n)]
+    cnt = torch.full((B,), K_F, dtype=torch.int32, device=dev)
+
+    def step(i):
+        idx, sc = rs.score_facts(qf[i], k=K_F)
+        idx = idx.clamp(min=0)      # foreign candidates are copies of the local ones here: keep the ids valid
+        return rs.retrieve(qp[i], idx, sc, cnt, link_top_k=K_F, damping=DAMPING, passage_node_weight=PASSAGE_W,
+                           ppr_iters=PPR_ITERS, k=K_P)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n):
+        step(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    lay = eng.shard_layout(B, args.exchange_groups)
+    rps = sidx.rows_per_shard
+    nnz_own = int(sidx.csr.row_ptr[rps] - sidx.csr.row_ptr[0])
+    wire = (world - 1) / world * sidx.num_vertices * 128 * lay.n_slabs
+    # the share of SURVEY 8(d)'s per-iteration bytes this GPU owns: its rows of the CSR, of y and of v; all of x
+    alg_share = nnz_own * 8 + (rps + 1) * 4 + (sidx.num_vertices + rps) * B * 4 + (kg.n_passages // world) * B * 4
+    ms = el * 1e3 / max(args.steps, 1)
+    result = {
+        "metric": "retrieval_queries_per_sec", "value": B * args.steps / el, "unit": "queries/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["label"], "V": V, "E": E, "nnz": kg.csr.nnz, "global_batch": B,
+                   "shard": f"0 of {world}", "rows_per_shard": rps, "nnz_this_shard": nnz_own,
+                   "exchange_groups": int(lay.n_groups), "ppr_iters": PPR_ITERS,
+                   "parallelism": f"compute share of one of {world} row shards; exchanges NOT performed (1 GPU)"},
+        "note": "value = global batch / compute time of ONE shard: an upper bound of the sharded job's rate "
+                "(exchange time comes on top: wire_bytes_received_per_gpu_per_sweep over xGMI)",
+        "wire_bytes_received_per_gpu_per_sweep": wire, "state_bytes_per_buffer": int(lay.state_bytes),
+        "algorithmic_bytes_per_iteration_this_shard": alg_share,
+    }
+    eng.close()
+    print(json.dumps(result))
+    return 0
 
 
 def main():
@@ -173,7 +337,10 @@ def main():
                     help="multi-GPU mode (N > 1)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-queries", type=int, default=12)
+    ap.add_argument("--cpu-vec-queries", type=int, default=32, help="batch of the vectorised CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange-groups", type=int, default=2,
+                    help="row-sharded mode: exchange groups pipelined against the sweeps")
     ap.add_argument("--sweep-launches", type=int, default=40)
     ap.add_argument("--no-rowshard", action="store_true", help="N > 1: skip the secondary row-sharded leg")
     ap.add_argument("--rowshard-timeout-s", type=float, default=240.0,
@@ -197,6 +364,8 @@ def main():
     torch.cuda.set_device(dev)
     cfg = CONFIGS[args.config]
     V, E, D, B, seed = cfg["V"], cfg["E"], cfg["D"], args.batch or cfg["B"], cfg["seed"]
+    if cfg.get("shard_of"):
+        return bench_shard_share(args, cfg, dev)
 
     t_setup = time.perf_counter()
     kg = synth.make_kg(V, E, seed, power_law=bool(cfg.get("power_law")))
@@ -257,10 +426,13 @@ def main():
     if not args.no_cpu_baseline:
         last = n_batches - 1
         cb, parity = cpu_baseline(kg, fact_emb, pass_emb, qf[last], qp[last], out.doc_idx.cpu().numpy(),
-                                  out.doc_score.cpu().numpy(), args.cpu_budget_s, args.cpu_queries)
+                                  out.doc_score.cpu().numpy(), args.cpu_budget_s, args.cpu_queries,
+                                  vec_queries=args.cpu_vec_queries)
         result["cpu_baseline"] = cb
         result["parity_spot_check"] = parity
         result["speedup_vs_cpu_port"] = qps / cb["value"]
+        if "value" in cb.get("vectorised", {}):
+            result["speedup_vs_cpu_vectorised"] = qps / cb["vectorised"]["value"]
     eng.close()
     print(json.dumps(result))
     return 0

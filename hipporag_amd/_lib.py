@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "libhrag.so")
 
 HRAG_OK, HRAG_EINVAL, HRAG_ENOMEM, HRAG_EHIP, HRAG_EZERO_RESET, HRAG_ECAPACITY = range(6)
 SEED_STRIDE = 32
-FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE = 1, 2, 4
+HRAG_VERSION = 3      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
+FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, FLAG_FP8_SATURATED = 1, 2, 4, 8
 # hrag_opts.flags (include/hrag.h HRAG_OPT_*)
 OPT_NATURAL_ROW_ORDER, OPT_NT_CSR, OPT_NT_STORE, OPT_F32_STATE, OPT_TEMPORAL16, OPT_NO_FP8 = 1, 2, 4, 8, 16, 32
 
@@ -52,6 +53,12 @@ class Timings(C.Structure):
                 ("n_long_rows", C.c_int32)]
 
 
+class ShardLayout(C.Structure):
+    _fields_ = [("n_slabs", C.c_int32), ("n_groups", C.c_int32), ("slabs_per_group", C.c_int32),
+                ("reserved", C.c_int32), ("state_bytes", C.c_int64), ("group_bytes", C.c_int64),
+                ("own_offset", C.c_int64), ("own_bytes", C.c_int64)]
+
+
 _P = C.c_void_p
 _I32, _I64, _F32 = C.c_int32, C.c_int64, C.c_float
 
@@ -80,6 +87,14 @@ SIGNATURES = {
     "hrag_stage_doc_scores": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _P, _P, _P, _P, _I64, _P]),
     "hrag_normalize_split_bf16": (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _P]),
     "hrag_sim_gemm": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P]),
+    "hrag_shard_layout_query": (C.c_int, [_P, _I32, _I32, C.POINTER(ShardLayout)]),
+    "hrag_shard_score_facts": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
+    "hrag_shard_passage_scores": (C.c_int, [_P, _P, _I32, _P, _P, _P]),
+    "hrag_shard_prior_stats": (C.c_int, [_P, _P, _P, _F32, _P, _I32, _P, _P, _P]),
+    "hrag_shard_ppr_begin": (C.c_int, [_P, _P, _P, _P, _P, _F32, _P, _P, _P, _P, _I32, _F32, _I32, _I32, _P, _P, _P, _P]),
+    "hrag_shard_ppr_sweep": (C.c_int, [_P, _I32, _I32, C.POINTER(_I32), _P]),
+    "hrag_shard_finish": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P]),
+    "hrag_engine_set_flags": (C.c_int, [_P, _I32, _I32]),
     "hrag_get_timings": (C.c_int, [_P, C.POINTER(Timings)]),
     "hrag_set_profiling": (C.c_int, [_P, _I32]),
 }
@@ -102,16 +117,26 @@ def load(build_if_missing: bool = True):
     # runtime instance torch uses; loading libhrag first pulls in /opt/rocm's copy as a second
     # runtime, which then sees "no ROCm-capable device" (observed on the GPU box).
     import torch  # noqa: F401
+    if build_if_missing:
+        # digest-stamped: a no-op when neither a source nor a header changed, so a stale library can never
+        # be loaded against newer ctypes struct layouts.  Without hipcc (a deployment box that received the
+        # built library) the existing file is used and the version check below is the guard.
+        try:
+            build_library()
+        except Exception:
+            if not os.path.exists(LIB_PATH):
+                raise
     if not os.path.exists(LIB_PATH):
-        if not build_if_missing:
-            raise ImportError(f"{LIB_PATH} is missing; run `python -m hipporag_amd.csrc.build`")
-        build_library()
+        raise ImportError(f"{LIB_PATH} is missing; run `python -m hipporag_amd.csrc.build`")
     # RTLD_LAZY: the CPU-only container has no HIP driver; symbols resolve at first use on a GPU box
     lib = C.CDLL(LIB_PATH, mode=os.RTLD_LAZY if hasattr(os, "RTLD_LAZY") else C.DEFAULT_MODE)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError => the library does not export what hrag.h declares
         fn.restype = res
         fn.argtypes = args
+    if lib.hrag_version() != HRAG_VERSION:
+        raise ImportError(f"{LIB_PATH} reports version {lib.hrag_version()}, this binding expects {HRAG_VERSION}: "
+                          "rebuild with `python -m hipporag_amd.csrc.build --force`")
     _lib = lib
     return lib
 

@@ -140,58 +140,87 @@ hrag_status launch_ppr16_scale(const float *mn, const float *mx, const float *ss
                                float passage_weight, const float *seed_w, const int32_t *seed_cnt,
                                const int32_t *flags, int32_t batch, float *qscale, hipStream_t s);
 // bc: columns per teleport row (64 on the fp16 path, BP on the small-batch path); qscale may be null
+// row_offset / n_rows: the owned vertex range (row_slot is indexed by LOCAL row); n_passages = owned passages
 hrag_status launch_ppr16_seed_rows(const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
                                    const float *qscale, int32_t batch, int64_t n_passages,
                                    int64_t num_vertices, int32_t *row_slot, float *tele,
-                                   int64_t tele_rows, int32_t bc, hipStream_t s);
+                                   int64_t tele_rows, int32_t bc, hipStream_t s, int64_t row_offset = 0,
+                                   int64_t n_rows = -1);
 
-// ppr8.hip : staged fp8 (e4m3) state + fp32 true residual, 128 queries per 128-byte line, same
-// SELL-8 structure with the row-normalised values At = D^-1 A
+// ppr8.hip : staged fp8 (e4m3) state + fp32 true residual, 128 queries per 128-byte line, SELL-8 over the
+// OWNED rows (row shard; single GPU: all rows) with the row-normalised values At = D^-1 A
 enum Ppr8Mode { kP8ModeC = 0, kP8ModeB = 1, kP8ModeF = 2, kP8ModeB0 = 3 };   // B0: first boundary, R_in = b v/d
-constexpr int kP8MaxStages = 12;      // stage lengths 1,2,2,3,3,3,... => 12 stages cover ppr_iters <= 32
+constexpr int kP8MaxStages = 12;      // stage lengths 1,2,3,..,3,4,..,4 => <= 10 stages for ppr_iters <= 30
 constexpr float kP8C0Scale = 128.f;   // c_0 = Q(v/d * 2^7),  max(v/d) in (1/2, 1]
-struct Ppr8Args {
-    const int2 *pairs;         // (col, fp32 bits of at_ij), step-major per chunk (ppr16.hip layout)
-    uint32_t pairs_bytes;
-    const int2 *chunk_meta;
-    const int32_t *vrow;
+constexpr int32_t kFlagFp8Saturated = 8;   // flags bit 3 (HRAG_FLAG_FP8_SATURATED)
+struct Sell8Dev {
+    const int2 *pairs;         // (col, fp32 bits of the value), step-major per chunk (ppr16.hip layout)
+    uint32_t pairs_bytes;      // incl. the read-ahead padding (< 2^31)
+    const int2 *chunk_meta;    // [n_chunks] (first step, number of steps)
+    const int32_t *vrow;       // [n_chunks * 8] LOCAL row >= 0 | -(partial slot + 1) | kVrowNone
     int32_t n_chunks;
-    const int32_t *lrow_row, *lrow_first, *lrow_cnt;
+    const int32_t *lrow_row, *lrow_first, *lrow_cnt;  // [n_lrow] long rows and their partial slots
     int32_t n_lrow;
     int32_t n_partial;
-    float *partial;            // [n_slabs][n_partial][128] fp32
-    int64_t num_vertices;
-    const uint8_t *x;          // gather source: e4m3 [n_slabs][V][128]
-    uint8_t *y;                // mode C: the new iterate; mode B: rt of the next stage
-    const uint8_t *rt;         // mode C: the stage's quantised right-hand side
-    float *R;                  // mode B / F: true residual, fp32 [n_slabs][V][128] (B rewrites it)
-    float alpha, beta, inv_cs, cs_next;
-    const float *tele;         // mode B0: teleport rows fp32 [n_slabs64][tele_rows][64] (v, scaled per query)
-    int64_t tele_rows;
-    // mode F
-    const uint8_t *stage[kP8MaxStages];   // final iterate of every stage (incl. the one in x)
-    float stage_inv[kP8MaxStages];
-    int32_t n_stage;
-    const float *deg;          // [V] weighted degree (1 for isolated vertices)
-    const int32_t *row_slot;   // [V] teleport slot of a vertex: slot < n_passages <=> passage number
-    int64_t n_passages;
-    float *out;                // x = d z at the passage vertices, fp32 [n_slabs64][Np][64] (passage order)
-    int32_t n_slabs64;
-    float *csum;               // [n_slabs][n_csum][128] fp32: column sums of x per chunk / long row
-    int32_t n_csum;            // n_chunks + n_lrow
-    int32_t n_slabs;           // 128-query slabs of this launch (set by launch_ppr8_sweep)
 };
-hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, int n_slabs, bool main_only, hipStream_t s);
-hrag_status launch_ppr8_colsum(const float *csum, int32_t n_csum, int n_slabs, int32_t batch, double *partial,
-                               double *sums, hipStream_t s);
-hrag_status launch_ppr8_init(const float *tele, int64_t tele_rows, const int32_t *row_slot, const float *deg,
-                             int64_t num_vertices, int n_slabs, int n_slabs64, float c0_scale, uint8_t *c0,
-                             hipStream_t s);
-hrag_status launch_ppr8_scale(const float *scores, int64_t ld, int64_t n_passages, const float *mn,
-                              const float *mx, float passage_weight, const float *pinvdeg,
+// State buffers: e4m3 [n_groups][V + 1][spg][128]; slab s lives in group s / spg, column block s % spg;
+// row V of every group is all-zero (the target of masked-out gathers in mode B0).  An owner's rows
+// [row_offset, row_offset + n_rows) of one group are one contiguous block = the unit of the exchange.
+struct Ppr8Args {
+    Sell8Dev m;                // main matrix (owned rows) or, in mode F, its passage rows only
+    float *partial;            // [n_slabs][n_partial][128] fp32 (lane-interleaved rows)
+    int64_t row_offset, n_rows;   // owned rows (global id of local row 0, count)
+    int32_t spg;               // slabs per exchange group
+    uint32_t row_stride;       // spg * 128: bytes between consecutive vertices of a group
+    int64_t group_bytes;       // (V + 1) * row_stride
+    const uint8_t *x;          // gather source
+    uint8_t *y;                // mode C: the new iterate; mode B: rt of the next stage (owned rows written)
+    const uint8_t *rt;         // mode C: the stage's quantised right-hand side
+    float *R;                  // true residual, fp32 [n_slabs][n_rows][128] lane-interleaved (LOCAL rows)
+    float alpha, beta, inv_cs, cs_next;
+    const float *tele;         // fp32 [n_slabs64][tele_rows][64]: v at the owned passages, then the seed rows
+    int64_t tele_rows;
+    int32_t n_slabs64;
+    const int32_t *row_slot;   // [n_rows] teleport slot of a LOCAL row: slot < p_rows <=> owned passage number
+    const float *deg;          // [V] weighted degree (1 for isolated vertices), GLOBAL vertex ids
+    int64_t p_rows;            // owned passages
+    uint8_t *stage_out;        // mode B / B0: c of this stage at the owned passage rows, [n_slabs][p_rows][128]
+    // mode F
+    const uint8_t *stage[kP8MaxStages];   // stage_out of the earlier stages (the last stage's c is read from x)
+    float stage_inv[kP8MaxStages];        // 1 / cs of every stage, the last one included
+    int32_t n_stage;
+    float *out;                // x = d z at the owned passages, fp32 [n_slabs64][p_rows][64] (passage order)
+    // mode B0: only columns with v != 0 (passages, seeds) are gathered; the others read the zero row
+    const uint32_t *colmask;   // [ceil(V / 32)] bit = column may be non-zero in c_0
+    uint32_t colmask_bytes;
+    uint32_t zero_row;         // V
+    int32_t *flags;            // [batch] bit 3 is set when a value had to be clamped to the e4m3 range
+    int32_t batch;
+    int32_t slab0, n_slabs;    // 128-query slabs covered by this launch
+};
+hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, bool main_only, hipStream_t s);
+// c_0 = Q(v/d * c0_scale) on the owned rows of slabs [slab0, slab0 + n_slabs)
+hrag_status launch_ppr8_init(const Ppr8Args &a, float c0_scale, hipStream_t s);
+// per-query statistics of the passage prior over the OWNED passages (scores fp32 [B, ld], local order):
+//   zmax[q]  = max_p minmax(score_qp) * pinvdeg[p]          (0 for queries on the DPR fallback)
+//   mass[q]  = sum_p float(minmax(score_qp) * weight)       mass[B + q] = the same over isolated passages
+// part: kP8PriorSplit * batch * 2 doubles of scratch
+constexpr int kP8PriorSplit = 16;
+hrag_status launch_ppr8_prior(const float *scores, int64_t ld, int64_t p_rows, const float *mn, const float *mx,
+                              float passage_weight, const float *pinvdeg, const uint8_t *piso,
+                              const int32_t *flags, int32_t batch, int32_t *zmax_bits, double *part,
+                              float *zmax, double *mass, hipStream_t s);
+// qscale[q] (power of two, max v/d in (1/2, 1]) from the GLOBAL zmax + the seeds; sums[q] = the mass of the
+// `iters`-sweep iterate of x <- a P x + (1 - a) v from x_0 = v, in the units of the scaled v (analytic:
+// P is column-stochastic except for isolated vertices, whose mass is known sweep by sweep)
+hrag_status launch_ppr8_scale(const float *zmax, const double *mass, float passage_weight,
                               const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
-                              const float *deg, int64_t num_vertices, const int32_t *flags, int32_t batch,
-                              int32_t *zmax_bits, float *qscale, hipStream_t s);
+                              const float *deg, const uint8_t *iso, int64_t num_vertices, const int32_t *flags,
+                              int32_t batch, float damping, int32_t iters, float *qscale, double *sums,
+                              hipStream_t s);
+// colmask |= bits of the seed vertices
+hrag_status launch_ppr8_mask_seeds(const int32_t *seed_vtx, const int32_t *seed_cnt, int32_t batch,
+                                   int64_t num_vertices, uint32_t *colmask, hipStream_t s);
 
 // ppr_sv.hip : small batches (B <= 8), fp32 state [V][BP], same SELL-8 matrix
 struct PprSvArgs {
@@ -240,6 +269,7 @@ hrag_status launch_slab_to_rows(const float *slab, int64_t slab_rows, const int3
                                 int64_t ld, const float *alt, int64_t alt_ld, const float *mn,
                                 const float *mx, const int32_t *flags, SlabLayout lay,
                                 hipStream_t s);
+hrag_status launch_fill_i32(int32_t *dst, int32_t value, int64_t n, hipStream_t s);
 hrag_status launch_flag_zero_mass(const double *sums, int32_t batch, int32_t *flags, int32_t bit,
                                   hipStream_t s);
 

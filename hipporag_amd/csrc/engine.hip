@@ -11,132 +11,16 @@
 #include <numeric>
 #include <vector>
 
-#include "common.h"
-
-using namespace hrag;
+#include "engine_impl.h"
 
 namespace {
 
-constexpr int kSvMaxBatch = 8;         // batches up to this take the small-batch kernels (ppr_sv.hip)
-constexpr float kPpr16CScale = 64.f;  // correction / residual are stored as f16(c * 64); see ppr16.hip
-
-enum EvId { EV_START = 0, EV_SIM, EV_SEED, EV_PPR, EV_RANK, EV_FACT0, EV_FACT1, EV_COUNT };
-
-template <typename T>
-hrag_status dev_alloc(T **p, int64_t count) {
-    *p = nullptr;
-    if (count <= 0) return HRAG_OK;
-    hipError_t err = hipMalloc(reinterpret_cast<void **>(p), (size_t)count * sizeof(T));
-    if (err != hipSuccess) {
-        set_error("hipMalloc of %lld bytes failed: %s", (long long)(count * (int64_t)sizeof(T)),
-                  hipGetErrorString(err));
-        *p = nullptr;
-        return HRAG_ENOMEM;
-    }
-    return HRAG_OK;
+void free_store(Sell8Store &m) {
+    void *ptrs[] = {m.pairs, m.pairs_at, m.chunk_meta, m.vrow, m.lrow_row, m.lrow_first, m.lrow_cnt};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    m = Sell8Store();
 }
-
-template <typename T>
-hrag_status dev_upload(T **p, const T *src, int64_t count) {
-    HRAG_TRY(dev_alloc(p, count));
-    if (count > 0) HRAG_HIP_TRY(hipMemcpy(*p, src, (size_t)count * sizeof(T), hipMemcpyDefault));
-    return HRAG_OK;
-}
-
-int auto_slab_width(int batch, int cap) {
-    int bc = 4;
-    while (bc < batch && bc < cap) bc <<= 1;
-    return bc;
-}
-
-}  // namespace
-
-struct hrag_engine {
-    int device = 0;
-    // graph (owned rows)
-    int64_t V = 0, row_offset = 0, n_rows = 0, nnz = 0, n_passages = 0;
-    int32_t *d_row_ptr = nullptr, *d_col = nullptr;
-    float *d_val = nullptr;
-    int32_t *d_row_order = nullptr;
-    int32_t n_short = 0;
-    int32_t *d_seg_row = nullptr, *d_seg_begin = nullptr, *d_seg_end = nullptr, *d_seg_slot = nullptr;
-    int32_t *d_mrow_row = nullptr, *d_mrow_first = nullptr, *d_mrow_cnt = nullptr;
-    int32_t n_seg = 0, n_mrow = 0, n_partial = 0, n_long_rows = 0;
-    float *d_partial = nullptr;
-    int32_t *d_passage_vertex = nullptr;  // [Np] global vertex ids
-    int32_t *d_row_to_tele = nullptr;     // [n_rows] global passage index of an owned row, or -1
-    // embeddings (owned rows)
-    int32_t dim = 0, emb_dtype = HRAG_BF16;
-    int64_t p_rows = 0, p_offset = 0, f_rows = 0, f_offset = 0, n_facts = 0;
-    uint16_t *d_pemb = nullptr, *d_femb = nullptr;
-    int32_t *d_subj = nullptr, *d_obj = nullptr, *d_num_chunks = nullptr;
-    // options
-    int32_t max_batch = 0, max_topk = 0, slab_cap = 32, short_thresh = 0, seg_len = 0, opt_flags = 0;
-    // workspace
-    int64_t state_elems = 0;  // floats in each of d_x / d_y
-    float *d_x = nullptr, *d_y = nullptr, *d_tele = nullptr, *d_tele_dense = nullptr;
-    int64_t ld_p = 0, ld_f = 0;
-    float *d_spass = nullptr, *d_sfact = nullptr, *d_doc = nullptr;
-    float *d_mn_p = nullptr, *d_mx_p = nullptr;
-    int32_t *d_seed_vtx = nullptr, *d_seed_cnt = nullptr, *d_flags = nullptr;
-    float *d_seed_w = nullptr;
-    double *d_colsum_partial = nullptr, *d_sums = nullptr;
-    void *d_topk_ws = nullptr;   // kTopkWsBytes: lets small batches split a row over several workgroups
-    // fused fact top-k (sim_gemm.hip): tile max / min, selected tiles, global min / max per query
-    float *d_fused_ws = nullptr, *d_mn_f = nullptr, *d_mx_f = nullptr;
-    int32_t *d_fused_sel = nullptr;
-    // two-stage fp16 PPR (ppr16.hip): SELL-8 matrix + fp16 state, unsharded engines with max_batch > 8
-    bool f16_ready = false;   // fp16 state buffers present (max_batch > 8)
-    int32_t f16_max_batch = 0;  // ... sized for this many queries (64 when the fp8 path serves the larger batches)
-    bool sell_ready = false;  // SELL-8 matrix + small-batch buffers present (every unsharded engine)
-    float *d_tele_sv = nullptr, *d_partial_sv = nullptr;   // small-batch path (ppr_sv.hip), BP <= 8
-    int2 *d_pairs = nullptr, *d_chunk_meta = nullptr;
-    int32_t *d_vrow = nullptr, *d_lrow_row = nullptr, *d_lrow_first = nullptr, *d_lrow_cnt = nullptr;
-    int32_t n_chunks = 0, n_lrow = 0, n_partial16 = 0;
-    int64_t sell_steps = 0;
-    float *d_partial16 = nullptr;
-    uint16_t *d_h16[4] = {nullptr, nullptr, nullptr, nullptr};  // hA, hB, r, cA
-    int64_t state16_elems = 0;
-    float *d_tele16 = nullptr;      // fp32 [n_slabs64][tele16_rows][64]: passages, then seed rows
-    int64_t tele16_rows = 0;
-    int32_t *d_row_slot = nullptr;  // [V] per-batch copy of d_row_to_tele with the seed rows patched in
-    float *d_qscale = nullptr, *d_ssum = nullptr;
-    // staged fp8 PPR (ppr8.hip): SELL-8 matrix with the row-normalised values, fp32 residual, a pool of
-    // e4m3 state buffers; needs hrag_graph_desc.col_sum, max_batch > 64
-    bool f8_ready = false;
-    int2 *d_pairs8 = nullptr;
-    float *d_deg = nullptr, *d_pinvdeg = nullptr, *d_R8 = nullptr, *d_partial8 = nullptr;
-    float *d_csum8 = nullptr, *d_xp8 = nullptr;   // mode F outputs: column-sum partial rows, x at the passages
-    static constexpr int kP8Pool = kP8MaxStages + 3;
-    uint8_t *d_pool8[kP8Pool] = {};
-    int64_t state8_bytes = 0;
-    // timing
-    hipEvent_t ev[EV_COUNT] = {};
-    bool profiling = false, have_retrieve_ev = false, have_fact_ev = false;
-    hrag_timings last = {};
-
-    SlabLayout layout(int batch) const {
-        SlabLayout l;
-        l.bc = auto_slab_width(batch, slab_cap);
-        l.n_slabs = (int)ceil_div(batch, l.bc);
-        return l;
-    }
-    SpmmArgs spmm_args(const float *x, float *y, const float *tele, int64_t tele_rows,
-                       const int32_t *row_to_tele, float damping) const {
-        SpmmArgs a;
-        a.row_ptr = d_row_ptr; a.col_idx = d_col; a.val = d_val;
-        a.row_order = d_row_order; a.n_short = n_short;
-        a.seg_row = d_seg_row; a.seg_begin = d_seg_begin; a.seg_end = d_seg_end; a.seg_slot = d_seg_slot;
-        a.n_seg = n_seg; a.mrow_row = d_mrow_row; a.mrow_first = d_mrow_first; a.mrow_cnt = d_mrow_cnt;
-        a.n_mrow = n_mrow; a.partial = d_partial; a.n_partial = n_partial;
-        a.n_rows = n_rows; a.row_offset = row_offset; a.num_vertices = V;
-        a.x = x; a.y = y; a.row_to_tele = row_to_tele; a.tele = tele; a.tele_rows = tele_rows;
-        a.alpha = damping; a.beta = 1.0f - damping; a.flags = opt_flags;
-        return a;
-    }
-};
-
-namespace {
 
 void free_engine(hrag_engine *e) {
     if (!e) return;
@@ -145,15 +29,17 @@ void free_engine(hrag_engine *e) {
                     e->d_passage_vertex, e->d_row_to_tele, e->d_pemb, e->d_femb, e->d_subj, e->d_obj,
                     e->d_num_chunks, e->d_x, e->d_y, e->d_tele, e->d_tele_dense, e->d_spass,
                     e->d_sfact, e->d_doc, e->d_mn_p, e->d_mx_p, e->d_seed_vtx, e->d_seed_cnt,
-                    e->d_flags, e->d_seed_w, e->d_colsum_partial, e->d_sums, e->d_pairs, e->d_chunk_meta,
-                    e->d_vrow, e->d_lrow_row, e->d_lrow_first, e->d_lrow_cnt, e->d_partial16, e->d_h16[0],
+                    e->d_flags, e->d_seed_w, e->d_colsum_partial, e->d_sums, e->d_partial16, e->d_h16[0],
                     e->d_h16[1], e->d_h16[2], e->d_h16[3], e->d_tele16, e->d_row_slot, e->d_qscale,
-                    e->d_ssum, e->d_tele_sv, e->d_partial_sv, e->d_topk_ws, e->d_pairs8, e->d_deg,
-                    e->d_pinvdeg, e->d_R8, e->d_partial8, e->d_fused_ws, e->d_mn_f, e->d_mx_f, e->d_fused_sel, e->d_csum8, e->d_xp8};
+                    e->d_ssum, e->d_tele_sv, e->d_partial_sv, e->d_topk_ws, e->d_deg,
+                    e->d_pinvdeg, e->d_R8, e->d_partial8, e->d_fused_ws, e->d_mn_f, e->d_mx_f, e->d_fused_sel,
+                    e->d_xp8, e->d_row_ptele, e->d_iso, e->d_piso, e->d_colmask_static, e->d_colmask,
+                    e->d_stagep, e->d_pool8[0], e->d_pool8[1], e->d_pool8[2], e->d_zmax_bits, e->d_zmax,
+                    e->d_mass, e->d_prior_part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    for (void *p : e->d_pool8)
-        if (p) (void)hipFree(p);
+    free_store(e->sell);
+    free_store(e->fsell);
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     delete e;
@@ -191,31 +77,35 @@ hrag_status ppr_step(hrag_engine *e, const float *tele, int64_t tele_rows, const
     return HRAG_OK;
 }
 
-// SELL-8 form of the owned CSR for ppr16.hip (see the header comment there).
-// deg (may be null): weighted degrees; when given, a second pairs array with the row-normalised
-// values at_ij = p_ij d_j / d_i (the degree-scaled iteration of ppr8.hip) is built as well.
-hrag_status build_sell8(hrag_engine *e, const std::vector<int32_t> &row_ptr, const int32_t *col,
-                        const float *val, const double *deg) {
+// SELL-8 form of (a subset of) the owned CSR rows for ppr16.hip / ppr8.hip (see the header comments there).
+// rows (may be null = all): LOCAL rows to include.  want_p: the (col, P value) pairs of ppr16 / ppr_sv.
+// deg (may be null): weighted degrees by GLOBAL vertex id; when given, the pairs with the row-normalised
+// values at_ij = p_ij d_j / d_i (the degree-scaled iteration of ppr8.hip) are built.
+hrag_status build_sell8(const hrag_engine *e, const std::vector<int32_t> &row_ptr, const int32_t *col,
+                        const float *val, const double *deg, const std::vector<int32_t> *rows, bool want_p,
+                        Sell8Store *out) {
     struct VRow { int32_t len, begin, target, row; };
     std::vector<VRow> vr;
-    vr.reserve((size_t)e->n_rows + 1024);
+    const int64_t n_sel = rows ? (int64_t)rows->size() : e->n_rows;
+    vr.reserve((size_t)n_sel + 1024);
     std::vector<int32_t> lrow_row, lrow_first, lrow_cnt;
     int32_t n_partial = 0;
-    for (int64_t r = 0; r < e->n_rows; ++r) {
-        const int32_t b0 = row_ptr[(size_t)r], deg = row_ptr[(size_t)r + 1] - b0;
-        if (deg <= kSell8SegLen) {
-            vr.push_back({deg, b0, (int32_t)r, (int32_t)r});
+    for (int64_t k = 0; k < n_sel; ++k) {
+        const int64_t r = rows ? (*rows)[(size_t)k] : k;
+        const int32_t b0 = row_ptr[(size_t)r], len = row_ptr[(size_t)r + 1] - b0;
+        if (len <= kSell8SegLen) {
+            vr.push_back({len, b0, (int32_t)r, (int32_t)r});
             continue;
         }
         // at most 64 segments per row, each a multiple of 8 entries
-        int32_t nseg = std::min<int32_t>((deg + kSell8SegLen - 1) / kSell8SegLen, 64);
-        const int32_t seg_len = (int32_t)round_up((deg + nseg - 1) / nseg, 8);
-        nseg = (deg + seg_len - 1) / seg_len;
+        int32_t nseg = std::min<int32_t>((len + kSell8SegLen - 1) / kSell8SegLen, 64);
+        const int32_t seg_len = (int32_t)round_up((len + nseg - 1) / nseg, 8);
+        nseg = (len + seg_len - 1) / seg_len;
         lrow_row.push_back((int32_t)r);
         lrow_first.push_back(n_partial);
         lrow_cnt.push_back(nseg);
         for (int32_t i = 0; i < nseg; ++i)
-            vr.push_back({std::min(seg_len, deg - i * seg_len), b0 + i * seg_len, -(n_partial++ + 1), (int32_t)r});
+            vr.push_back({std::min(seg_len, len - i * seg_len), b0 + i * seg_len, -(n_partial++ + 1), (int32_t)r});
     }
     // longest first (stable => deterministic); a chunk = 8 consecutive virtual rows
     std::stable_sort(vr.begin(), vr.end(), [](const VRow &a, const VRow &b) { return a.len > b.len; });
@@ -229,8 +119,8 @@ hrag_status build_sell8(hrag_engine *e, const std::vector<int32_t> &row_ptr, con
         steps += ns;
     }
     HRAG_REQUIRE((steps + 4) * 512 < (int64_t)0x7fffffff, "graph too large for the SELL-8 buffer range (2 GiB)");
-    std::vector<int2> pairs((size_t)(steps + 4) * 64, make_int2(0, 0));  // +4 steps: read-ahead padding
-    std::vector<int2> pairs8(deg ? pairs.size() : 0, make_int2(0, 0));
+    std::vector<int2> pairs(want_p ? (size_t)(steps + 4) * 64 : 0, make_int2(0, 0));  // +4 steps: read-ahead padding
+    std::vector<int2> pairs8(deg ? (size_t)(steps + 4) * 64 : 0, make_int2(0, 0));
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int64_t base = (int64_t)meta[(size_t)c].x * 64;
         for (int g = 0; g < 8; ++g) {
@@ -240,40 +130,41 @@ hrag_status build_sell8(hrag_engine *e, const std::vector<int32_t> &row_ptr, con
             vrow[(size_t)vi] = v.target;
             for (int32_t i = 0; i < v.len; ++i) {
                 int32_t bits;
-                std::memcpy(&bits, &val[v.begin + i], 4);
                 const size_t at = (size_t)(base + (int64_t)(i >> 3) * 64 + g * 8 + (i & 7));
-                pairs[at] = make_int2(col[v.begin + i], bits);
+                if (want_p) {
+                    std::memcpy(&bits, &val[v.begin + i], 4);
+                    pairs[at] = make_int2(col[v.begin + i], bits);
+                }
                 if (deg) {
-                    const float atv = (float)((double)val[v.begin + i] * deg[col[v.begin + i]] / deg[v.row]);
+                    const float atv = (float)((double)val[v.begin + i] * deg[col[v.begin + i]] /
+                                              deg[(size_t)(e->row_offset + v.row)]);
                     std::memcpy(&bits, &atv, 4);
                     pairs8[at] = make_int2(col[v.begin + i], bits);
                 }
             }
         }
     }
-    e->n_chunks = (int32_t)n_chunks;
-    e->n_lrow = (int32_t)lrow_row.size();
-    e->n_partial16 = n_partial;
-    e->sell_steps = steps;
-    HRAG_TRY(dev_upload(&e->d_pairs, pairs.data(), (int64_t)pairs.size()));
-    if (deg) HRAG_TRY(dev_upload(&e->d_pairs8, pairs8.data(), (int64_t)pairs8.size()));
-    HRAG_TRY(dev_upload(&e->d_chunk_meta, meta.data(), (int64_t)meta.size()));
-    HRAG_TRY(dev_upload(&e->d_vrow, vrow.data(), (int64_t)vrow.size()));
-    HRAG_TRY(dev_upload(&e->d_lrow_row, lrow_row.data(), (int64_t)lrow_row.size()));
-    HRAG_TRY(dev_upload(&e->d_lrow_first, lrow_first.data(), (int64_t)lrow_first.size()));
-    HRAG_TRY(dev_upload(&e->d_lrow_cnt, lrow_cnt.data(), (int64_t)lrow_cnt.size()));
+    out->n_chunks = (int32_t)n_chunks;
+    out->n_lrow = (int32_t)lrow_row.size();
+    out->n_partial = n_partial;
+    out->steps = steps;
+    if (want_p) HRAG_TRY(dev_upload(&out->pairs, pairs.data(), (int64_t)pairs.size()));
+    if (deg) HRAG_TRY(dev_upload(&out->pairs_at, pairs8.data(), (int64_t)pairs8.size()));
+    HRAG_TRY(dev_upload(&out->chunk_meta, meta.data(), (int64_t)meta.size()));
+    HRAG_TRY(dev_upload(&out->vrow, vrow.data(), (int64_t)vrow.size()));
+    HRAG_TRY(dev_upload(&out->lrow_row, lrow_row.data(), (int64_t)lrow_row.size()));
+    HRAG_TRY(dev_upload(&out->lrow_first, lrow_first.data(), (int64_t)lrow_first.size()));
+    HRAG_TRY(dev_upload(&out->lrow_cnt, lrow_cnt.data(), (int64_t)lrow_cnt.size()));
     return HRAG_OK;
 }
-
-inline int n_slabs64(int batch) { return (int)ceil_div(batch, 64); }
 
 Ppr16Args ppr16_args(const hrag_engine *e, const uint16_t *x, uint16_t *y, const uint16_t *aux,
                      float damping) {
     Ppr16Args a;
-    a.pairs = e->d_pairs; a.pairs_bytes = (uint32_t)((e->sell_steps + 4) * 512);
-    a.chunk_meta = e->d_chunk_meta; a.vrow = e->d_vrow; a.n_chunks = e->n_chunks;
-    a.lrow_row = e->d_lrow_row; a.lrow_first = e->d_lrow_first; a.lrow_cnt = e->d_lrow_cnt;
-    a.n_lrow = e->n_lrow; a.n_partial = e->n_partial16; a.partial = e->d_partial16;
+    a.pairs = e->sell.pairs; a.pairs_bytes = e->sell.pairs_bytes();
+    a.chunk_meta = e->sell.chunk_meta; a.vrow = e->sell.vrow; a.n_chunks = e->sell.n_chunks;
+    a.lrow_row = e->sell.lrow_row; a.lrow_first = e->sell.lrow_first; a.lrow_cnt = e->sell.lrow_cnt;
+    a.n_lrow = e->sell.n_lrow; a.n_partial = e->sell.n_partial; a.partial = e->d_partial16;
     a.num_vertices = e->V; a.x = x; a.y = y; a.aux = aux; a.row_slot = e->d_row_slot;
     a.tele = e->d_tele16; a.tele_rows = e->tele16_rows;
     a.alpha = damping; a.beta = 1.0f - damping; a.cscale = kPpr16CScale;
@@ -309,114 +200,16 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
 inline bool use_f16(const hrag_engine *e, int batch, int iters) {
     return e->f16_ready && batch > kSvMaxBatch && batch <= e->f16_max_batch && iters >= 16;
 }
-inline int n_slabs128(int batch) { return (int)ceil_div(batch, 128); }
-
-// Stage lengths of the fp8 scheme (ppr8.hip): 1 (the quantised start), then 2, 2, 3, 3, 3, ...
-// (tools/exp_fp8_final.py: as accurate as 1,2,2,2,2,3,3,3,2 with one boundary sweep fewer at 20)
-inline int ppr8_plan(int iters, int *plan) {
-    int n = 0, left = iters;
-    plan[n++] = 1; left -= 1;
-    for (int i = 0; i < 2 && left >= 2; ++i) { plan[n++] = 2; left -= 2; }
-    while (left > 0) { const int m = std::min(3, left); plan[n++] = m; left -= m; }
-    return n;
-}
-// damping: the stage plan is tuned for the reference's 0.5 (config_utils.py:192, HippoRAG.py:1734); the
-// rounding noise a stage adds is fixed while the contraction it buys shrinks with larger factors
-// (measured 3.5e-6 at 0.7 / 30 sweeps against 2.5e-7 for the fp32 state), so above 0.7 the fp32 slabs serve.
-inline bool use_f8(const hrag_engine *e, int batch, int iters, float damping) {
-    return e->f8_ready && batch > 64 && iters >= 16 && iters <= 30 && damping <= 0.7f;   // <= kP8MaxStages stages
-}
-
-Ppr8Args ppr8_args(const hrag_engine *e, float damping) {
-    Ppr8Args a = {};
-    a.pairs = e->d_pairs8; a.pairs_bytes = (uint32_t)((e->sell_steps + 4) * 512);
-    a.chunk_meta = e->d_chunk_meta; a.vrow = e->d_vrow; a.n_chunks = e->n_chunks;
-    a.lrow_row = e->d_lrow_row; a.lrow_first = e->d_lrow_first; a.lrow_cnt = e->d_lrow_cnt;
-    a.n_lrow = e->n_lrow; a.n_partial = e->n_partial16; a.partial = e->d_partial8;
-    a.num_vertices = e->V; a.R = e->d_R8; a.alpha = damping; a.beta = 1.0f - damping; a.deg = e->d_deg;
-    a.tele = e->d_tele16; a.tele_rows = e->tele16_rows; a.row_slot = e->d_row_slot;
-    a.n_passages = e->n_passages; a.n_slabs64 = n_slabs64(e->max_batch);
-    return a;
-}
-
-// The staged iteration of ppr8.hip; v comes from d_tele16 / d_row_slot (scaled so that max v/d is in
-// (1/2, 1]); the result x = d z lands in d_xp8 ([n_slabs64][Np][64] fp32, passage rows only) and its
-// column sums over ALL vertices as partial rows in d_csum8 (launch_ppr8_colsum adds them up).
-hrag_status ppr8_run(hrag_engine *e, int batch, float damping, int iters, hipStream_t s) {
-    const int ns = n_slabs128(batch), ns64 = n_slabs64(batch);
-    int plan[kP8MaxStages + 4];
-    const int n_stage = ppr8_plan(iters, plan);
-    HRAG_REQUIRE(n_stage >= 2 && n_stage <= kP8MaxStages, "ppr_iters=%d needs %d fp8 stages (2..%d)", iters, n_stage,
-                 kP8MaxStages);
-    static_assert(hrag_engine::kP8Pool >= kP8MaxStages + 3, "fp8 buffer pool too small for the stage plan");
-    std::vector<uint8_t *> pool(e->d_pool8, e->d_pool8 + hrag_engine::kP8Pool);
-    // <= kP8MaxStages stage results + the stage's right-hand side + one iterate in flight <= kP8Pool
-    auto take = [&]() { uint8_t *p = pool.back(); pool.pop_back(); return p; };
-    const uint8_t *stage_buf[kP8MaxStages];
-    float stage_inv[kP8MaxStages];
-    uint8_t *c = take();   // c_0 = Q(v/d * 2^7)
-    HRAG_TRY(launch_ppr8_init(e->d_tele16, e->tele16_rows, e->d_row_slot, e->d_deg, e->V, ns, ns64, kP8C0Scale,
-                              c, s));
-    // static scales: the max-norm of the true residual contracts by `damping` per sweep (At is row-
-    // stochastic), |R_0| <= max(a, 1 - a) max(v/d) + the rounding of c_0; a stage of m sweeps grows its
-    // iterate by at most (1 - a^m) / (1 - a).  cs = the power of two that maps that bound to <= 224
-    // (half the e4m3 range: the bound ignores rounding noise, and the conversion saturates anyway).
-    const double al = (double)damping;
-    double bound = std::max(al, 1.0 - al) + 0.07;
-    auto scale_for = [&](int m) {
-        const double growth = al < 1.0 ? (1.0 - std::pow(al, m)) / (1.0 - al) : (double)m;
-        int ex = (int)std::floor(std::log2(224.0 / std::max(bound * std::max(growth, 1.0), 1e-18)));   // damping ~ 0: bound -> 0
-        ex = std::min(std::max(ex, -60), 60);
-        return std::ldexp(1.0f, ex);
-    };
-    float cs = kP8C0Scale, cs_next = n_stage > 1 ? scale_for(plan[1]) : 1.0f;
-    uint8_t *rt = nullptr;
-    for (int si = 0; si < n_stage; ++si) {
-        const int m = plan[si];
-        if (si > 0) {
-            cs = cs_next;
-            c = rt;
-            for (int j = 1; j < m; ++j) {
-                uint8_t *dst = take();
-                Ppr8Args a = ppr8_args(e, damping);
-                a.x = c; a.y = dst; a.rt = rt;
-                HRAG_TRY(launch_ppr8_sweep(a, kP8ModeC, ns, false, s));
-                if (c != rt) pool.push_back(c);
-                c = dst;
-            }
-            if (c != rt) pool.push_back(rt);
-            bound *= std::pow(al, m);
-            cs_next = si + 1 < n_stage ? scale_for(plan[si + 1]) : 1.0f;
-        }
-        stage_buf[si] = c;
-        stage_inv[si] = 1.0f / cs;
-        Ppr8Args a = ppr8_args(e, damping);
-        a.x = c; a.inv_cs = 1.0f / cs; a.cs_next = cs_next;
-        if (si + 1 < n_stage) {
-            rt = take();
-            a.y = rt;
-            a.n_slabs64 = ns64;
-            HRAG_TRY(launch_ppr8_sweep(a, si == 0 ? kP8ModeB0 : kP8ModeB, ns, false, s));
-        } else {
-            for (int k = 0; k <= si; ++k) { a.stage[k] = stage_buf[k]; a.stage_inv[k] = stage_inv[k]; }
-            a.n_stage = si + 1; a.out = e->d_xp8; a.n_slabs64 = ns64;
-            a.row_slot = e->d_row_slot; a.n_passages = e->n_passages;
-            a.csum = e->d_csum8; a.n_csum = e->n_chunks + e->n_lrow;
-            HRAG_TRY(launch_ppr8_sweep(a, kP8ModeF, ns, false, s));
-        }
-    }
-    return HRAG_OK;
-}
-
 inline bool use_sv(const hrag_engine *e, int batch) { return e->sell_ready && batch <= kSvMaxBatch; }
 inline int sv_width(int batch) { return batch <= 1 ? 1 : batch <= 2 ? 2 : batch <= 4 ? 4 : 8; }
 
 PprSvArgs ppr_sv_args(const hrag_engine *e, const float *x, float *y, const int32_t *row_slot,
                       const float *tele, float damping) {
     PprSvArgs a;
-    a.pairs = e->d_pairs; a.pairs_bytes = (uint32_t)((e->sell_steps + 4) * 512); a.chunk_meta = e->d_chunk_meta; a.vrow = e->d_vrow; a.n_chunks = e->n_chunks;
-    a.lrow_row = e->d_lrow_row; a.lrow_first = e->d_lrow_first; a.lrow_cnt = e->d_lrow_cnt;
-    a.n_lrow = e->n_lrow; a.partial = e->d_partial_sv; a.num_vertices = e->V;
+    a.pairs = e->sell.pairs; a.pairs_bytes = e->sell.pairs_bytes(); a.chunk_meta = e->sell.chunk_meta;
+    a.vrow = e->sell.vrow; a.n_chunks = e->sell.n_chunks;
+    a.lrow_row = e->sell.lrow_row; a.lrow_first = e->sell.lrow_first; a.lrow_cnt = e->sell.lrow_cnt;
+    a.n_lrow = e->sell.n_lrow; a.partial = e->d_partial_sv; a.num_vertices = e->V;
     a.x = x; a.y = y; a.row_slot = row_slot; a.tele = tele;
     a.alpha = damping; a.beta = 1.0f - damping;
     a.nt = (e->opt_flags & HRAG_OPT_NT_CSR) ? 1 : 0;   // measured: nt loads are 25 % slower at B = 1
@@ -545,71 +338,14 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         E_TRY(dev_upload(&e->d_mrow_first, mrow_first.data(), (int64_t)mrow_first.size()));
         E_TRY(dev_upload(&e->d_mrow_cnt, mrow_cnt.data(), (int64_t)mrow_cnt.size()));
     }
-    // ---- SELL-8 + fp16 state for the two-stage PPR (unsharded engines, batches > 32)
-    const bool want_sell = !(opts->flags & HRAG_OPT_F32_STATE) && e->n_rows == e->V &&
-                           e->V * 128 < ((int64_t)1 << 32);
-    const bool want_f16 = want_sell && opts->max_batch > kSvMaxBatch;
-    if (want_sell) {
-        std::vector<int32_t> h_col((size_t)e->nnz);
-        std::vector<float> h_val((size_t)e->nnz);
-        if (e->nnz) {
-            E_HIP(hipMemcpy(h_col.data(), g->col_idx, h_col.size() * sizeof(int32_t), hipMemcpyDefault));
-            E_HIP(hipMemcpy(h_val.data(), g->val, h_val.size() * sizeof(float), hipMemcpyDefault));
-        }
-        // staged fp8 path (ppr8.hip): needs the weighted degrees the caller normalised P with
-        std::vector<double> h_deg;
-        const bool want_f8 = want_f16 && opts->max_batch > 64 && g->col_sum && !(opts->flags & HRAG_OPT_NO_FP8);
-        if (want_f8) {
-            h_deg.resize((size_t)e->V);
-            E_HIP(hipMemcpy(h_deg.data(), g->col_sum, h_deg.size() * sizeof(double), hipMemcpyDefault));
-            for (auto &d : h_deg) {
-                if (!(d >= 0.0) || !(d < 1e300)) {
-                    set_error("col_sum must be finite and >= 0");
-                    free_engine(e);
-                    return HRAG_EINVAL;
-                }
-                if (d == 0.0) d = 1.0;   // isolated vertex: no entries, z = x
-            }
-            // P d = d must hold (P = A D^-1 with A symmetric): it makes At = D^-1 P D row-stochastic,
-            // which is what keeps the static fp8 scales of ppr8.hip valid
-            double worst = 0.0;
-            for (int64_t r = 0; r < e->n_rows; ++r) {
-                double acc = 0.0;
-                for (int32_t k = h_row_ptr[(size_t)r]; k < h_row_ptr[(size_t)r + 1]; ++k)
-                    acc += (double)h_val[(size_t)k] * h_deg[(size_t)h_col[(size_t)k]];
-                if (h_row_ptr[(size_t)r + 1] > h_row_ptr[(size_t)r])
-                    worst = std::max(worst, std::fabs(acc / h_deg[(size_t)r] - 1.0));
-            }
-            if (worst > 1e-3) {
-                set_error("col_sum is not the weighted degree of a symmetric adjacency: max |sum_j P_ij d_j / d_i - 1| = %.3g",
-                          worst);
-                free_engine(e);
-                return HRAG_EINVAL;
-            }
-        }
-        E_TRY(build_sell8(e, h_row_ptr, h_col.data(), h_val.data(), want_f8 ? h_deg.data() : nullptr));
-        if (want_f8) {
-            std::vector<float> f_deg((size_t)e->V);
-            for (int64_t i = 0; i < e->V; ++i) f_deg[(size_t)i] = (float)h_deg[(size_t)i];
-            E_TRY(dev_upload(&e->d_deg, f_deg.data(), e->V));
-            std::vector<int32_t> h_pv((size_t)e->n_passages);
-            if (e->n_passages)
-                E_HIP(hipMemcpy(h_pv.data(), g->passage_vertex, h_pv.size() * sizeof(int32_t), hipMemcpyDefault));
-            std::vector<float> pinv((size_t)e->n_passages);
-            for (int64_t q = 0; q < e->n_passages; ++q) {
-                const int64_t v = h_pv[(size_t)q];
-                pinv[(size_t)q] = (v >= 0 && v < e->V) ? 1.0f / f_deg[(size_t)v] : 0.f;
-            }
-            E_TRY(dev_upload(&e->d_pinvdeg, pinv.data(), e->n_passages));
-            e->f8_ready = true;   // buffers follow with the workspace
-        }
-    }
     // ---- passages: vertex map and its inverse on the owned rows
+    std::vector<int32_t> h_pv((size_t)e->n_passages);
+    std::vector<int32_t> h_r2t((size_t)e->n_rows, -1);
+    e->p_rows = passages->rows; e->p_offset = passages->row_offset;
     {
-        std::vector<int32_t> h_pv((size_t)e->n_passages);
         if (e->n_passages)
             E_HIP(hipMemcpy(h_pv.data(), g->passage_vertex, h_pv.size() * sizeof(int32_t), hipMemcpyDefault));
-        std::vector<int32_t> r2t((size_t)e->n_rows, -1);
+        int64_t owned_in_range = 0, owned_total = 0;
         for (int64_t p = 0; p < e->n_passages; ++p) {
             const int64_t v = h_pv[(size_t)p];
             if (v < 0 || v >= e->V) {
@@ -618,15 +354,104 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
                 return HRAG_EINVAL;
             }
             const int64_t lr = v - e->row_offset;
-            if (lr >= 0 && lr < e->n_rows) r2t[(size_t)lr] = (int32_t)p;
+            if (lr >= 0 && lr < e->n_rows) {
+                h_r2t[(size_t)lr] = (int32_t)p;
+                ++owned_total;
+                if (p >= e->p_offset && p < e->p_offset + e->p_rows) ++owned_in_range;
+            }
         }
+        // the passage prior stays on its GPU when the passage embedding shard == the passages of the owned rows
+        e->shard_aligned = owned_total == e->p_rows && owned_in_range == e->p_rows;
         E_TRY(dev_upload(&e->d_passage_vertex, h_pv.data(), e->n_passages));
-        E_TRY(dev_upload(&e->d_row_to_tele, r2t.data(), e->n_rows));
+        E_TRY(dev_upload(&e->d_row_to_tele, h_r2t.data(), e->n_rows));
+    }
+    // ---- SELL-8 matrices: P-valued for the fp16 / small-batch kernels (unsharded engines), At-valued for the
+    //      staged fp8 iteration (any row shard, needs the weighted degrees the caller normalised P with)
+    const bool unsharded = e->n_rows == e->V;
+    const bool want_sell = !(opts->flags & HRAG_OPT_F32_STATE) && unsharded && e->V * 128 < ((int64_t)1 << 32);
+    const bool want_f16 = want_sell && opts->max_batch > kSvMaxBatch;
+    const bool want_f8 = !(opts->flags & HRAG_OPT_F32_STATE) && !(opts->flags & HRAG_OPT_NO_FP8) && g->col_sum &&
+                         e->V + 1 <= ((int64_t)1 << 24) && e->shard_aligned &&
+                         (unsharded ? (want_f16 && opts->max_batch > 64) : true);
+    if (want_sell || want_f8) {
+        std::vector<int32_t> h_col((size_t)e->nnz);
+        std::vector<float> h_val((size_t)e->nnz);
+        if (e->nnz) {
+            E_HIP(hipMemcpy(h_col.data(), g->col_idx, h_col.size() * sizeof(int32_t), hipMemcpyDefault));
+            E_HIP(hipMemcpy(h_val.data(), g->val, h_val.size() * sizeof(float), hipMemcpyDefault));
+        }
+        std::vector<double> h_deg;
+        std::vector<uint8_t> h_iso;
+        if (want_f8) {
+            h_deg.resize((size_t)e->V);
+            h_iso.assign((size_t)e->V, 0);
+            E_HIP(hipMemcpy(h_deg.data(), g->col_sum, h_deg.size() * sizeof(double), hipMemcpyDefault));
+            for (int64_t i = 0; i < e->V; ++i) {
+                double &d = h_deg[(size_t)i];
+                if (!(d >= 0.0) || !(d < 1e300)) {
+                    set_error("col_sum must be finite and >= 0");
+                    free_engine(e);
+                    return HRAG_EINVAL;
+                }
+                if (d == 0.0) { d = 1.0; h_iso[(size_t)i] = 1; }   // isolated vertex: no entries, z = x
+            }
+            // P d = d must hold (P = A D^-1 with A symmetric): it makes At = D^-1 P D row-stochastic,
+            // which is what keeps the static fp8 scales of ppr8.hip valid (checked on the owned rows)
+            double worst = 0.0;
+            for (int64_t r = 0; r < e->n_rows; ++r) {
+                double acc = 0.0;
+                for (int32_t k = h_row_ptr[(size_t)r]; k < h_row_ptr[(size_t)r + 1]; ++k)
+                    acc += (double)h_val[(size_t)k] * h_deg[(size_t)h_col[(size_t)k]];
+                if (h_row_ptr[(size_t)r + 1] > h_row_ptr[(size_t)r])
+                    worst = std::max(worst, std::fabs(acc / h_deg[(size_t)(e->row_offset + r)] - 1.0));
+                else if (!h_iso[(size_t)(e->row_offset + r)])
+                    worst = 1.0;   // a vertex with weight but no row entries: not a symmetric adjacency
+            }
+            if (worst > 1e-3) {
+                set_error("col_sum is not the weighted degree of a symmetric adjacency: max |sum_j P_ij d_j / d_i - 1| = %.3g",
+                          worst);
+                free_engine(e);
+                return HRAG_EINVAL;
+            }
+        }
+        E_TRY(build_sell8(e, h_row_ptr, h_col.data(), h_val.data(), want_f8 ? h_deg.data() : nullptr, nullptr,
+                          want_sell, &e->sell));
+        if (want_f8) {
+            // the last sweep only needs the passage rows (HippoRAG.py:1745 reads nothing else)
+            std::vector<int32_t> prow_list;
+            std::vector<int32_t> ptele((size_t)e->n_rows, -1);
+            for (int64_t r = 0; r < e->n_rows; ++r)
+                if (h_r2t[(size_t)r] >= 0) {
+                    prow_list.push_back((int32_t)r);
+                    ptele[(size_t)r] = h_r2t[(size_t)r] - (int32_t)e->p_offset;
+                }
+            E_TRY(build_sell8(e, h_row_ptr, h_col.data(), h_val.data(), h_deg.data(), &prow_list, false, &e->fsell));
+            E_TRY(dev_upload(&e->d_row_ptele, ptele.data(), e->n_rows));
+            std::vector<float> f_deg((size_t)e->V);
+            for (int64_t i = 0; i < e->V; ++i) f_deg[(size_t)i] = (float)h_deg[(size_t)i];
+            E_TRY(dev_upload(&e->d_deg, f_deg.data(), e->V));
+            E_TRY(dev_upload(&e->d_iso, h_iso.data(), e->V));
+            std::vector<float> pinv((size_t)e->p_rows);
+            std::vector<uint8_t> piso((size_t)e->p_rows);
+            for (int64_t q = 0; q < e->p_rows; ++q) {
+                const int64_t v = h_pv[(size_t)(e->p_offset + q)];
+                pinv[(size_t)q] = 1.0f / f_deg[(size_t)v];
+                piso[(size_t)q] = h_iso[(size_t)v];
+            }
+            E_TRY(dev_upload(&e->d_pinvdeg, pinv.data(), e->p_rows));
+            E_TRY(dev_upload(&e->d_piso, piso.data(), e->p_rows));
+            // column bitmap of the passage vertices (ALL passages: the columns are global)
+            e->colmask_words = ceil_div(e->V + 1, 32);
+            std::vector<uint32_t> mask((size_t)e->colmask_words, 0u);
+            for (int64_t q = 0; q < e->n_passages; ++q) mask[(size_t)(h_pv[(size_t)q] >> 5)] |= 1u << (h_pv[(size_t)q] & 31);
+            E_TRY(dev_upload(&e->d_colmask_static, mask.data(), e->colmask_words));
+            E_TRY(dev_alloc(&e->d_colmask, e->colmask_words));
+            e->f8_ready = true;   // buffers follow with the workspace
+        }
     }
     // ---- embeddings + fact lookup arrays
     e->dim = passages->dim;
     e->emb_dtype = passages->dtype;
-    e->p_rows = passages->rows; e->p_offset = passages->row_offset;
     E_TRY(dev_upload(&e->d_pemb, static_cast<const uint16_t *>(passages->data), e->p_rows * e->dim));
     if (facts) {
         e->f_rows = facts->rows; e->f_offset = facts->row_offset; e->n_facts = fd->n_facts;
@@ -638,48 +463,62 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     // ---- workspace, sized once for max_batch
     const int B = e->max_batch;
     SlabLayout lay = e->layout(B);
-    e->state_elems = (int64_t)lay.n_slabs * e->V * lay.bc;
+    e->state_elems = unsharded ? (int64_t)lay.n_slabs * e->V * lay.bc : 0;   // d_x / d_y: hrag_retrieve, hrag_ppr
     if (want_sell) {
         E_TRY(dev_alloc(&e->d_tele_sv, (e->n_passages + (int64_t)kSvMaxBatch * kMaxSeeds) * kSvMaxBatch));
-        E_TRY(dev_alloc(&e->d_partial_sv, (int64_t)std::max(e->n_partial16, 1) * kSvMaxBatch));
-        E_TRY(dev_alloc(&e->d_row_slot, e->V));
-        E_HIP(hipMemcpy(e->d_row_slot, e->d_row_to_tele, (size_t)e->V * sizeof(int32_t), hipMemcpyDeviceToDevice));
+        E_TRY(dev_alloc(&e->d_partial_sv, (int64_t)std::max(e->sell.n_partial, 1) * kSvMaxBatch));
         e->sell_ready = true;
+    }
+    if (want_sell || e->f8_ready) {
+        // per-batch copy of the row -> teleport slot map with the seed rows patched in (local rows)
+        E_TRY(dev_alloc(&e->d_row_slot, e->n_rows));
+        E_HIP(hipMemcpy(e->d_row_slot, e->f8_ready ? e->d_row_ptele : e->d_row_to_tele,
+                        (size_t)e->n_rows * sizeof(int32_t), hipMemcpyDeviceToDevice));
+    }
+    if (want_f16 || e->f8_ready) {
+        // teleport rows of the fp16 and fp8 paths: the owned passages, then the seed rows (fp32, 64-query slabs)
+        const int ns = n_slabs64(B);
+        e->tele16_rows = e->p_rows + (int64_t)B * kMaxSeeds;
+        E_TRY(dev_alloc(&e->d_tele16, (int64_t)ns * e->tele16_rows * 64));
+        E_HIP(hipMemset(e->d_tele16, 0, (size_t)ns * e->tele16_rows * 64 * sizeof(float)));
+        E_TRY(dev_alloc(&e->d_qscale, B));
+        E_TRY(dev_alloc(&e->d_ssum, B));
     }
     if (want_f16) {
         const int ns = n_slabs64(B);
-        // the fp16 STATE only has to hold the batches the fp8 path does not take (<= 64 queries); the
-        // teleport rows below are shared with the fp8 path and stay sized for max_batch
+        // the fp16 STATE only has to hold the batches the fp8 path does not take (<= 64 queries)
         e->f16_max_batch = e->f8_ready ? std::min(B, 64) : B;
         e->state16_elems = (int64_t)n_slabs64(e->f16_max_batch) * e->V * 64;
         e->state_elems = std::max(e->state_elems, e->state16_elems);  // d_x also receives h + c
         for (auto &p : e->d_h16) E_TRY(dev_alloc(&p, e->state16_elems));
-        e->tele16_rows = e->n_passages + (int64_t)B * kMaxSeeds;
-        E_TRY(dev_alloc(&e->d_tele16, (int64_t)ns * e->tele16_rows * 64));
-        E_TRY(dev_alloc(&e->d_partial16, (int64_t)ns * std::max(e->n_partial16, 1) * 64));
-        E_TRY(dev_alloc(&e->d_qscale, B));
-        E_TRY(dev_alloc(&e->d_ssum, B));
+        E_TRY(dev_alloc(&e->d_partial16, (int64_t)ns * std::max(e->sell.n_partial, 1) * 64));
         for (auto &p : e->d_h16) E_HIP(hipMemset(p, 0, (size_t)e->state16_elems * sizeof(uint16_t)));
-        E_HIP(hipMemset(e->d_tele16, 0, (size_t)ns * e->tele16_rows * 64 * sizeof(float)));
         e->f16_ready = true;
     }
     if (e->f8_ready) {
         const int ns = n_slabs128(B);
-        e->state8_bytes = (int64_t)ns * e->V * 128;
-        for (auto &p : e->d_pool8) {
-            E_TRY(dev_alloc(&p, e->state8_bytes));
-            E_HIP(hipMemset(p, 0, (size_t)e->state8_bytes));
+        E_TRY(dev_alloc(&e->d_R8, (int64_t)ns * std::max<int64_t>(e->n_rows, 1) * 128));
+        E_TRY(dev_alloc(&e->d_partial8, (int64_t)ns * std::max({e->sell.n_partial, e->fsell.n_partial, 1}) * 128));
+        E_TRY(dev_alloc(&e->d_stagep, (int64_t)kP8MaxStages * ns * std::max<int64_t>(e->p_rows, 1) * 128));
+        E_TRY(dev_alloc(&e->d_xp8, (int64_t)n_slabs64(B) * std::max<int64_t>(e->p_rows, 1) * 64));
+        E_TRY(dev_alloc(&e->d_zmax_bits, B));
+        E_TRY(dev_alloc(&e->d_zmax, B));
+        E_TRY(dev_alloc(&e->d_mass, 2 * (int64_t)B));
+        E_TRY(dev_alloc(&e->d_prior_part, (int64_t)kP8PriorSplit * B * 2));
+        if (unsharded) {
+            // hrag_retrieve's own state buffers: one exchange group per slab, (V + 1) rows (the last one zero)
+            e->state8_bytes = (int64_t)ns * (e->V + 1) * 128;
+            for (auto &p : e->d_pool8) {
+                E_TRY(dev_alloc(&p, e->state8_bytes));
+                E_HIP(hipMemset(p, 0, (size_t)e->state8_bytes));
+            }
         }
-        E_TRY(dev_alloc(&e->d_R8, e->state8_bytes));
-        E_TRY(dev_alloc(&e->d_partial8, (int64_t)ns * std::max(e->n_partial16, 1) * 128));
-        E_TRY(dev_alloc(&e->d_csum8, (int64_t)ns * std::max(e->n_chunks + e->n_lrow, 1) * 128));
-        E_TRY(dev_alloc(&e->d_xp8, (int64_t)n_slabs64(B) * std::max<int64_t>(e->n_passages, 1) * 64));
     }
     E_TRY(dev_alloc(&e->d_partial, (int64_t)(round_up(B, 4) + 64) * std::max(e->n_partial, 1)));
     E_TRY(dev_alloc(&e->d_x, e->state_elems));
     E_TRY(dev_alloc(&e->d_y, e->state_elems));
-    E_TRY(dev_alloc(&e->d_tele, (int64_t)lay.n_slabs * std::max<int64_t>(e->n_passages, 1) * lay.bc));
-    e->ld_p = round_up(std::max<int64_t>(e->n_passages, 1), 4);
+    if (unsharded) E_TRY(dev_alloc(&e->d_tele, (int64_t)lay.n_slabs * std::max<int64_t>(e->n_passages, 1) * lay.bc));
+    e->ld_p = round_up(std::max<int64_t>(e->p_rows, 1), 4);   // score rows cover the OWNED passages
     e->ld_f = round_up(std::max<int64_t>(e->f_rows, 1), 4);
     E_TRY(dev_alloc(&e->d_spass, (int64_t)B * e->ld_p));
     E_TRY(dev_alloc(&e->d_doc, (int64_t)B * e->ld_p));
@@ -704,8 +543,10 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         E_TRY(dev_alloc(&ws, (int64_t)kTopkWsBytes));
         e->d_topk_ws = ws;
     }
-    E_HIP(hipMemset(e->d_x, 0, (size_t)e->state_elems * sizeof(float)));
-    E_HIP(hipMemset(e->d_y, 0, (size_t)e->state_elems * sizeof(float)));
+    if (e->state_elems) {
+        E_HIP(hipMemset(e->d_x, 0, (size_t)e->state_elems * sizeof(float)));
+        E_HIP(hipMemset(e->d_y, 0, (size_t)e->state_elems * sizeof(float)));
+    }
     E_HIP(hipMemset(e->d_seed_cnt, 0, (size_t)B * sizeof(int32_t)));
     for (auto &ev : e->ev) E_HIP(hipEventCreate(&ev));
     E_HIP(hipDeviceSynchronize());
@@ -891,7 +732,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     HRAG_REQUIRE(e->n_passages >= 1, "engine has no passages");
     hipStream_t s = (hipStream_t)stream;
     const bool sv = use_sv(e, batch);
-    const bool f8 = !sv && use_f8(e, batch, ppr_iters, damping);
+    const bool f8 = !sv && batch > 64 && e->d_pool8[0] && ppr8_usable(e, batch, ppr_iters, damping);
     const bool f16 = !sv && !f8 && use_f16(e, batch, ppr_iters);
     const int bp = sv_width(batch);
     SlabLayout lay = e->layout(batch);
@@ -907,20 +748,27 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
                                f16 ? e->d_ssum : nullptr));   // fp8 path: d_ssum is the z-max scratch
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SIM], s));
     // reset vector: entity seeds + passage prior (HippoRAG.py:1574-1638)
-    HRAG_TRY(hrag_stage_seeds(e, kept_idx, kept_score, kept_count, kf, link_top_k, batch, e->d_seed_vtx,
-                              e->d_seed_w, e->d_seed_cnt, e->d_flags, stream));
-    if (f16 || f8) {
-        // v is scaled per query by a power of two -- so that every iterate fits fp16 (ppr16.hip), or so
-        // that max v/d is in (1/2, 1] (ppr8.hip); the seeds become extra teleport rows, i.e. v is one
-        // array that every sweep (ppr16) / the init kernel (ppr8) reads identically
-        if (f8)
-            HRAG_TRY(launch_ppr8_scale(e->d_spass, e->ld_p, e->n_passages, e->d_mn_p, e->d_mx_p,
-                                       passage_node_weight, e->d_pinvdeg, e->d_seed_vtx, e->d_seed_w,
-                                       e->d_seed_cnt, e->d_deg, e->V, e->d_flags, batch,
-                                       reinterpret_cast<int32_t *>(e->d_ssum), e->d_qscale, s));
-        else
-            HRAG_TRY(launch_ppr16_scale(e->d_mn_p, e->d_mx_p, e->d_ssum, e->n_passages, passage_node_weight,
-                                        e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, e->d_qscale, s));
+    if (e->d_subj) {
+        HRAG_TRY(hrag_stage_seeds(e, kept_idx, kept_score, kept_count, kf, link_top_k, batch, e->d_seed_vtx,
+                                  e->d_seed_w, e->d_seed_cnt, e->d_flags, stream));
+    } else {
+        // an index without facts (no triples extracted): every query takes the DPR ranking, as the
+        // reference does when rerank_facts returns nothing (HippoRAG.py:467-469, :1453-1455)
+        HRAG_TRY(launch_fill_i32(e->d_flags, 1, batch, s));
+        HRAG_HIP_TRY(hipMemsetAsync(e->d_seed_cnt, 0, (size_t)batch * sizeof(int32_t), s));
+    }
+    if (f8) {
+        // staged fp8 state (ppr8.hip / shard.hip): the single-GPU engine is the row shard that owns everything
+        hrag_shard_layout sl;
+        HRAG_TRY(ppr8_layout(e, batch, 0, &sl));
+        HRAG_TRY(ppr8_prior(e, e->d_mn_p, e->d_mx_p, passage_node_weight, e->d_flags, batch, e->d_zmax, e->d_mass, s));
+        HRAG_TRY(ppr8_begin(e, e->d_mn_p, e->d_mx_p, e->d_zmax, e->d_mass, passage_node_weight, e->d_seed_vtx,
+                            e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, damping, ppr_iters, sl, e->d_pool8, s));
+    } else if (f16) {
+        // v is scaled per query by a power of two so that every iterate fits fp16 (ppr16.hip); the seeds
+        // become extra teleport rows, i.e. v is one array that every sweep reads identically
+        HRAG_TRY(launch_ppr16_scale(e->d_mn_p, e->d_mx_p, e->d_ssum, e->n_passages, passage_node_weight,
+                                    e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, e->d_qscale, s));
         HRAG_TRY(launch_rows_to_slab(e->d_spass, e->ld_p, e->n_passages, batch, kMinMaxScale, e->d_mn_p,
                                      e->d_mx_p, passage_node_weight, e->d_flags, e->d_tele16, lay, s,
                                      e->tele16_rows, e->d_qscale));
@@ -948,7 +796,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SEED], s));
     // PPR (HippoRAG.py:1736-1743): fixed-count leaky power iteration
     if (f8) {
-        HRAG_TRY(ppr8_run(e, batch, damping, ppr_iters, s));
+        for (int it = 0; it < ppr_iters; ++it) HRAG_TRY(ppr8_sweep(e, it, -1, nullptr, s));
     } else if (f16) {
         HRAG_TRY(ppr16_run(e, batch, damping, ppr_iters, s));
     } else if (sv) {
@@ -971,11 +819,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
         HRAG_TRY(launch_ppr_sv_rows(e->d_x, e->d_passage_vertex, e->n_passages, batch, e->d_sums, e->d_doc,
                                     e->ld_p, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, e->d_flags, bp, s));
     } else if (f8) {
-        HRAG_TRY(launch_ppr8_colsum(e->d_csum8, e->n_chunks + e->n_lrow, n_slabs128(batch), batch,
-                                    e->d_colsum_partial, e->d_sums, s));
-        HRAG_TRY(launch_slab_to_rows(e->d_xp8, e->n_passages, nullptr, e->n_passages, batch, e->d_sums,
-                                     e->d_doc, e->ld_p, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, e->d_flags,
-                                     lay, s));
+        HRAG_TRY(ppr8_doc_scores(e, e->d_mn_p, e->d_mx_p, e->d_flags, batch, s));   // d_sums: the analytic mass
     } else {
         HRAG_TRY(launch_colsum(e->d_x, e->V, 0, e->V, batch, lay, e->d_colsum_partial, e->d_sums, s));
         HRAG_TRY(launch_slab_to_rows(e->d_x, e->V, e->d_passage_vertex, e->n_passages, batch, e->d_sums,
@@ -1068,15 +912,12 @@ hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damp
         if (x != e->d_x) std::swap(e->d_x, e->d_y);
         return HRAG_OK;
     }
-    if (flags & 8) {   // fp8 mode-C sweeps over the pool buffers left by the last hrag_retrieve
-        HRAG_REQUIRE(e->f8_ready && batch > 64, "engine has no fp8 PPR state (needs col_sum, max_batch > 64)");
-        uint8_t *c = e->d_pool8[0], *cn = e->d_pool8[1];
-        for (int it = 0; it < n; ++it) {
-            Ppr8Args a = ppr8_args(e, damping);
-            a.x = c; a.y = cn; a.rt = e->d_pool8[2];
-            HRAG_TRY(launch_ppr8_sweep(a, kP8ModeC, n_slabs128(batch), (flags & 1) != 0, (hipStream_t)stream));
-            std::swap(c, cn);
-        }
+    if (flags & 8) {   // fp8 sweeps over the state the last hrag_retrieve left; flags bits 4..5 pick the mode
+        HRAG_REQUIRE(e->f8_ready && e->d_pool8[0] && e->p8.active && e->p8.batch == batch,
+                     "no fp8 PPR state for batch %d (needs col_sum, max_batch > 64 and a preceding hrag_retrieve)", batch);
+        const int mode = (flags >> 4) & 3;   // 0 = C, 1 = B, 2 = F, 3 = B0 (Ppr8Mode)
+        for (int it = 0; it < n; ++it)
+            HRAG_TRY(ppr8_bench_sweep(e, mode, it, (flags & 1) != 0, (hipStream_t)stream));
         return HRAG_OK;
     }
     if (flags & 2) {
@@ -1091,6 +932,7 @@ hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damp
         if (h != e->d_h16[0]) std::swap(e->d_h16[0], e->d_h16[1]);
         return HRAG_OK;
     }
+    HRAG_REQUIRE(e->d_x && e->d_tele, "the fp32-state sweep hook needs an unsharded engine");
     const SlabLayout lay = e->layout(batch);
     float *x = e->d_x, *y = e->d_y;
     for (int it = 0; it < n; ++it) {

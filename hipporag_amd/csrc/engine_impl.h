@@ -1,0 +1,208 @@
+// Internal: the engine object behind the opaque hrag_engine handle of include/hrag.h, shared by
+// engine.hip (creation, single-GPU entry points) and shard.hip (staged fp8 PPR driver + row-shard ABI).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+namespace hrag {
+
+constexpr int kSvMaxBatch = 8;         // batches up to this take the small-batch kernels (ppr_sv.hip)
+constexpr float kPpr16CScale = 64.f;  // correction / residual are stored as f16(c * 64); see ppr16.hip
+
+enum EvId { EV_START = 0, EV_SIM, EV_SEED, EV_PPR, EV_RANK, EV_FACT0, EV_FACT1, EV_COUNT };
+
+template <typename T>
+inline hrag_status dev_alloc(T **p, int64_t count) {
+    *p = nullptr;
+    if (count <= 0) return HRAG_OK;
+    hipError_t err = hipMalloc(reinterpret_cast<void **>(p), (size_t)count * sizeof(T));
+    if (err != hipSuccess) {
+        set_error("hipMalloc of %lld bytes failed: %s", (long long)(count * (int64_t)sizeof(T)),
+                  hipGetErrorString(err));
+        *p = nullptr;
+        return HRAG_ENOMEM;
+    }
+    return HRAG_OK;
+}
+
+template <typename T>
+inline hrag_status dev_upload(T **p, const T *src, int64_t count) {
+    HRAG_TRY(dev_alloc(p, count));
+    if (count > 0) HRAG_HIP_TRY(hipMemcpy(*p, src, (size_t)count * sizeof(T), hipMemcpyDefault));
+    return HRAG_OK;
+}
+
+inline int auto_slab_width(int batch, int cap) {
+    int bc = 4;
+    while (bc < batch && bc < cap) bc <<= 1;
+    return bc;
+}
+inline int n_slabs64(int batch) { return (int)ceil_div(batch, 64); }
+inline int n_slabs128(int batch) { return (int)ceil_div(batch, 128); }
+
+// SELL-8 matrix on the device (ppr16.hip header): the structure arrays + up to two value variants
+struct Sell8Store {
+    int2 *pairs = nullptr;      // (col, P value)                      -- ppr16 / ppr_sv
+    int2 *pairs_at = nullptr;   // (col, At value = p_ij d_j / d_i)    -- ppr8
+    int2 *chunk_meta = nullptr;
+    int32_t *vrow = nullptr, *lrow_row = nullptr, *lrow_first = nullptr, *lrow_cnt = nullptr;
+    int32_t n_chunks = 0, n_lrow = 0, n_partial = 0;
+    int64_t steps = 0;
+    uint32_t pairs_bytes() const { return (uint32_t)((steps + 4) * 512); }
+    Sell8Dev dev_at() const {
+        Sell8Dev d;
+        d.pairs = pairs_at; d.pairs_bytes = pairs_bytes(); d.chunk_meta = chunk_meta; d.vrow = vrow;
+        d.n_chunks = n_chunks; d.lrow_row = lrow_row; d.lrow_first = lrow_first; d.lrow_cnt = lrow_cnt;
+        d.n_lrow = n_lrow; d.n_partial = n_partial;
+        return d;
+    }
+};
+
+// One step of the staged fp8 iteration (csrc/ppr8.hip): which kernel mode, on which of the three state
+// buffers, with which static scales.
+struct Ppr8Step {
+    int32_t mode;        // Ppr8Mode
+    int32_t stage;       // stage the step belongs to (B / B0 / F: the stage being closed)
+    int32_t x, y, rt;    // state buffer indices (y: written = to be exchanged; -1 for mode F; rt: mode C)
+    float inv_cs, cs_next;
+};
+struct Ppr8Session {
+    bool active = false;
+    int32_t batch = 0, iters = 0, n_steps = 0, n_stage = 0;
+    int32_t n_slabs = 0, n_groups = 0, spg = 0;
+    int64_t group_bytes = 0;
+    float damping = 0.f;
+    uint8_t *buf[3] = {nullptr, nullptr, nullptr};
+    const int32_t *flags = nullptr;      // the batch's flag words (bit 3: fp8 saturation)
+    Ppr8Step steps[40];
+    float stage_inv[kP8MaxStages];
+};
+
+}  // namespace hrag
+
+using namespace hrag;
+
+struct hrag_engine {
+    int device = 0;
+    // graph (owned rows)
+    int64_t V = 0, row_offset = 0, n_rows = 0, nnz = 0, n_passages = 0;
+    int32_t *d_row_ptr = nullptr, *d_col = nullptr;
+    float *d_val = nullptr;
+    int32_t *d_row_order = nullptr;
+    int32_t n_short = 0;
+    int32_t *d_seg_row = nullptr, *d_seg_begin = nullptr, *d_seg_end = nullptr, *d_seg_slot = nullptr;
+    int32_t *d_mrow_row = nullptr, *d_mrow_first = nullptr, *d_mrow_cnt = nullptr;
+    int32_t n_seg = 0, n_mrow = 0, n_partial = 0, n_long_rows = 0;
+    float *d_partial = nullptr;
+    int32_t *d_passage_vertex = nullptr;  // [Np] global vertex ids
+    int32_t *d_row_to_tele = nullptr;     // [n_rows] global passage index of an owned row, or -1
+    // embeddings (owned rows)
+    int32_t dim = 0, emb_dtype = HRAG_BF16;
+    int64_t p_rows = 0, p_offset = 0, f_rows = 0, f_offset = 0, n_facts = 0;
+    uint16_t *d_pemb = nullptr, *d_femb = nullptr;
+    int32_t *d_subj = nullptr, *d_obj = nullptr, *d_num_chunks = nullptr;
+    // options
+    int32_t max_batch = 0, max_topk = 0, slab_cap = 32, short_thresh = 0, seg_len = 0, opt_flags = 0;
+    // workspace
+    int64_t state_elems = 0;  // floats in each of d_x / d_y
+    float *d_x = nullptr, *d_y = nullptr, *d_tele = nullptr, *d_tele_dense = nullptr;
+    int64_t ld_p = 0, ld_f = 0;
+    float *d_spass = nullptr, *d_sfact = nullptr, *d_doc = nullptr;
+    float *d_mn_p = nullptr, *d_mx_p = nullptr;
+    int32_t *d_seed_vtx = nullptr, *d_seed_cnt = nullptr, *d_flags = nullptr;
+    float *d_seed_w = nullptr;
+    double *d_colsum_partial = nullptr, *d_sums = nullptr;
+    void *d_topk_ws = nullptr;   // kTopkWsBytes: lets small batches split a row over several workgroups
+    // fused fact top-k (sim_gemm.hip): tile max / min, selected tiles, global min / max per query
+    float *d_fused_ws = nullptr, *d_mn_f = nullptr, *d_mx_f = nullptr;
+    int32_t *d_fused_sel = nullptr;
+    // two-stage fp16 PPR (ppr16.hip): SELL-8 matrix + fp16 state, unsharded engines with max_batch > 8
+    bool f16_ready = false;   // fp16 state buffers present (max_batch > 8)
+    int32_t f16_max_batch = 0;  // ... sized for this many queries (64 when the fp8 path serves the larger batches)
+    bool sell_ready = false;  // SELL-8 matrix + small-batch buffers present (every unsharded engine)
+    float *d_tele_sv = nullptr, *d_partial_sv = nullptr;   // small-batch path (ppr_sv.hip), BP <= 8
+    float *d_partial16 = nullptr;
+    uint16_t *d_h16[4] = {nullptr, nullptr, nullptr, nullptr};  // hA, hB, r, cA
+    int64_t state16_elems = 0;
+    float *d_tele16 = nullptr;      // fp32 [n_slabs64][tele16_rows][64]: passages, then seed rows
+    int64_t tele16_rows = 0;
+    int32_t *d_row_slot = nullptr;  // [V] per-batch copy of d_row_to_tele with the seed rows patched in
+    float *d_qscale = nullptr, *d_ssum = nullptr;
+    // staged fp8 PPR (ppr8.hip): SELL-8 over the OWNED rows with the row-normalised values, fp32 residual on
+    // the owned rows, three e4m3 state buffers; needs hrag_graph_desc.col_sum.  Serves hrag_retrieve for
+    // batches > 64 on an unsharded engine and the hrag_shard_* entry points on a row shard.
+    bool f8_ready = false;
+    bool shard_aligned = false;   // owned passages == passages whose vertex is an owned row
+    Sell8Store sell;              // owned rows (unsharded engines: also the P-valued pairs of ppr16 / ppr_sv)
+    Sell8Store fsell;             // the owned PASSAGE rows only: the last sweep (mode F)
+    int32_t *d_row_ptele = nullptr;   // [n_rows] LOCAL passage number of an owned row (-1: not a passage)
+    float *d_deg = nullptr, *d_pinvdeg = nullptr, *d_R8 = nullptr, *d_partial8 = nullptr;
+    uint8_t *d_iso = nullptr, *d_piso = nullptr;   // [V] / [p_rows]: vertex (of the passage) has no edges
+    uint32_t *d_colmask_static = nullptr, *d_colmask = nullptr;   // [ceil(V / 32)] passage columns (+ seeds)
+    int64_t colmask_words = 0;
+    uint8_t *d_stagep = nullptr;   // [kP8MaxStages][n_slabs][p_rows][128]: c of every stage at the owned passages
+    float *d_xp8 = nullptr;        // mode F output: x at the owned passages [n_slabs64][p_rows][64]
+    uint8_t *d_pool8[3] = {nullptr, nullptr, nullptr};   // engine-owned state buffers (max_batch > 64, unsharded)
+    int64_t state8_bytes = 0;
+    int32_t *d_zmax_bits = nullptr;
+    float *d_zmax = nullptr;
+    double *d_mass = nullptr, *d_prior_part = nullptr;
+    Ppr8Session p8;
+    // timing
+    hipEvent_t ev[EV_COUNT] = {};
+    bool profiling = false, have_retrieve_ev = false, have_fact_ev = false;
+    hrag_timings last = {};
+
+    SlabLayout layout(int batch) const {
+        SlabLayout l;
+        l.bc = auto_slab_width(batch, slab_cap);
+        l.n_slabs = (int)ceil_div(batch, l.bc);
+        return l;
+    }
+    SpmmArgs spmm_args(const float *x, float *y, const float *tele, int64_t tele_rows,
+                       const int32_t *row_to_tele, float damping) const {
+        SpmmArgs a;
+        a.row_ptr = d_row_ptr; a.col_idx = d_col; a.val = d_val;
+        a.row_order = d_row_order; a.n_short = n_short;
+        a.seg_row = d_seg_row; a.seg_begin = d_seg_begin; a.seg_end = d_seg_end; a.seg_slot = d_seg_slot;
+        a.n_seg = n_seg; a.mrow_row = d_mrow_row; a.mrow_first = d_mrow_first; a.mrow_cnt = d_mrow_cnt;
+        a.n_mrow = n_mrow; a.partial = d_partial; a.n_partial = n_partial;
+        a.n_rows = n_rows; a.row_offset = row_offset; a.num_vertices = V;
+        a.x = x; a.y = y; a.row_to_tele = row_to_tele; a.tele = tele; a.tele_rows = tele_rows;
+        a.alpha = damping; a.beta = 1.0f - damping; a.flags = opt_flags;
+        return a;
+    }
+};
+
+namespace hrag {
+// ---- shared between engine.hip and shard.hip
+// The fp8 path serves a batch when the truncation error of `iters` sweeps is below the parity bar
+// (damping^iters <= 2^-18) and the stage plan fits.
+bool ppr8_usable(const hrag_engine *e, int batch, int iters, float damping);
+int ppr8_plan(int iters, int *plan);
+// layout of the state buffers for `batch` queries in `want_groups` exchange groups (0 = one slab per group)
+hrag_status ppr8_layout(const hrag_engine *e, int32_t batch, int32_t want_groups, hrag_shard_layout *out);
+// local statistics of the passage prior over the owned passages (d_spass must hold the local scores)
+hrag_status ppr8_prior(hrag_engine *e, const float *mn, const float *mx, float passage_weight,
+                       const int32_t *flags, int32_t batch, float *zmax_out, double *mass_out, hipStream_t s);
+// scale, teleport rows, seed rows, column mask, stage plan, c_0 on the owned rows of buf[0]
+hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const float *zmax, const double *mass,
+                       float passage_weight, const int32_t *seed_vtx, const float *seed_w,
+                       const int32_t *seed_cnt, int32_t *flags, int32_t batch, float damping, int32_t iters,
+                       const hrag_shard_layout &lay, uint8_t *const bufs[3], hipStream_t s);
+// sweep `i` (0-based) on exchange group `group` (-1: every group); *exchange = buffer written (-1: none)
+hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchange, hipStream_t s);
+// d_doc[q][p_local] = x / mass, or the normalised DPR score on the fallback; flags bit 1 on zero mass
+hrag_status ppr8_doc_scores(hrag_engine *e, const float *mn, const float *mx, int32_t *flags, int32_t batch,
+                            hipStream_t s);
+// measurement hook: one launch of kernel mode `mode` over the buffers of the active session (it: parity of
+// the ping-pong); results are garbage, the memory traffic is that of a real sweep of that mode
+hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int it, bool main_only, hipStream_t s);
+}  // namespace hrag

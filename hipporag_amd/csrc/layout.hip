@@ -107,6 +107,11 @@ __global__ __launch_bounds__(256) void slab_to_rows_kernel(
     }
 }
 
+__global__ void fill_i32_kernel(int32_t *dst, int32_t value, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+
 __global__ void flag_zero_mass_kernel(const double *sums, int32_t batch, int32_t *flags, int32_t bit) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= batch) return;
@@ -157,6 +162,13 @@ hrag_status launch_slab_to_rows(const float *slab, int64_t slab_rows, const int3
         default: set_error("unsupported slab width %d", lay.bc); return HRAG_EINVAL;
     }
 #undef CALL
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_fill_i32(int32_t *dst, int32_t value, int64_t n, hipStream_t s) {
+    if (n <= 0) return HRAG_OK;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, dst, value, n);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -259,14 +259,17 @@ __global__ void ppr16_scale_kernel(const float *mn, const float *mx, const float
 __global__ void ppr16_seed_rows_kernel(const int32_t *seed_vtx, const float *seed_w,
                                        const int32_t *seed_cnt, const float *qscale, int32_t batch,
                                        int64_t n_passages, int64_t num_vertices, int32_t *row_slot,
-                                       float *tele, int64_t tele_rows, int32_t bc) {
+                                       float *tele, int64_t tele_rows, int32_t bc, int64_t row_offset,
+                                       int64_t n_rows) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int q = t / kMaxSeeds, j = t % kMaxSeeds;
     if (q >= batch || j >= seed_cnt[q]) return;
     const int64_t v = seed_vtx[q * kMaxSeeds + j];
     if (v < 0 || v >= num_vertices) return;
+    const int64_t lv = v - row_offset;          // row shard: only the owner of v carries its teleport row
+    if (lv < 0 || lv >= n_rows) return;
     const int mine = (int)n_passages + q * kMaxSeeds + j;
-    const int old = atomicCAS(&row_slot[v], -1, mine);
+    const int old = atomicCAS(&row_slot[lv], -1, mine);
     const int slot = old == -1 ? mine : old;
     const int slab = q / bc, col = q % bc;
     // vertices are unique within a query, so (slot, col) has a single writer
@@ -335,11 +338,12 @@ hrag_status launch_ppr16_scale(const float *mn, const float *mx, const float *ss
 hrag_status launch_ppr16_seed_rows(const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
                                    const float *qscale, int32_t batch, int64_t n_passages,
                                    int64_t num_vertices, int32_t *row_slot, float *tele,
-                                   int64_t tele_rows, int32_t bc, hipStream_t s) {
+                                   int64_t tele_rows, int32_t bc, hipStream_t s, int64_t row_offset,
+                                   int64_t n_rows) {
     const int total = batch * kMaxSeeds;
     hipLaunchKernelGGL(ppr16_seed_rows_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s,
                        seed_vtx, seed_w, seed_cnt, qscale, batch, n_passages, num_vertices, row_slot,
-                       tele, tele_rows, bc);
+                       tele, tele_rows, bc, row_offset, n_rows < 0 ? num_vertices : n_rows);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -36,6 +36,19 @@
 // Matrix: the SELL-8 form of ppr16.hip with the row-normalised values At (engine.hip builds it
 // from P and the weighted degrees: at_ij = p_ij d_j / d_i).  Long rows: segments + fixed-order
 // reduce, no atomics, bit-reproducible.  All arithmetic is fp32; fp8 -> fp32 is exact.
+//
+// Row shards (multi-GPU, the layout BASELINE.json's north star names): an engine owns rows
+// [row_offset, row_offset + n_rows); its SELL-8 matrix, R, the stage copies and v cover those rows only,
+// the e4m3 iterate is replicated and the owners' blocks are exchanged between sweeps (1 byte per
+// vertex and query on the wire).  A single GPU is the shard that owns everything.
+//
+// What the sweeps do NOT compute (both follow from the structure of the path, HippoRAG.py:1745):
+//   * only the passage rows of the result are ever read, so the last sweep (mode F) runs over the passage
+//     rows of the matrix alone (~6 % of the entries on the benchmark graph), and the normalisation
+//     sum(x) is not summed up: P is column-stochastic apart from isolated vertices, whose share is known
+//     sweep by sweep, so the mass of the K-sweep iterate is a closed form of sum(v) (ppr8_scale_kernel);
+//   * c_0 = Q(v/d) is zero outside the passage and seed vertices, so the first sweep (mode B0) tests a
+//     column bitmap and sends every other gather to an all-zero row that stays in the L2.
 #include "common.h"
 
 namespace hrag {
@@ -79,6 +92,23 @@ __device__ __forceinline__ v4i_t encode16(const f32x2_t (&f)[8]) {
     return o;
 }
 
+// true when a value lies outside the e4m3 range (the static scale bound of its stage was violated)
+__device__ __forceinline__ bool any_sat16(const f32x2_t (&f)[8]) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fmaxf(fabsf(f[j].x), fabsf(f[j].y)));
+    return m > kE4m3Max;
+}
+// rare path: name the queries whose value was clamped (flags bit 3); lane gl owns queries 16 gl .. 16 gl + 15
+__device__ __forceinline__ void flag_sat16(const f32x2_t (&f)[8], int slab, int gl, int32_t batch, int32_t *flags) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = slab * 128 + gl * 16 + 2 * j;
+        if (fabsf(f[j].x) > kE4m3Max && q < batch) atomicOr(&flags[q], kFlagFp8Saturated);
+        if (fabsf(f[j].y) > kE4m3Max && q + 1 < batch) atomicOr(&flags[q + 1], kFlagFp8Saturated);
+    }
+}
+
 // acc += float(x) * w : 8 conversions + 8 packed FMAs per 16 gathered elements
 __device__ __forceinline__ void fma16(f32x2_t (&acc)[8], float w, const v4i_t &x) {
     const f32x2_t w2 = {w, w};
@@ -97,19 +127,20 @@ __device__ __forceinline__ void fma16(f32x2_t (&acc)[8], float w, const v4i_t &x
 template <int K>
 struct Gather8 {
     __device__ __forceinline__ static void load(v4i_t (&xv)[8], float (&wk)[8], int c, int wbits,
-                                                const char *xs, unsigned lane_off) {
+                                                const char *xs, unsigned stride, unsigned lane_off) {
         const unsigned ck = (unsigned)bcast8<K>(c);
         wk[K] = __int_as_float(bcast8<K>(wbits));
-        // 128 bytes per vertex, 16 per lane; V * 128 < 2^32 is checked at engine creation
-        xv[K] = *reinterpret_cast<const v4i_t *>(xs + (size_t)(ck * 128u + lane_off));
-        if constexpr (K + 1 < 8) Gather8<K + 1>::load(xv, wk, c, wbits, xs, lane_off);
+        // `stride` bytes per vertex, 16 per lane; V + 1 <= 2^24 and (V + 1) * stride <= 2^32 are guaranteed by
+        // the state layout, so the full-rate 24-bit multiply-add forms the offset
+        xv[K] = *reinterpret_cast<const v4i_t *>(xs + (size_t)(__umul24(ck, stride) + lane_off));
+        if constexpr (K + 1 < 8) Gather8<K + 1>::load(xv, wk, c, wbits, xs, stride, lane_off);
     }
 };
 __device__ __forceinline__ void gather_step(f32x2_t (&acc)[8], int c, int wbits, const char *xs,
-                                            unsigned lane_off) {
+                                            unsigned stride, unsigned lane_off) {
     v4i_t xv[8];
     float wk[8];
-    Gather8<0>::load(xv, wk, c, wbits, xs, lane_off);
+    Gather8<0>::load(xv, wk, c, wbits, xs, stride, lane_off);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) fma16(acc, wk[k], xv[k]);
@@ -155,19 +186,20 @@ __device__ __forceinline__ void st16f(float *p, const f32x2_t (&f)[8]) {
     }
 }
 
-// z_v = v / d for one vertex row: v comes from the teleport rows of the fp16 path's layout
-// (fp32 [n_slabs64][tele_rows][64] + row_slot), already scaled per query.
+// z_v = v / d for one owned row (lrow: LOCAL index, grow: global vertex id): v comes from the teleport
+// rows (fp32 [n_slabs64][tele_rows][64] + row_slot), already scaled per query.
 __device__ __forceinline__ void load_zv(const float *__restrict__ tele, int64_t tele_rows,
                                         const int32_t *__restrict__ row_slot, const float *__restrict__ deg,
-                                        int32_t n_slabs64, int slab, int64_t row, int gl, f32x2_t (&z)[8]) {
+                                        int32_t n_slabs64, int slab, int64_t lrow, int64_t grow, int gl,
+                                        f32x2_t (&z)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) z[j] = f32x2_t{0.f, 0.f};
-    const int slot = row_slot[row];
+    const int slot = row_slot[lrow];
     const int slab64 = 2 * slab + (gl >> 2);
     if (slot >= 0 && slab64 < n_slabs64) {
         const f32x4_t *tp = reinterpret_cast<const f32x4_t *>(
             tele + ((size_t)slab64 * tele_rows + (size_t)slot) * 64 + (size_t)(gl & 3) * 16);
-        const float invd = __fdiv_rn(1.0f, deg[row]);
+        const float invd = __fdiv_rn(1.0f, deg[grow]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x4_t v = tp[i];
@@ -177,25 +209,35 @@ __device__ __forceinline__ void load_zv(const float *__restrict__ tele, int64_t 
     }
 }
 
-// Finish one output row: lane gl of its group owns queries 16*gl .. 16*gl+15 of the 128-wide slab.
-// Mode F returns the row's x (16 queries of this lane) in xs for the caller's column sums.
+// byte offset of (slab, vertex, lane) in a state buffer [n_groups][V + 1][spg][128]
+__device__ __forceinline__ size_t state_off(const Ppr8Args &a, int slab, int64_t grow, int gl) {
+    const int g = slab / a.spg, k = slab - g * a.spg;
+    return (size_t)g * (size_t)a.group_bytes + (size_t)grow * a.row_stride + (size_t)k * 128 + (size_t)gl * 16;
+}
+
+// Finish one output row (lrow: LOCAL row): lane gl of its group owns queries 16*gl .. 16*gl+15 of the slab.
 template <int MODE>
-__device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int row, int gl,
-                                           const f32x2_t (&acc)[8], f32x2_t (&xs)[8]) {
-    const size_t off = ((size_t)slab * a.num_vertices + (size_t)row) * 128 + (size_t)gl * 16;
+__device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow, int gl,
+                                           const f32x2_t (&acc)[8]) {
+    const int64_t grow = a.row_offset + lrow;
+    const size_t off = state_off(a, slab, grow, gl);
     f32x2_t out[8];
     if constexpr (MODE == kP8ModeC) {
         f32x2_t r[8];
         decode16(__builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(a.rt + off)), r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[j] = __builtin_elementwise_fma(acc[j], f32x2_t{a.alpha, a.alpha}, r[j]);
+        if (__builtin_expect(any_sat16(out), 0)) flag_sat16(out, slab, gl, a.batch, a.flags);
         __builtin_nontemporal_store(encode16(out), reinterpret_cast<v4i_t *>(a.y + off));
     } else {
         f32x2_t c[8], rin[8];
-        decode16(__builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(a.x + off)), c);
-        float *rrow = a.R + ((size_t)slab * a.num_vertices + (size_t)row) * 128;
+        const v4i_t cv = __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(a.x + off));
+        decode16(cv, c);
+        float *rrow = a.R + ((size_t)slab * a.n_rows + (size_t)lrow) * 128;
+        const int slot = a.row_slot[lrow];
+        const bool is_passage = slot >= 0 && slot < a.p_rows;
         if constexpr (MODE == kP8ModeB0) {
-            load_zv(a.tele, a.tele_rows, a.row_slot, a.deg, a.n_slabs64, slab, row, gl, rin);   // R_in = b v/d
+            load_zv(a.tele, a.tele_rows, a.row_slot, a.deg, a.n_slabs64, slab, lrow, grow, gl, rin);   // R_in = b v/d
 #pragma unroll
             for (int j = 0; j < 8; ++j) rin[j] *= a.beta;
         } else {
@@ -212,29 +254,42 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int row,
             f32x2_t q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) q[j] = out[j] * a.cs_next;
+            if (__builtin_expect(any_sat16(q), 0)) flag_sat16(q, slab, gl, a.batch, a.flags);
             __builtin_nontemporal_store(encode16(q), reinterpret_cast<v4i_t *>(a.y + off));
+            // the final combine needs every stage's c at the passage rows only: keep a compact copy
+            if (is_passage)
+                *reinterpret_cast<v4i_t *>(a.stage_out + ((size_t)slab * a.p_rows + (size_t)slot) * 128 + (size_t)gl * 16) = cv;
         } else {   // kP8ModeF: z = R' + sum_s c_s / cs_s (earliest stage first), x = d z
+            if (!is_passage) return;
+            const size_t poff = ((size_t)slab * a.p_rows + (size_t)slot) * 128 + (size_t)gl * 16;
             f32x2_t z[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[j] = f32x2_t{0.f, 0.f};
-            for (int s = 0; s < a.n_stage; ++s) {
+            for (int s = 0; s + 1 < a.n_stage; ++s) {
                 f32x2_t cs[8];
-                decode16(__builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(a.stage[s] + off)), cs);
+                decode16(*reinterpret_cast<const v4i_t *>(a.stage[s] + poff), cs);
                 const f32x2_t si = {a.stage_inv[s], a.stage_inv[s]};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) z[j] = __builtin_elementwise_fma(cs[j], si, z[j]);
             }
-            const float dg = a.deg[row];
+            const f32x2_t sl = {a.stage_inv[a.n_stage - 1], a.stage_inv[a.n_stage - 1]};
+            const float dg = a.deg[grow];
+            f32x2_t xs[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xs[j] = (z[j] + out[j]) * dg;
-            // only the passage rows are needed downstream (HippoRAG.py:1745), in passage order:
-            // xp is [n_slabs64][Np][64] fp32, the layout slab_to_rows reads without a gather
-            const int slot = a.row_slot[row];
+            for (int j = 0; j < 8; ++j) {
+                z[j] = __builtin_elementwise_fma(c[j], sl, z[j]);
+                xs[j] = (z[j] + out[j]) * dg;
+            }
+            // passage order: xp is [n_slabs64][p_rows][64] fp32, the layout slab_to_rows reads without a gather
             const int slab64 = 2 * slab + (gl >> 2);
-            if (slot >= 0 && slot < a.n_passages && slab64 < a.n_slabs64)
-                st16f(a.out + ((size_t)slab64 * a.n_passages + (size_t)slot) * 64 + (size_t)(gl & 3) * 16, xs);
+            if (slab64 < a.n_slabs64)
+                st16f(a.out + ((size_t)slab64 * a.p_rows + (size_t)slot) * 64 + (size_t)(gl & 3) * 16, xs);
         }
     }
+}
+
+__device__ __forceinline__ int ld_mask(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0);
 }
 
 // 1-D grid, XCD-aware: workgroups are dealt to the 8 XCDs round-robin, so ids 8 apart run back to back
@@ -246,15 +301,17 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
     const int id = blockIdx.x, ns = a.n_slabs;
-    const int slab = (id >> 3) % ns;
+    const int slab = a.slab0 + (id >> 3) % ns;
     const int cg = (id / (8 * ns)) * 8 + (id & 7);
     const int chunk = __builtin_amdgcn_readfirstlane(cg * 4 + (threadIdx.x >> 6));
-    if (chunk >= a.n_chunks) return;
-    const int2 meta = a.chunk_meta[chunk];  // (first step, number of steps)
+    if (chunk >= a.m.n_chunks) return;
+    const int2 meta = a.m.chunk_meta[chunk];  // (first step, number of steps)
     const int n_steps = meta.y;
-    const char *xs = reinterpret_cast<const char *>(a.x + (size_t)slab * a.num_vertices * 128);
+    const int g = slab / a.spg, k = slab - g * a.spg;
+    const char *xs = reinterpret_cast<const char *>(a.x) + (size_t)g * (size_t)a.group_bytes + (size_t)k * 128;
+    const unsigned stride = a.row_stride;
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int2 *>(a.pairs), 0, (int)a.pairs_bytes, 0x00020000);
+        const_cast<int2 *>(a.m.pairs), 0, (int)a.m.pairs_bytes, 0x00020000);
     const unsigned pbase = (unsigned)meta.x * 512u;   // scalar: first byte of this chunk's pairs
     const unsigned poff = (unsigned)lane * 8u;
     const unsigned lane_off = (unsigned)gl * 16u;
@@ -264,32 +321,34 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     // pair stream read two steps ahead, unconditionally (the array carries the padding)
     int2 p0 = ld_pair(prs, poff, pbase);
     int2 p1 = ld_pair(prs, poff + 512u, pbase);
-    for (int s = 0; s < n_steps; ++s) {
-        const int2 p2 = ld_pair(prs, poff + (unsigned)(s + 2) * 512u, pbase);
-        gather_step(acc, p0.x, p0.y, xs, lane_off);
-        p0 = p1;
-        p1 = p2;
+    if constexpr (MODE == kP8ModeB0) {
+        // c_0 is zero outside the passage / seed vertices: test the column bitmap (one step ahead) and send
+        // the gathers of all other columns to the all-zero row, which never leaves the cache
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t *>(a.colmask), 0, (int)a.colmask_bytes, 0x00020000);
+        int m0 = ld_mask(mrs, ((unsigned)p0.x >> 5) * 4u);
+        for (int s = 0; s < n_steps; ++s) {
+            const int2 p2 = ld_pair(prs, poff + (unsigned)(s + 2) * 512u, pbase);
+            const int m1 = ld_mask(mrs, ((unsigned)p1.x >> 5) * 4u);
+            const int c = ((m0 >> (p0.x & 31)) & 1) ? p0.x : (int)a.zero_row;
+            gather_step(acc, c, p0.y, xs, stride, lane_off);
+            p0 = p1;
+            p1 = p2;
+            m0 = m1;
+        }
+    } else {
+        for (int s = 0; s < n_steps; ++s) {
+            const int2 p2 = ld_pair(prs, poff + (unsigned)(s + 2) * 512u, pbase);
+            gather_step(acc, p0.x, p0.y, xs, stride, lane_off);
+            p0 = p1;
+            p1 = p2;
+        }
     }
-    const int tgt = a.vrow[chunk * 8 + grp];
-    f32x2_t xr[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xr[j] = f32x2_t{0.f, 0.f};
+    const int tgt = a.m.vrow[chunk * 8 + grp];
     if (tgt >= 0) {
-        finish_row<MODE>(a, slab, tgt, gl, acc, xr);
+        finish_row<MODE>(a, slab, tgt, gl, acc);
     } else if (tgt != kVrowNone) {
-        st16i(a.partial + ((size_t)slab * a.n_partial + (size_t)(-(tgt + 1))) * 128, gl, acc);
-    }
-    if constexpr (MODE == kP8ModeF) {
-        // column sums of x over this wavefront's 8 rows (fixed order), one partial row per chunk;
-        // ppr8_colsum_kernel adds the partial rows up in double
-#pragma unroll
-        for (int o = 8; o < 64; o <<= 1)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                xr[j].x += __shfl_xor(xr[j].x, o, 64);
-                xr[j].y += __shfl_xor(xr[j].y, o, 64);
-            }
-        if (grp == 0) st16i(a.csum + ((size_t)slab * a.n_csum + (size_t)chunk) * 128, gl, xr);
+        st16i(a.partial + ((size_t)slab * a.m.n_partial + (size_t)(-(tgt + 1))) * 128, gl, acc);
     }
 }
 
@@ -299,11 +358,11 @@ template <int MODE>
 __global__ __launch_bounds__(256) void ppr8_reduce_kernel(const Ppr8Args a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
-    const int slab = blockIdx.y;
+    const int slab = a.slab0 + blockIdx.y;
     const int m = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (m >= a.n_lrow) return;
-    const int first = a.lrow_first[m], cnt = a.lrow_cnt[m];
-    const float *base = a.partial + ((size_t)slab * a.n_partial + (size_t)first) * 128;
+    if (m >= a.m.n_lrow) return;
+    const int first = a.m.lrow_first[m], cnt = a.m.lrow_cnt[m];
+    const float *base = a.partial + ((size_t)slab * a.m.n_partial + (size_t)first) * 128;
     f32x2_t acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = f32x2_t{0.f, 0.f};
@@ -320,113 +379,115 @@ __global__ __launch_bounds__(256) void ppr8_reduce_kernel(const Ppr8Args a) {
             acc[j].x += __shfl_xor(acc[j].x, o, 64);
             acc[j].y += __shfl_xor(acc[j].y, o, 64);
         }
-    if (grp == 0) {
-        f32x2_t xs[8];
-        finish_row<MODE>(a, slab, a.lrow_row[m], gl, acc, xs);
-        if constexpr (MODE == kP8ModeF)   // a long row is its own partial row (after the chunk rows)
-            st16i(a.csum + ((size_t)slab * a.n_csum + (size_t)a.n_chunks + (size_t)m) * 128, gl, xs);
-    }
+    if (grp == 0) finish_row<MODE>(a, slab, a.m.lrow_row[m], gl, acc);
 }
 
-// Column sums of x = d z from the partial rows mode F wrote (lane-interleaved 128-float rows):
-// pass 1 (grid kP8ColsumBlocks x n_slabs): block b sums rows b, b + kP8ColsumBlocks, ... in double;
-// pass 2: sums[q] = sum over blocks, q -> (slab, interleaved position).  Fixed order, no atomics.
-constexpr int kP8ColsumBlocks = 128;
-__global__ __launch_bounds__(256) void ppr8_colsum_kernel(const float *__restrict__ csum, int32_t n_csum,
-                                                          double *__restrict__ partial) {
-    __shared__ double red[8][128];
-    const int tid = threadIdx.x, f4 = tid & 31, rl = tid >> 5;   // 32 float4 per row, 8 rows per pass
-    const int slab = blockIdx.y;
-    const f32x4_t *base = reinterpret_cast<const f32x4_t *>(csum + (size_t)slab * n_csum * 128);
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int64_t r = (int64_t)blockIdx.x * 8 + rl; r < n_csum; r += (int64_t)kP8ColsumBlocks * 8) {
-        const f32x4_t v = base[r * 32 + f4];
-        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
-    }
-    red[rl][f4 * 4 + 0] = s0; red[rl][f4 * 4 + 1] = s1; red[rl][f4 * 4 + 2] = s2; red[rl][f4 * 4 + 3] = s3;
-    __syncthreads();
-    if (tid < 128) {
-        double t = 0;
-        for (int i = 0; i < 8; ++i) t += red[i][tid];
-        partial[((size_t)slab * kP8ColsumBlocks + blockIdx.x) * 128 + tid] = t;
-    }
-}
-__global__ void ppr8_colsum_final_kernel(const double *__restrict__ partial, int32_t batch, double *sums) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= batch) return;
-    const int slab = q >> 7, qq = q & 127;
-    const int gl = qq >> 4, i = (qq >> 2) & 3, k = qq & 3;   // query qq sits in float4 8 i + gl, component k
-    const int phys = (8 * i + gl) * 4 + k;
-    double s = 0;
-    for (int b = 0; b < kP8ColsumBlocks; ++b) s += partial[((size_t)slab * kP8ColsumBlocks + b) * 128 + phys];
-    sums[q] = s;
-}
-
-// c_0 = Q(v/d * c0_scale) for every vertex row of every slab (R_0 = b v/d is formed on the fly by the
-// first boundary sweep, mode B0).
-__global__ __launch_bounds__(256) void ppr8_init_kernel(const float *__restrict__ tele, int64_t tele_rows,
-                                                        const int32_t *__restrict__ row_slot,
-                                                        const float *__restrict__ deg, int64_t num_vertices,
-                                                        int32_t n_slabs64, float c0_scale,
-                                                        uint8_t *__restrict__ c0) {
+// c_0 = Q(v/d * c0_scale) for every OWNED row of the launch's slabs (R_0 = b v/d is formed on the fly by
+// the first boundary sweep, mode B0).
+__global__ __launch_bounds__(256) void ppr8_init_kernel(const Ppr8Args a, float c0_scale) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t row = t >> 3;
+    const int64_t lrow = t >> 3;
     const int gl = (int)(t & 7);
-    const int slab = blockIdx.y;
-    if (row >= num_vertices) return;
+    const int slab = a.slab0 + blockIdx.y;
+    if (lrow >= a.n_rows) return;
+    const int64_t grow = a.row_offset + lrow;
     f32x2_t z[8], q[8];
-    load_zv(tele, tele_rows, row_slot, deg, n_slabs64, slab, row, gl, z);
+    load_zv(a.tele, a.tele_rows, a.row_slot, a.deg, a.n_slabs64, slab, lrow, grow, gl, z);
 #pragma unroll
     for (int j = 0; j < 8; ++j) q[j] = z[j] * c0_scale;
-    const size_t off = ((size_t)slab * num_vertices + (size_t)row) * 128 + (size_t)gl * 16;
-    *reinterpret_cast<v4i_t *>(c0 + off) = encode16(q);
+    *reinterpret_cast<v4i_t *>(a.y + state_off(a, slab, grow, gl)) = encode16(q);
 }
 
-// Per-query power-of-two scale s_q with  max_i v_i / d_i * s_q  in (1/2, 1]:
-//   bound_q = passage_weight * max_p minmax(score_qp) / d_p  +  max_j seed_w / d(seed_j)
-// (the sum of the two maxima covers a seed that is also a passage vertex).
-// Pass 1: grid (kScaleSplit, B) partial maxima, combined with an integer atomicMax on the bits of the
-// non-negative floats (order-preserving, so the result does not depend on the arrival order).
-constexpr int kScaleSplit = 16;
-__global__ __launch_bounds__(256) void ppr8_zmax_kernel(const float *__restrict__ scores, int64_t ld,
-                                                        int64_t n_passages, const float *__restrict__ mn,
-                                                        const float *__restrict__ mx,
-                                                        const float *__restrict__ pinvdeg,
-                                                        const int32_t *__restrict__ flags, int32_t *zmax_bits) {
+// Per-query statistics of the passage prior over the owned passages, one streaming pass:
+//   zmax = max_p minmax(score_qp) / d_p  (the passage part of the bound that fixes the query's scale),
+//   mass = sum_p v_p with v_p = float(minmax(score_qp) * weight) exactly as rows_to_slab forms it, and
+//   the same sum over the passages whose vertex has no edges.
+// Grid (kP8PriorSplit, B).  The maxima are combined with an integer atomicMax on the bits of the
+// non-negative floats (order-preserving: independent of the arrival order); the sums go through
+// per-block partials that ppr8_prior_final_kernel adds in a fixed order (no atomics on doubles).
+__global__ __launch_bounds__(256) void ppr8_prior_kernel(const float *__restrict__ scores, int64_t ld,
+                                                         int64_t p_rows, const float *__restrict__ mn,
+                                                         const float *__restrict__ mx, float weight,
+                                                         const float *__restrict__ pinvdeg,
+                                                         const uint8_t *__restrict__ piso,
+                                                         const int32_t *__restrict__ flags, int32_t batch,
+                                                         int32_t *zmax_bits, double *part) {
     __shared__ float red[256];
+    __shared__ double reds[256], redi[256];
     const int q = blockIdx.y, tid = threadIdx.x;
     float best = 0.f;
+    double sum = 0.0, siso = 0.0;
     if (!(flags[q] & 1)) {
         const float lo = mn[q], range = mx[q] - mn[q];
         const float *row = scores + (size_t)q * ld;
-        for (int64_t p = (int64_t)blockIdx.x * 256 + tid; p < n_passages; p += (int64_t)kScaleSplit * 256) {
+        for (int64_t p = (int64_t)blockIdx.x * 256 + tid; p < p_rows; p += (int64_t)kP8PriorSplit * 256) {
             const float nrm = range == 0.f ? 1.f : __fdiv_rn(row[p] - lo, range);
             best = fmaxf(best, nrm * pinvdeg[p]);
+            const float v = nrm * weight;
+            sum += (double)v;
+            if (piso[p]) siso += (double)v;
         }
     }
-    red[tid] = best;
+    red[tid] = best; reds[tid] = sum; redi[tid] = siso;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        if (tid < s) {
+            red[tid] = fmaxf(red[tid], red[tid + s]);
+            reds[tid] += reds[tid + s];
+            redi[tid] += redi[tid + s];
+        }
         __syncthreads();
     }
-    if (tid == 0) atomicMax(&zmax_bits[q], __float_as_int(fmaxf(red[0], 0.f)));
+    if (tid == 0) {
+        atomicMax(&zmax_bits[q], __float_as_int(fmaxf(red[0], 0.f)));
+        part[((size_t)blockIdx.x * batch + q) * 2 + 0] = reds[0];
+        part[((size_t)blockIdx.x * batch + q) * 2 + 1] = redi[0];
+    }
+}
+__global__ void ppr8_prior_final_kernel(const int32_t *__restrict__ zmax_bits, const double *__restrict__ part,
+                                        int32_t batch, float *zmax, double *mass) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= batch) return;
+    double s = 0.0, si = 0.0;
+    for (int b = 0; b < kP8PriorSplit; ++b) {
+        s += part[((size_t)b * batch + q) * 2 + 0];
+        si += part[((size_t)b * batch + q) * 2 + 1];
+    }
+    zmax[q] = __int_as_float(zmax_bits[q]);
+    mass[q] = s;
+    mass[batch + q] = si;
 }
 
-__global__ void ppr8_scale_kernel(const int32_t *__restrict__ zmax_bits, float passage_weight,
-                                  const int32_t *__restrict__ seed_vtx, const float *__restrict__ seed_w,
-                                  const int32_t *__restrict__ seed_cnt, const float *__restrict__ deg,
+// Per-query power-of-two scale s_q with  max_i v_i / d_i * s_q  in (1/2, 1]:
+//   bound_q = passage_weight * zmax_q  +  max_j seed_w / d(seed_j)
+// (the sum of the two maxima covers a seed that is also a passage vertex), and the mass of the result:
+// x_{k+1} = a P x_k + b v with x_0 = v keeps sum(x) = sum(v) except for what sits on isolated vertices
+// (P has an empty column there), and an isolated vertex i holds x_0[i] = v_i, x_k[i] = b v_i (k >= 1):
+//   m_0 = M,  m_{k+1} = a (m_k - iso_k) + b M,  iso_0 = S, iso_k = b S     (M = sum v, S = sum over isolated)
+// -- the value the reference's final division by sum(x) uses (PRPACK normalises, HippoRAG.py:1745), without
+// a column sum over all vertices.  zmax / mass are GLOBAL (all-reduced over the row shards).
+__global__ void ppr8_scale_kernel(const float *__restrict__ zmax, const double *__restrict__ mass,
+                                  float passage_weight, const int32_t *__restrict__ seed_vtx,
+                                  const float *__restrict__ seed_w, const int32_t *__restrict__ seed_cnt,
+                                  const float *__restrict__ deg, const uint8_t *__restrict__ iso,
                                   int64_t num_vertices, const int32_t *__restrict__ flags, int32_t batch,
-                                  float *qscale) {
+                                  float damping, int32_t iters, float *qscale, double *sums) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= batch) return;
     float bound = 0.f;
+    double M = 0.0, S = 0.0;
     if (!(flags[q] & 1)) {
-        bound = fmaxf(passage_weight, 0.f) * __int_as_float(zmax_bits[q]);
+        bound = fmaxf(passage_weight, 0.f) * zmax[q];
+        M = mass[q];
+        S = mass[batch + q];
         float sb = 0.f;
         for (int j = 0; j < seed_cnt[q]; ++j) {
             const int64_t v = seed_vtx[q * kMaxSeeds + j];
-            if (v >= 0 && v < num_vertices) sb = fmaxf(sb, __fdiv_rn(fmaxf(seed_w[q * kMaxSeeds + j], 0.f), deg[v]));
+            if (v < 0 || v >= num_vertices) continue;
+            const float w = seed_w[q * kMaxSeeds + j];
+            sb = fmaxf(sb, __fdiv_rn(fmaxf(w, 0.f), deg[v]));
+            M += (double)w;
+            if (iso[v]) S += (double)w;
         }
         bound += sb;
     }
@@ -439,20 +500,34 @@ __global__ void ppr8_scale_kernel(const int32_t *__restrict__ zmax_bits, float p
         s = ldexpf(1.f, -ex);
     }
     qscale[q] = s;
+    M *= (double)s;   // powers of two: exact
+    S *= (double)s;
+    const double al = (double)damping, be = (double)(1.0f - damping);
+    double m = M;
+    for (int k = 0; k < iters; ++k) m = al * (m - (k == 0 ? S : be * S)) + be * M;
+    sums[q] = m;
+}
+
+__global__ void ppr8_mask_seeds_kernel(const int32_t *__restrict__ seed_vtx, const int32_t *__restrict__ seed_cnt,
+                                       int32_t batch, int64_t num_vertices, uint32_t *colmask) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = t / kMaxSeeds, j = t % kMaxSeeds;
+    if (q >= batch || j >= seed_cnt[q]) return;
+    const int64_t v = seed_vtx[q * kMaxSeeds + j];
+    if (v < 0 || v >= num_vertices) return;
+    atomicOr(&colmask[v >> 5], 1u << (v & 31));
 }
 
 template <int MODE>
-hrag_status sweep_mode(const Ppr8Args &a, int n_slabs, bool main_only, hipStream_t s) {
-    if (a.n_chunks > 0) {
-        const unsigned ncg = (unsigned)ceil_div(a.n_chunks, 4);
-        Ppr8Args b = a;
-        b.n_slabs = n_slabs;
+hrag_status sweep_mode(const Ppr8Args &a, bool main_only, hipStream_t s) {
+    if (a.m.n_chunks > 0) {
+        const unsigned ncg = (unsigned)ceil_div(a.m.n_chunks, 4);
         // (86 VGPRs = 5 wavefronts per SIMD; 6 measured the same: the sweep is bandwidth-bound)
-        hipLaunchKernelGGL(ppr8_kernel<MODE>, dim3((unsigned)round_up(ncg, 8) * (unsigned)n_slabs), dim3(256), 0, s, b);
+        hipLaunchKernelGGL(ppr8_kernel<MODE>, dim3((unsigned)round_up(ncg, 8) * (unsigned)a.n_slabs), dim3(256), 0, s, a);
         HRAG_LAUNCH_CHECK();
     }
-    if (!main_only && a.n_lrow > 0) {
-        dim3 grid((unsigned)ceil_div(a.n_lrow, 4), (unsigned)n_slabs);
+    if (!main_only && a.m.n_lrow > 0) {
+        dim3 grid((unsigned)ceil_div(a.m.n_lrow, 4), (unsigned)a.n_slabs);
         hipLaunchKernelGGL(ppr8_reduce_kernel<MODE>, grid, dim3(256), 0, s, a);
         HRAG_LAUNCH_CHECK();
     }
@@ -461,51 +536,56 @@ hrag_status sweep_mode(const Ppr8Args &a, int n_slabs, bool main_only, hipStream
 
 }  // namespace
 
-hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, int n_slabs, bool main_only, hipStream_t s) {
+hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, bool main_only, hipStream_t s) {
+    if (a.n_slabs <= 0) return HRAG_OK;
     switch (mode) {
-        case kP8ModeC: return sweep_mode<kP8ModeC>(a, n_slabs, main_only, s);
-        case kP8ModeB: return sweep_mode<kP8ModeB>(a, n_slabs, main_only, s);
-        case kP8ModeB0: return sweep_mode<kP8ModeB0>(a, n_slabs, main_only, s);
-        case kP8ModeF: return sweep_mode<kP8ModeF>(a, n_slabs, main_only, s);
+        case kP8ModeC: return sweep_mode<kP8ModeC>(a, main_only, s);
+        case kP8ModeB: return sweep_mode<kP8ModeB>(a, main_only, s);
+        case kP8ModeB0: return sweep_mode<kP8ModeB0>(a, main_only, s);
+        case kP8ModeF: return sweep_mode<kP8ModeF>(a, main_only, s);
         default: set_error("bad ppr8 mode %d", mode); return HRAG_EINVAL;
     }
 }
 
-// partial: n_slabs * 128 * 128 doubles
-hrag_status launch_ppr8_colsum(const float *csum, int32_t n_csum, int n_slabs, int32_t batch, double *partial,
-                               double *sums, hipStream_t s) {
-    hipLaunchKernelGGL(ppr8_colsum_kernel, dim3(kP8ColsumBlocks, (unsigned)n_slabs), dim3(256), 0, s, csum,
-                       n_csum, partial);
-    HRAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ppr8_colsum_final_kernel, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, s, partial,
-                       batch, sums);
+hrag_status launch_ppr8_init(const Ppr8Args &a, float c0_scale, hipStream_t s) {
+    if (a.n_rows <= 0 || a.n_slabs <= 0) return HRAG_OK;
+    dim3 grid((unsigned)ceil_div(a.n_rows * 8, 256), (unsigned)a.n_slabs);
+    hipLaunchKernelGGL(ppr8_init_kernel, grid, dim3(256), 0, s, a, c0_scale);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }
 
-hrag_status launch_ppr8_init(const float *tele, int64_t tele_rows, const int32_t *row_slot, const float *deg,
-                             int64_t num_vertices, int n_slabs, int n_slabs64, float c0_scale, uint8_t *c0,
-                             hipStream_t s) {
-    dim3 grid((unsigned)ceil_div(num_vertices * 8, 256), (unsigned)n_slabs);
-    hipLaunchKernelGGL(ppr8_init_kernel, grid, dim3(256), 0, s, tele, tele_rows, row_slot, deg, num_vertices,
-                       n_slabs64, c0_scale, c0);
-    HRAG_LAUNCH_CHECK();
-    return HRAG_OK;
-}
-
-hrag_status launch_ppr8_scale(const float *scores, int64_t ld, int64_t n_passages, const float *mn,
-                              const float *mx, float passage_weight, const float *pinvdeg,
-                              const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
-                              const float *deg, int64_t num_vertices, const int32_t *flags, int32_t batch,
-                              int32_t *zmax_bits, float *qscale, hipStream_t s) {
+hrag_status launch_ppr8_prior(const float *scores, int64_t ld, int64_t p_rows, const float *mn, const float *mx,
+                              float passage_weight, const float *pinvdeg, const uint8_t *piso,
+                              const int32_t *flags, int32_t batch, int32_t *zmax_bits, double *part,
+                              float *zmax, double *mass, hipStream_t s) {
     HRAG_HIP_TRY(hipMemsetAsync(zmax_bits, 0, (size_t)batch * sizeof(int32_t), s));
-    if (n_passages > 0) {
-        hipLaunchKernelGGL(ppr8_zmax_kernel, dim3(kScaleSplit, (unsigned)batch), dim3(256), 0, s, scores, ld,
-                           n_passages, mn, mx, pinvdeg, flags, zmax_bits);
-        HRAG_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(ppr8_scale_kernel, dim3((unsigned)ceil_div(batch, 64)), dim3(64), 0, s, zmax_bits,
-                       passage_weight, seed_vtx, seed_w, seed_cnt, deg, num_vertices, flags, batch, qscale);
+    hipLaunchKernelGGL(ppr8_prior_kernel, dim3(kP8PriorSplit, (unsigned)batch), dim3(256), 0, s, scores, ld,
+                       p_rows, mn, mx, passage_weight, pinvdeg, piso, flags, batch, zmax_bits, part);
+    HRAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ppr8_prior_final_kernel, dim3((unsigned)ceil_div(batch, 64)), dim3(64), 0, s, zmax_bits,
+                       part, batch, zmax, mass);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr8_scale(const float *zmax, const double *mass, float passage_weight,
+                              const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
+                              const float *deg, const uint8_t *iso, int64_t num_vertices, const int32_t *flags,
+                              int32_t batch, float damping, int32_t iters, float *qscale, double *sums,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(ppr8_scale_kernel, dim3((unsigned)ceil_div(batch, 64)), dim3(64), 0, s, zmax, mass,
+                       passage_weight, seed_vtx, seed_w, seed_cnt, deg, iso, num_vertices, flags, batch, damping,
+                       iters, qscale, sums);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr8_mask_seeds(const int32_t *seed_vtx, const int32_t *seed_cnt, int32_t batch,
+                                   int64_t num_vertices, uint32_t *colmask, hipStream_t s) {
+    const int total = batch * kMaxSeeds;
+    hipLaunchKernelGGL(ppr8_mask_seeds_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, seed_vtx,
+                       seed_cnt, batch, num_vertices, colmask);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -1,0 +1,352 @@
+// Host driver of the staged fp8 PPR (csrc/ppr8.hip) and the row-shard entry points of include/hrag.h.
+//
+// The reference runs one igraph/PRPACK solve per query on the host (src/hipporag/HippoRAG.py:459 loop,
+// :1736-1743); there is no distributed code upstream.  Here a row shard (one GPU of a node, or the
+// single GPU that owns every row) iterates its rows of  z <- a At z + b v/d  on an e4m3 state that is
+// replicated across the shards; between two sweeps the host exchanges the owners' row blocks
+// (hipporag_amd/dist.py: one RCCL all-gather per exchange group, 1 byte per vertex and query).
+// hrag_retrieve drives the same code with every exchange being a no-op.
+#include "engine_impl.h"
+
+namespace hrag {
+
+// Stage lengths: 1 (the quantised start), 2, then 3-sweep stages and 4-sweep stages last, where the
+// residual is smallest -- e.g. 20 = 1+2+3+3+3+4+4: 7 stages = 6 boundary sweeps (they carry the fp32
+// residual: 30 instead of 22 bytes per vertex and query) and as accurate as the 1,2,2,3,3,3,3,3 of the
+// first version (tools/exp_fp8_final.py: 2.7e-7 vs 3.5e-7 on the benchmark graph at 20 sweeps).
+int ppr8_plan(int iters, int *plan) {
+    int n = 0;
+    plan[n++] = 1;
+    plan[n++] = 2;
+    const int r = iters - 3;
+    int b = r % 3, a = (r - 4 * b) / 3;
+    if (a >= 4) { a -= 4; b += 3; }
+    for (int i = 0; i < a; ++i) plan[n++] = 3;
+    for (int i = 0; i < b; ++i) plan[n++] = 4;
+    return n;
+}
+
+// The truncation error of K sweeps is ~ damping^K of the mass whatever the state type; the staged scheme
+// adds its rounding noise on top (a few 1e-7, independent of K), so it takes a batch when
+// damping^K <= 2^-18 (0.5: K >= 18; 0.3: the minimum of 16; 0.7 needs 35 > 30 sweeps: the fp32 slabs serve).
+bool ppr8_usable(const hrag_engine *e, int batch, int iters, float damping) {
+    if (!e->f8_ready || (e->opt_flags & HRAG_OPT_NO_FP8) || batch < 1) return false;
+    if (iters < 16 || iters > 30 || !(damping >= 0.f)) return false;
+    return std::pow((double)damping, (double)iters) <= 1.0 / 262144.0;
+}
+
+hrag_status ppr8_layout(const hrag_engine *e, int32_t batch, int32_t want_groups, hrag_shard_layout *out) {
+    HRAG_REQUIRE(e->f8_ready, "engine has no fp8 PPR state (needs col_sum, V < 2^24, aligned passage shard)");
+    const int ns = n_slabs128(batch);
+    const int64_t row_bytes = (e->V + 1) * 128;
+    const int spg_max = (int)std::max<int64_t>(1, std::min<int64_t>(ns, ((int64_t)1 << 32) / row_bytes));
+    int spg = want_groups <= 0 ? 1 : (int)ceil_div(ns, std::min(want_groups, ns));
+    spg = std::max(1, std::min(spg, spg_max));
+    hrag_shard_layout l = {};
+    l.n_slabs = ns;
+    l.slabs_per_group = spg;
+    l.n_groups = (int)ceil_div(ns, spg);
+    l.group_bytes = row_bytes * spg;
+    l.state_bytes = l.group_bytes * l.n_groups;
+    l.own_offset = e->row_offset * (int64_t)spg * 128;
+    l.own_bytes = e->n_rows * (int64_t)spg * 128;
+    *out = l;
+    return HRAG_OK;
+}
+
+namespace {
+
+Ppr8Args base_args(const hrag_engine *e) {
+    const Ppr8Session &p = e->p8;
+    Ppr8Args a = {};
+    a.m = e->sell.dev_at();
+    a.partial = e->d_partial8;
+    a.row_offset = e->row_offset; a.n_rows = e->n_rows;
+    a.spg = p.spg; a.row_stride = (uint32_t)p.spg * 128u; a.group_bytes = p.group_bytes;
+    a.R = e->d_R8;
+    a.alpha = p.damping; a.beta = 1.0f - p.damping;
+    a.tele = e->d_tele16; a.tele_rows = e->tele16_rows; a.n_slabs64 = n_slabs64(p.batch);
+    a.row_slot = e->d_row_slot; a.deg = e->d_deg; a.p_rows = e->p_rows;
+    a.colmask = e->d_colmask; a.colmask_bytes = (uint32_t)(e->colmask_words * 4); a.zero_row = (uint32_t)e->V;
+    a.flags = const_cast<int32_t *>(p.flags); a.batch = p.batch;
+    a.slab0 = 0; a.n_slabs = p.n_slabs;
+    return a;
+}
+
+uint8_t *stage_copy(const hrag_engine *e, int stage) {
+    return e->d_stagep + (size_t)stage * (size_t)e->p8.n_slabs * (size_t)std::max<int64_t>(e->p_rows, 1) * 128;
+}
+
+}  // namespace
+
+hrag_status ppr8_prior(hrag_engine *e, const float *mn, const float *mx, float passage_weight,
+                       const int32_t *flags, int32_t batch, float *zmax_out, double *mass_out, hipStream_t s) {
+    HRAG_REQUIRE(e->f8_ready, "engine has no fp8 PPR state");
+    return launch_ppr8_prior(e->d_spass, e->ld_p, e->p_rows, mn, mx, passage_weight, e->d_pinvdeg, e->d_piso,
+                             flags, batch, e->d_zmax_bits, e->d_prior_part, zmax_out, mass_out, s);
+}
+
+hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const float *zmax, const double *mass,
+                       float passage_weight, const int32_t *seed_vtx, const float *seed_w,
+                       const int32_t *seed_cnt, int32_t *flags, int32_t batch, float damping, int32_t iters,
+                       const hrag_shard_layout &lay, uint8_t *const bufs[3], hipStream_t s) {
+    HRAG_REQUIRE(ppr8_usable(e, batch, iters, damping),
+                 "the fp8-state PPR does not serve ppr_iters=%d at damping %g (needs 16..30 sweeps and "
+                 "damping^ppr_iters <= 2^-18) or the engine has no fp8 state", iters, (double)damping);
+    HRAG_REQUIRE(bufs[0] && bufs[1] && bufs[2] && bufs[0] != bufs[1] && bufs[1] != bufs[2] && bufs[0] != bufs[2],
+                 "three distinct state buffers are needed");
+    Ppr8Session &p = e->p8;
+    p.active = false;
+    p.batch = batch; p.iters = iters; p.damping = damping; p.flags = flags;
+    p.n_slabs = lay.n_slabs; p.n_groups = lay.n_groups; p.spg = lay.slabs_per_group; p.group_bytes = lay.group_bytes;
+    for (int i = 0; i < 3; ++i) p.buf[i] = bufs[i];
+
+    // ---- stage plan with static power-of-two scales: the max-norm of the true residual contracts by
+    // `damping` per sweep (At is row-stochastic), |R_0| <= max(a, 1 - a) max(v/d) + the rounding of c_0; a stage
+    // of m sweeps grows its iterate by at most (1 - a^m) / (1 - a).  cs = the power of two that maps that bound
+    // to <= 224 (half the e4m3 range: the bound ignores rounding noise; a clamped value raises flags bit 3).
+    int plan[kP8MaxStages + 4];
+    const int n_stage = ppr8_plan(iters, plan);
+    HRAG_REQUIRE(n_stage >= 2 && n_stage <= kP8MaxStages, "ppr_iters=%d needs %d fp8 stages (2..%d)", iters, n_stage,
+                 kP8MaxStages);
+    const double al = (double)damping;
+    double bound = std::max(al, 1.0 - al) + 0.07;
+    auto scale_for = [&](int m) {
+        const double growth = al < 1.0 ? (1.0 - std::pow(al, m)) / (1.0 - al) : (double)m;
+        int ex = (int)std::floor(std::log2(224.0 / std::max(bound * std::max(growth, 1.0), 1e-18)));   // damping ~ 0: bound -> 0
+        ex = std::min(std::max(ex, -60), 60);
+        return std::ldexp(1.0f, ex);
+    };
+    int n = 0, c = 0, rt = -1;   // c_0 lives in buffer 0
+    float cs = kP8C0Scale, cs_next = scale_for(plan[1]);
+    for (int si = 0; si < n_stage; ++si) {
+        const int m = plan[si];
+        if (si > 0) {
+            cs = cs_next;
+            c = rt;
+            for (int j = 1; j < m; ++j) {
+                const int dst = c == rt ? (c + 1) % 3 : 3 - c - rt;
+                p.steps[n++] = Ppr8Step{kP8ModeC, si, c, dst, rt, 0.f, 0.f};
+                c = dst;
+            }
+            bound *= std::pow(al, m);
+            cs_next = si + 1 < n_stage ? scale_for(plan[si + 1]) : 1.0f;
+        }
+        p.stage_inv[si] = 1.0f / cs;
+        if (si + 1 < n_stage) {
+            const int y = (rt >= 0 && c != rt) ? rt : (c + 1) % 3;   // the old right-hand side is dead: R carries it
+            p.steps[n++] = Ppr8Step{si == 0 ? kP8ModeB0 : kP8ModeB, si, c, y, -1, 1.0f / cs, cs_next};
+            rt = y;
+        } else {
+            p.steps[n++] = Ppr8Step{kP8ModeF, si, c, -1, -1, 1.0f / cs, 1.0f};
+        }
+    }
+    HRAG_REQUIRE(n == iters, "internal: stage plan has %d sweeps for ppr_iters=%d", n, iters);
+    p.n_steps = n;
+    p.n_stage = n_stage;
+
+    // ---- reset vector on the owned rows: per-query scale, passage prior rows, seed rows, column bitmap
+    HRAG_TRY(launch_ppr8_scale(zmax, mass, passage_weight, seed_vtx, seed_w, seed_cnt, e->d_deg, e->d_iso, e->V,
+                               flags, batch, damping, iters, e->d_qscale, e->d_sums, s));
+    SlabLayout l64;
+    l64.bc = 64; l64.n_slabs = n_slabs64(batch);
+    HRAG_TRY(launch_rows_to_slab(e->d_spass, e->ld_p, e->p_rows, batch, kMinMaxScale, mn, mx, passage_weight,
+                                 flags, e->d_tele16, l64, s, e->tele16_rows, e->d_qscale));
+    for (int sl = 0; sl < l64.n_slabs; ++sl)
+        HRAG_HIP_TRY(hipMemsetAsync(e->d_tele16 + ((size_t)sl * e->tele16_rows + (size_t)e->p_rows) * 64, 0,
+                                    (size_t)batch * kMaxSeeds * 64 * sizeof(float), s));
+    if (e->n_rows > 0)
+        HRAG_HIP_TRY(hipMemcpyAsync(e->d_row_slot, e->d_row_ptele, (size_t)e->n_rows * sizeof(int32_t),
+                                    hipMemcpyDeviceToDevice, s));
+    HRAG_TRY(launch_ppr16_seed_rows(seed_vtx, seed_w, seed_cnt, e->d_qscale, batch, e->p_rows, e->V, e->d_row_slot,
+                                    e->d_tele16, e->tele16_rows, 64, s, e->row_offset, e->n_rows));
+    HRAG_HIP_TRY(hipMemcpyAsync(e->d_colmask, e->d_colmask_static, (size_t)e->colmask_words * sizeof(uint32_t),
+                                hipMemcpyDeviceToDevice, s));
+    HRAG_TRY(launch_ppr8_mask_seeds(seed_vtx, seed_cnt, batch, e->V, e->d_colmask, s));
+    // ---- c_0 = Q(v/d * 2^7) on the owned rows of every group
+    Ppr8Args a = base_args(e);
+    a.y = p.buf[0];
+    HRAG_TRY(launch_ppr8_init(a, kP8C0Scale, s));
+    p.active = true;
+    return HRAG_OK;
+}
+
+hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchange, hipStream_t s) {
+    const Ppr8Session &p = e->p8;
+    HRAG_REQUIRE(p.active, "no fp8 PPR session: call the begin step first");
+    HRAG_REQUIRE(i >= 0 && i < p.n_steps, "sweep %d outside [0, %d)", i, p.n_steps);
+    HRAG_REQUIRE(group >= -1 && group < p.n_groups, "group %d outside [0, %d)", group, p.n_groups);
+    const Ppr8Step &st = p.steps[i];
+    Ppr8Args a = base_args(e);
+    if (group >= 0) {
+        a.slab0 = group * p.spg;
+        a.n_slabs = std::min(p.spg, p.n_slabs - a.slab0);
+    }
+    a.x = p.buf[st.x];
+    a.inv_cs = st.inv_cs; a.cs_next = st.cs_next;
+    if (st.mode == kP8ModeC) {
+        a.y = p.buf[st.y];
+        a.rt = p.buf[st.rt];
+    } else if (st.mode == kP8ModeB || st.mode == kP8ModeB0) {
+        a.y = p.buf[st.y];
+        a.stage_out = stage_copy(e, st.stage);
+    } else {   // kP8ModeF: the passage rows only
+        a.m = e->fsell.dev_at();
+        for (int k = 0; k + 1 < p.n_stage; ++k) a.stage[k] = stage_copy(e, k);
+        for (int k = 0; k < p.n_stage; ++k) a.stage_inv[k] = p.stage_inv[k];
+        a.n_stage = p.n_stage;
+        a.out = e->d_xp8;
+    }
+    if (exchange) *exchange = st.y;
+    return launch_ppr8_sweep(a, st.mode, false, s);
+}
+
+hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int it, bool main_only, hipStream_t s) {
+    const Ppr8Session &p = e->p8;
+    HRAG_REQUIRE(p.active, "no fp8 PPR session");
+    Ppr8Args a = base_args(e);
+    a.x = p.buf[it & 1];
+    a.y = p.buf[(it & 1) ^ 1];
+    a.rt = p.buf[2];
+    a.inv_cs = 1.0f / 64.f; a.cs_next = 64.f;
+    a.stage_out = stage_copy(e, 0);
+    if (mode == kP8ModeF) {
+        a.m = e->fsell.dev_at();
+        for (int k = 0; k + 1 < p.n_stage; ++k) a.stage[k] = stage_copy(e, k);
+        for (int k = 0; k < p.n_stage; ++k) a.stage_inv[k] = p.stage_inv[k];
+        a.n_stage = p.n_stage;
+        a.out = e->d_xp8;
+    }
+    return launch_ppr8_sweep(a, mode, main_only, s);
+}
+
+hrag_status ppr8_doc_scores(hrag_engine *e, const float *mn, const float *mx, int32_t *flags, int32_t batch,
+                            hipStream_t s) {
+    SlabLayout l64;
+    l64.bc = 64; l64.n_slabs = n_slabs64(batch);
+    HRAG_TRY(launch_slab_to_rows(e->d_xp8, e->p_rows, nullptr, e->p_rows, batch, e->d_sums, e->d_doc, e->ld_p,
+                                 e->d_spass, e->ld_p, mn, mx, flags, l64, s));
+    if (flags) HRAG_TRY(launch_flag_zero_mass(e->d_sums, batch, flags, 2, s));
+    return HRAG_OK;
+}
+
+}  // namespace hrag
+
+namespace {
+
+hrag_status shard_batch(const hrag_engine *e, int32_t batch) {
+    HRAG_REQUIRE(e != nullptr, "engine is NULL");
+    if (batch < 1 || batch > e->max_batch) {
+        set_error("batch %d outside [1, max_batch=%d]", batch, e->max_batch);
+        return HRAG_ECAPACITY;
+    }
+    return HRAG_OK;
+}
+
+// an empty shard contributes the neutral elements of the min / max all-reduce
+hrag_status fill_minmax_neutral(float *mn, float *mx, int32_t batch, hipStream_t s) {
+    HRAG_TRY(launch_fill_i32(reinterpret_cast<int32_t *>(mn), 0x7f800000, batch, s));            // +inf
+    HRAG_TRY(launch_fill_i32(reinterpret_cast<int32_t *>(mx), (int32_t)0xff800000u, batch, s));  // -inf
+    return HRAG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+hrag_status hrag_shard_layout_query(hrag_engine *e, int32_t batch, int32_t want_groups, hrag_shard_layout *out) {
+    HRAG_TRY(shard_batch(e, batch));
+    HRAG_REQUIRE(out != nullptr, "NULL argument");
+    return ppr8_layout(e, batch, want_groups, out);
+}
+
+hrag_status hrag_shard_score_facts(hrag_engine *e, const uint16_t *q, int32_t batch, int32_t k, int32_t *idx_out,
+                                   float *score_out, float *mn_out, float *mx_out, hrag_stream stream) {
+    HRAG_TRY(shard_batch(e, batch));
+    HRAG_REQUIRE(q && idx_out && score_out && mn_out && mx_out, "NULL argument");
+    HRAG_REQUIRE(k >= 1 && k <= kTopkMax, "k=%d outside [1, %d]", k, kTopkMax);
+    HRAG_REQUIRE(e->d_subj != nullptr, "engine was created without facts");
+    hipStream_t s = (hipStream_t)stream;
+    if (e->f_rows == 0) {
+        HRAG_TRY(launch_fill_i32(idx_out, -1, (int64_t)batch * k, s));
+        HRAG_HIP_TRY(hipMemsetAsync(score_out, 0, (size_t)batch * k * sizeof(float), s));
+        return fill_minmax_neutral(mn_out, mx_out, batch, s);
+    }
+    if (batch > 16 && k <= 16 && e->d_fused_ws)
+        return launch_sim_topk_fused(e->d_femb, e->f_rows, e->dim, q, batch, k, (int32_t)e->f_offset, 0, e->d_fused_ws,
+                                     e->d_fused_sel, mn_out, mx_out, idx_out, score_out, s, e->emb_dtype);
+    HRAG_TRY(launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, e->d_sfact, e->ld_f, s, 0, e->emb_dtype));
+    return launch_row_topk(e->d_sfact, batch, e->f_rows, e->ld_f, k, (int32_t)e->f_offset, kNormNone, idx_out,
+                           score_out, mn_out, mx_out, s, e->d_topk_ws, kTopkWsBytes);
+}
+
+hrag_status hrag_shard_passage_scores(hrag_engine *e, const uint16_t *q, int32_t batch, float *mn_out,
+                                      float *mx_out, hrag_stream stream) {
+    HRAG_TRY(shard_batch(e, batch));
+    HRAG_REQUIRE(q && mn_out && mx_out, "NULL argument");
+    HRAG_REQUIRE(e->shard_aligned, "the passage embedding shard must hold exactly the passages of the owned rows");
+    hipStream_t s = (hipStream_t)stream;
+    if (e->p_rows == 0) return fill_minmax_neutral(mn_out, mx_out, batch, s);
+    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
+    return launch_row_minmax(e->d_spass, batch, e->p_rows, e->ld_p, mn_out, mx_out, s);
+}
+
+hrag_status hrag_shard_prior_stats(hrag_engine *e, const float *mn, const float *mx, float passage_node_weight,
+                                   const int32_t *flags, int32_t batch, float *zmax_out, double *mass_out,
+                                   hrag_stream stream) {
+    HRAG_TRY(shard_batch(e, batch));
+    HRAG_REQUIRE(mn && mx && flags && zmax_out && mass_out, "NULL argument");
+    return ppr8_prior(e, mn, mx, passage_node_weight, flags, batch, zmax_out, mass_out, (hipStream_t)stream);
+}
+
+hrag_status hrag_shard_ppr_begin(hrag_engine *e, const float *mn, const float *mx, const float *zmax,
+                                 const double *mass, float passage_node_weight, const int32_t *seed_vtx,
+                                 const float *seed_w, const int32_t *seed_cnt, int32_t *flags, int32_t batch,
+                                 float damping, int32_t ppr_iters, int32_t n_groups, void *state0, void *state1,
+                                 void *state2, hrag_stream stream) {
+    HRAG_TRY(shard_batch(e, batch));
+    HRAG_REQUIRE(mn && mx && zmax && mass && seed_vtx && seed_w && seed_cnt && flags, "NULL argument");
+    HRAG_REQUIRE(damping >= 0.f && damping < 1.f, "damping %g outside [0, 1)", (double)damping);
+    hrag_shard_layout lay;
+    HRAG_TRY(ppr8_layout(e, batch, n_groups, &lay));
+    HRAG_REQUIRE(n_groups <= 0 || lay.n_groups == n_groups || n_groups > lay.n_slabs,
+                 "the engine lays %d queries out in %d exchange groups, not %d: size the state buffers with "
+                 "hrag_shard_layout_query and pass its n_groups", batch, lay.n_groups, n_groups);
+    uint8_t *bufs[3] = {static_cast<uint8_t *>(state0), static_cast<uint8_t *>(state1), static_cast<uint8_t *>(state2)};
+    return ppr8_begin(e, mn, mx, zmax, mass, passage_node_weight, seed_vtx, seed_w, seed_cnt, flags, batch, damping,
+                      ppr_iters, lay, bufs, (hipStream_t)stream);
+}
+
+hrag_status hrag_shard_ppr_sweep(hrag_engine *e, int32_t sweep, int32_t group, int32_t *exchange_out,
+                                 hrag_stream stream) {
+    HRAG_REQUIRE(e != nullptr, "engine is NULL");
+    HRAG_REQUIRE(group >= 0, "group must be >= 0");
+    return ppr8_sweep(e, sweep, group, exchange_out, (hipStream_t)stream);
+}
+
+hrag_status hrag_shard_finish(hrag_engine *e, const float *mn, const float *mx, int32_t *flags, int32_t batch,
+                              int32_t k, int32_t *idx_out, float *score_out, hrag_stream stream) {
+    HRAG_TRY(shard_batch(e, batch));
+    HRAG_REQUIRE(mn && mx && flags && idx_out && score_out, "NULL argument");
+    HRAG_REQUIRE(k >= 1 && k <= e->max_topk, "k=%d outside [1, max_topk=%d]", k, e->max_topk);
+    HRAG_REQUIRE(e->p8.active && e->p8.batch == batch, "no fp8 PPR session for batch %d", batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (e->p_rows == 0) {
+        HRAG_TRY(launch_fill_i32(idx_out, -1, (int64_t)batch * k, s));
+        HRAG_HIP_TRY(hipMemsetAsync(score_out, 0, (size_t)batch * k * sizeof(float), s));
+        return launch_flag_zero_mass(e->d_sums, batch, flags, 2, s);
+    }
+    HRAG_TRY(ppr8_doc_scores(e, mn, mx, flags, batch, s));
+    return launch_row_topk(e->d_doc, batch, e->p_rows, e->ld_p, k, (int32_t)e->p_offset, kNormNone, idx_out,
+                           score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes);
+}
+
+hrag_status hrag_engine_set_flags(hrag_engine *e, int32_t flags, int32_t on) {
+    HRAG_REQUIRE(e != nullptr, "engine is NULL");
+    const int32_t runtime = HRAG_OPT_NO_FP8 | HRAG_OPT_NT_CSR | HRAG_OPT_NT_STORE | HRAG_OPT_TEMPORAL16;
+    HRAG_REQUIRE((flags & ~runtime) == 0, "only HRAG_OPT_NO_FP8 / NT_CSR / NT_STORE / TEMPORAL16 can change after creation");
+    if (on) e->opt_flags |= flags; else e->opt_flags &= ~flags;
+    return HRAG_OK;
+}
+
+}  // extern "C"

@@ -183,8 +183,8 @@ class RowShardedRetriever:
 
 def build_sharded_engine(kg, pass_emb, fact_emb, rank: int, world: int, max_batch: int, max_topk: int,
                          slab_width: int = 0):
-    """Row-shard the index for `rank` and create its engine (embeddings: torch bf16 on device or
-    numpy bf16 bits; full matrices are sliced here)."""
+    """fp32-state row shard (hrag_stage_* operators): the index is sliced in its given vertex order
+    (embeddings: torch bf16 on device or numpy bf16 bits; full matrices are sliced here)."""
     from .engine import EngineStages, HippoRAGEngine
     plan = ShardPlan(balanced_row_shards(kg.csr.row_ptr, world), even_shards(kg.n_passages, world),
                      even_shards(kg.n_facts, world))
@@ -196,6 +196,280 @@ def build_sharded_engine(kg, pass_emb, fact_emb, rank: int, world: int, max_batc
                          slab_width=slab_width, row_offset=r_lo, passage_offset=p_lo, fact_offset=f_lo,
                          n_passages=kg.n_passages, n_facts=kg.n_facts)
     return eng, EngineStages(eng), plan
+
+
+# --------------------------------------------------------------------------------------------
+# fp8-state row shards (hrag_shard_* entry points): equal-sized shards in an internal vertex order
+# --------------------------------------------------------------------------------------------
+@dataclass
+class ShardedIndex:
+    """The index relabelled so that shard g owns the vertex ids [g * rows_per_shard, (g + 1) * rows_per_shard):
+    the passages of passage-embedding shard g (passage order), then entity vertices dealt round-robin by
+    descending degree (every shard gets the same number of rows and ~the same number of matrix entries),
+    then isolated padding vertices.  Passage POSITIONS (the ids the caller sees) are unchanged."""
+    world: int
+    rows_per_shard: int
+    perm: np.ndarray                 # int64 [V_original]: original vertex id -> internal id
+    csr: "object"                    # CSRGraph over world * rows_per_shard internal vertices
+    passage_vertex: np.ndarray
+    subj_vertex: Optional[np.ndarray]
+    obj_vertex: Optional[np.ndarray]
+    num_chunks: Optional[np.ndarray]
+    passages: List[Tuple[int, int]]
+    facts: List[Tuple[int, int]]
+
+    @property
+    def num_vertices(self) -> int:
+        return self.world * self.rows_per_shard
+
+
+def shard_index(csr, passage_vertex, world: int, subj_vertex=None, obj_vertex=None, num_chunks=None,
+                n_facts: Optional[int] = None) -> ShardedIndex:
+    from .graph import CSRGraph
+    v = int(csr.num_vertices)
+    pv = np.asarray(passage_vertex, dtype=np.int64)
+    n_p = pv.shape[0]
+    pshards = even_shards(n_p, world)
+    deg = np.diff(np.asarray(csr.row_ptr, dtype=np.int64))
+    is_pass = np.zeros(v, dtype=bool)
+    is_pass[pv] = True
+    ent = np.flatnonzero(~is_pass)
+    ent = ent[np.argsort(-deg[ent], kind="stable")]               # heaviest first
+    n_pass_of = np.array([hi - lo for lo, hi in pshards], dtype=np.int64)
+    # 2 % of slack rows per shard: the balance below trades row counts for entry counts
+    cap_ent = -(-ent.shape[0] // world) + max(1, ent.shape[0] // (50 * world))
+    rps = int(n_pass_of.max()) + cap_ent
+    perm = np.full(v, -1, dtype=np.int64)
+    for g, (lo, hi) in enumerate(pshards):
+        perm[pv[lo:hi]] = g * rps + np.arange(hi - lo)
+    # longest-processing-time greedy: every entity (heaviest first) goes to the shard with the fewest matrix
+    # entries so far that still has a free row; the remaining rows of a shard are isolated padding vertices
+    import heapq
+    load0 = [int(deg[pv[lo:hi]].sum()) for lo, hi in pshards]
+    heap = [(load0[g], g) for g in range(world)]
+    heapq.heapify(heap)
+    count = [0] * world
+    shard = np.empty(ent.shape[0], dtype=np.int64)
+    local = np.empty(ent.shape[0], dtype=np.int64)
+    ent_deg = deg[ent].tolist()
+    for i, d in enumerate(ent_deg):
+        ld, g = heapq.heappop(heap)
+        shard[i], local[i] = g, count[g]
+        count[g] += 1
+        if count[g] < cap_ent:
+            heapq.heappush(heap, (ld + d, g))
+    perm[ent] = shard * rps + n_pass_of[shard] + local
+    assert (perm >= 0).all() and np.unique(perm).shape[0] == v
+    v_pad = world * rps
+    rows = np.repeat(np.arange(v, dtype=np.int64), deg)
+    new_r, new_c = perm[rows], perm[np.asarray(csr.col_idx, dtype=np.int64)]
+    order = np.argsort(new_r * v_pad + new_c, kind="stable")
+    row_ptr = np.zeros(v_pad + 1, dtype=np.int64)
+    np.cumsum(np.bincount(new_r, minlength=v_pad), out=row_ptr[1:])
+    col_sum = None
+    if csr.col_sum is not None:
+        col_sum = np.zeros(v_pad, dtype=np.float64)
+        col_sum[perm] = csr.col_sum
+    new_csr = CSRGraph(v_pad, row_ptr.astype(np.int32), new_c[order].astype(np.int32),
+                       np.asarray(csr.val)[order], np.asarray(csr.raw)[order], col_sum)
+
+    def relabel(a):
+        if a is None:
+            return None
+        a = np.asarray(a, dtype=np.int64)
+        return np.where(a >= 0, perm[np.clip(a, 0, v - 1)], -1).astype(np.int32)
+
+    nc = None
+    if num_chunks is not None:
+        nc = np.zeros(v_pad, dtype=np.int32)
+        nc[perm] = np.asarray(num_chunks, dtype=np.int32)
+    nf = int(n_facts if n_facts is not None else (len(subj_vertex) if subj_vertex is not None else 0))
+    return ShardedIndex(world, rps, perm, new_csr, perm[pv].astype(np.int32), relabel(subj_vertex),
+                        relabel(obj_vertex), nc, pshards, even_shards(nf, world))
+
+
+def build_shard_engine(sidx: ShardedIndex, pass_emb, fact_emb, rank: int, max_batch: int, max_topk: int,
+                       flags: int = 0):
+    """The engine of shard `rank` of a ShardedIndex (full embedding matrices are sliced here)."""
+    from .engine import HippoRAGEngine
+    rps = sidx.rows_per_shard
+    p_lo, p_hi = sidx.passages[rank]
+    f_lo, f_hi = sidx.facts[rank]
+    has_facts = fact_emb is not None and sidx.subj_vertex is not None
+    return HippoRAGEngine(sidx.csr.rows(rank * rps, (rank + 1) * rps), sidx.passage_vertex, pass_emb[p_lo:p_hi],
+                          fact_emb[f_lo:f_hi] if has_facts else None, sidx.subj_vertex if has_facts else None,
+                          sidx.obj_vertex if has_facts else None, sidx.num_chunks if has_facts else None,
+                          max_batch=max_batch, max_topk=max_topk, row_offset=rank * rps, passage_offset=p_lo,
+                          fact_offset=f_lo, n_passages=len(sidx.passage_vertex),
+                          n_facts=sidx.facts[-1][1] if has_facts else None, flags=flags)
+
+
+class TorchComm:
+    """The exchange steps of the row-sharded path over torch.distributed (nccl = RCCL over xGMI; gloo in
+    the CPU tests).  State exchange = ONE in-place all-gather per exchange group: the owned rows of a group
+    are one contiguous block at rank * own_bytes."""
+
+    def __init__(self, rank: int, world: int, group=None):
+        self.rank, self.world, self.group = rank, world, group
+
+    def all_reduce(self, t, op: str):
+        torch, dist = _td()
+        if self.world > 1:
+            dist.all_reduce(t, op={"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX,
+                                   "sum": dist.ReduceOp.SUM}[op], group=self.group)
+        return t
+
+    def all_gather(self, t):
+        torch, dist = _td()
+        if self.world == 1:
+            return [t]
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return out
+
+    def exchange(self, buf, lay, g: int):
+        """Start the all-gather of exchange group g of state buffer `buf` (uint8 [state_bytes]); returns a
+        handle for wait().  The collective is ordered after everything enqueued on the current stream."""
+        torch, dist = _td()
+        if self.world == 1:
+            return None
+        if lay.own_offset != self.rank * lay.own_bytes:
+            raise ValueError("state exchange needs equal-sized row shards in rank order (dist.shard_index)")
+        base = g * lay.group_bytes
+        out = buf[base: base + self.world * lay.own_bytes]
+        inp = buf[base + lay.own_offset: base + lay.own_offset + lay.own_bytes]
+        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+
+    def wait(self, handle):
+        if handle is not None:
+            handle.wait()          # the current stream waits for the collective; the host does not block
+
+
+class LocalComm:
+    """All `world` shards inside ONE process on ONE device, one thread per shard, meeting at barriers:
+    the emulated gather SURVEY.md 8(e) asks for ("8 shards sequentially on one GPU must reproduce the
+    single-GPU result").  The shards share the three state buffers (LocalComm.shared_buffers), so the
+    state exchange is a barrier: every owner has enqueued its rows on the (common) stream before
+    anybody enqueues the next sweep."""
+
+    def __init__(self, rank: int, world: int, shared: dict):
+        import threading
+        self.rank, self.world, self.sh = rank, world, shared
+        with shared.setdefault("_lock", threading.Lock()):
+            if "_barrier" not in shared:
+                shared["_barrier"] = threading.Barrier(world)
+                shared["_slots"] = [None] * world
+
+    def _barrier(self):
+        self.sh["_barrier"].wait()
+
+    def _collect(self, t):
+        self.sh["_slots"][self.rank] = t
+        self._barrier()
+        parts = list(self.sh["_slots"])
+        self._barrier()
+        return parts
+
+    def all_reduce(self, t, op: str):
+        torch = _td()[0]
+        parts = self._collect(t.clone())
+        st = torch.stack(parts)
+        # rank order: the same summation order on every shard (and in TorchComm's ring for world = 2)
+        t.copy_({"min": lambda: st.min(0).values, "max": lambda: st.max(0).values, "sum": lambda: st.sum(0)}[op]())
+        return t
+
+    def all_gather(self, t):
+        return self._collect(t)
+
+    def shared_buffers(self, key, make):
+        if self.rank == 0:
+            self.sh[key] = make()
+        self._barrier()
+        bufs = self.sh[key]
+        self._barrier()
+        return bufs
+
+    def exchange(self, buf, lay, g: int):
+        self._barrier()
+        return None
+
+    def wait(self, handle):
+        pass
+
+
+def merge_ranked(idx_parts, val_parts, k: int, topk):
+    """Merge per-shard top-k lists (each sorted score desc, id desc; shard id ranges ascending in rank
+    order) into the global top-k under the same rule.  Reversed and concatenated in rank order, "later
+    position" == "larger (score, id)" among equal scores, so the library's positional tie rule
+    reproduces the global order exactly.  Returns (ids int32 [B, k], values [B, k], -1 / 0 beyond)."""
+    torch = _td()[0]
+    cand_idx = torch.cat([t.flip(1) for t in idx_parts], dim=1).contiguous()
+    cand_val = torch.cat([t.flip(1) for t in val_parts], dim=1)
+    cand_val = torch.where(cand_idx < 0, torch.full_like(cand_val, float("-inf")), cand_val).contiguous()
+    pos, top_val, _, _ = topk(cand_val, k)
+    top_idx = torch.gather(cand_idx, 1, pos.clamp(min=0).long())
+    top_idx = torch.where(pos < 0, torch.full_like(top_idx, -1), top_idx).to(torch.int32)
+    top_val = torch.where(top_idx < 0, torch.zeros_like(top_val), top_val)
+    return top_idx, top_val
+
+
+class ShardedRetriever:
+    """The hot path over fp8-state row shards: phase A / phase B with the exchange steps of
+    include/hrag.h's hrag_shard_* section.  `stages` = the shard's engine (hipporag_amd.engine.ShardStages)
+    or a CPU stand-in with the same methods (tests)."""
+
+    def __init__(self, stages, comm, groups: int = 2):
+        self.st, self.comm, self.groups = stages, comm, groups
+        self._bufs = {}
+
+    def _state(self, batch: int):
+        if batch not in self._bufs:
+            lay = self.st.shard_layout(batch, self.groups)
+            make = lambda: [self.st.new_state(lay) for _ in range(3)]
+            bufs = self.comm.shared_buffers(("state", batch), make) if hasattr(self.comm, "shared_buffers") else make()
+            self._bufs[batch] = (lay, bufs)
+        return self._bufs[batch]
+
+    def score_facts(self, q_fact, k: int = 5):
+        """Global (fact ids int32 [B, k], min-max normalised scores fp32 [B, k]), replicated."""
+        torch = _td()[0]
+        c = self.comm
+        idx, val, mn, mx = self.st.shard_score_facts(q_fact, k)
+        idx_all, val_all = c.all_gather(idx), c.all_gather(val)
+        c.all_reduce(mn, "min")
+        c.all_reduce(mx, "max")
+        top_idx, top_val = merge_ranked(idx_all, val_all, k, self.st.topk)
+        rng = (mx - mn).unsqueeze(1)
+        norm = torch.where(rng == 0, torch.ones_like(top_val), (top_val - mn.unsqueeze(1)) / rng)   # misc_utils.py:130-139
+        return top_idx, torch.where(top_idx < 0, torch.zeros_like(norm), norm)
+
+    def retrieve(self, q_pass, kept_idx, kept_score, kept_count, *, link_top_k=5, damping=0.5,
+                 passage_node_weight=0.05, ppr_iters=20, k=200):
+        st, c = self.st, self.comm
+        b = q_pass.shape[0]
+        lay, bufs = self._state(b)
+        mn, mx = st.shard_passage_scores(q_pass)
+        c.all_reduce(mn, "min")
+        c.all_reduce(mx, "max")
+        sv, sw, sc, flags = st.seeds(kept_idx, kept_score, kept_count, link_top_k)
+        zmax, mass = st.shard_prior_stats(mn, mx, passage_node_weight, flags)
+        c.all_reduce(zmax, "max")
+        c.all_reduce(mass, "sum")
+        st.shard_ppr_begin(mn, mx, zmax, mass, passage_node_weight, (sv, sw, sc), flags, damping, ppr_iters,
+                           lay.n_groups, bufs)
+        # group g's exchange overlaps with the sweep of the other groups: a sweep of group g only waits for
+        # group g's previous exchange
+        pend = [c.exchange(bufs[0], lay, g) for g in range(lay.n_groups)]
+        for i in range(ppr_iters):
+            for g in range(lay.n_groups):
+                c.wait(pend[g])
+                xb = st.shard_ppr_sweep(i, g)
+                pend[g] = c.exchange(bufs[xb], lay, g) if xb >= 0 else None
+        idx, val = st.shard_finish(mn, mx, flags, k)
+        top_idx, top_val = merge_ranked(c.all_gather(idx), c.all_gather(val), k, st.topk)
+        sat = (flags & 8).contiguous()               # raised on the shard that owns the row that saturated
+        c.all_reduce(sat, "max")
+        return top_idx, top_val, flags | sat
 
 
 # --------------------------------------------------------------------------------------------
@@ -266,10 +540,6 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
         eng.set_profiling(False)
         roofline, _, _ = roofline_fn(eng, kg, V, B, phases, args.config, getattr(args, "sweep_launches", 40))
         barrier_sync()
-    eng.close()
-    del eng
-    torch.cuda.empty_cache()
-
     result = {
         "metric": "retrieval_queries_per_sec", "value": replica_qps, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -283,11 +553,13 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
         "roofline": roofline,
         "phases_ms": ({k: phases[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")}
                       if phases else None),
+        "replica": {"value": replica_qps, "unit": "queries/s", "ms_per_step": replica_s * 1e3 / max(args.steps, 1),
+                    "parallelism": f"replica x{world}: every GPU holds the whole index and serves its own {B} queries"},
         "rowshard": None,
     }
 
-    # The row-sharded leg below is a secondary number.  It must never cost the primary one: a
-    # watchdog prints the line (rank 0) and ends the process if the leg or the teardown stalls.
+    # The row-sharded leg (the layout BASELINE.json's north star names) must never cost the line: a
+    # watchdog prints what has been measured (rank 0) and ends the process if the leg or the teardown stalls.
     import threading
     printed = threading.Event()
 
@@ -295,6 +567,12 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
         if rank == 0 and not printed.is_set():
             printed.set()
             result["rowshard"] = rowshard
+            ok = isinstance(rowshard, dict) and "value" in rowshard and rowshard.get("parity", {}).get("ok")
+            if ok and args.mode == "rowshard":
+                # primary number = the mandated layout; the replica figure stays beside it
+                result["value"] = rowshard["value"]
+                result["ms_per_step"] = rowshard["ms_per_step"]
+                result["config"]["parallelism"] = rowshard["parallelism"]
             try:   # RCCL's version banner sits in the C stdio buffer: emit it first so that the JSON is the last line
                 import ctypes
                 ctypes.CDLL(None).fflush(None)
@@ -320,10 +598,11 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
         leg_done = watchdog(limit, "row-sharded leg")
         try:
             rowshard = _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW,
-                                     seed, V, dev, barrier_sync, max_over_ranks)
-        except Exception as exc:  # the measured mode above stays valid; report instead of dying
+                                     seed, V, dev, barrier_sync, max_over_ranks, eng)
+        except Exception as exc:  # the replica measurement above stays valid; report instead of dying
             rowshard = {"error": f"{type(exc).__name__}: {exc}"}
         leg_done.set()
+    eng.close()
     emit(rowshard)
     teardown_done = watchdog(30.0, "process-group teardown")
     dist.barrier()
@@ -333,16 +612,21 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
 
 
 def _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW, seed, V, dev,
-                  barrier_sync, max_over_ranks):
-    """The global batch (world * B) over the row-sharded corpus (north-star layout)."""
+                  barrier_sync, max_over_ranks, replica_eng):
+    """The global batch (world * B) over the row-sharded corpus: fp8-state shards, one all-gather per
+    exchange group and sweep; checked against the single-GPU engine on the same queries."""
     torch, dist = _td()
     from . import synth
+    from .engine import ShardStages
     gb = world * B
-    seng, stages, plan = build_sharded_engine(kg, pass_emb, fact_emb, rank, world, gb, K_P, args.slab_width)
-    rs = RowShardedRetriever(stages, plan, rank, world)
-    rs_steps, rs_warm = max(1, min(args.steps, 2)), 1
-    gqf = [synth.make_queries_torch(fact_emb, gb, seed + 9000 + i)[0] for i in range(rs_steps + rs_warm)]
-    gqp = [synth.make_queries_torch(pass_emb, gb, seed + 9500 + i)[0] for i in range(rs_steps + rs_warm)]
+    groups = int(getattr(args, "exchange_groups", 2))
+    sidx = shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+    seng = build_shard_engine(sidx, pass_emb, fact_emb, rank, gb, K_P)
+    rs = ShardedRetriever(ShardStages(seng), TorchComm(rank, world), groups=groups)
+    rs_steps, rs_warm = max(1, args.steps), max(1, min(args.warmup, 2))
+    n = rs_steps + rs_warm
+    gqf = [synth.make_queries_torch(fact_emb, gb, seed + 9000 + i)[0] for i in range(n)]
+    gqp = [synth.make_queries_torch(pass_emb, gb, seed + 9500 + i)[0] for i in range(n)]
     gcnt = torch.full((gb,), K_F, dtype=torch.int32, device=dev)
 
     def rs_step(i):
@@ -354,16 +638,35 @@ def _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS,
         rs_step(i)
     barrier_sync()
     t0 = time.perf_counter()
-    for i in range(rs_warm, rs_warm + rs_steps):
-        rs_step(i)
+    for i in range(rs_warm, n):
+        out = rs_step(i)
     barrier_sync()
     rs_s = max_over_ranks(time.perf_counter() - t0)
-    bc, ns = stages.layout(gb)
-    wire = (world - 1) / world * V * gb * 4          # bytes each GPU receives per sweep
-    out = {"value": gb * rs_steps / rs_s, "unit": "queries/s", "global_batch": gb,
-           "steps": rs_steps, "ms_per_step": rs_s * 1e3 / rs_steps,
-           "exchange": "per-sweep all-gather of the owned rows of x (broadcast per owner)",
-           "wire_bytes_per_gpu_per_sweep": wire, "slab_width": bc, "n_slabs": ns,
-           "row_shards": plan.rows}
+    # parity: the last global batch's first B queries through the single-GPU engine of this rank
+    qf, qp = gqf[n - 1][:B], gqp[n - 1][:B]
+    idx1, sc1 = replica_eng.score_facts(qf, k=K_F)
+    one = replica_eng.retrieve(qp, idx1, sc1, gcnt[:B], link_top_k=K_F, damping=DAMP, passage_node_weight=PW,
+                               ppr_iters=ITERS, k=K_P)
+    torch.cuda.synchronize()
+    ids_s, sc_s = out[0][:B].cpu().numpy(), out[1][:B].cpu().numpy()
+    ids_1, sc_1 = one.doc_idx.cpu().numpy(), one.doc_score.cpu().numpy()
+    same_ids = float((ids_s == ids_1).mean())
+    rel = np.abs(sc_s - sc_1) / np.maximum(np.abs(sc_1), 1e-30)
+    flags_any = int(out[2].max().item())
+    parity = {"against": "single-GPU engine, same queries (first per-GPU batch of the last global batch)",
+              "queries": int(B), "fraction_of_ranked_ids_equal": same_ids, "max_rel_score_diff": float(rel.max()),
+              "flags_or": flags_any, "ok": bool(rel.max() < 1e-5 and same_ids > 0.999 and not (flags_any & 8))}
+    lay = seng.shard_layout(gb, groups)
+    wire = (world - 1) / world * sidx.num_vertices * 128 * lay.n_slabs     # e4m3 bytes each GPU receives per sweep
+    nnz_own = int(sidx.csr.row_ptr[(rank + 1) * sidx.rows_per_shard] - sidx.csr.row_ptr[rank * sidx.rows_per_shard])
+    res = {"value": gb * rs_steps / rs_s, "unit": "queries/s", "global_batch": gb, "steps": rs_steps,
+           "ms_per_step": rs_s * 1e3 / rs_steps,
+           "parallelism": f"rowshard x{world}: CSR rows + passage / fact embeddings sharded, e4m3 PPR iterate "
+                          f"replicated, one all-gather per exchange group and sweep",
+           "exchange": "in-place all_gather_into_tensor of the owners' row blocks (RCCL), "
+                       f"{lay.n_groups} exchange group(s) pipelined against the sweeps of the other group(s)",
+           "wire_bytes_received_per_gpu_per_sweep": wire, "state_bytes_per_buffer": int(lay.state_bytes),
+           "n_slabs": int(lay.n_slabs), "exchange_groups": int(lay.n_groups),
+           "rows_per_shard": int(sidx.rows_per_shard), "nnz_this_shard": nnz_own, "parity": parity}
     seng.close()
-    return out
+    return res

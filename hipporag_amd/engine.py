@@ -14,8 +14,8 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import (EmbedDesc, FactDesc, GraphDesc, Opts, Timings, check, FLAG_DPR_FALLBACK,
-                   FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, SEED_STRIDE)
+from ._lib import (EmbedDesc, FactDesc, GraphDesc, Opts, ShardLayout, Timings, check, FLAG_DPR_FALLBACK,
+                   FLAG_FP8_SATURATED, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, SEED_STRIDE)
 from .graph import CSRGraph
 
 
@@ -252,11 +252,79 @@ class HippoRAGEngine:
         return x, flags
 
     def ppr_sweeps(self, batch: int, n: int, damping: float = 0.5, main_only: bool = False,
-                   f16: bool = False, small: bool = False, f8: bool = False):
+                   f16: bool = False, small: bool = False, f8: bool = False, f8_mode: str = "C"):
         """Measurement hook: n sweeps of the fp32 slab kernel, of the fp16-state kernel (f16=True), of
-        the small-batch kernel (small=True, batch <= 8) or of the fp8-state kernel (f8=True, mode C)."""
+        the small-batch kernel (small=True, batch <= 8) or of the fp8-state kernel (f8=True; f8_mode picks
+        the kernel instantiation: "C" stage sweep, "B" boundary, "B0" first boundary, "F" final)."""
         flags = (1 if main_only else 0) | (2 if f16 else 0) | (4 if small else 0) | (8 if f8 else 0)
+        flags |= {"C": 0, "B": 1, "F": 2, "B0": 3}[f8_mode] << 4
         check(self._lib.hrag_ppr_sweeps(self._handle, batch, n, damping, flags, _stream()))
+
+    def set_flags(self, flags: int, on: bool = True):
+        """Set / clear HRAG_OPT_* bits after creation (e.g. _lib.OPT_NO_FP8 to rerun a saturated batch)."""
+        check(self._lib.hrag_engine_set_flags(self._handle, flags, 1 if on else 0))
+
+    # ------------------------------------------------------------------ row shard (include/hrag.h hrag_shard_*)
+    def shard_layout(self, batch: int, groups: int = 0) -> ShardLayout:
+        lay = ShardLayout()
+        check(self._lib.hrag_shard_layout_query(self._handle, batch, groups, C.byref(lay)))
+        return lay
+
+    def shard_score_facts(self, q_fact, k: int = 5):
+        """Local phase A: (global fact ids [B,k], RAW scores [B,k], local min [B], local max [B])."""
+        torch = _torch()
+        q = self._q(q_fact)
+        b = q.shape[0]
+        idx = self._empty((b, k), torch.int32)
+        val = self._empty((b, k), torch.float32)
+        mn = self._empty((b,), torch.float32)
+        mx = self._empty((b,), torch.float32)
+        check(self._lib.hrag_shard_score_facts(self._handle, q.data_ptr(), b, k, idx.data_ptr(), val.data_ptr(),
+                                               mn.data_ptr(), mx.data_ptr(), _stream()))
+        return idx, val, mn, mx
+
+    def shard_passage_scores(self, q_pass):
+        torch = _torch()
+        q = self._q(q_pass)
+        b = q.shape[0]
+        mn = self._empty((b,), torch.float32)
+        mx = self._empty((b,), torch.float32)
+        check(self._lib.hrag_shard_passage_scores(self._handle, q.data_ptr(), b, mn.data_ptr(), mx.data_ptr(),
+                                                  _stream()))
+        return mn, mx
+
+    def shard_prior_stats(self, mn, mx, passage_node_weight: float, flags):
+        torch = _torch()
+        b = mn.shape[0]
+        zmax = self._empty((b,), torch.float32)
+        mass = self._empty((2 * b,), torch.float64)
+        check(self._lib.hrag_shard_prior_stats(self._handle, mn.data_ptr(), mx.data_ptr(), passage_node_weight,
+                                               flags.data_ptr(), b, zmax.data_ptr(), mass.data_ptr(), _stream()))
+        return zmax, mass
+
+    def shard_ppr_begin(self, mn, mx, zmax, mass, passage_node_weight, seeds, flags, damping, ppr_iters,
+                        n_groups, bufs):
+        sv, sw, sc = seeds
+        b = mn.shape[0]
+        check(self._lib.hrag_shard_ppr_begin(self._handle, mn.data_ptr(), mx.data_ptr(), zmax.data_ptr(),
+                                             mass.data_ptr(), passage_node_weight, sv.data_ptr(), sw.data_ptr(),
+                                             sc.data_ptr(), flags.data_ptr(), b, damping, ppr_iters, n_groups,
+                                             bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(),
+                                             _stream()))
+
+    def shard_ppr_sweep(self, sweep: int, group: int) -> int:
+        x = C.c_int32(-1)
+        check(self._lib.hrag_shard_ppr_sweep(self._handle, sweep, group, C.byref(x), _stream()))
+        return x.value
+
+    def shard_finish(self, mn, mx, flags, k: int):
+        torch = _torch()
+        b = mn.shape[0]
+        idx = self._empty((b, k), torch.int32)
+        val = self._empty((b, k), torch.float32)
+        check(self._lib.hrag_shard_finish(self._handle, mn.data_ptr(), mx.data_ptr(), flags.data_ptr(), b, k,
+                                          idx.data_ptr(), val.data_ptr(), _stream()))
+        return idx, val
 
 
 class CapturedPipeline:
@@ -411,3 +479,32 @@ class EngineStages:
                                              mx.data_ptr(), flags.data_ptr(), out.data_ptr(),
                                              self.e.n_passages, _stream()))
         return out
+
+
+class ShardStages(EngineStages):
+    """The hrag_shard_* operators of a row-shard engine (staged fp8 PPR state) -- what
+    hipporag_amd.dist.ShardedRetriever composes with its exchange steps."""
+
+    def shard_layout(self, batch, groups=0):
+        return self.e.shard_layout(batch, groups)
+
+    def new_state(self, lay):           # one e4m3 state buffer, zero (row V of every group must stay zero)
+        return _torch().zeros((lay.state_bytes,), dtype=_torch().uint8, device=self.device)
+
+    def shard_score_facts(self, q_fact, k):
+        return self.e.shard_score_facts(q_fact, k)
+
+    def shard_passage_scores(self, q_pass):
+        return self.e.shard_passage_scores(q_pass)
+
+    def shard_prior_stats(self, mn, mx, weight, flags):
+        return self.e.shard_prior_stats(mn, mx, weight, flags)
+
+    def shard_ppr_begin(self, *a):
+        return self.e.shard_ppr_begin(*a)
+
+    def shard_ppr_sweep(self, sweep, group):
+        return self.e.shard_ppr_sweep(sweep, group)
+
+    def shard_finish(self, mn, mx, flags, k):
+        return self.e.shard_finish(mn, mx, flags, k)

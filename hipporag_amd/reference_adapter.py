@@ -84,7 +84,7 @@ def index_arrays_from_reference(rag) -> dict:
             "subj_vertex": subj, "obj_vertex": obj, "num_chunks": nchunks, "facts": facts}
 
 
-def build_engine_from_reference(rag, *, max_batch: int = 256, ppr_iters: int = 20):
+def build_engine_from_reference(rag, *, max_batch: int = 256):
     """Device index from the reference object's host state (prepare_retrieval_objects must have run)."""
     from .engine import HippoRAGEngine
     a = index_arrays_from_reference(rag)
@@ -101,7 +101,7 @@ def build_engine_from_reference(rag, *, max_batch: int = 256, ppr_iters: int = 2
     return eng, facts
 
 
-def attach(rag, *, max_batch: int = 256, ppr_iters: int = 20, batched_retrieve: bool = True):
+def attach(rag, *, max_batch: int = 256, ppr_iters: Optional[int] = None, batched_retrieve: bool = True):
     """Patch ``rag`` in place; returns it.  Call again after ``index()`` / ``delete()`` (they change
     the graph and the stores; the reference only resets ``ready_to_retrieve`` on delete, :411)."""
     import torch
@@ -109,8 +109,11 @@ def attach(rag, *, max_batch: int = 256, ppr_iters: int = 20, batched_retrieve: 
         detach(rag)
     if not getattr(rag, "ready_to_retrieve", False):
         rag.prepare_retrieval_objects()
-    eng, facts = build_engine_from_reference(rag, max_batch=max_batch, ppr_iters=ppr_iters)
+    eng, facts = build_engine_from_reference(rag, max_batch=max_batch)
     cfg = rag.global_config
+    from .retriever import sweeps_for_damping
+    # fixed sweep count of the power iteration: given, or derived from the damping factor (20 at 0.5)
+    sweeps = int(ppr_iters) if ppr_iters else sweeps_for_damping(float(cfg.damping))
     saved = {name: rag.__dict__.get(name, None) for name in _PATCHED}
     QuerySolution, RetrievalResult = _solution_types()
     dev = eng.device
@@ -142,7 +145,7 @@ def attach(rag, *, max_batch: int = 256, ppr_iters: int = 20, batched_retrieve: 
         if damping is None:
             damping = 0.5
         r = torch.from_numpy(np.asarray(reset_prob, dtype=np.float32).reshape(1, -1))
-        x, flags = eng.ppr(r, damping=damping, iters=ppr_iters)
+        x, flags = eng.ppr(r, damping=damping, iters=int(ppr_iters) if ppr_iters else sweeps_for_damping(float(damping)))
         if int(flags[0].item()) & 2:
             raise ValueError("reset vector has no positive entry")        # igraph raises here
         doc = x[0].cpu().numpy()[np.asarray(rag.passage_node_idxs)]
@@ -159,55 +162,21 @@ def attach(rag, *, max_batch: int = 256, ppr_iters: int = 20, batched_retrieve: 
                                doc_metadata=meta, graph_seeds=seeds or [])
 
     def retrieve(queries: List[str], num_to_retrieve: Optional[int] = None, gold_docs=None):   # :413-499
+        from .retriever import batched_retrieve
         t_start = time.time()
         if num_to_retrieve is None:
             num_to_retrieve = cfg.retrieval_top_k
         rag.get_query_embeddings(queries)
-        k_f = int(cfg.linking_top_k)
-        k_docs = max(1, min(int(num_to_retrieve), len(rag.passage_node_keys), eng.max_topk))
+        rows = batched_retrieve(eng, queries, q_tensor, facts, rag.rerank_filter,
+                                linking_top_k=int(cfg.linking_top_k), damping=cfg.damping,
+                                passage_node_weight=cfg.passage_node_weight, ppr_iters=sweeps,
+                                num_to_retrieve=int(num_to_retrieve), n_passages=len(rag.passage_node_keys),
+                                timers=rag)
         results = []
-        for lo in range(0, len(queries), eng.max_batch):
-            qs = queries[lo: lo + eng.max_batch]
-            b = len(qs)
-            kept_idx = np.full((b, max(k_f, 1)), -1, np.int32)
-            kept_sc = np.zeros((b, max(k_f, 1)), np.float32)
-            kept_cnt = np.zeros(b, np.int32)
-            seeds = [[] for _ in range(b)]
-            t_r = time.time()
-            if len(facts) > 0 and k_f > 0:
-                idx, sc = eng.score_facts(q_tensor(qs, "triple"), k=k_f)             # phase A
-                idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
-                for i, q in enumerate(qs):                                            # rerank_facts :1659-1707
-                    cand = [int(j) for j in idx_h[i] if j >= 0]
-                    try:
-                        kidx, kfacts, _ = rag.rerank_filter(q, [facts[j] for j in cand], cand,
-                                                            len_after_rerank=k_f)
-                    except Exception as exc:                                          # :1705-1707
-                        logger.error("Error in rerank_facts: %s", exc)
-                        kidx, kfacts = [], []
-                    score_of = {int(j): sc_h[i][p] for p, j in enumerate(idx_h[i]) if j >= 0}
-                    kidx = [int(j) for j in kidx if int(j) in score_of][:k_f]
-                    kept_idx[i, :len(kidx)] = kidx
-                    kept_sc[i, :len(kidx)] = [score_of[j] for j in kidx]
-                    kept_cnt[i] = len(kidx)
-                    seeds[i] = list(kfacts)
-            rag.rerank_time = getattr(rag, "rerank_time", 0.0) + time.time() - t_r
-            t_p = time.time()
-            out = eng.retrieve(q_tensor(qs, "passage"), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc),
-                               torch.from_numpy(kept_cnt), link_top_k=k_f, damping=cfg.damping,
-                               passage_node_weight=cfg.passage_node_weight, ppr_iters=ppr_iters, k=k_docs)   # phase B
-            d_idx, d_sc, flags = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy(), out.flags.cpu().numpy()
-            rag.ppr_time = getattr(rag, "ppr_time", 0.0) + time.time() - t_p
-            for i, q in enumerate(qs):
-                if flags[i] & 4:                                                      # :1541
-                    raise AssertionError("count_nonzero(all_phrase_weights) != len(linking_score_map)")
-                if flags[i] & 2:                                                      # :1644
-                    raise AssertionError(f"No phrases found in the graph for the given facts: {seeds[i]}")
-                if flags[i] & 1:
-                    logger.info("No facts found after reranking, return DPR results")   # :468
-                r = build_result(q, d_idx[i], d_sc[i], num_to_retrieve, seeds[i])
-                results.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
-                                             doc_metadata=r.doc_metadata, graph_seeds=r.graph_seeds))
+        for q, (d_idx, d_sc, seeds) in zip(queries, rows):
+            r = build_result(q, d_idx, d_sc, num_to_retrieve, seeds)
+            results.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
+                                         doc_metadata=r.doc_metadata, graph_seeds=r.graph_seeds))
         rag.all_retrieval_time = getattr(rag, "all_retrieval_time", 0.0) + time.time() - t_start
         if gold_docs is not None:
             try:

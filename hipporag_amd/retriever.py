@@ -99,6 +99,27 @@ def min_max_normalize(x):                                           # misc_utils
     return (x - mn) / rng
 
 
+# prompts/linking.py:1-10 -- the instruction sentences the reference hands to its (instruction-tuned)
+# embedding models for the two query encodings of this path; stores embedded by the reference can only be
+# searched with queries encoded under the same sentences
+_QUERY_INSTRUCTIONS = {
+    "query_to_fact": "Given a question, retrieve relevant triplet facts that matches this question.",
+    "query_to_passage": "Given a question, retrieve relevant documents that best answer the question.",
+}
+
+
+def get_query_instruction(linking_method: str) -> str:
+    return _QUERY_INSTRUCTIONS.get(linking_method, _QUERY_INSTRUCTIONS["query_to_passage"])
+
+
+def sweeps_for_damping(damping: float, tol: float = 1e-6, lo: int = 16, hi: int = 400) -> int:
+    """Number of power-iteration sweeps whose truncation error bound damping^K is <= tol (PRPACK iterates
+    to 1e-10; the parity bar of this path is 1e-5 relative): 20 at the reference's 0.5, 86 at 0.85."""
+    if not (0.0 < damping < 1.0):
+        return lo
+    return int(min(hi, max(lo, np.ceil(np.log(tol) / np.log(damping)))))
+
+
 @dataclass
 class RetrievalConfig:
     """The BaseConfig fields this path reads (utils/config_utils.py), same names and defaults."""
@@ -110,7 +131,7 @@ class RetrievalConfig:
     embedding_return_as_normalized: bool = True   # :144
     is_directed_graph: bool = False      # :176
     # engine-only knobs (no reference analogue)
-    ppr_iters: int = 20
+    ppr_iters: Optional[int] = None      # None: derived from damping (sweeps_for_damping: 20 at 0.5)
     max_batch: int = 256
     slab_width: int = 0
 
@@ -119,6 +140,83 @@ def identity_rerank_filter(query, candidate_items, candidate_indices, len_after_
     """Stand-in for DSPyFilter.__call__ (rerank.py:108-131): keeps every candidate."""
     n = len_after_rerank or len(candidate_items)
     return list(candidate_indices)[:n], list(candidate_items)[:n], {"confidence": None}
+
+
+def batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Sequence, rerank_filter: Callable, *,
+                     linking_top_k: int, damping: float, passage_node_weight: float, ppr_iters: int,
+                     num_to_retrieve: int, n_passages: int, timers=None):
+    """The body of retrieve() (HippoRAG.py:459-480) for all queries at once, shared by the mirror class below
+    and by reference_adapter.attach(): phase A on the device, the recognition-memory filter on the host
+    (rerank_facts :1659-1707), phase B on the device.  Returns one (doc ids, doc scores, kept facts) per
+    query; raises where the reference's asserts would (:1541, :1644).  timers: object whose rerank_time /
+    ppr_time attributes are advanced like the reference's accumulators (:184-186)."""
+    import torch
+    from ._lib import FLAG_FP8_SATURATED, OPT_NO_FP8
+    k_f = int(linking_top_k)
+    want = max(1, min(int(num_to_retrieve), n_passages))
+    k_docs = min(want, eng.max_topk)
+    if k_docs < want:
+        logger.warning("num_to_retrieve=%d exceeds the engine's max_topk=%d: %d documents per query are returned "
+                       "(create the engine with a larger retrieval_top_k, <= 2048)", num_to_retrieve, eng.max_topk, k_docs)
+    out_rows = []
+    for lo in range(0, len(queries), eng.max_batch):
+        qs = queries[lo: lo + eng.max_batch]
+        b = len(qs)
+        kept_idx = np.full((b, max(k_f, 1)), -1, np.int32)
+        kept_sc = np.zeros((b, max(k_f, 1)), np.float32)
+        kept_cnt = np.zeros(b, np.int32)
+        seeds: List[List[Tuple]] = [[] for _ in range(b)]
+        t_r = time.time()
+        if len(facts) > 0 and k_f > 0:
+            idx, sc = eng.score_facts(q_tensor(qs, "triple"), k=k_f)                   # phase A
+            idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
+            for i, q in enumerate(qs):                                                 # host: LLM filter
+                cand = [int(j) for j in idx_h[i] if j >= 0]
+                try:
+                    kidx, kfacts, _ = rerank_filter(q, [facts[j] for j in cand], cand, len_after_rerank=k_f)
+                except Exception as exc:                                               # :1705-1707
+                    logger.error("Error in rerank_facts: %s", exc)
+                    kidx, kfacts = [], []
+                score_of = {int(j): sc_h[i][p] for p, j in enumerate(idx_h[i]) if j >= 0}
+                kidx = [int(j) for j in kidx if int(j) in score_of][:k_f]
+                kept_idx[i, :len(kidx)] = kidx
+                kept_sc[i, :len(kidx)] = [score_of[j] for j in kidx]
+                kept_cnt[i] = len(kidx)
+                seeds[i] = list(kfacts)
+        if timers is not None:
+            timers.rerank_time = getattr(timers, "rerank_time", 0.0) + time.time() - t_r
+        t_p = time.time()
+
+        def phase_b():
+            return eng.retrieve(q_tensor(qs, "passage"), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc),
+                                torch.from_numpy(kept_cnt), link_top_k=k_f, damping=damping,
+                                passage_node_weight=passage_node_weight, ppr_iters=ppr_iters, k=k_docs)
+
+        out = phase_b()
+        flags = out.flags.cpu().numpy()
+        if (flags & FLAG_FP8_SATURATED).any():
+            # a static scale bound of the fp8-state PPR was violated (include/hrag.h): never return clipped
+            # scores -- repeat the batch on the fp16 / fp32 state
+            logger.warning("fp8 PPR state saturated for %d queries: repeating the batch on the wider state",
+                           int(((flags & FLAG_FP8_SATURATED) != 0).sum()))
+            eng.set_flags(OPT_NO_FP8, True)
+            try:
+                out = phase_b()
+            finally:
+                eng.set_flags(OPT_NO_FP8, False)
+            flags = out.flags.cpu().numpy()
+        d_idx, d_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+        if timers is not None:
+            timers.ppr_time = getattr(timers, "ppr_time", 0.0) + time.time() - t_p
+        for i in range(b):
+            if flags[i] & 4:      # :1541
+                raise AssertionError("count_nonzero(all_phrase_weights) != len(linking_score_map)")
+            if flags[i] & 2:      # :1644
+                raise AssertionError(f"No phrases found in the graph for the given facts: {seeds[i]}")
+            if flags[i] & 1:
+                logger.info("No facts found after reranking, return DPR results")      # :468
+            out_rows.append((d_idx[i], d_sc[i], seeds[i]))
+    return out_rows
 
 
 class HippoRAG:
@@ -288,8 +386,9 @@ class HippoRAG:
         if strings:
             if self.embedding_model is None:
                 raise ValueError("embedding_model is required to encode queries")
-            for kind, instr in (("triple", "query_to_fact"), ("passage", "query_to_passage")):
-                embs = self.embedding_model.batch_encode(strings, instruction=instr, norm=True)
+            for kind, method in (("triple", "query_to_fact"), ("passage", "query_to_passage")):   # :1414-1423
+                embs = self.embedding_model.batch_encode(strings, instruction=get_query_instruction(method),
+                                                         norm=True)
                 for s, e in zip(strings, embs):
                     self.query_to_embedding[kind][s] = np.asarray(e, dtype=np.float32)
 
@@ -321,7 +420,7 @@ class HippoRAG:
         if damping is None:
             damping = 0.5
         r = torch.from_numpy(np.asarray(reset_prob, dtype=np.float32).reshape(1, -1))
-        x, flags = self.engine.ppr(r, damping=damping, iters=self.global_config.ppr_iters)
+        x, flags = self.engine.ppr(r, damping=damping, iters=self._ppr_iters(damping))
         if int(flags[0].item()) & 2:
             raise ValueError("reset vector has no positive entry")     # igraph raises here
         doc_scores = x[0].cpu().numpy()[self._arrays["passage_vertex"]]
@@ -345,67 +444,81 @@ class HippoRAG:
         if not self.ready_to_retrieve:
             self.prepare_retrieval_objects()
 
+    def _ppr_iters(self, damping: Optional[float] = None) -> int:
+        cfg = self.global_config
+        return int(cfg.ppr_iters) if cfg.ppr_iters else sweeps_for_damping(cfg.damping if damping is None else damping)
+
     # ------------------------------------------------------------------ retrieve :413-499
     def retrieve(self, queries: List[str], num_to_retrieve: Optional[int] = None,
                  gold_docs: Optional[List[List[str]]] = None):
-        import torch
         t_start = time.time()
         cfg = self.global_config
         if num_to_retrieve is None:
             num_to_retrieve = cfg.retrieval_top_k
         self._ensure_ready()
         self.get_query_embeddings(queries)
-        k_f, n_q = cfg.linking_top_k, len(queries)
-        eng = self.engine
-        k_docs = max(1, min(num_to_retrieve, len(self.passage_node_keys), eng.max_topk))
+        rows = batched_retrieve(self.engine, queries, self._q_tensor, self.facts if self.fact_node_keys else [],
+                                self.rerank_filter, linking_top_k=cfg.linking_top_k, damping=cfg.damping,
+                                passage_node_weight=cfg.passage_node_weight, ppr_iters=self._ppr_iters(),
+                                num_to_retrieve=num_to_retrieve, n_passages=len(self.passage_node_keys), timers=self)
         results: List[QuerySolution] = []
-        for lo in range(0, n_q, eng.max_batch):
-            qs = queries[lo: lo + eng.max_batch]
-            b = len(qs)
-            kept_idx = np.full((b, max(k_f, 1)), -1, np.int32)
-            kept_sc = np.zeros((b, max(k_f, 1)), np.float32)
-            kept_cnt = np.zeros(b, np.int32)
-            seeds: List[List[Tuple]] = [[] for _ in range(b)]
-            t_r = time.time()
-            if len(self.fact_node_keys) > 0 and k_f > 0:
-                idx, sc = eng.score_facts(self._q_tensor(qs, "triple"), k=k_f)         # phase A
-                idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
-                for i, q in enumerate(qs):                                             # host: LLM filter
-                    cand = [int(j) for j in idx_h[i] if j >= 0]
-                    try:
-                        cand_facts = [self.facts[j] for j in cand]
-                        kidx, kfacts, _ = self.rerank_filter(q, cand_facts, cand, len_after_rerank=k_f)
-                    except Exception as exc:                                           # :1705-1707
-                        logger.error("Error in rerank_facts: %s", exc)
-                        kidx, kfacts = [], []
-                    score_of = {j: sc_h[i][p] for p, j in enumerate(idx_h[i]) if j >= 0}
-                    kidx = [j for j in kidx if j in score_of][:k_f]
-                    kept_idx[i, :len(kidx)] = kidx
-                    kept_sc[i, :len(kidx)] = [score_of[j] for j in kidx]
-                    kept_cnt[i] = len(kidx)
-                    seeds[i] = list(kfacts)
-            self.rerank_time += time.time() - t_r
-            t_p = time.time()
-            out = eng.retrieve(self._q_tensor(qs, "passage"), torch.from_numpy(kept_idx),
-                               torch.from_numpy(kept_sc), torch.from_numpy(kept_cnt),
-                               link_top_k=k_f, damping=cfg.damping, passage_node_weight=cfg.passage_node_weight,
-                               ppr_iters=cfg.ppr_iters, k=k_docs)                      # phase B
-            d_idx, d_sc, flags = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy(), out.flags.cpu().numpy()
-            self.ppr_time += time.time() - t_p
-            for i, q in enumerate(qs):
-                if flags[i] & 4:      # :1541
-                    raise AssertionError("count_nonzero(all_phrase_weights) != len(linking_score_map)")
-                if flags[i] & 2:      # :1644
-                    raise AssertionError(f"No phrases found in the graph for the given facts: {seeds[i]}")
-                if flags[i] & 1:
-                    logger.info("No facts found after reranking, return DPR results")   # :468
-                r = self._build_retrieval_result(q, d_idx[i], d_sc[i], num_to_retrieve, seeds[i])
-                results.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
-                                             doc_metadata=r.doc_metadata, graph_seeds=r.graph_seeds))
+        for q, (d_idx, d_sc, seeds) in zip(queries, rows):
+            r = self._build_retrieval_result(q, d_idx, d_sc, num_to_retrieve, seeds)
+            results.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
+                                         doc_metadata=r.doc_metadata, graph_seeds=r.graph_seeds))
         self.all_retrieval_time += time.time() - t_start
         logger.info("Total Retrieval Time %.2fs", self.all_retrieval_time)
         logger.info("Total Recognition Memory Time %.2fs", self.rerank_time)
         logger.info("Total PPR Time %.2fs", self.ppr_time)
+        if gold_docs is not None:
+            return results, self._recall(gold_docs, [r.docs for r in results])
+        return results
+
+    # ------------------------------------------------------------------ retrieve_ircot :509-558
+    def retrieve_ircot(self, queries: List[str], max_qa_steps: int, num_to_retrieve: Optional[int] = None,
+                       gold_docs: Optional[List[List[str]]] = None, reason_fn: Optional[Callable] = None):
+        """Iterative retrieval: alternate retrieval and one reasoning step per query, merging the document
+        scores by max (:526-543).  reason_fn(query, ranked_docs, thoughts) -> str stands for
+        utils/qa_utils.reason_step (the IRCoT prompt + reader LLM are outside this package).  The reference
+        walks the queries one by one and retrieves with a batch of one per step; queries are independent, so
+        here every step retrieves for ALL still-active queries in one batched device call -- same result per
+        query, batch kernels instead of 2 * max_qa_steps single-query passes."""
+        if max_qa_steps < 1:
+            raise ValueError("max_qa_steps must be at least 1.")
+        if max_qa_steps > 1 and reason_fn is None:
+            raise ValueError("retrieve_ircot with max_qa_steps > 1 needs a reason_fn (the reader LLM is outside this package)")
+        if num_to_retrieve is None:
+            num_to_retrieve = self.global_config.retrieval_top_k
+        first = self.retrieve(list(queries), num_to_retrieve=num_to_retrieve)
+        merged = [dict(zip(r.docs, r.doc_scores.tolist())) for r in first]
+        meta = [dict(zip(r.docs, r.doc_metadata or [])) for r in first]
+        thoughts: List[List[str]] = [[] for _ in queries]
+        active = list(range(len(queries)))
+        for _ in range(1, max_qa_steps):
+            step_q, step_i = [], []
+            for i in active:
+                ranked = sorted(merged[i], key=merged[i].get, reverse=True)
+                thought = reason_fn(queries[i], ranked[:num_to_retrieve], thoughts[i])
+                if not isinstance(thought, str):
+                    raise TypeError(f"IRCoT reasoning expected a string response, got {type(thought).__name__}.")
+                thoughts[i].append(thought)
+                if "So the answer is:" in thought:
+                    continue
+                step_q.append(thought)
+                step_i.append(i)
+            if not step_q:
+                break
+            for i, r in zip(step_i, self.retrieve(step_q, num_to_retrieve=num_to_retrieve)):
+                for doc, score in zip(r.docs, r.doc_scores.tolist()):
+                    merged[i][doc] = max(merged[i].get(doc, float("-inf")), score)
+                meta[i].update(dict(zip(r.docs, r.doc_metadata or [])))
+            active = step_i
+        results = []
+        for i, q in enumerate(queries):
+            items = sorted(merged[i].items(), key=lambda kv: kv[1], reverse=True)
+            results.append(QuerySolution(question=q, docs=[d for d, _ in items],
+                                         doc_scores=np.asarray([s for _, s in items]), thoughts=thoughts[i],
+                                         doc_metadata=[meta[i].get(d, {}) for d, _ in items]))
         if gold_docs is not None:
             return results, self._recall(gold_docs, [r.docs for r in results])
         return results
@@ -427,7 +540,11 @@ class HippoRAG:
         self._ensure_ready()
         self.get_query_embeddings(queries)
         eng = self.engine
-        k_docs = max(1, min(num_to_retrieve, len(self.passage_node_keys), eng.max_topk))
+        want = max(1, min(num_to_retrieve, len(self.passage_node_keys)))
+        k_docs = min(want, eng.max_topk)
+        if k_docs < want:
+            logger.warning("num_to_retrieve=%d exceeds the engine's max_topk=%d: %d documents per query are returned",
+                           num_to_retrieve, eng.max_topk, k_docs)
         results = []
         for lo in range(0, len(queries), eng.max_batch):
             qs = queries[lo: lo + eng.max_batch]

@@ -33,14 +33,15 @@ extern "C" {
 #endif
 
 #define HRAG_VERSION_MAJOR 0
-#define HRAG_VERSION_MINOR 2
+#define HRAG_VERSION_MINOR 3
 
 typedef enum hrag_status {
     HRAG_OK = 0,
     HRAG_EINVAL = 1,      /* bad shape / null pointer / unsupported option                    */
     HRAG_ENOMEM = 2,      /* hipMalloc failed                                                  */
     HRAG_EHIP = 3,        /* a HIP runtime call failed; text in hrag_last_error()              */
-    HRAG_EZERO_RESET = 4, /* reset vector without positive mass (HippoRAG.py:1644 assert)      */
+    HRAG_EZERO_RESET = 4, /* reserved: a reset vector without positive mass (HippoRAG.py:1644 assert) is       */
+                          /* reported per query through flags bit 1, never as a status                         */
     HRAG_ECAPACITY = 5    /* batch / k larger than the engine was created for                  */
 } hrag_status;
 
@@ -80,7 +81,7 @@ typedef enum hrag_dtype { HRAG_BF16 = 0, HRAG_FP16 = 1 } hrag_dtype; /* IEEE bin
 typedef struct hrag_embed_desc {
     int64_t rows;
     int64_t row_offset;
-    int32_t dim; /* D, multiple of 32 */
+    int32_t dim; /* D, multiple of 8 */
     hrag_dtype dtype;
     const void *data;
 } hrag_embed_desc;
@@ -99,14 +100,14 @@ typedef struct hrag_fact_desc {
 #define HRAG_OPT_NATURAL_ROW_ORDER 1 /* keep CSR row order instead of degree-descending          */
 #define HRAG_OPT_NT_CSR 2            /* fp32-state kernel: non-temporal loads for the col_idx / val stream */
 #define HRAG_OPT_NT_STORE 4          /* fp32-state kernel: non-temporal stores for the new PPR state       */
-#define HRAG_OPT_F32_STATE 8         /* plain CSR + fp32 slab state only: neither the two-stage fp16   */
-                                     /* state (hrag_retrieve: batch > 8, ppr_iters >= 16) nor the       */
-                                     /* small-batch kernels (batch <= 8); same 1e-5 parity bar          */
+#define HRAG_OPT_F32_STATE 8         /* plain CSR + fp32 slab state only: none of the staged fp8 state  */
+                                     /* (batch > 64), the two-stage fp16 state (batch > 8, ppr_iters    */
+                                     /* >= 16) and the small-batch kernels (batch <= 8); same 1e-5 bar  */
 #define HRAG_OPT_TEMPORAL16 16       /* fp16-state kernels: plain instead of non-temporal (col, val)   */
                                      /* loads and state stores (non-temporal is 3 % faster at cfg 3)   */
 
-#define HRAG_OPT_NO_FP8 32           /* never take the fp8-state PPR (batch > 64, 16 <= ppr_iters <= 30, damping <= 0.7,  */
-                                     /* col_sum given); the fp16 two-stage path serves those batches    */
+#define HRAG_OPT_NO_FP8 32           /* never take the fp8-state PPR (batch > 64, 16 <= ppr_iters <= 30,                 */
+                                     /* damping^ppr_iters <= 2^-18, col_sum given); the fp16 / fp32 state serves instead */
 
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */
@@ -166,6 +167,10 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q_fact_dev, int32_t
  *   doc_score_out_dev fp32 [B, k] PPR probability (or normalised DPR score on fallback)
  *   flags_out_dev    int32 [B]    bit0: DPR fallback used; bit1: reset vector had no mass
  *                                 bit2: the :1541 assert would fire (kept phrase weight 0)
+ *                                 bit3: HRAG_FLAG_FP8_SATURATED -- a value of the fp8-state PPR left the e4m3
+ *                                       range (a static scale bound was violated): this query's scores are
+ *                                       not trustworthy; rerun the batch after
+ *                                       hrag_engine_set_flags(e, HRAG_OPT_NO_FP8, 1)
  *   ppr_iters: fixed number of power iterations (20 in BASELINE.json). */
 hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass_dev, int32_t batch,
                           const int32_t *kept_idx_dev, const float *kept_score_dev,
@@ -283,6 +288,92 @@ hrag_status hrag_stage_doc_scores(hrag_engine *e, const float *x_dev, const doub
                                   int32_t batch, const float *scores_dev, int64_t ld,
                                   const float *min_dev, const float *max_dev, int32_t *flags_dev,
                                   float *out_dev, int64_t out_ld, hrag_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-sharded hot path (multi-GPU): one engine per GPU, each created with the row shard
+ * [row_offset, row_offset + n_rows) of the graph, the passage embeddings of the passages whose
+ * vertex lies in that range (hrag_embed_desc.row_offset / rows must describe exactly those: the
+ * passage prior then never crosses GPUs) and any contiguous slice of the fact embeddings.
+ * The reference has no analogue (HippoRAG.py:459 is a serial loop over queries); this is the layout
+ * BASELINE.json's north star names.  The PPR iterate is the staged e4m3 state of csrc/ppr8.hip,
+ * replicated; after every sweep the host exchanges the owners' row blocks (1 byte per vertex and
+ * query on the wire) -- hipporag_amd/dist.py does it with one RCCL all-gather per exchange group.
+ * Needs hrag_graph_desc.col_sum; damping^ppr_iters <= 2^-18, 16 <= ppr_iters <= 30.
+ *
+ * State buffers (caller-owned, three of them, zero-initialised once): e4m3
+ *   [n_groups][num_vertices + 1][slabs_per_group][128]; query q lives in slab q / 128; slab s in
+ *   group s / slabs_per_group.  Row num_vertices of every group stays zero.  The owned rows of one
+ *   group are ONE contiguous block (own_offset, own_bytes inside the group): with equal-sized shards
+ *   in rank order (own_offset == rank * own_bytes) an in-place all-gather over the first
+ *   world * own_bytes bytes of the group completes the buffer.
+ *
+ * Per batch:  hrag_shard_score_facts -> gather + merge candidates, min / max all-reduce
+ *             hrag_shard_passage_scores -> all-reduce MIN / MAX of mn / mx
+ *             hrag_stage_seeds (replicated)
+ *             hrag_shard_prior_stats -> all-reduce MAX of zmax, SUM of mass
+ *             hrag_shard_ppr_begin -> exchange every group of state[0]
+ *             ppr_iters x n_groups x hrag_shard_ppr_sweep -> exchange group g of state[*exchange_out]
+ *             hrag_shard_finish -> gather + merge the local top-k lists
+ * ------------------------------------------------------------------------------------------ */
+#define HRAG_FLAG_FP8_SATURATED 8
+
+typedef struct hrag_shard_layout {
+    int32_t n_slabs;         /* 128-query slabs of the batch                                   */
+    int32_t n_groups;        /* exchange groups                                                */
+    int32_t slabs_per_group;
+    int32_t reserved;
+    int64_t state_bytes;     /* size of ONE state buffer = n_groups * group_bytes               */
+    int64_t group_bytes;     /* (num_vertices + 1) * slabs_per_group * 128                      */
+    int64_t own_offset;      /* byte offset of the owned rows inside a group                    */
+    int64_t own_bytes;       /* n_rows * slabs_per_group * 128                                  */
+} hrag_shard_layout;
+
+/* want_groups: 0 = one group per slab; otherwise the number of exchange groups asked for (the engine
+ * may return more: a group is limited to 4 GiB and 2^24 vertices). */
+hrag_status hrag_shard_layout_query(hrag_engine *e, int32_t batch, int32_t want_groups,
+                                    hrag_shard_layout *out);
+
+/* local phase A: the k best facts of the owned fact rows per query, RAW cosine scores (global fact
+ * ids, -1 beyond the shard's size) + the local min / max of every score row. */
+hrag_status hrag_shard_score_facts(hrag_engine *e, const uint16_t *q_fact_dev, int32_t batch, int32_t k,
+                                   int32_t *idx_out_dev, float *score_out_dev, float *min_out_dev,
+                                   float *max_out_dev, hrag_stream stream);
+
+/* cosine scores of the owned passages (kept inside the engine) + their local min / max fp32 [B]. */
+hrag_status hrag_shard_passage_scores(hrag_engine *e, const uint16_t *q_pass_dev, int32_t batch,
+                                      float *min_out_dev, float *max_out_dev, hrag_stream stream);
+
+/* given the GLOBAL min / max: zmax_out_dev fp32 [B] (max over the owned passages of the normalised
+ * score / weighted degree) and mass_out_dev double [2 * B] (prior mass, prior mass on isolated
+ * passages) -- all-reduce MAX / SUM them.  flags_dev: bit0 queries carry no prior. */
+hrag_status hrag_shard_prior_stats(hrag_engine *e, const float *min_dev, const float *max_dev,
+                                   float passage_node_weight, const int32_t *flags_dev, int32_t batch,
+                                   float *zmax_out_dev, double *mass_out_dev, hrag_stream stream);
+
+/* reset vector on the owned rows + c_0 into the owned rows of state[0] (all groups). */
+hrag_status hrag_shard_ppr_begin(hrag_engine *e, const float *min_dev, const float *max_dev,
+                                 const float *zmax_dev, const double *mass_dev, float passage_node_weight,
+                                 const int32_t *seed_vtx_dev, const float *seed_w_dev,
+                                 const int32_t *seed_cnt_dev, int32_t *flags_dev, int32_t batch,
+                                 float damping, int32_t ppr_iters, int32_t n_groups, void *state0_dev,
+                                 void *state1_dev, void *state2_dev, hrag_stream stream);
+
+/* sweep `sweep` (0 .. ppr_iters - 1, in order per group) on the owned rows of exchange group `group`;
+ * *exchange_out = index of the state buffer whose owned block of that group was written and must be
+ * exchanged before the group's next sweep (-1 after the last sweep: nothing to exchange). */
+hrag_status hrag_shard_ppr_sweep(hrag_engine *e, int32_t sweep, int32_t group, int32_t *exchange_out,
+                                 hrag_stream stream);
+
+/* doc scores of the owned passages (PPR probability, or the normalised DPR score on the fallback)
+ * and their local top-k: idx_out_dev int32 [B, k] GLOBAL passage positions, score_out_dev fp32 [B, k].
+ * flags_dev is read-modify-written (bit 1). */
+hrag_status hrag_shard_finish(hrag_engine *e, const float *min_dev, const float *max_dev, int32_t *flags_dev,
+                              int32_t batch, int32_t k, int32_t *idx_out_dev, float *score_out_dev,
+                              hrag_stream stream);
+
+/* set / clear HRAG_OPT_* tuning bits after creation (e.g. HRAG_OPT_NO_FP8 to rerun a batch that
+ * reported HRAG_FLAG_FP8_SATURATED on the fp16 / fp32 state). */
+hrag_status hrag_engine_set_flags(hrag_engine *e, int32_t flags, int32_t on);
 
 hrag_status hrag_get_timings(hrag_engine *e, hrag_timings *out); /* synchronises the events */
 hrag_status hrag_set_profiling(hrag_engine *e, int32_t enabled);

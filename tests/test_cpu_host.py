@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hrag_version() == 2            # 0 * 1000 + 2 (hrag_graph_desc.col_sum)
+    assert lib.hrag_version() == _lib.HRAG_VERSION == 3            # 0 * 1000 + 3 (hrag_shard_* entry points)
 
 
 def test_ctypes_structs_match_the_header_layout(tmp_path):
@@ -36,7 +36,8 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     if not shutil.which("gcc"):
         pytest.skip("gcc not available")
     structs = {"hrag_graph_desc": _lib.GraphDesc, "hrag_embed_desc": _lib.EmbedDesc,
-               "hrag_fact_desc": _lib.FactDesc, "hrag_opts": _lib.Opts, "hrag_timings": _lib.Timings}
+               "hrag_fact_desc": _lib.FactDesc, "hrag_opts": _lib.Opts, "hrag_timings": _lib.Timings,
+               "hrag_shard_layout": _lib.ShardLayout}
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "hrag.h"', "int main(void) {"]
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')

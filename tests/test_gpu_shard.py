@@ -1,0 +1,160 @@
+"""Row-sharded hot path (include/hrag.h hrag_shard_*, hipporag_amd/dist.py) on ONE device: the
+`world` shard engines run as threads of this process and meet at barriers (dist.LocalComm), sharing the
+three e4m3 state buffers -- the emulated gather SURVEY.md 8(e) prescribes.  Every output row of every
+sweep is computed by exactly one shard from the same replicated iterate, in the same order of
+additions as the single-GPU kernel, so the result must be BIT-IDENTICAL to the unsharded engine on the
+same (relabelled) index, and within the 1e-5 parity bar of the oracle on the original index."""
+
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from hipporag_amd import synth
+from hipporag_amd.graph import bf16_bits_to_float
+from tests.helpers import make_case, tie_aware_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(bits, device):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).to(device).view(torch.bfloat16)
+
+
+def _run_shards(world, sidx, pass_bits, fact_bits, qf, qp, kw, groups, device, max_topk, filter_fn=None):
+    """All shards of `sidx` as threads on one device; returns rank 0's (fact idx, fact score, doc idx,
+    doc score, flags) and asserts that every rank computed the same replicated result."""
+    import torch
+    from hipporag_amd import dist as hd
+    from hipporag_amd.engine import ShardStages
+    shared, results, errors = {}, [None] * world, []
+    b = qf.shape[0]
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(device)
+            eng = hd.build_shard_engine(sidx, pass_bits, fact_bits, rank, max_batch=b, max_topk=max_topk)
+            rs = hd.ShardedRetriever(ShardStages(eng), hd.LocalComm(rank, world, shared), groups=groups)
+            idx, sc = rs.score_facts(qf, k=5)
+            cnt = torch.full((b,), 5, dtype=torch.int32, device=device)
+            if filter_fn is not None:
+                idx, sc, cnt = filter_fn(idx, sc)
+            d_idx, d_sc, flags = rs.retrieve(qp, idx, sc, cnt, **kw)
+            torch.cuda.synchronize()
+            results[rank] = tuple(t.cpu().numpy() for t in (idx, sc, d_idx, d_sc, flags))
+            shared["_barrier"].wait()          # nobody frees its engine while another shard still runs
+            eng.close()
+        except Exception as exc:               # a dead shard must not leave the others at a barrier for ever
+            errors.append((rank, exc))
+            try:
+                shared["_barrier"].abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    for r in range(1, world):
+        for a, w in zip(results[r], results[0]):
+            np.testing.assert_array_equal(a, w)
+    return results[0]
+
+
+@pytest.mark.parametrize("world,b,groups,iters", [(8, 130, 2, 20), (8, 256, 1, 20), (3, 70, 0, 24), (2, 40, 2, 20)])
+def test_shards_on_one_device_are_bit_identical_to_the_single_gpu_engine(gpu_device, world, b, groups, iters):
+    import torch
+    from hipporag_amd import dist as hd
+    from hipporag_amd.engine import HippoRAGEngine
+    kg, pass_bits, fact_bits, index = make_case(12000, 120000, 128, seed=500 + world, power_law=(world == 3))
+    sidx = hd.shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+    assert sidx.num_vertices % world == 0 and sidx.num_vertices >= kg.num_vertices
+    nnz_shard = [int(sidx.csr.row_ptr[(g + 1) * sidx.rows_per_shard] - sidx.csr.row_ptr[g * sidx.rows_per_shard])
+                 for g in range(world)]
+    assert max(nnz_shard) < 1.02 * (sum(nnz_shard) / world) + 64, nnz_shard      # balanced by construction
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=3)
+    qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=4)
+    qf_t, qp_t = _bf16(qf_bits, gpu_device), _bf16(qp_bits, gpu_device)
+    kw = dict(link_top_k=5, damping=0.5, passage_node_weight=0.05, ppr_iters=iters, k=100)
+    got = _run_shards(world, sidx, pass_bits, fact_bits, qf_t, qp_t, kw, groups, gpu_device, 100)
+    # ---- the single-GPU engine on the same relabelled index (every query on the fp8 state: batch > 64)
+    with HippoRAGEngine(sidx.csr, sidx.passage_vertex, pass_bits, fact_bits, sidx.subj_vertex, sidx.obj_vertex,
+                        sidx.num_chunks, max_batch=max(b, 65), max_topk=100) as eng:
+        idx, sc = eng.score_facts(qf_t, k=5)
+        cnt = torch.full((b,), 5, dtype=torch.int32, device=gpu_device)
+        out = eng.retrieve(qp_t, idx, sc, cnt, **kw)
+        torch.cuda.synchronize()
+        one = tuple(t.cpu().numpy() for t in (idx, sc, out.doc_idx, out.doc_score, out.flags))
+        path_width = eng.timings()["slab_width"]
+    np.testing.assert_array_equal(got[0], one[0])                 # fact ids
+    np.testing.assert_array_equal(got[1], one[1])                 # normalised fact scores, bit for bit
+    assert np.all(got[4] == 0) and np.all(one[4] == 0)
+    if b > 64:
+        assert path_width == 128
+        np.testing.assert_array_equal(got[2], one[2])             # ranked passage positions
+        np.testing.assert_array_equal(got[3], one[3])             # PPR probabilities, bit for bit
+    # ---- and the oracle on the ORIGINAL index (passage positions do not change under the relabelling)
+    qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+    worst = 0.0
+    for q in list(range(0, b, 13)) + [b - 1]:
+        ref = oracle.retrieve_one(index, qf[q], qp[q])
+        assert tie_aware_equal(got[2][q], ref.sorted_doc_ids[:100], ref.sorted_doc_scores[:100], rel_gap=2e-5), q
+        want = ref.x[kg.passage_vertex][got[2][q]]
+        worst = max(worst, float((np.abs(got[3][q] - want) / want).max()))
+    assert worst < 3e-6, worst
+
+
+def test_shards_with_filter_subsets_dpr_fallback_isolated_passages_and_empty_fact_rows(gpu_device):
+    """Rows that keep nothing (DPR ranking), partial filters, passages without any edge (their mass
+    leaves the iteration: the closed-form normalisation must account for it) and a seed that is a
+    passage vertex."""
+    import torch
+    from hipporag_amd import dist as hd
+    world, b = 4, 96
+    kg, pass_bits, fact_bits, index = make_case(6000, 50000, 64, seed=321)
+    # cut every edge of 40 passages: isolated (dangling) passage vertices
+    lonely = kg.passage_vertex[::19][:40]
+    keep = ~(np.isin(kg.src, lonely) | np.isin(kg.dst, lonely))
+    from hipporag_amd.graph import build_csr
+    import dataclasses
+    kg = dataclasses.replace(kg, src=kg.src[keep], dst=kg.dst[keep], weight=kg.weight[keep],
+                             csr=build_csr(kg.num_vertices, kg.src[keep], kg.dst[keep], kg.weight[keep]))
+    subj = kg.subj_vertex.copy()
+    subj[:50] = kg.passage_vertex[:50]          # facts whose subject is a passage vertex
+    kg = dataclasses.replace(kg, subj_vertex=subj)
+    a = oracle.build_symmetric_csr(kg.num_vertices, kg.src, kg.dst, kg.weight)
+    index = dataclasses.replace(index, p=oracle.column_normalize(a), subj_vertex=subj)
+    sidx = hd.shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=7)
+    qf_bits[:10] = fact_bits[:10]               # top fact = one of the passage-subject facts
+    qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=8)
+    rng = np.random.default_rng(1)
+    n_keep = rng.integers(0, 6, b)
+    n_keep[:10] = 5
+
+    def filt(idx, sc):
+        cnt = torch.from_numpy(n_keep.astype(np.int32)).to(idx.device)
+        return idx, sc, cnt                      # the first n entries of every row survive
+
+    kw = dict(link_top_k=5, damping=0.5, passage_node_weight=0.05, ppr_iters=20, k=50)
+    got = _run_shards(world, sidx, pass_bits, fact_bits, _bf16(qf_bits, gpu_device), _bf16(qp_bits, gpu_device),
+                      kw, 2, gpu_device, 50, filter_fn=filt)
+    qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+    pv = kg.passage_vertex
+    for q in range(b):
+        kept = got[0][q][: n_keep[q]].tolist()
+        ref = oracle.retrieve_one(index, qf[q], qp[q], filter_fn=lambda cand, kept=kept: kept)
+        assert bool(got[4][q] & 1) == ref.used_dpr == (n_keep[q] == 0), q
+        assert not (got[4][q] & 8), q
+        want_ids, want_sc = ref.sorted_doc_ids[:50], ref.sorted_doc_scores[:50]
+        if ref.used_dpr:
+            assert tie_aware_equal(got[2][q], want_ids, want_sc, abs_gap=3e-6), q
+            np.testing.assert_allclose(got[3][q], want_sc, rtol=0, atol=3e-6)
+        else:
+            assert tie_aware_equal(got[2][q], want_ids, want_sc, rel_gap=2e-5), q
+            want = ref.x[pv][got[2][q]]
+            assert (np.abs(got[3][q] - want) / want).max() < 1e-5, q

@@ -85,12 +85,9 @@ def _time_launches(fn, n_l):
 
 
 def fp8_mode_counts(iters):
-    """(C, B, B0, F) launches of one retrieve: ppr8_plan in csrc/shard.hip (1, 2, 3.., 4..)."""
-    r = iters - 3
-    b4, a3 = r % 3, (r - 4 * (r % 3)) // 3
-    if a3 >= 4:
-        a3, b4 = a3 - 4, b4 + 3
-    stages = [1, 2] + [3] * a3 + [4] * b4
+    """(C, B, B0, F) launches of one retrieve: ppr8_plan in csrc/shard.hip (1, 2, 3.., remainder)."""
+    left = iters - 3
+    stages = [1, 2] + [3] * (left // 3) + ([left % 3] if left % 3 else [])
     return {"C": sum(m - 1 for m in stages[1:]), "B": len(stages) - 2, "B0": 1, "F": 1}
 
 

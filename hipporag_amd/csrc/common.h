@@ -150,7 +150,7 @@ hrag_status launch_ppr16_seed_rows(const int32_t *seed_vtx, const float *seed_w,
 // ppr8.hip : staged fp8 (e4m3) state + fp32 true residual, 128 queries per 128-byte line, SELL-8 over the
 // OWNED rows (row shard; single GPU: all rows) with the row-normalised values At = D^-1 A
 enum Ppr8Mode { kP8ModeC = 0, kP8ModeB = 1, kP8ModeF = 2, kP8ModeB0 = 3 };   // B0: first boundary, R_in = b v/d
-constexpr int kP8MaxStages = 12;      // stage lengths 1,2,3,..,3,4,..,4 => <= 10 stages for ppr_iters <= 30
+constexpr int kP8MaxStages = 12;      // stage lengths 1,2,3,..,3,(1|2) => <= 11 stages for ppr_iters <= 30
 constexpr float kP8C0Scale = 128.f;   // c_0 = Q(v/d * 2^7),  max(v/d) in (1/2, 1]
 constexpr int32_t kFlagFp8Saturated = 8;   // flags bit 3 (HRAG_FLAG_FP8_SATURATED)
 struct Sell8Dev {
@@ -269,6 +269,8 @@ hrag_status launch_slab_to_rows(const float *slab, int64_t slab_rows, const int3
                                 int64_t ld, const float *alt, int64_t alt_ld, const float *mn,
                                 const float *mx, const int32_t *flags, SlabLayout lay,
                                 hipStream_t s);
+hrag_status launch_gather_rows(const void *emb, const void *fresh, const int32_t *src, int64_t n, int32_t row_bytes,
+                               void *out, hipStream_t s);
 hrag_status launch_fill_i32(int32_t *dst, int32_t value, int64_t n, hipStream_t s);
 hrag_status launch_flag_zero_mass(const double *sums, int32_t batch, int32_t *flags, int32_t bit,
                                   hipStream_t s);

@@ -107,6 +107,20 @@ __global__ __launch_bounds__(256) void slab_to_rows_kernel(
     }
 }
 
+// out[i][:] = src[i] >= 0 ? emb[src[i]][:] : fresh[-src[i] - 1][:]   -- rows of row_bytes (multiple of 16) bytes
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t *__restrict__ emb, const uint8_t *__restrict__ fresh,
+                                                          const int32_t *__restrict__ src, int64_t n, int32_t row_bytes,
+                                                          uint8_t *__restrict__ out) {
+    const int chunks = row_bytes / 16;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = t / chunks;
+    const int c = (int)(t % chunks);
+    if (i >= n) return;
+    const int32_t r = src[i];
+    const uint8_t *from = r >= 0 ? emb + (size_t)r * row_bytes : fresh + (size_t)(-r - 1) * row_bytes;
+    reinterpret_cast<int4 *>(out + (size_t)i * row_bytes)[c] = reinterpret_cast<const int4 *>(from)[c];
+}
+
 __global__ void fill_i32_kernel(int32_t *dst, int32_t value, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = value;
@@ -162,6 +176,17 @@ hrag_status launch_slab_to_rows(const float *slab, int64_t slab_rows, const int3
         default: set_error("unsupported slab width %d", lay.bc); return HRAG_EINVAL;
     }
 #undef CALL
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_gather_rows(const void *emb, const void *fresh, const int32_t *src, int64_t n, int32_t row_bytes,
+                               void *out, hipStream_t s) {
+    if (n <= 0) return HRAG_OK;
+    const int64_t threads = n * (row_bytes / 16);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, s,
+                       static_cast<const uint8_t *>(emb), static_cast<const uint8_t *>(fresh), src, n, row_bytes,
+                       static_cast<uint8_t *>(out));
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

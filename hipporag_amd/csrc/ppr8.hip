@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void ppr8_init_kernel(const Ppr8Args a, float 
     load_zv(a.tele, a.tele_rows, a.row_slot, a.deg, a.n_slabs64, slab, lrow, grow, gl, z);
 #pragma unroll
     for (int j = 0; j < 8; ++j) q[j] = z[j] * c0_scale;
+    if (__builtin_expect(any_sat16(q), 0)) flag_sat16(q, slab, gl, a.batch, a.flags);
     *reinterpret_cast<v4i_t *>(a.y + state_off(a, slab, grow, gl)) = encode16(q);
 }
 

@@ -10,29 +10,32 @@
 
 namespace hrag {
 
-// Stage lengths: 1 (the quantised start), 2, then 3-sweep stages and 4-sweep stages last, where the
-// residual is smallest -- e.g. 20 = 1+2+3+3+3+4+4: 7 stages = 6 boundary sweeps (they carry the fp32
-// residual: 30 instead of 22 bytes per vertex and query) and as accurate as the 1,2,2,3,3,3,3,3 of the
-// first version (tools/exp_fp8_final.py: 2.7e-7 vs 3.5e-7 on the benchmark graph at 20 sweeps).
+// Stage lengths: 1 (the quantised start), 2, then 3-sweep stages, the remainder (1 or 2 sweeps) last --
+// 20 = 1+2+3+3+3+3+3+2.  Why: in exact arithmetic a stage of m sweeps leaves R_new = (aAt)^m R + (R - rt/cs),
+// i.e. the residual contracts by a^m and the e4m3 rounding of the right-hand side (~2^-4.5 |R|) comes on
+// top un-attenuated: a factor (1 + 0.044 / a^m) per stage over the plain iteration.  Stages of 2-3 sweeps
+// minimise the product (measured over star / bipartite / tree / grid / benchmark graphs,
+// tools/exp_fp8_final.py and DESIGN.md section 4: this plan ~1.8x the truncation error of the sweep count on
+// average, 4.2x worst; 4-sweep stages save a boundary sweep each but cost 25 % accuracy), and a short
+// LAST stage keeps the final rounding small.
 int ppr8_plan(int iters, int *plan) {
     int n = 0;
     plan[n++] = 1;
     plan[n++] = 2;
-    const int r = iters - 3;
-    int b = r % 3, a = (r - 4 * b) / 3;
-    if (a >= 4) { a -= 4; b += 3; }
-    for (int i = 0; i < a; ++i) plan[n++] = 3;
-    for (int i = 0; i < b; ++i) plan[n++] = 4;
+    int left = iters - 3;
+    while (left >= 3) { plan[n++] = 3; left -= 3; }
+    if (left > 0) plan[n++] = left;
     return n;
 }
 
 // The truncation error of K sweeps is ~ damping^K of the mass whatever the state type; the staged scheme
-// adds its rounding noise on top (a few 1e-7, independent of K), so it takes a batch when
-// damping^K <= 2^-18 (0.5: K >= 18; 0.3: the minimum of 16; 0.7 needs 35 > 30 sweeps: the fp32 slabs serve).
+// multiplies it by up to ~6 on graphs whose spectrum makes the bound tight (bipartite hubs), so it takes a
+// batch when damping^K <= 2^-20 (0.5: K >= 20; 0.3: the minimum of 16; 0.6: K >= 28; 0.7 would need 39 > 30
+// sweeps: the fp16 / fp32 state serves).
 bool ppr8_usable(const hrag_engine *e, int batch, int iters, float damping) {
     if (!e->f8_ready || (e->opt_flags & HRAG_OPT_NO_FP8) || batch < 1) return false;
     if (iters < 16 || iters > 30 || !(damping >= 0.f)) return false;
-    return std::pow((double)damping, (double)iters) <= 1.0 / 262144.0;
+    return std::pow((double)damping, (double)iters) <= 1.0 / 1048576.0;
 }
 
 hrag_status ppr8_layout(const hrag_engine *e, int32_t batch, int32_t want_groups, hrag_shard_layout *out) {
@@ -92,7 +95,7 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
                        const hrag_shard_layout &lay, uint8_t *const bufs[3], hipStream_t s) {
     HRAG_REQUIRE(ppr8_usable(e, batch, iters, damping),
                  "the fp8-state PPR does not serve ppr_iters=%d at damping %g (needs 16..30 sweeps and "
-                 "damping^ppr_iters <= 2^-18) or the engine has no fp8 state", iters, (double)damping);
+                 "damping^ppr_iters <= 2^-20) or the engine has no fp8 state", iters, (double)damping);
     HRAG_REQUIRE(bufs[0] && bufs[1] && bufs[2] && bufs[0] != bufs[1] && bufs[1] != bufs[2] && bufs[0] != bufs[2],
                  "three distinct state buffers are needed");
     Ppr8Session &p = e->p8;
@@ -339,6 +342,15 @@ hrag_status hrag_shard_finish(hrag_engine *e, const float *mn, const float *mx, 
     HRAG_TRY(ppr8_doc_scores(e, mn, mx, flags, batch, s));
     return launch_row_topk(e->d_doc, batch, e->p_rows, e->ld_p, k, (int32_t)e->p_offset, kNormNone, idx_out,
                            score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes);
+}
+
+hrag_status hrag_engine_gather_embeddings(hrag_engine *e, int32_t which, const int32_t *src_rows, int64_t n,
+                                          const void *new_rows, void *out, hrag_stream stream) {
+    HRAG_REQUIRE(e && src_rows && out && n >= 0, "bad argument");
+    HRAG_REQUIRE(which == 0 || which == 1, "which must be 0 (facts) or 1 (passages)");
+    const void *emb = which == 0 ? (const void *)e->d_femb : (const void *)e->d_pemb;
+    HRAG_REQUIRE(emb != nullptr || (which == 0 ? e->f_rows : e->p_rows) == 0, "engine holds no such embeddings");
+    return launch_gather_rows(emb, new_rows, src_rows, n, e->dim * 2, out, (hipStream_t)stream);
 }
 
 hrag_status hrag_engine_set_flags(hrag_engine *e, int32_t flags, int32_t on) {

@@ -264,6 +264,27 @@ class HippoRAGEngine:
         """Set / clear HRAG_OPT_* bits after creation (e.g. _lib.OPT_NO_FP8 to rerun a saturated batch)."""
         check(self._lib.hrag_engine_set_flags(self._handle, flags, 1 if on else 0))
 
+    def gather_embeddings(self, which: str, src_rows, new_rows=None):
+        """The embedding matrix of the next engine after an index update, composed ON THE DEVICE:
+        out[i] = this engine's row src_rows[i] (>= 0) or new_rows[-src_rows[i] - 1].  new_rows: bf16 / fp16
+        tensor or uint16 bit patterns (host or device).  Returns a device tensor [n, dim] in the engine's dtype."""
+        torch = _torch()
+        src = torch.as_tensor(np.ascontiguousarray(src_rows, dtype=np.int32)).to(self.device)
+        n = int(src.shape[0])
+        fresh = None
+        if new_rows is not None and len(new_rows):
+            obj, rows, dim, dt = _as_16bit(new_rows)
+            if dim != self.dim or (torch.float16 if dt == 1 else torch.bfloat16) != self.emb_dtype:
+                raise ValueError("new rows must match the engine's embedding dim / dtype")
+            fresh = (torch.from_numpy(obj.view(np.int16)) if isinstance(obj, np.ndarray) else obj.view(torch.int16)).to(self.device).contiguous()
+        if n and int(src.min().item()) < 0 and (fresh is None or int((-src.min()).item()) > fresh.shape[0]):
+            raise ValueError("src_rows refers to a new row that was not given")
+        out = torch.empty((n, self.dim), dtype=self.emb_dtype, device=self.device)
+        check(self._lib.hrag_engine_gather_embeddings(self._handle, 0 if which == "facts" else 1, src.data_ptr(), n,
+                                                      fresh.data_ptr() if fresh is not None else None,
+                                                      out.data_ptr(), _stream()))
+        return out
+
     # ------------------------------------------------------------------ row shard (include/hrag.h hrag_shard_*)
     def shard_layout(self, batch: int, groups: int = 0) -> ShardLayout:
         lay = ShardLayout()

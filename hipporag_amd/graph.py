@@ -88,3 +88,72 @@ def float_to_bf16_bits(x: np.ndarray) -> np.ndarray:
 
 def bf16_bits_to_float(b: np.ndarray) -> np.ndarray:
     return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+class IncrementalGraph:
+    """The reference's igraph object as this path needs it: named vertices in insertion order and an
+    undirected MULTI-graph edge list (every add_edges call appends, parallel edges are legal and are summed
+    by build_csr -- exactly what PRPACK sees, HippoRAG.py:1189-1223).  Incremental index() appends vertices
+    and edges (:1159-1223); delete() removes vertices with igraph's renumbering (Graph.delete_vertices,
+    :408): incident edges go, the remaining vertices keep their relative order and become 0..n-1."""
+
+    def __init__(self):
+        self.names: list = []
+        self.index: dict = {}
+        self._src = np.zeros(0, np.int64)
+        self._dst = np.zeros(0, np.int64)
+        self._w = np.zeros(0, np.float64)
+
+    @property
+    def num_vertices(self) -> int:
+        return len(self.names)
+
+    @property
+    def num_edges(self) -> int:
+        return int(self._src.shape[0])
+
+    def edge_list(self):
+        return self._src, self._dst, self._w
+
+    def add_vertices(self, names) -> int:
+        """Append the names that are not vertices yet (add_new_nodes :1159-1187); returns how many were new."""
+        n0 = len(self.names)
+        for nm in names:
+            if nm not in self.index:
+                self.index[nm] = len(self.names)
+                self.names.append(nm)
+        return len(self.names) - n0
+
+    def add_edges(self, pairs, weights) -> int:
+        """Append one edge per (source name, target name) whose endpoints both exist and differ
+        (add_new_edges :1200-1223 drops self pairs and warns about unknown endpoints); returns the number added."""
+        s, d, w = [], [], []
+        for (a, b), wt in zip(pairs, weights):
+            if a == b:
+                continue
+            ia, ib = self.index.get(a), self.index.get(b)
+            if ia is None or ib is None:
+                continue
+            s.append(ia); d.append(ib); w.append(float(wt))
+        self._src = np.concatenate([self._src, np.asarray(s, np.int64)])
+        self._dst = np.concatenate([self._dst, np.asarray(d, np.int64)])
+        self._w = np.concatenate([self._w, np.asarray(w, np.float64)])
+        return len(s)
+
+    def delete_vertices(self, names) -> np.ndarray:
+        """Remove the named vertices and every edge touching them; returns old id -> new id (-1: deleted)."""
+        n = len(self.names)
+        gone = np.zeros(n, dtype=bool)
+        for nm in names:
+            i = self.index.get(nm)
+            if i is not None:
+                gone[i] = True
+        remap = np.where(gone, -1, np.cumsum(~gone) - 1).astype(np.int64)
+        keep_e = ~(gone[self._src] | gone[self._dst]) if self._src.size else np.zeros(0, bool)
+        self._src, self._dst, self._w = remap[self._src[keep_e]], remap[self._dst[keep_e]], self._w[keep_e]
+        self.names = [nm for nm, g in zip(self.names, gone) if not g]
+        self.index = {nm: i for i, nm in enumerate(self.names)}
+        return remap
+
+    def to_csr(self) -> CSRGraph:
+        return build_csr(len(self.names), self._src, self._dst, self._w)

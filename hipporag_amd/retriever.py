@@ -244,55 +244,72 @@ class HippoRAG:
         self.node_name_to_vertex_idx: Dict[str, int] = {}
         self.ent_node_to_chunk_ids: Dict[str, set] = {}
         self.node_to_node_stats: Dict[Tuple[str, str], float] = {}
+        self.proc_triples_to_docs: Dict[Tuple[str, str, str], set] = {}
+        self._chunk_triples: Dict[str, list] = {}          # chunk key -> processed triples (the OpenIE store)
+        self._graph = None                                 # graph.IncrementalGraph (the igraph object)
+        self._pass_emb = self._fact_emb = None             # fp32 rows in store order
         self._arrays = None
 
     # ------------------------------------------------------------------ index side
     def index_from_openie(self, docs: Sequence, chunk_triples: Sequence[Sequence[Sequence[str]]],
                           synonym_edges: Optional[Sequence[Tuple[str, str, float]]] = None,
                           passage_embeddings=None, entity_embeddings=None, fact_embeddings=None):
-        """Build the index from documents and their OpenIE triples (what index() has after the LLM
-        steps, HippoRAG.py:307-335).  Embeddings are taken as given or computed with
-        embedding_model.batch_encode(texts) (embedding_store.py:131)."""
+        """index() after its LLM steps (HippoRAG.py:262-335): documents + their OpenIE triples in, graph /
+        fact / passage arrays out.  Like the reference it is INCREMENTAL: a later call adds the chunks that
+        are new (duplicates collapse on their hash), appends the entities / facts / vertices that did not
+        exist (stores and igraph keep insertion order), and appends edges for the NEW chunks only
+        (add_fact_edges counts a triple only while its chunk is not a graph vertex yet, :899-903;
+        add_passage_edges likewise, :939-947) -- parallel to the existing ones, which is how an entity pair
+        seen again gains weight (igraph multigraph; graph.build_csr sums).  Embeddings are taken as given
+        (rows for the docs of THIS call / for the NEW entities and facts in the order this method appends
+        them) or computed with embedding_model.batch_encode(texts) (embedding_store.py:131)."""
+        from .graph import IncrementalGraph
         chunks = [d if isinstance(d, Chunk) else Chunk(content=d) for d in docs]
         if len(chunks) != len(chunk_triples):
             raise ValueError("one triple list per document")
-        texts, seen = [], {}
-        triples_by_key: Dict[str, list] = {}
-        for ch, tr in zip(chunks, chunk_triples):          # duplicate docs collapse on their hash
+        if self._graph is None:
+            self._graph = IncrementalGraph()
+        g = self._graph
+        new_chunk_keys, new_chunk_rows = [], []
+        for pos, (ch, tr) in enumerate(zip(chunks, chunk_triples)):   # duplicate docs collapse on their hash
             key = compute_mdhash_id(ch.content, "chunk-")
-            if key not in seen:
-                seen[key] = len(texts)
-                texts.append(ch.content)
-                triples_by_key[key] = [tuple(text_processing(list(t))) for t in tr if len(t) == 3]
             meta = dict(ch.metadata)
             if ch.source_id is not None:
                 meta["source_id"] = ch.source_id
             self.chunk_metadata[key] = meta
-        self.passage_texts = texts
-        self.passage_node_keys = list(seen.keys())
-        proc = [triples_by_key[k] for k in self.passage_node_keys]
-        # extract_entity_nodes (misc_utils.py:110-121): sorted unique entities
-        ents = sorted({e for tr in proc for t in tr for e in (t[0], t[2])})
-        self.entity_texts = ents
-        self.entity_node_keys = [compute_mdhash_id(e, "entity-") for e in ents]
-        # flatten_facts (:123-128), deterministic first-occurrence order
-        facts, fseen = [], set()
-        for tr in proc:
+            if key not in self._chunk_triples:
+                self._chunk_triples[key] = [tuple(text_processing(list(t))) for t in tr if len(t) == 3]
+                self.passage_node_keys.append(key)
+                self.passage_texts.append(ch.content)
+                new_chunk_keys.append(key)
+                new_chunk_rows.append(pos)
+        proc_new = [self._chunk_triples[k] for k in new_chunk_keys]
+        # entity / fact stores: insert_strings appends what is missing (:316-320); sorted unique entities
+        # (extract_entity_nodes, misc_utils.py:110-121), facts in first-occurrence order (flatten_facts :123-128)
+        known_e = set(self.entity_node_keys)
+        new_ents = [e for e in sorted({e for tr in proc_new for t in tr for e in (t[0], t[2])})
+                    if compute_mdhash_id(e, "entity-") not in known_e]
+        self.entity_texts += new_ents
+        self.entity_node_keys += [compute_mdhash_id(e, "entity-") for e in new_ents]
+        known_f = set(self.facts)
+        new_facts = []
+        for tr in proc_new:
             for t in tr:
-                if t not in fseen:
-                    fseen.add(t)
-                    facts.append(t)
-        self.facts = facts
-        self.fact_node_keys = [compute_mdhash_id(str(f), "fact-") for f in facts]
-        # graph bookkeeping: add_fact_edges (:867-913) + add_passage_edges (:915-957)
-        self.node_to_node_stats, self.ent_node_to_chunk_ids = {}, {}
-        for chunk_key, tr in zip(self.passage_node_keys, proc):
+                if t not in known_f:
+                    known_f.add(t)
+                    new_facts.append(t)
+        self.facts += new_facts
+        self.fact_node_keys += [compute_mdhash_id(str(f), "fact-") for f in new_facts]
+        # graph bookkeeping: add_fact_edges (:867-913) + add_passage_edges (:915-957), new chunks only
+        self.node_to_node_stats = {}
+        for chunk_key, tr in zip(new_chunk_keys, proc_new):
             in_chunk = set()
             for t in tr:
                 a, b = compute_mdhash_id(t[0], "entity-"), compute_mdhash_id(t[2], "entity-")
                 in_chunk.update((a, b))
                 self.node_to_node_stats[(a, b)] = self.node_to_node_stats.get((a, b), 0.0) + 1
                 self.node_to_node_stats[(b, a)] = self.node_to_node_stats.get((b, a), 0.0) + 1
+                self.proc_triples_to_docs.setdefault(t, set()).add(chunk_key)          # :1353-1361
             for n in in_chunk:
                 self.ent_node_to_chunk_ids.setdefault(n, set()).add(chunk_key)
             for e in sorted({e for t in tr for e in (t[0], t[2])}):
@@ -301,43 +318,116 @@ class HippoRAG:
             ka = compute_mdhash_id(text_processing(a), "entity-")
             kb = compute_mdhash_id(text_processing(b), "entity-")
             self.node_to_node_stats[(ka, kb)] = float(w)
-        # vertices: entities, then passages (add_new_nodes :1171-1175)
-        names = self.entity_node_keys + self.passage_node_keys
-        self.node_name_to_vertex_idx = {n: i for i, n in enumerate(names)}
-        src, dst, wts = [], [], []
-        for (a, b), w in self.node_to_node_stats.items():   # add_new_edges :1200-1223
-            if a == b or a not in self.node_name_to_vertex_idx or b not in self.node_name_to_vertex_idx:
-                continue
-            src.append(self.node_name_to_vertex_idx[a])
-            dst.append(self.node_name_to_vertex_idx[b])
-            wts.append(w)
-        csr = build_csr(len(names), src, dst, wts)
+        if new_chunk_keys:                                 # augment_graph only when chunks were added (:329-335)
+            # vertices: the entity store's rows, then the chunk store's, that are not vertices yet (:1171-1187)
+            g.add_vertices(self.entity_node_keys)
+            g.add_vertices(self.passage_node_keys)
+            g.add_edges(list(self.node_to_node_stats.keys()), list(self.node_to_node_stats.values()))   # :1200-1223
 
-        def embed(given, strings):
+        def embed(given, strings, dim=None):
             if given is not None:
-                return np.asarray(given, dtype=np.float32)
+                given = np.asarray(given, dtype=np.float32)
+                if given.shape[0] != len(strings):
+                    raise ValueError(f"{given.shape[0]} embedding rows for {len(strings)} new strings")
+                return given
+            if not strings:
+                return np.zeros((0, dim or 0), np.float32)
             if self.embedding_model is None:
                 raise ValueError("no embeddings given and no embedding_model to compute them")
             return np.asarray(self.embedding_model.batch_encode(list(strings)), dtype=np.float32)
 
-        pe = embed(passage_embeddings, texts)
-        fe = embed(fact_embeddings, [str(f) for f in facts]) if facts else np.zeros((0, pe.shape[1]), np.float32)
-        self.entity_embeddings = embed(entity_embeddings, ents) if (entity_embeddings is not None or self.embedding_model) and ents else None
-        v = len(names)
-        num_chunks = np.zeros(v, np.int32)
-        for k, s in self.ent_node_to_chunk_ids.items():
-            num_chunks[self.node_name_to_vertex_idx[k]] = len(s)
+        if passage_embeddings is not None:                 # rows of THIS call's docs: keep the new chunks' rows
+            passage_embeddings = np.asarray(passage_embeddings, np.float32)[new_chunk_rows]
+        pe_new = embed(passage_embeddings, [self.passage_texts[self.passage_node_keys.index(k)] for k in new_chunk_keys])
+        dim = pe_new.shape[1] if pe_new.size else (self._pass_emb.shape[1] if self._pass_emb is not None else 0)
+        fe_new = embed(fact_embeddings, [str(f) for f in new_facts], dim)
+        self._pass_emb = pe_new if self._pass_emb is None else np.concatenate([self._pass_emb, pe_new])
+        self._fact_emb = fe_new if self._fact_emb is None or not self._fact_emb.size else (
+            np.concatenate([self._fact_emb, fe_new]) if fe_new.size else self._fact_emb)
+        if entity_embeddings is not None or (self.embedding_model is not None and new_ents):
+            ee_new = embed(entity_embeddings, new_ents, dim)
+            self.entity_embeddings = ee_new if getattr(self, "entity_embeddings", None) is None else (
+                np.concatenate([self.entity_embeddings, ee_new]) if ee_new.size else self.entity_embeddings)
+        elif not hasattr(self, "entity_embeddings"):
+            self.entity_embeddings = None
+        self._refresh_arrays()
+        return self
+
+    def _refresh_arrays(self):
+        """The engine-facing arrays from the current graph / stores (what prepare_retrieval_objects reads,
+        HippoRAG.py:1287-1389)."""
+        g = self._graph
+        self.node_name_to_vertex_idx = dict(g.index)
+        csr = g.to_csr()
+        num_chunks = np.zeros(g.num_vertices, np.int32)
+        for k, srcs in self.ent_node_to_chunk_ids.items():
+            if k in g.index:
+                num_chunks[g.index[k]] = len(srcs)
 
         def vid(phrase):                                   # HippoRAG.py:1584-1597
-            return self.node_name_to_vertex_idx.get(compute_mdhash_id(phrase.lower(), "entity-"), -1)
+            return g.index.get(compute_mdhash_id(phrase.lower(), "entity-"), -1)
 
-        subj = np.array([vid(f[0]) for f in facts], np.int32)
-        obj = np.array([vid(f[2]) for f in facts], np.int32)
-        pv = np.array([self.node_name_to_vertex_idx[k] for k in self.passage_node_keys], np.int32)
-        self._arrays = dict(csr=csr, passage_vertex=pv, passage_emb=float_to_bf16_bits(pe),
-                            fact_emb=float_to_bf16_bits(fe) if len(facts) else None, subj=subj, obj=obj,
+        subj = np.array([vid(f[0]) for f in self.facts], np.int32)
+        obj = np.array([vid(f[2]) for f in self.facts], np.int32)
+        pv = np.array([g.index[k] for k in self.passage_node_keys], np.int32)
+        has_facts = len(self.facts) > 0
+        self._arrays = dict(csr=csr, passage_vertex=pv, passage_emb=float_to_bf16_bits(self._pass_emb),
+                            fact_emb=float_to_bf16_bits(self._fact_emb) if has_facts else None, subj=subj, obj=obj,
                             num_chunks=num_chunks)
         self.ready_to_retrieve = False                      # explicit invalidate hook (SURVEY.md section 5)
+
+    # ------------------------------------------------------------------ delete :337-411
+    def delete(self, docs_to_delete: Sequence[str]):
+        """Remove documents: their chunk vertices, the facts no remaining chunk states, and the entities no
+        remaining chunk mentions (stores, embeddings and graph vertices -- igraph renumbers the rest, :408).
+        Like the reference, edges between entities that survive are NOT decremented (delete only removes
+        vertices), and the surviving entities lose the deleted chunks from ent_node_to_chunk_ids (the
+        divisor of the seed weights, :1600-1601)."""
+        if self._graph is None:
+            return self
+        key_of = {t: k for k, t in zip(self.passage_node_keys, self.passage_texts)}
+        chunk_ids = {key_of[d] for d in docs_to_delete if d in key_of}                 # :351-356
+        if not chunk_ids:
+            return self
+        affected = {t for k in chunk_ids for t in self._chunk_triples[k]}                # :359-374
+        dead_facts = set()
+        for t in affected:
+            left = self.proc_triples_to_docs.get(t, set()) - chunk_ids
+            if left:
+                self.proc_triples_to_docs[t] = left
+            else:
+                self.proc_triples_to_docs.pop(t, None)
+                dead_facts.add(t)
+        dead_ents = set()
+        for e in {x for t in affected for x in (t[0], t[2])}:                            # :377-390
+            k = compute_mdhash_id(e, "entity-")
+            left = self.ent_node_to_chunk_ids.get(k, set()) - chunk_ids
+            if left:
+                self.ent_node_to_chunk_ids[k] = left
+            else:
+                self.ent_node_to_chunk_ids.pop(k, None)
+                dead_ents.add(k)
+        logger.info("Deleting %d Chunks", len(chunk_ids))
+        logger.info("Deleting %d Triples", len(dead_facts))
+        logger.info("Deleting %d Entities", len(dead_ents))
+        keep_p = [i for i, k in enumerate(self.passage_node_keys) if k not in chunk_ids]   # stores (:398-403)
+        keep_f = [i for i, f in enumerate(self.facts) if f not in dead_facts]
+        keep_e = [i for i, k in enumerate(self.entity_node_keys) if k not in dead_ents]
+        self.passage_node_keys = [self.passage_node_keys[i] for i in keep_p]
+        self.passage_texts = [self.passage_texts[i] for i in keep_p]
+        self._pass_emb = self._pass_emb[keep_p]
+        self.facts = [self.facts[i] for i in keep_f]
+        self.fact_node_keys = [self.fact_node_keys[i] for i in keep_f]
+        self._fact_emb = self._fact_emb[keep_f] if self._fact_emb is not None and self._fact_emb.size else self._fact_emb
+        self.entity_texts = [self.entity_texts[i] for i in keep_e]
+        self.entity_node_keys = [self.entity_node_keys[i] for i in keep_e]
+        if getattr(self, "entity_embeddings", None) is not None:
+            self.entity_embeddings = self.entity_embeddings[keep_e]
+        for k in chunk_ids:
+            self._chunk_triples.pop(k, None)
+            self.chunk_metadata.pop(k, None)
+        self._graph.delete_vertices(list(dead_ents) + list(chunk_ids))                  # :408
+        self._refresh_arrays()                                                          # :411 ready_to_retrieve = False
         return self
 
     @classmethod
@@ -358,21 +448,41 @@ class HippoRAG:
 
     # ------------------------------------------------------------------ HippoRAG.py:1287-1389
     def prepare_retrieval_objects(self):
+        """Stage the index on the device.  After an incremental index() / delete() the embedding rows the old
+        engine already holds are gathered device-side into the new matrices (hrag_engine_gather_embeddings):
+        only the rows that are new cross PCIe, the graph (CSR -> SELL-8) is recompiled from the edge list."""
         from .engine import HippoRAGEngine
         if self._arrays is None:
             raise RuntimeError("nothing indexed yet")
-        if self.engine is not None:
-            self.engine.close()
         a = self._arrays
         self.query_to_embedding = {"triple": {}, "passage": {}}
         has_facts = a["fact_emb"] is not None and a["fact_emb"].shape[0] > 0
-        self.engine = HippoRAGEngine(a["csr"], a["passage_vertex"], a["passage_emb"],
-                                     a["fact_emb"] if has_facts else None,
-                                     a["subj"] if has_facts else None, a["obj"] if has_facts else None,
-                                     a["num_chunks"] if has_facts else None,
-                                     max_batch=self.global_config.max_batch,
-                                     max_topk=min(2048, max(self.global_config.retrieval_top_k, 1)),
-                                     slab_width=self.global_config.slab_width)
+        pe, fe = a["passage_emb"], (a["fact_emb"] if has_facts else None)
+        old, held = self.engine, getattr(self, "_engine_rows", None)
+        if old is not None and held is not None and old.dim == a["passage_emb"].shape[1]:
+            def compose(which, keys, bits, held_keys):
+                pos = {k: i for i, k in enumerate(held_keys)}
+                src, fresh = [], []
+                for i, k in enumerate(keys):
+                    if k in pos:
+                        src.append(pos[k])
+                    else:
+                        fresh.append(i)
+                        src.append(-len(fresh))
+                return old.gather_embeddings(which, np.asarray(src, np.int32), bits[fresh] if fresh else None)
+            pe = compose("passages", self.passage_node_keys, a["passage_emb"], held["passages"])
+            if has_facts and held["facts"]:
+                fe = compose("facts", self.fact_node_keys, a["fact_emb"], held["facts"])
+        engine = HippoRAGEngine(a["csr"], a["passage_vertex"], pe, fe,
+                                a["subj"] if has_facts else None, a["obj"] if has_facts else None,
+                                a["num_chunks"] if has_facts else None,
+                                max_batch=self.global_config.max_batch,
+                                max_topk=min(2048, max(self.global_config.retrieval_top_k, 1)),
+                                slab_width=self.global_config.slab_width)
+        if old is not None:
+            old.close()
+        self.engine = engine
+        self._engine_rows = {"passages": list(self.passage_node_keys), "facts": list(self.fact_node_keys) if has_facts else []}
         self.passage_node_idxs = a["passage_vertex"].tolist()
         self.ready_to_retrieve = True
 

@@ -107,7 +107,7 @@ typedef struct hrag_fact_desc {
                                      /* loads and state stores (non-temporal is 3 % faster at cfg 3)   */
 
 #define HRAG_OPT_NO_FP8 32           /* never take the fp8-state PPR (batch > 64, 16 <= ppr_iters <= 30,                 */
-                                     /* damping^ppr_iters <= 2^-18, col_sum given); the fp16 / fp32 state serves instead */
+                                     /* damping^ppr_iters <= 2^-20, col_sum given); the fp16 / fp32 state serves instead */
 
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */
@@ -298,7 +298,7 @@ hrag_status hrag_stage_doc_scores(hrag_engine *e, const float *x_dev, const doub
  * BASELINE.json's north star names.  The PPR iterate is the staged e4m3 state of csrc/ppr8.hip,
  * replicated; after every sweep the host exchanges the owners' row blocks (1 byte per vertex and
  * query on the wire) -- hipporag_amd/dist.py does it with one RCCL all-gather per exchange group.
- * Needs hrag_graph_desc.col_sum; damping^ppr_iters <= 2^-18, 16 <= ppr_iters <= 30.
+ * Needs hrag_graph_desc.col_sum; damping^ppr_iters <= 2^-20, 16 <= ppr_iters <= 30.
  *
  * State buffers (caller-owned, three of them, zero-initialised once): e4m3
  *   [n_groups][num_vertices + 1][slabs_per_group][128]; query q lives in slab q / 128; slab s in
@@ -370,6 +370,15 @@ hrag_status hrag_shard_ppr_sweep(hrag_engine *e, int32_t sweep, int32_t group, i
 hrag_status hrag_shard_finish(hrag_engine *e, const float *min_dev, const float *max_dev, int32_t *flags_dev,
                               int32_t batch, int32_t k, int32_t *idx_out_dev, float *score_out_dev,
                               hrag_stream stream);
+
+/* Index update with the embeddings staying on the device (incremental index() / delete(), HippoRAG.py:262-411:
+ * the reference re-reads everything from its stores in prepare_retrieval_objects): compose the embedding
+ * matrix of the NEXT engine from the rows this engine already holds and the rows that are new,
+ *   out[i] = src_rows_dev[i] >= 0 ? held row src_rows_dev[i] : new_rows_dev[-src_rows_dev[i] - 1],
+ * which: 0 = facts, 1 = passages; rows are dim 16-bit elements; out_dev [n, dim] is caller-owned and can be
+ * handed to hrag_engine_create as hrag_embed_desc.data (device pointers are accepted there). */
+hrag_status hrag_engine_gather_embeddings(hrag_engine *e, int32_t which, const int32_t *src_rows_dev, int64_t n,
+                                          const void *new_rows_dev, void *out_dev, hrag_stream stream);
 
 /* set / clear HRAG_OPT_* tuning bits after creation (e.g. HRAG_OPT_NO_FP8 to rerun a batch that
  * reported HRAG_FLAG_FP8_SATURATED on the fp16 / fp32 state). */

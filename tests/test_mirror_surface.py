@@ -1,0 +1,132 @@
+"""The host-side mirror of the reference surface (hipporag_amd/retriever.py): what it hands to the
+embedding model, how it derives the sweep count, retrieve_ircot, and the behaviour of an index without
+facts.  CPU tests use recording stand-ins; GPU tests run the toy corpus of tests/golden."""
+
+import numpy as np
+import pytest
+
+from hipporag_amd.retriever import (HippoRAG, QuerySolution, RetrievalConfig, get_query_instruction,
+                                    sweeps_for_damping)
+
+
+class RecordingEmbedder:
+    def __init__(self, dim=16):
+        self.calls, self.dim = [], dim
+
+    def batch_encode(self, texts, instruction=None, norm=True):
+        texts = [texts] if isinstance(texts, str) else list(texts)
+        self.calls.append((tuple(texts), instruction, norm))
+        rng = np.random.default_rng(len(texts[0]))
+        v = rng.standard_normal((len(texts), self.dim)).astype(np.float32)
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def test_queries_are_encoded_under_the_references_instruction_sentences():
+    """HippoRAG.py:1414-1423 passes get_query_instruction(...) (prompts/linking.py:1-10), not the lookup
+    key: an instruction-tuned embedder must see the same sentences the reference used."""
+    emb = RecordingEmbedder()
+    rag = HippoRAG(embedding_model=emb)
+    rag.get_query_embeddings(["who founded the company?", QuerySolution(question="where?", docs=[])])
+    assert [c[1] for c in emb.calls] == [
+        "Given a question, retrieve relevant triplet facts that matches this question.",
+        "Given a question, retrieve relevant documents that best answer the question."]
+    assert all(c[0] == ("who founded the company?", "where?") and c[2] is True for c in emb.calls)
+    rag.get_query_embeddings(["where?"])                   # cached: no further encoder call
+    assert len(emb.calls) == 2
+    assert get_query_instruction("query_to_fact").startswith("Given a question, retrieve relevant triplet facts")
+    assert get_query_instruction("anything else") == get_query_instruction("query_to_passage")
+
+
+def test_sweep_count_follows_the_damping_factor():
+    """A fixed 20 sweeps are only enough at the reference's damping 0.5 (0.5^20 ~ 1e-6); the count is
+    derived from damping unless the caller pins it."""
+    assert sweeps_for_damping(0.5) == 20
+    assert sweeps_for_damping(0.85) == 86 and 0.85 ** 86 <= 1e-6 < 0.85 ** 85
+    assert sweeps_for_damping(0.3) == 16                   # never below the 16 the reduced-precision states need
+    assert HippoRAG(RetrievalConfig(damping=0.85))._ppr_iters() == 86
+    assert HippoRAG(RetrievalConfig(damping=0.85, ppr_iters=40))._ppr_iters() == 40
+    assert HippoRAG(RetrievalConfig())._ppr_iters() == 20
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_index_without_facts_returns_dpr_results(gpu_device):
+    """No triples extracted -> no fact store: the reference returns the dense passage ranking
+    (HippoRAG.py:1453-1455, :467-469).  Both through the mirror class and through hrag_retrieve on an
+    engine created without fact_desc (every query takes the fallback, flags bit 0)."""
+    import torch
+    from tests.golden.make_golden import DOCS, QUERIES, MockEmbeddingModel
+    from hipporag_amd.engine import HippoRAGEngine
+    rag = HippoRAG(RetrievalConfig(max_batch=4), embedding_model=MockEmbeddingModel())
+    rag.index_from_openie(DOCS, [[] for _ in DOCS])
+    sols = rag.retrieve(QUERIES, num_to_retrieve=4)
+    dpr = rag.retrieve_dpr(QUERIES, num_to_retrieve=4)
+    for s, d in zip(sols, dpr):
+        assert s.docs == d.docs and len(s.docs) == 4
+        np.testing.assert_allclose(s.doc_scores, d.doc_scores, rtol=0, atol=1e-6)
+        assert s.doc_scores[0] == 1.0
+    # the C entry point itself, wide batch (fp8-capable engine) and narrow batch
+    a = rag._arrays
+    for b in (3, 70):
+        with HippoRAGEngine(a["csr"], a["passage_vertex"], a["passage_emb"], max_batch=b, max_topk=4) as eng:
+            q = torch.randn(b, a["passage_emb"].shape[1], device=gpu_device).to(torch.bfloat16)
+            none_i = torch.zeros((b, 5), dtype=torch.int32, device=gpu_device)
+            none_s = torch.zeros((b, 5), dtype=torch.float32, device=gpu_device)
+            cnt = torch.full((b,), 5, dtype=torch.int32, device=gpu_device)   # ignored: there are no facts
+            out = eng.retrieve(q, none_i, none_s, cnt, k=4)
+            d_idx, d_sc = eng.dense_retrieve(q, k=4)
+            assert torch.all(out.flags == 1)
+            assert torch.equal(out.doc_idx, d_idx) and torch.allclose(out.doc_score, d_sc, atol=1e-6, rtol=0)
+
+
+@pytest.mark.gpu
+def test_gpu_retrieve_ircot_matches_the_per_query_loop(gpu_device):
+    """retrieve_ircot (HippoRAG.py:509-558) steps all queries in lockstep through batched retrievals; the
+    merged rankings must equal the reference's per-query loop (retrieve([query]) / retrieve([thought]) one
+    at a time, max-merge of the scores), including the early stop on 'So the answer is:'."""
+    from tests.golden.make_golden import DOCS, QUERIES, TRIPLES, MockEmbeddingModel
+    rag = HippoRAG(RetrievalConfig(max_batch=4, ppr_iters=40), embedding_model=MockEmbeddingModel())
+    rag.index_from_openie(DOCS, TRIPLES)
+    seen = []
+
+    def reason(query, docs, thoughts):
+        seen.append((query, len(docs), tuple(thoughts)))
+        if QUERIES.index(query) == 1 and len(thoughts) == 1:
+            return "So the answer is: done"
+        return f"thought {len(thoughts)} about {docs[0][:24]} for {query}"
+
+    got = rag.retrieve_ircot(QUERIES, max_qa_steps=3, num_to_retrieve=4, reason_fn=reason)
+    # the reference's control flow, literally (:524-549)
+    for qi, query in enumerate(QUERIES):
+        step = rag.retrieve([query], num_to_retrieve=4)[0]
+        merged = dict(zip(step.docs, step.doc_scores.tolist()))
+        thoughts = []
+        for _ in range(1, 3):
+            ranked = sorted(merged, key=merged.get, reverse=True)
+            thought = reason(query, ranked[:4], thoughts)
+            thoughts.append(thought)
+            if "So the answer is:" in thought:
+                break
+            step = rag.retrieve([thought], num_to_retrieve=4)[0]
+            for doc, score in zip(step.docs, step.doc_scores.tolist()):
+                merged[doc] = max(merged.get(doc, float("-inf")), score)
+        items = sorted(merged.items(), key=lambda kv: kv[1], reverse=True)
+        assert got[qi].question == query and got[qi].thoughts == thoughts
+        assert got[qi].docs == [d for d, _ in items]
+        np.testing.assert_allclose(got[qi].doc_scores, [s for _, s in items], rtol=1e-6)
+    assert len(got[1].thoughts) == 2 and len(got[0].thoughts) == 2
+    with pytest.raises(ValueError):
+        rag.retrieve_ircot(QUERIES, max_qa_steps=0)
+    assert [s.docs for s in rag.retrieve_ircot(QUERIES, max_qa_steps=1, num_to_retrieve=4)] == \
+        [s.docs for s in rag.retrieve(QUERIES, num_to_retrieve=4)]
+
+
+@pytest.mark.gpu
+def test_gpu_num_to_retrieve_beyond_max_topk_warns(gpu_device, caplog):
+    import logging
+    from tests.golden.make_golden import DOCS, QUERIES, TRIPLES, MockEmbeddingModel
+    rag = HippoRAG(RetrievalConfig(max_batch=4, retrieval_top_k=3), embedding_model=MockEmbeddingModel())
+    rag.index_from_openie(DOCS, TRIPLES)
+    with caplog.at_level(logging.WARNING, logger="hipporag_amd"):
+        sols = rag.retrieve(QUERIES[:1], num_to_retrieve=6)
+    assert len(sols[0].docs) == 3 and any("max_topk" in r.message for r in caplog.records)

@@ -22,15 +22,9 @@ from exp_fp8_zspace import graphs, q8  # noqa: E402
 
 
 def plan_for(iters):
-    """stage lengths: [1] + two 2-sweep stages + 3-sweep stages (remainder last) -- ppr8_plan in engine.hip"""
-    plan, left = [1], iters - 1
-    for _ in range(2):
-        if left >= 2:
-            plan.append(2); left -= 2
-    while left > 0:
-        m = min(3, left)
-        plan.append(m); left -= m
-    return plan
+    """stage lengths: 1, 2, 3-sweep stages, remainder last -- ppr8_plan in csrc/shard.hip"""
+    left = iters - 3
+    return [1, 2] + [3] * (left // 3) + ([left % 3] if left % 3 else [])
 
 
 def ppr8(at32, d1, v, alpha, plan):

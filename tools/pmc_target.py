@@ -34,7 +34,11 @@ cnt = torch.full((B,), 5, dtype=torch.int32, device=dev)
 idx, sc = eng.score_facts(qf, k=5)
 eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=200)   # fp8 state for B > 64, fp16 for B > 8, small-batch below
 width = eng.timings()["slab_width"]
-eng.ppr_sweeps(B, 4, 0.5, main_only=True, f8=width == 128, f16=width == 64 and B > 8, small=B <= 8 and width <= 8)
+if width == 128:      # staged fp8 state: every instantiation of ppr8_kernel (template argument = Ppr8Mode: C 0, B 1, F 2, B0 3)
+    for mode in ("C", "B", "B0", "F"):
+        eng.ppr_sweeps(B, 4, 0.5, main_only=True, f8=True, f8_mode=mode)
+else:
+    eng.ppr_sweeps(B, 4, 0.5, main_only=True, f16=width == 64 and B > 8, small=B <= 8 and width <= 8)
 torch.cuda.synchronize()
 eng.close()
 print("pmc target done")

@@ -84,11 +84,27 @@ def _time_launches(fn, n_l):
     return e0.elapsed_time(e1) / n_l
 
 
-def fp8_mode_counts(iters):
-    """(C, B, B0, F) launches of one retrieve: ppr8_plan in csrc/shard.hip (1, 2, 3.., remainder)."""
+def fp8_mode_counts(iters, damping=None):
+    """Launches of one retrieve by kernel instantiation "<mode>" or "<mode>/<residual form>": ppr8_plan and the
+    residual-form schedule of ppr8_begin in csrc/shard.hip (stages 1, 2, 3.., remainder; the residual travels in
+    its 3-byte form once damping^k <= 2^-9)."""
+    damping = DAMPING if damping is None else damping
     left = iters - 3
     stages = [1, 2] + [3] * (left // 3) + ([left % 3] if left % 3 else [])
-    return {"C": sum(m - 1 for m in stages[1:]), "B": len(stages) - 2, "B0": 1, "F": 1}
+    counts = {"C": sum(m - 1 for m in stages[1:]), "B0": 1}
+    k, r16 = 0, False
+    for si, m in enumerate(stages):
+        k += m
+        if si == 0:
+            continue
+        if si + 1 < len(stages):
+            out16 = damping ** k <= 1.0 / 512.0
+            key = f"B/{(1 if r16 else 0) | (2 if out16 else 0)}"
+            counts[key] = counts.get(key, 0) + 1
+            r16 = out16
+        else:
+            counts[f"F/{1 if r16 else 0}"] = 1
+    return counts
 
 
 def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
@@ -101,9 +117,12 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
     f16 = phases["slab_width"] == 64 and B > 32     # ... the two-stage fp16-state path
     per_mode = None
     if f8:
-        per_mode = {m: _time_launches(lambda n, m=m: eng.ppr_sweeps(B, n, DAMPING, f8=True, f8_mode=m), n_l)
-                    for m in ("C", "B", "B0", "F")}
         counts = fp8_mode_counts(PPR_ITERS)
+        per_mode = {}
+        for key in counts:
+            mode, _, rio = key.partition("/")
+            per_mode[key] = _time_launches(lambda n, mode=mode, rio=int(rio or 0): eng.ppr_sweeps(
+                B, n, DAMPING, f8=True, f8_mode=mode, f8_rio=rio), n_l)
         spmm_ms = sum(counts[m] * per_mode[m] for m in counts) / PPR_ITERS
         main_ms = _time_launches(lambda n: eng.ppr_sweeps(B, n, DAMPING, main_only=True, f8=True), n_l)
     else:

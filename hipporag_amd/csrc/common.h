@@ -175,8 +175,10 @@ struct Ppr8Args {
     int64_t group_bytes;       // (V + 1) * row_stride
     const uint8_t *x;          // gather source
     uint8_t *y;                // mode C: the new iterate; mode B: rt of the next stage (owned rows written)
-    const uint8_t *rt;         // mode C: the stage's quantised right-hand side
+    const uint8_t *rt;         // mode C / rio bit 0: the quantised right-hand side of the stage (being closed)
     float *R;                  // true residual, fp32 [n_slabs][n_rows][128] lane-interleaved (LOCAL rows)
+    uint16_t *rho;             // ... or its fp16 remainder next to the fp8 right-hand side (same shape), see rio
+    int32_t rio;               // bit 0: R is read as (rt + rho) / cs; bit 1: R is written as rho (ppr8.hip finish_row)
     float alpha, beta, inv_cs, cs_next;
     const float *tele;         // fp32 [n_slabs64][tele_rows][64]: v at the owned passages, then the seed rows
     int64_t tele_rows;

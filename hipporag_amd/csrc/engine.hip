@@ -32,7 +32,7 @@ void free_engine(hrag_engine *e) {
                     e->d_flags, e->d_seed_w, e->d_colsum_partial, e->d_sums, e->d_partial16, e->d_h16[0],
                     e->d_h16[1], e->d_h16[2], e->d_h16[3], e->d_tele16, e->d_row_slot, e->d_qscale,
                     e->d_ssum, e->d_tele_sv, e->d_partial_sv, e->d_topk_ws, e->d_deg,
-                    e->d_pinvdeg, e->d_R8, e->d_partial8, e->d_fused_ws, e->d_mn_f, e->d_mx_f, e->d_fused_sel,
+                    e->d_pinvdeg, e->d_R8, e->d_rho8, e->d_partial8, e->d_fused_ws, e->d_mn_f, e->d_mx_f, e->d_fused_sel,
                     e->d_xp8, e->d_row_ptele, e->d_iso, e->d_piso, e->d_colmask_static, e->d_colmask,
                     e->d_stagep, e->d_pool8[0], e->d_pool8[1], e->d_pool8[2], e->d_zmax_bits, e->d_zmax,
                     e->d_mass, e->d_prior_part};
@@ -109,6 +109,47 @@ hrag_status build_sell8(const hrag_engine *e, const std::vector<int32_t> &row_pt
     }
     // longest first (stable => deterministic); a chunk = 8 consecutive virtual rows
     std::stable_sort(vr.begin(), vr.end(), [](const VRow &a, const VRow &b) { return a.len > b.len; });
+    if (e->opt_flags & (HRAG_OPT_ROWS_BY_MINCOL | HRAG_OPT_ROWS_BFS)) {
+        // EXPERIMENT ("row order and L2 reuse"): rows of equal length may be processed in any
+        // order, so put rows that share in-neighbours next to each other -- they run on the same XCD at about the
+        // same time and the second one could find the first one's gathered lines in that XCD's L2.
+        //   BY_MINCOL: secondary key = the row's smallest column id;
+        //   BFS:       secondary key = breadth-first rank of the row's vertex (from the vertex of largest degree,
+        //              restarting at the next unvisited vertex), i.e. a Cuthill-McKee-like clustering.
+        std::vector<int32_t> key((size_t)e->n_rows, 0);
+        if (e->opt_flags & HRAG_OPT_ROWS_BFS) {
+            std::vector<int32_t> rank((size_t)e->n_rows, -1), queue;
+            queue.reserve((size_t)e->n_rows);
+            std::vector<int32_t> by_deg((size_t)e->n_rows);
+            std::iota(by_deg.begin(), by_deg.end(), 0);
+            std::stable_sort(by_deg.begin(), by_deg.end(), [&](int32_t a, int32_t b) {
+                return row_ptr[(size_t)a + 1] - row_ptr[(size_t)a] > row_ptr[(size_t)b + 1] - row_ptr[(size_t)b];
+            });
+            int32_t next_rank = 0;
+            for (int32_t root : by_deg) {
+                if (rank[(size_t)root] >= 0) continue;
+                rank[(size_t)root] = next_rank++;
+                queue.push_back(root);
+                for (size_t h = queue.size() - 1; h < queue.size(); ++h) {
+                    const int32_t u = queue[h];
+                    for (int32_t k = row_ptr[(size_t)u]; k < row_ptr[(size_t)u + 1]; ++k) {
+                        const int64_t w = (int64_t)col[k] - e->row_offset;
+                        if (w >= 0 && w < e->n_rows && rank[(size_t)w] < 0) {
+                            rank[(size_t)w] = next_rank++;
+                            queue.push_back((int32_t)w);
+                        }
+                    }
+                }
+            }
+            key = rank;
+        } else {
+            for (int64_t r = 0; r < e->n_rows; ++r)
+                key[(size_t)r] = row_ptr[(size_t)r + 1] > row_ptr[(size_t)r] ? col[row_ptr[(size_t)r]] : 0;   // columns are sorted
+        }
+        std::stable_sort(vr.begin(), vr.end(), [&](const VRow &a, const VRow &b) {
+            return a.len != b.len ? a.len > b.len : key[(size_t)a.row] < key[(size_t)b.row];
+        });
+    }
     const int64_t n_chunks = ceil_div((int64_t)vr.size(), 8);
     std::vector<int2> meta((size_t)n_chunks);
     std::vector<int32_t> vrow((size_t)n_chunks * 8, kVrowNone);
@@ -498,6 +539,7 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     if (e->f8_ready) {
         const int ns = n_slabs128(B);
         E_TRY(dev_alloc(&e->d_R8, (int64_t)ns * std::max<int64_t>(e->n_rows, 1) * 128));
+        E_TRY(dev_alloc(&e->d_rho8, (int64_t)ns * std::max<int64_t>(e->n_rows, 1) * 128));
         E_TRY(dev_alloc(&e->d_partial8, (int64_t)ns * std::max({e->sell.n_partial, e->fsell.n_partial, 1}) * 128));
         E_TRY(dev_alloc(&e->d_stagep, (int64_t)kP8MaxStages * ns * std::max<int64_t>(e->p_rows, 1) * 128));
         E_TRY(dev_alloc(&e->d_xp8, (int64_t)n_slabs64(B) * std::max<int64_t>(e->p_rows, 1) * 64));
@@ -916,8 +958,9 @@ hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damp
         HRAG_REQUIRE(e->f8_ready && e->d_pool8[0] && e->p8.active && e->p8.batch == batch,
                      "no fp8 PPR state for batch %d (needs col_sum, max_batch > 64 and a preceding hrag_retrieve)", batch);
         const int mode = (flags >> 4) & 3;   // 0 = C, 1 = B, 2 = F, 3 = B0 (Ppr8Mode)
+        const int rio = (flags >> 6) & 3;    // residual form of B / F (Ppr8Args.rio)
         for (int it = 0; it < n; ++it)
-            HRAG_TRY(ppr8_bench_sweep(e, mode, it, (flags & 1) != 0, (hipStream_t)stream));
+            HRAG_TRY(ppr8_bench_sweep(e, mode, rio, it, (flags & 1) != 0, (hipStream_t)stream));
         return HRAG_OK;
     }
     if (flags & 2) {

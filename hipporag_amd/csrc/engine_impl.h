@@ -70,8 +70,9 @@ struct Sell8Store {
 struct Ppr8Step {
     int32_t mode;        // Ppr8Mode
     int32_t stage;       // stage the step belongs to (B / B0 / F: the stage being closed)
-    int32_t x, y, rt;    // state buffer indices (y: written = to be exchanged; -1 for mode F; rt: mode C)
+    int32_t x, y, rt;    // state buffer indices (y: written = to be exchanged, -1 for mode F; rt: the stage's rhs)
     float inv_cs, cs_next;
+    int32_t rio;         // residual form of a boundary / final step (Ppr8Args.rio)
 };
 struct Ppr8Session {
     bool active = false;
@@ -144,6 +145,7 @@ struct hrag_engine {
     Sell8Store fsell;             // the owned PASSAGE rows only: the last sweep (mode F)
     int32_t *d_row_ptele = nullptr;   // [n_rows] LOCAL passage number of an owned row (-1: not a passage)
     float *d_deg = nullptr, *d_pinvdeg = nullptr, *d_R8 = nullptr, *d_partial8 = nullptr;
+    uint16_t *d_rho8 = nullptr;    // fp16 remainder of the residual in its 3-byte form, same shape as d_R8
     uint8_t *d_iso = nullptr, *d_piso = nullptr;   // [V] / [p_rows]: vertex (of the passage) has no edges
     uint32_t *d_colmask_static = nullptr, *d_colmask = nullptr;   // [ceil(V / 32)] passage columns (+ seeds)
     int64_t colmask_words = 0;
@@ -204,5 +206,5 @@ hrag_status ppr8_doc_scores(hrag_engine *e, const float *mn, const float *mx, in
                             hipStream_t s);
 // measurement hook: one launch of kernel mode `mode` over the buffers of the active session (it: parity of
 // the ping-pong); results are garbage, the memory traffic is that of a real sweep of that mode
-hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int it, bool main_only, hipStream_t s);
+hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int rio, int it, bool main_only, hipStream_t s);
 }  // namespace hrag

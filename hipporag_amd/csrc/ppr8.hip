@@ -48,7 +48,7 @@
 //     sum(x) is not summed up: P is column-stochastic apart from isolated vertices, whose share is known
 //     sweep by sweep, so the mass of the K-sweep iterate is a closed form of sum(v) (ppr8_scale_kernel);
 //   * c_0 = Q(v/d) is zero outside the passage and seed vertices, so the first sweep (mode B0) tests a
-//     column bitmap and sends every other gather to an all-zero row that stays in the L2.
+//     column bitmap and issues only the gathers of those columns.
 #include "common.h"
 
 namespace hrag {
@@ -146,6 +146,31 @@ __device__ __forceinline__ void gather_step(f32x2_t (&acc)[8], int c, int wbits,
     for (int k = 0; k < 8; ++k) fma16(acc, wk[k], xv[k]);
 }
 
+// Mode B0: the gather of a column whose c_0 row is known to be zero is not issued at all (its lanes are
+// masked off for the load): c_0 is non-zero only at the passage and seed vertices, ~6 % of the entries.
+template <int K>
+struct Gather8M {
+    __device__ __forceinline__ static void load(v4i_t (&xv)[8], float (&wk)[8], int c, int wbits, int on,
+                                                const char *xs, unsigned stride, unsigned lane_off) {
+        const unsigned ck = (unsigned)bcast8<K>(c);
+        wk[K] = __int_as_float(bcast8<K>(wbits));
+        const int onk = bcast8<K>(on);
+        v4i_t v = {0, 0, 0, 0};
+        if (onk) v = *reinterpret_cast<const v4i_t *>(xs + (size_t)(__umul24(ck, stride) + lane_off));
+        xv[K] = v;
+        if constexpr (K + 1 < 8) Gather8M<K + 1>::load(xv, wk, c, wbits, on, xs, stride, lane_off);
+    }
+};
+__device__ __forceinline__ void gather_step_masked(f32x2_t (&acc)[8], int c, int wbits, int on, const char *xs,
+                                                   unsigned stride, unsigned lane_off) {
+    v4i_t xv[8];
+    float wk[8];
+    Gather8M<0>::load(xv, wk, c, wbits, on, xs, stride, lane_off);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fma16(acc, wk[k], xv[k]);
+}
+
 // (col, val) pairs through a buffer descriptor (hipcc keeps raw buffer loads where they are written:
 // see ld_pair in ppr16.hip)
 // plain (cacheable) loads: the workgroup of the next slab re-reads the same blocks from L2, see below
@@ -186,6 +211,33 @@ __device__ __forceinline__ void st16f(float *p, const f32x2_t (&f)[8]) {
     }
 }
 
+// fp16 rows (the remainder rho of the 3-byte residual form, see finish_row): 128 halfs = 16 chunks of 16 bytes,
+// chunk 8 * i + gl holds queries 16 * gl + 8 * i .. + 7 (lane gl's i-th half): every store instruction of an
+// 8-lane group writes one whole 128-byte line, like the fp32 rows above.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void ld16h(const uint16_t *row, int gl, f32x2_t (&f)[8]) {
+    const half8_t *p = reinterpret_cast<const half8_t *>(row) + gl;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const half8_t v = __builtin_nontemporal_load(p + 8 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[4 * i + j] = f32x2_t{(float)v[2 * j], (float)v[2 * j + 1]};
+    }
+}
+__device__ __forceinline__ void st16h(uint16_t *row, int gl, const f32x2_t (&f)[8]) {
+    half8_t *p = reinterpret_cast<half8_t *>(row) + gl;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        half8_t v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[2 * j] = (_Float16)f[4 * i + j].x;
+            v[2 * j + 1] = (_Float16)f[4 * i + j].y;
+        }
+        __builtin_nontemporal_store(v, p + 8 * i);
+    }
+}
+
 // z_v = v / d for one owned row (lrow: LOCAL index, grow: global vertex id): v comes from the teleport
 // rows (fp32 [n_slabs64][tele_rows][64] + row_slot), already scaled per query.
 __device__ __forceinline__ void load_zv(const float *__restrict__ tele, int64_t tele_rows,
@@ -216,7 +268,14 @@ __device__ __forceinline__ size_t state_off(const Ppr8Args &a, int slab, int64_t
 }
 
 // Finish one output row (lrow: LOCAL row): lane gl of its group owns queries 16*gl .. 16*gl+15 of the slab.
-template <int MODE>
+// RIO (boundary / final modes): how the true residual R travels between two boundaries.
+//   bit 0: R_in  = (rt + rho) / cs  -- the stage's quantised right-hand side rt = Q(R cs) (still in its state
+//          buffer: it is only ever read at the own row) plus the fp16 remainder rho = f16(R cs - rt) that
+//          the previous boundary stored: 3 bytes instead of 4, |error| <= 2^-11 |rho| <= 2^-15 |R|;
+//   bit 1: R_out is stored in that form (rho only: the new rt is written anyway).
+// The host switches a boundary to this form once damping^k <= 2^-9 (k = sweeps done), where 2^-15 |R| is
+// below 1e-7 of the solution (csrc/shard.hip); the early boundaries keep the fp32 R.
+template <int MODE, int RIO>
 __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow, int gl,
                                            const f32x2_t (&acc)[8]) {
     const int64_t grow = a.row_offset + lrow;
@@ -234,12 +293,19 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow
         const v4i_t cv = __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(a.x + off));
         decode16(cv, c);
         float *rrow = a.R + ((size_t)slab * a.n_rows + (size_t)lrow) * 128;
+        uint16_t *hrow = a.rho + ((size_t)slab * a.n_rows + (size_t)lrow) * 128;
         const int slot = a.row_slot[lrow];
         const bool is_passage = slot >= 0 && slot < a.p_rows;
         if constexpr (MODE == kP8ModeB0) {
             load_zv(a.tele, a.tele_rows, a.row_slot, a.deg, a.n_slabs64, slab, lrow, grow, gl, rin);   // R_in = b v/d
 #pragma unroll
             for (int j = 0; j < 8; ++j) rin[j] *= a.beta;
+        } else if constexpr ((RIO & 1) != 0) {
+            f32x2_t r8[8];
+            decode16(__builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(a.rt + off)), r8);
+            ld16h(hrow, gl, rin);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rin[j] = (rin[j] + r8[j]) * a.inv_cs;   // inv_cs is a power of two: exact
         } else {
             ld16i(rrow, gl, rin);
         }
@@ -250,12 +316,21 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow
             out[j] = __builtin_elementwise_fma(t, inv, rin[j]);              // inv is a power of two: exact
         }
         if constexpr (MODE == kP8ModeB || MODE == kP8ModeB0) {
-            st16i(rrow, gl, out);
             f32x2_t q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) q[j] = out[j] * a.cs_next;
             if (__builtin_expect(any_sat16(q), 0)) flag_sat16(q, slab, gl, a.batch, a.flags);
-            __builtin_nontemporal_store(encode16(q), reinterpret_cast<v4i_t *>(a.y + off));
+            const v4i_t enc = encode16(q);
+            __builtin_nontemporal_store(enc, reinterpret_cast<v4i_t *>(a.y + off));
+            if constexpr ((RIO & 2) != 0) {
+                f32x2_t back[8];
+                decode16(enc, back);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) back[j] = q[j] - back[j];          // exact: |q - Q(q)| <= 2^-4 |q|
+                st16h(hrow, gl, back);
+            } else {
+                st16i(rrow, gl, out);
+            }
             // the final combine needs every stage's c at the passage rows only: keep a compact copy
             if (is_passage)
                 *reinterpret_cast<v4i_t *>(a.stage_out + ((size_t)slab * a.p_rows + (size_t)slot) * 128 + (size_t)gl * 16) = cv;
@@ -296,7 +371,7 @@ __device__ __forceinline__ int ld_mask(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 // on the same XCD.  They are given the SAME chunk group for consecutive slabs: the second reader of
 // a (col, val) block then finds it in that XCD's L2 (measured: C sweep 0.822 -> 0.802 ms at cfg 3;
 // with non-temporal pair loads the remap alone changes nothing).
-template <int MODE>
+template <int MODE, int RIO>
 __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
@@ -322,16 +397,15 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     int2 p0 = ld_pair(prs, poff, pbase);
     int2 p1 = ld_pair(prs, poff + 512u, pbase);
     if constexpr (MODE == kP8ModeB0) {
-        // c_0 is zero outside the passage / seed vertices: test the column bitmap (one step ahead) and send
-        // the gathers of all other columns to the all-zero row, which never leaves the cache
+        // c_0 is zero outside the passage / seed vertices: test the column bitmap (one step ahead) and issue
+        // only the gathers of those columns
         const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint32_t *>(a.colmask), 0, (int)a.colmask_bytes, 0x00020000);
         int m0 = ld_mask(mrs, ((unsigned)p0.x >> 5) * 4u);
         for (int s = 0; s < n_steps; ++s) {
             const int2 p2 = ld_pair(prs, poff + (unsigned)(s + 2) * 512u, pbase);
             const int m1 = ld_mask(mrs, ((unsigned)p1.x >> 5) * 4u);
-            const int c = ((m0 >> (p0.x & 31)) & 1) ? p0.x : (int)a.zero_row;
-            gather_step(acc, c, p0.y, xs, stride, lane_off);
+            gather_step_masked(acc, p0.x, p0.y, (m0 >> (p0.x & 31)) & 1, xs, stride, lane_off);
             p0 = p1;
             p1 = p2;
             m0 = m1;
@@ -346,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     }
     const int tgt = a.m.vrow[chunk * 8 + grp];
     if (tgt >= 0) {
-        finish_row<MODE>(a, slab, tgt, gl, acc);
+        finish_row<MODE, RIO>(a, slab, tgt, gl, acc);
     } else if (tgt != kVrowNone) {
         st16i(a.partial + ((size_t)slab * a.m.n_partial + (size_t)(-(tgt + 1))) * 128, gl, acc);
     }
@@ -354,7 +428,7 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
 
 // One wavefront per long row: the 8 lane groups stride over the row's partial sums, then the 8
 // group totals are added with xor-shuffles -- a fixed summation order.
-template <int MODE>
+template <int MODE, int RIO>
 __global__ __launch_bounds__(256) void ppr8_reduce_kernel(const Ppr8Args a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
@@ -379,7 +453,7 @@ __global__ __launch_bounds__(256) void ppr8_reduce_kernel(const Ppr8Args a) {
             acc[j].x += __shfl_xor(acc[j].x, o, 64);
             acc[j].y += __shfl_xor(acc[j].y, o, 64);
         }
-    if (grp == 0) finish_row<MODE>(a, slab, a.m.lrow_row[m], gl, acc);
+    if (grp == 0) finish_row<MODE, RIO>(a, slab, a.m.lrow_row[m], gl, acc);
 }
 
 // c_0 = Q(v/d * c0_scale) for every OWNED row of the launch's slabs (R_0 = b v/d is formed on the fly by
@@ -519,17 +593,17 @@ __global__ void ppr8_mask_seeds_kernel(const int32_t *__restrict__ seed_vtx, con
     atomicOr(&colmask[v >> 5], 1u << (v & 31));
 }
 
-template <int MODE>
+template <int MODE, int RIO>
 hrag_status sweep_mode(const Ppr8Args &a, bool main_only, hipStream_t s) {
     if (a.m.n_chunks > 0) {
         const unsigned ncg = (unsigned)ceil_div(a.m.n_chunks, 4);
         // (86 VGPRs = 5 wavefronts per SIMD; 6 measured the same: the sweep is bandwidth-bound)
-        hipLaunchKernelGGL(ppr8_kernel<MODE>, dim3((unsigned)round_up(ncg, 8) * (unsigned)a.n_slabs), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((ppr8_kernel<MODE, RIO>), dim3((unsigned)round_up(ncg, 8) * (unsigned)a.n_slabs), dim3(256), 0, s, a);
         HRAG_LAUNCH_CHECK();
     }
     if (!main_only && a.m.n_lrow > 0) {
         dim3 grid((unsigned)ceil_div(a.m.n_lrow, 4), (unsigned)a.n_slabs);
-        hipLaunchKernelGGL(ppr8_reduce_kernel<MODE>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((ppr8_reduce_kernel<MODE, RIO>), grid, dim3(256), 0, s, a);
         HRAG_LAUNCH_CHECK();
     }
     return HRAG_OK;
@@ -539,13 +613,23 @@ hrag_status sweep_mode(const Ppr8Args &a, bool main_only, hipStream_t s) {
 
 hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, bool main_only, hipStream_t s) {
     if (a.n_slabs <= 0) return HRAG_OK;
+    const int rio = a.rio & 3;
     switch (mode) {
-        case kP8ModeC: return sweep_mode<kP8ModeC>(a, main_only, s);
-        case kP8ModeB: return sweep_mode<kP8ModeB>(a, main_only, s);
-        case kP8ModeB0: return sweep_mode<kP8ModeB0>(a, main_only, s);
-        case kP8ModeF: return sweep_mode<kP8ModeF>(a, main_only, s);
-        default: set_error("bad ppr8 mode %d", mode); return HRAG_EINVAL;
+        case kP8ModeC: return sweep_mode<kP8ModeC, 0>(a, main_only, s);
+        case kP8ModeB0: return sweep_mode<kP8ModeB0, 0>(a, main_only, s);
+        case kP8ModeB:
+            if (rio == 0) return sweep_mode<kP8ModeB, 0>(a, main_only, s);
+            if (rio == 2) return sweep_mode<kP8ModeB, 2>(a, main_only, s);
+            if (rio == 3) return sweep_mode<kP8ModeB, 3>(a, main_only, s);
+            break;
+        case kP8ModeF:
+            if (rio == 0) return sweep_mode<kP8ModeF, 0>(a, main_only, s);
+            if (rio == 1) return sweep_mode<kP8ModeF, 1>(a, main_only, s);
+            break;
+        default: break;
     }
+    set_error("bad ppr8 mode %d / residual form %d", mode, rio);
+    return HRAG_EINVAL;
 }
 
 hrag_status launch_ppr8_init(const Ppr8Args &a, float c0_scale, hipStream_t s) {

@@ -66,7 +66,7 @@ Ppr8Args base_args(const hrag_engine *e) {
     a.partial = e->d_partial8;
     a.row_offset = e->row_offset; a.n_rows = e->n_rows;
     a.spg = p.spg; a.row_stride = (uint32_t)p.spg * 128u; a.group_bytes = p.group_bytes;
-    a.R = e->d_R8;
+    a.R = e->d_R8; a.rho = e->d_rho8; a.rio = 0;
     a.alpha = p.damping; a.beta = 1.0f - p.damping;
     a.tele = e->d_tele16; a.tele_rows = e->tele16_rows; a.n_slabs64 = n_slabs64(p.batch);
     a.row_slot = e->d_row_slot; a.deg = e->d_deg; a.p_rows = e->p_rows;
@@ -121,6 +121,8 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
         return std::ldexp(1.0f, ex);
     };
     int n = 0, c = 0, rt = -1;   // c_0 lives in buffer 0
+    int k_done = 0;              // sweeps completed
+    bool r16 = false;            // the stored residual is in the 3-byte form (rt + fp16 remainder)
     float cs = kP8C0Scale, cs_next = scale_for(plan[1]);
     for (int si = 0; si < n_stage; ++si) {
         const int m = plan[si];
@@ -129,19 +131,28 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
             c = rt;
             for (int j = 1; j < m; ++j) {
                 const int dst = c == rt ? (c + 1) % 3 : 3 - c - rt;
-                p.steps[n++] = Ppr8Step{kP8ModeC, si, c, dst, rt, 0.f, 0.f};
+                p.steps[n++] = Ppr8Step{kP8ModeC, si, c, dst, rt, 0.f, 0.f, 0};
                 c = dst;
+                ++k_done;
             }
             bound *= std::pow(al, m);
             cs_next = si + 1 < n_stage ? scale_for(plan[si + 1]) : 1.0f;
         }
         p.stage_inv[si] = 1.0f / cs;
+        ++k_done;
         if (si + 1 < n_stage) {
-            const int y = (rt >= 0 && c != rt) ? rt : (c + 1) % 3;   // the old right-hand side is dead: R carries it
-            p.steps[n++] = Ppr8Step{si == 0 ? kP8ModeB0 : kP8ModeB, si, c, y, -1, 1.0f / cs, cs_next};
+            // the new right-hand side overwrites the old one in place (row by row: a row only ever reads its own
+            // rt): R, or its fp16 remainder next to rt, carries everything else
+            const int y = (rt >= 0 && c != rt) ? rt : (c + 1) % 3;
+            // residual form: fp32 while it is large; (rt + fp16 remainder) once damping^k <= 2^-9, where the
+            // 2^-15 relative error of that form is below 1e-7 of the solution (ppr8.hip finish_row)
+            const bool out16 = si > 0 && std::pow(al, k_done) <= 1.0 / 512.0;
+            const int rio = (r16 ? 1 : 0) | (out16 ? 2 : 0);
+            p.steps[n++] = Ppr8Step{si == 0 ? kP8ModeB0 : kP8ModeB, si, c, y, rt, 1.0f / cs, cs_next, rio};
+            r16 = out16;
             rt = y;
         } else {
-            p.steps[n++] = Ppr8Step{kP8ModeF, si, c, -1, -1, 1.0f / cs, 1.0f};
+            p.steps[n++] = Ppr8Step{kP8ModeF, si, c, -1, rt, 1.0f / cs, 1.0f, r16 ? 1 : 0};
         }
     }
     HRAG_REQUIRE(n == iters, "internal: stage plan has %d sweeps for ppr_iters=%d", n, iters);
@@ -192,8 +203,12 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
         a.rt = p.buf[st.rt];
     } else if (st.mode == kP8ModeB || st.mode == kP8ModeB0) {
         a.y = p.buf[st.y];
+        a.rt = st.rt >= 0 ? p.buf[st.rt] : nullptr;
+        a.rio = st.rio;
         a.stage_out = stage_copy(e, st.stage);
     } else {   // kP8ModeF: the passage rows only
+        a.rt = st.rt >= 0 ? p.buf[st.rt] : nullptr;
+        a.rio = st.rio;
         a.m = e->fsell.dev_at();
         for (int k = 0; k + 1 < p.n_stage; ++k) a.stage[k] = stage_copy(e, k);
         for (int k = 0; k < p.n_stage; ++k) a.stage_inv[k] = p.stage_inv[k];
@@ -204,7 +219,7 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
     return launch_ppr8_sweep(a, st.mode, false, s);
 }
 
-hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int it, bool main_only, hipStream_t s) {
+hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int rio, int it, bool main_only, hipStream_t s) {
     const Ppr8Session &p = e->p8;
     HRAG_REQUIRE(p.active, "no fp8 PPR session");
     Ppr8Args a = base_args(e);
@@ -212,6 +227,7 @@ hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int it, bool main_only, h
     a.y = p.buf[(it & 1) ^ 1];
     a.rt = p.buf[2];
     a.inv_cs = 1.0f / 64.f; a.cs_next = 64.f;
+    a.rio = (mode == kP8ModeB && (rio == 2 || rio == 3)) || (mode == kP8ModeF && rio == 1) ? rio : 0;
     a.stage_out = stage_copy(e, 0);
     if (mode == kP8ModeF) {
         a.m = e->fsell.dev_at();

@@ -109,6 +109,10 @@ typedef struct hrag_fact_desc {
 #define HRAG_OPT_NO_FP8 32           /* never take the fp8-state PPR (batch > 64, 16 <= ppr_iters <= 30,                 */
                                      /* damping^ppr_iters <= 2^-20, col_sum given); the fp16 / fp32 state serves instead */
 
+#define HRAG_OPT_ROWS_BY_MINCOL 64    /* experiment: SELL-8 rows of equal length ordered by smallest column id  */
+#define HRAG_OPT_ROWS_BFS 128         /* experiment: ... by breadth-first rank (no L2 gain on  */
+                                      /* the benchmark graph; kept for graphs with community structure)           */
+
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */
     int32_t max_topk;     /* largest k_p (retrieval_top_k); <= 2048                              */
@@ -225,8 +229,10 @@ hrag_status hrag_sim_gemm(const uint16_t *emb_dev, int64_t rows, int32_t dim, co
  * flags bit1: the fp16-state kernel of the two-stage scheme (mode H) instead of the fp32 one
  *             (HRAG_EINVAL when the engine has no fp16 state: sharded, max_batch <= 8, F32_STATE);
  * flags bit2: the small-batch kernel (batch <= 8, state fp32 [V][1|2|4|8]);
- * flags bit3: the fp8-state kernel (mode C) over the buffers of the last hrag_retrieve
- *             (HRAG_EINVAL without col_sum / max_batch <= 64 / batch <= 64). */
+ * flags bit3: the fp8-state kernel over the buffers of the last hrag_retrieve (HRAG_EINVAL without col_sum /
+ *             max_batch <= 64 / batch <= 64 / no preceding hrag_retrieve); bits 4-5 pick the instantiation
+ *             (0 stage sweep C, 1 boundary B, 2 final F, 3 first boundary B0), bits 6-7 the residual form of
+ *             B / F (0 fp32, 2 fp32 in / 3-byte out, 3 3-byte in / out; F: 1 = 3-byte in). */
 hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damping, int32_t flags,
                             hrag_stream stream);
 

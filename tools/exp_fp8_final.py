@@ -27,8 +27,9 @@ def plan_for(iters):
     return [1, 2] + [3] * (left // 3) + ([left % 3] if left % 3 else [])
 
 
-def ppr8(at32, d1, v, alpha, plan):
-    """Mirror of ppr8_run (csrc/engine.hip) + the kernels of csrc/ppr8.hip, fp32 arithmetic."""
+def ppr8(at32, d1, v, alpha, plan, rho_form=True):
+    """Mirror of ppr8_begin / ppr8_sweep (csrc/shard.hip) + the kernels of csrc/ppr8.hip, fp32 arithmetic.
+    rho_form: the true residual travels as (rt + fp16 remainder) once damping^k <= 2^-9, like the device."""
     import math
     al, be = np.float32(alpha), np.float32(1 - alpha)
     zv = (v / d1[:, None])
@@ -44,17 +45,27 @@ def ppr8(at32, d1, v, alpha, plan):
         growth = (1 - alpha ** m) / (1 - alpha) if alpha < 1 else m
         return np.float32(2.0 ** math.floor(math.log2(224.0 / (bound * max(growth, 1.0)))))
 
+    k_done, r16, rho, rt = 0, False, None, None
+    cs_next = scale_for(plan[1]) if len(plan) > 1 else np.float32(1)
     for si, m in enumerate(plan):
         if si > 0:
-            cs = scale_for(m)
+            cs = cs_next
             inv = np.float32(1.0) / cs
-            rt = q8(R * cs)
             c = rt
             for _ in range(m - 1):
                 c = q8(al * (at32 @ c) + rt)
             bound *= alpha ** m
-        R = (R + (al * (at32 @ c) - c) * inv).astype(np.float32)
+            cs_next = scale_for(plan[si + 1]) if si + 1 < len(plan) else np.float32(1)
+        k_done += m
+        r_in = ((rt + rho) * inv).astype(np.float32) if r16 else R
+        R = (r_in + (al * (at32 @ c) - c) * inv).astype(np.float32)
         X = X + c.astype(np.float64) * inv
+        if si + 1 < len(plan):
+            q = (R * cs_next).astype(np.float32)
+            rt = q8(q)
+            r16 = rho_form and si > 0 and alpha ** k_done <= 1.0 / 512.0
+            if r16:
+                rho = (q - rt).astype(np.float16).astype(np.float32)
     z = X + R
     x = z * d1[:, None]
     return x / x.sum(0)

@@ -139,13 +139,26 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
     kernel = "ppr8_kernel" if f8 else "ppr16_kernel" if f16 else "ppr_spmm_kernel"
     ppr_iter_ms = phases["ppr_ms"] / PPR_ITERS      # every kernel of the PPR stage (init, reduce) / iterations
     tr = (traffic or {}).get(kernel, {})
+    traffic_bytes = tr.get("bytes_per_launch") if tr.get("workload") == f"{config_name}:B{B}" else None
+    if f8 and traffic_bytes is not None and tr.get("by_instantiation"):
+        # average launch of one retrieve, like `achieved`: instantiation <mode, residual form> weighted by the plan
+        num = {"C": 0, "B": 1, "F": 2, "B0": 3}
+        tot = cnt = 0
+        for key, c in counts.items():
+            mode, _, rio = key.partition("/")
+            inst = tr["by_instantiation"].get(f"<{num[mode]},{int(rio or 0)}>")
+            if inst:
+                tot += c * inst["bytes_per_launch"]
+                cnt += c
+        if cnt == PPR_ITERS:
+            traffic_bytes = tot / cnt
     roofline = {
         "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "frac_definition": ("average launch of one retrieve over the kernel's instantiations (stage plan counts)"
                             if f8 else "average launch of the sweep kernel (+ its long-row reduce)"),
         # PMC traffic is only meaningful for the workload it was collected on (profiles/pmc_traffic.json)
-        "traffic": tr.get("bytes_per_launch") if tr.get("workload") == f"{config_name}:B{B}" else None,
+        "traffic": traffic_bytes,
         "traffic_source": "replayed from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, "
                           "FETCH_SIZE x2-corrected + WRITE_SIZE); not measured in this run",
         "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_definition": "SURVEY 8(d): nnz*8 + (V+1)*4 + 2*V*B*4 + Np*B*4 per PPR iteration",

@@ -35,8 +35,9 @@ idx, sc = eng.score_facts(qf, k=5)
 eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=200)   # fp8 state for B > 64, fp16 for B > 8, small-batch below
 width = eng.timings()["slab_width"]
 if width == 128:      # staged fp8 state: every instantiation of ppr8_kernel (template argument = Ppr8Mode: C 0, B 1, F 2, B0 3)
-    for mode in ("C", "B", "B0", "F"):
-        eng.ppr_sweeps(B, 4, 0.5, main_only=True, f8=True, f8_mode=mode)
+    # ... and the residual forms of B / F (second template argument: 0 fp32, 2 fp32 in / 3-byte out, 3 3-byte, F: 1)
+    for mode, rio in (("C", 0), ("B0", 0), ("B", 0), ("B", 2), ("B", 3), ("F", 1)):
+        eng.ppr_sweeps(B, 4, 0.5, main_only=True, f8=True, f8_mode=mode, f8_rio=rio)
 else:
     eng.ppr_sweeps(B, 4, 0.5, main_only=True, f16=width == 64 and B > 8, small=B <= 8 and width <= 8)
 torch.cuda.synchronize()

@@ -67,13 +67,19 @@ def main():
         json.dump(out, open(dst + "_pmc.json", "w"), indent=1, sort_keys=True)
         # what bench.py's roofline.traffic reads: HBM bytes per launch of each SpMM kernel, latest run
         traffic, seen = {}, {}
+        inst8 = {}    # ppr8_kernel<mode, residual form> -> HBM bytes per launch (bench.py weights them by the stage plan)
         for k, d in out.items():
             base = k.split("::")[-1].split("<")[0]
+            if base == "ppr8_kernel" and "bytes_per_launch" in d and "<" in k:
+                inst8[k[k.index("<"):].replace(" ", "")] = {"bytes_per_launch": d["bytes_per_launch"],
+                                                            "l2_hit_rate": d.get("l2_hit_rate")}
             n = d["launches"].get("FETCH_SIZE", 0)
             if "bytes_per_launch" in d and base in ("ppr8_kernel", "ppr16_kernel", "ppr_spmm_kernel") and n > seen.get(base, 0):
                 seen[base] = n      # the variant with the most launches (mode H for ppr16_kernel, C for ppr8_kernel)
                 traffic[base] = {"bytes_per_launch": d["bytes_per_launch"], "l2_hit_rate": d.get("l2_hit_rate"),
                                  "workload": workload, "source": os.path.basename(dst) + "_pmc.json"}
+        if inst8 and "ppr8_kernel" in traffic:
+            traffic["ppr8_kernel"]["by_instantiation"] = inst8
         if traffic:
             tp = os.path.join(os.path.dirname(dst) or ".", "pmc_traffic.json")
             old = json.load(open(tp)) if os.path.exists(tp) else {}

@@ -199,6 +199,7 @@ struct Ppr8Args {
     int32_t *flags;            // [batch] bit 3 is set when a value had to be clamped to the e4m3 range
     int32_t batch;
     int32_t slab0, n_slabs;    // 128-query slabs covered by this launch
+    int32_t wps;               // slabs handled inside one workgroup (1, 2 or 4 wavefronts per chunk); 0 / 1 = one
 };
 hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, bool main_only, hipStream_t s);
 // c_0 = Q(v/d * c0_scale) on the owned rows of slabs [slab0, slab0 + n_slabs)
@@ -282,6 +283,13 @@ hrag_status launch_flag_zero_mass(const double *sums, int32_t batch, int32_t *fl
 hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
                             int32_t batch, float *out, int64_t ld, hipStream_t s, int32_t accumulate = 0,
                             int32_t dtype = HRAG_BF16);
+
+// sim_gemm256.hip : the same scores (bit-identical) for batch > 64, dim % 64 == 0, rows >= 256: 256-row x
+// (128 | 256)-query workgroup tiles, LDS-direct loads, 128 x (64 | 128) wave tiles
+bool sim_gemm256_serves(int64_t rows, int32_t dim, int32_t batch);
+bool sim_gemm_force_small_tiles();
+hrag_status launch_sim_gemm256(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch,
+                               float *out, int64_t ld, float *tmax, float *tmin, hipStream_t s, int32_t dtype);
 
 // fused similarity + top-k for k <= 16 (no [B, rows] score matrix; bit-identical to the two-step path)
 //   ws: 2 * sim_fused_tiles(rows) * batch floats; sel: batch * 16 ints; mn / mx: batch floats

@@ -375,10 +375,12 @@ template <int MODE, int RIO>
 __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
-    const int id = blockIdx.x, ns = a.n_slabs;
-    const int slab = a.slab0 + (id >> 3) % ns;
-    const int cg = (id / (8 * ns)) * 8 + (id & 7);
-    const int chunk = __builtin_amdgcn_readfirstlane(cg * 4 + (threadIdx.x >> 6));
+    // a workgroup = 4 wavefronts = (4 / wps) chunks x wps slabs: the wavefronts that work on the same chunk for
+    // different slabs read the same (col, val) blocks at about the same time from the same CU
+    const int id = blockIdx.x, wps = a.wps, nsg = a.n_slabs / wps, wave = threadIdx.x >> 6;
+    const int slab = a.slab0 + ((id >> 3) % nsg) * wps + (wave & (wps - 1));
+    const int cg = (id / (8 * nsg)) * 8 + (id & 7);
+    const int chunk = __builtin_amdgcn_readfirstlane(cg * (4 / wps) + wave / wps);
     if (chunk >= a.m.n_chunks) return;
     const int2 meta = a.m.chunk_meta[chunk];  // (first step, number of steps)
     const int n_steps = meta.y;
@@ -596,9 +598,12 @@ __global__ void ppr8_mask_seeds_kernel(const int32_t *__restrict__ seed_vtx, con
 template <int MODE, int RIO>
 hrag_status sweep_mode(const Ppr8Args &a, bool main_only, hipStream_t s) {
     if (a.m.n_chunks > 0) {
-        const unsigned ncg = (unsigned)ceil_div(a.m.n_chunks, 4);
         // (86 VGPRs = 5 wavefronts per SIMD; 6 measured the same: the sweep is bandwidth-bound)
-        hipLaunchKernelGGL((ppr8_kernel<MODE, RIO>), dim3((unsigned)round_up(ncg, 8) * (unsigned)a.n_slabs), dim3(256), 0, s, a);
+        Ppr8Args b = a;
+        b.wps = (a.wps == 4 && a.n_slabs % 4 == 0) ? 4 : (a.wps >= 2 && a.n_slabs % 2 == 0) ? 2 : 1;
+        const unsigned ncg = (unsigned)ceil_div(a.m.n_chunks, 4 / b.wps);
+        hipLaunchKernelGGL((ppr8_kernel<MODE, RIO>), dim3((unsigned)round_up(ncg, 8) * (unsigned)(a.n_slabs / b.wps)),
+                           dim3(256), 0, s, b);
         HRAG_LAUNCH_CHECK();
     }
     if (!main_only && a.m.n_lrow > 0) {

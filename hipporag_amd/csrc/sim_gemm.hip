@@ -17,6 +17,8 @@
 // MFMA block (T14 split), LDS rows padded to 144 bytes (conflict-free ds_read_b128 for 16 rows).
 // The embedding matrix is streamed from HBM once: the BN-tiles of one row tile are adjacent in
 // dispatch order so that they meet in the Infinity Cache.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hrag {
@@ -366,6 +368,13 @@ __global__ __launch_bounds__(256) void tile_rescore_kernel(const uint16_t *__res
 
 int64_t sim_fused_tiles(int64_t rows) { return ceil_div(rows, BM); }
 
+// A/B switch for measurements and for the bit-identity test of the two GEMM kernels: HRAG_SIM_SMALL_TILES=1 in the
+// environment keeps every shape on sim_gemm_kernel (read once)
+bool sim_gemm_force_small_tiles() {
+    static const bool v = [] { const char *e = getenv("HRAG_SIM_SMALL_TILES"); return e && e[0] == '1'; }();
+    return v;
+}
+
 // ws: 2 * tiles * batch floats (tile max / min) ; sel: batch * 16 ints ; mn / mx: batch floats
 hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
                                   int32_t batch, int32_t k, int32_t idx_offset, int32_t normalize,
@@ -389,7 +398,9 @@ hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim
             hipLaunchKernelGGL((sim_gemm_kernel<BN_, WM_, WN_, true, false>), grid, dim3(256), 0, s, emb, rows, \
                                dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);                                 \
     } while (0)
-    if (batch > 64) LAUNCH_TM(128, 2, 2);
+    if (sim_gemm256_serves(rows, dim, batch) && !(sim_gemm_force_small_tiles()))
+        HRAG_TRY(launch_sim_gemm256(emb, rows, dim, q, batch, nullptr, 0, tmax, tmin, s, dtype));
+    else if (batch > 64) LAUNCH_TM(128, 2, 2);
     else LAUNCH_TM(64, 4, 1);
 #undef LAUNCH_TM
     HRAG_LAUNCH_CHECK();
@@ -420,6 +431,8 @@ hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, cons
         HRAG_LAUNCH_CHECK();
         return HRAG_OK;
     }
+    if (!accumulate && sim_gemm256_serves(rows, dim, batch) && !sim_gemm_force_small_tiles())
+        return launch_sim_gemm256(emb, rows, dim, q, batch, out, ld, nullptr, nullptr, s, dtype);
     const int64_t tiles_m = ceil_div(rows, BM);
     const bool f16 = dtype == HRAG_FP16;
 #define LAUNCH(BN_, WM_, WN_, GRID, TN)                                                                       \

@@ -113,6 +113,9 @@ typedef struct hrag_fact_desc {
 #define HRAG_OPT_ROWS_BFS 128         /* experiment: ... by breadth-first rank (no L2 gain on  */
                                       /* the benchmark graph; kept for graphs with community structure)           */
 
+#define HRAG_OPT_SLABS_PER_WG_1 256   /* fp8 sweep: one slab per workgroup (4 chunks) instead of the wavefronts of a   */
+                                      /* workgroup sharing a chunk's (col, val) stream across 2 / 4 slabs             */
+
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */
     int32_t max_topk;     /* largest k_p (retrieval_top_k); <= 2048                              */

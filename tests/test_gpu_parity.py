@@ -743,3 +743,31 @@ def test_retrieve_on_graph_with_dangling_hub_and_parallel_edges(gpu_device, b):
             assert tie_aware_equal(got_idx[q], ref.sorted_doc_ids[:100], ref.sorted_doc_scores[:100], rel_gap=2e-5), (flags, q)
             want = ref.x[pv][got_idx[q]]
             assert (np.abs(got_sc[q] - want) / want).max() < 1e-5, (flags, q)
+
+
+# ----------------------------------------------------------------------------- wide-batch GEMM (sim_gemm256.hip)
+@pytest.mark.parametrize("rows,dim,batch", [(5000, 768, 256), (300, 64, 65), (1029, 128, 130), (40000, 1024, 200),
+                                            (256, 64, 128), (777, 192, 129)])
+def test_sim_gemm256_is_bit_identical_to_the_small_tile_kernel(gpu_device, rows, dim, batch):
+    """batch > 64 with dim % 64 == 0 takes the 256-row workgroup tile with LDS-direct loads; every score must be
+    the same chain of MFMAs as in sim_gemm_kernel (the fused top-k's rescore kernel depends on it).  The
+    accumulate path (out += product) always runs the small-tile kernel: into a zeroed buffer it yields that
+    kernel's plain result."""
+    import ctypes as C
+    import torch
+    from hipporag_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=gpu_device)
+    g.manual_seed(rows + batch)
+    emb = torch.randn((rows, dim), generator=g, device=gpu_device).to(torch.bfloat16).contiguous()
+    q = torch.randn((batch, dim), generator=g, device=gpu_device).to(torch.bfloat16).contiguous()
+    ld = rows + (-rows) % 4
+    new = torch.full((batch, ld), float("nan"), device=gpu_device)
+    old = torch.zeros((batch, ld), device=gpu_device)
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.hrag_sim_gemm(emb.data_ptr(), rows, dim, q.data_ptr(), batch, new.data_ptr(), ld, 0, stream))
+    _lib.check(lib.hrag_sim_gemm(emb.data_ptr(), rows, dim, q.data_ptr(), batch, old.data_ptr(), ld, 1, stream))
+    torch.cuda.synchronize()
+    assert torch.equal(new[:, :rows], old[:, :rows])
+    want = q.double() @ emb.double().T
+    assert float((new[:, :rows].double() - want).abs().max()) < 3e-4 * float(want.abs().max() + 1)

@@ -15,7 +15,7 @@ HRAG_VERSION = 3      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of includ
 FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, FLAG_FP8_SATURATED = 1, 2, 4, 8
 # hrag_opts.flags (include/hrag.h HRAG_OPT_*)
 OPT_NATURAL_ROW_ORDER, OPT_NT_CSR, OPT_NT_STORE, OPT_F32_STATE, OPT_TEMPORAL16, OPT_NO_FP8 = 1, 2, 4, 8, 16, 32
-OPT_ROWS_BY_MINCOL, OPT_ROWS_BFS = 64, 128
+OPT_ROWS_BY_MINCOL, OPT_ROWS_BFS, OPT_SLABS_PER_WG_1, OPT_FP8_MARGIN = 64, 128, 256, 512
 
 
 class HragError(RuntimeError):

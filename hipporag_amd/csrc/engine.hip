@@ -775,6 +775,8 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     hipStream_t s = (hipStream_t)stream;
     const bool sv = use_sv(e, batch);
     const bool f8 = !sv && batch > 64 && e->d_pool8[0] && ppr8_usable(e, batch, ppr_iters, damping);
+    // HRAG_OPT_FP8_MARGIN: two sweeps more than asked for on the fp8 state (accuracy margin, see hrag.h)
+    const int f8_iters = (f8 && (e->opt_flags & HRAG_OPT_FP8_MARGIN) && ppr_iters + 2 <= 30) ? ppr_iters + 2 : ppr_iters;
     const bool f16 = !sv && !f8 && use_f16(e, batch, ppr_iters);
     const int bp = sv_width(batch);
     SlabLayout lay = e->layout(batch);
@@ -805,7 +807,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
         HRAG_TRY(ppr8_layout(e, batch, 0, &sl));
         HRAG_TRY(ppr8_prior(e, e->d_mn_p, e->d_mx_p, passage_node_weight, e->d_flags, batch, e->d_zmax, e->d_mass, s));
         HRAG_TRY(ppr8_begin(e, e->d_mn_p, e->d_mx_p, e->d_zmax, e->d_mass, passage_node_weight, e->d_seed_vtx,
-                            e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, damping, ppr_iters, sl, e->d_pool8, s));
+                            e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, damping, f8_iters, sl, e->d_pool8, s));
     } else if (f16) {
         // v is scaled per query by a power of two so that every iterate fits fp16 (ppr16.hip); the seeds
         // become extra teleport rows, i.e. v is one array that every sweep reads identically
@@ -838,7 +840,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SEED], s));
     // PPR (HippoRAG.py:1736-1743): fixed-count leaky power iteration
     if (f8) {
-        for (int it = 0; it < ppr_iters; ++it) HRAG_TRY(ppr8_sweep(e, it, -1, nullptr, s));
+        for (int it = 0; it < f8_iters; ++it) HRAG_TRY(ppr8_sweep(e, it, -1, nullptr, s));
     } else if (f16) {
         HRAG_TRY(ppr16_run(e, batch, damping, ppr_iters, s));
     } else if (sv) {

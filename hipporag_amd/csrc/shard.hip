@@ -372,8 +372,9 @@ hrag_status hrag_engine_gather_embeddings(hrag_engine *e, int32_t which, const i
 
 hrag_status hrag_engine_set_flags(hrag_engine *e, int32_t flags, int32_t on) {
     HRAG_REQUIRE(e != nullptr, "engine is NULL");
-    const int32_t runtime = HRAG_OPT_NO_FP8 | HRAG_OPT_NT_CSR | HRAG_OPT_NT_STORE | HRAG_OPT_TEMPORAL16 | HRAG_OPT_SLABS_PER_WG_1;
-    HRAG_REQUIRE((flags & ~runtime) == 0, "only HRAG_OPT_NO_FP8 / NT_CSR / NT_STORE / TEMPORAL16 can change after creation");
+    const int32_t runtime = HRAG_OPT_NO_FP8 | HRAG_OPT_NT_CSR | HRAG_OPT_NT_STORE | HRAG_OPT_TEMPORAL16 | HRAG_OPT_SLABS_PER_WG_1 |
+                            HRAG_OPT_FP8_MARGIN;
+    HRAG_REQUIRE((flags & ~runtime) == 0, "only HRAG_OPT_NO_FP8 / NT_CSR / NT_STORE / TEMPORAL16 / SLABS_PER_WG_1 / FP8_MARGIN can change after creation");
     if (on) e->opt_flags |= flags; else e->opt_flags &= ~flags;
     return HRAG_OK;
 }

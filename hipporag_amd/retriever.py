@@ -134,6 +134,8 @@ class RetrievalConfig:
     ppr_iters: Optional[int] = None      # None: derived from damping (sweeps_for_damping: 20 at 0.5)
     max_batch: int = 256
     slab_width: int = 0
+    fp8_margin: bool = True              # HRAG_OPT_FP8_MARGIN: +2 sweeps on the fp8 PPR state (accuracy margin on
+                                         # bipartite-hub graphs, +8 % PPR time); benchmarks run the raw engine
 
 
 def identity_rerank_filter(query, candidate_items, candidate_indices, len_after_rerank=None):
@@ -452,6 +454,7 @@ class HippoRAG:
         engine already holds are gathered device-side into the new matrices (hrag_engine_gather_embeddings):
         only the rows that are new cross PCIe, the graph (CSR -> SELL-8) is recompiled from the edge list."""
         from .engine import HippoRAGEngine
+        from ._lib import OPT_FP8_MARGIN
         if self._arrays is None:
             raise RuntimeError("nothing indexed yet")
         a = self._arrays
@@ -478,7 +481,8 @@ class HippoRAG:
                                 a["num_chunks"] if has_facts else None,
                                 max_batch=self.global_config.max_batch,
                                 max_topk=min(2048, max(self.global_config.retrieval_top_k, 1)),
-                                slab_width=self.global_config.slab_width)
+                                slab_width=self.global_config.slab_width,
+                                flags=OPT_FP8_MARGIN if self.global_config.fp8_margin else 0)
         if old is not None:
             old.close()
         self.engine = engine

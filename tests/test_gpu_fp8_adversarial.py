@@ -148,6 +148,37 @@ def test_fp8_state_on_adversarial_graphs_all_passages(gpu_device, name, b):
         assert worst8 < 1e-5, (name, b, worst8)
 
 
+def test_margin_sweeps_restore_the_distance_to_the_bar_on_the_star_forest(gpu_device):
+    """HRAG_OPT_FP8_MARGIN: two sweeps more on the fp8 state (the mirror class sets it).  On the star forest -- the
+    case that sits AT the 1e-5 bar with the plain sweep count -- the error must drop by about damping^-2 = 4."""
+    import torch
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd._lib import OPT_FP8_MARGIN
+    n, src, dst, w, pv, pinned = _stars()
+    csr, pass_bits, fact_bits, index = _index(n, src, dst, w, pv, 64, seed=11)
+    b, n_p = 65, len(pv)
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=5)
+    qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=6)
+    qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+    worst = {}
+    for name, flags in (("plain", 0), ("margin", OPT_FP8_MARGIN)):
+        with HippoRAGEngine(csr, index.passage_vertex, pass_bits, fact_bits, index.subj_vertex, index.obj_vertex,
+                            index.num_chunks, max_batch=b, max_topk=n_p, flags=flags) as eng:
+            idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
+            out = eng.retrieve(_bf16(qp_bits, gpu_device), idx, sc, _t(np.full(b, 5, np.int32), gpu_device), ppr_iters=20, k=n_p)
+            torch.cuda.synchronize()
+            assert eng.timings()["slab_width"] == 128 and np.all(out.flags.cpu().numpy() == 0)
+            got_idx, got_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+        err = 0.0
+        for q in range(0, b, 5):
+            want = oracle.retrieve_one(index, qf[q], qp[q]).x[index.passage_vertex]
+            full = np.empty(n_p)
+            full[got_idx[q]] = got_sc[q]
+            err = max(err, float(np.abs(full / want - 1).max()))
+        worst[name] = err
+    assert worst["margin"] < 5e-6 and worst["margin"] < 0.5 * worst["plain"], worst
+
+
 def _small_engine_inputs(b, device):
     kg = synth.make_kg(4000, 40000, 9)
     pass_bits = synth.make_embeddings_np(kg.n_passages, 64, 1)

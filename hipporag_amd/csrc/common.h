@@ -236,18 +236,32 @@ struct PprSvArgs {
     int32_t n_lrow;
     float *partial;            // [n_partial][BP]
     int64_t num_vertices;
-    const float *x;            // [V][BP]
-    float *y;                  // [V][BP]
+    const void *x;             // [V][BP] fp32, or fp16 when half_state
+    void *y;                   // [V][BP]
     const int32_t *row_slot;   // [V] or nullptr (slot = vertex)
     const float *tele;         // [tele_rows][BP]
     float alpha, beta;
     int32_t nt;                // non-temporal (col, val) loads
+    // two-stage fp16 state (ppr_sv.hip header): mode = SvMode (0 plain / H, 1 residual, 2 correction, 3 final)
+    int32_t half_state = 0, mode = 0;
+    const uint16_t *aux16 = nullptr;   // modes 2, 3: r
+    const uint16_t *h16 = nullptr;     // mode 3: h (own row)
+    float *xout = nullptr;             // mode 3: x = h + c / cscale, fp32 [V][BP], written at the matrix' rows only
+    float cscale = 64.f;
+    const uint32_t *colmask = nullptr; // first sweep: bit = column may be non-zero in x_0 (nullptr: gather everything)
 };
 hrag_status launch_ppr_sv_sweep(const PprSvArgs &a, int bp, bool main_only, hipStream_t s);
 hrag_status launch_ppr_sv_init(const PprSvArgs &a, int bp, hipStream_t s);
 hrag_status launch_ppr_sv_tele(const float *scores, int64_t ld, int64_t n, int32_t batch, const float *mn,
                                const float *mx, float weight, const int32_t *flags, float *tele, int bp,
-                               hipStream_t s);
+                               hipStream_t s, const float *qscale = nullptr);
+// sums[b] = mass of the `iters`-sweep iterate, closed form (tele: [tele_rows][bp]; piso / iso: isolated flags of the
+// passages / of all vertices; passage_of_vertex: [V] passage number or -1)
+hrag_status launch_ppr_sv_mass(const float *tele, int64_t n_passages, int64_t tele_rows, const uint8_t *piso,
+                               const uint8_t *iso, const int32_t *passage_of_vertex, const int32_t *seed_vtx,
+                               const float *seed_w, const int32_t *seed_cnt, const float *qscale, int64_t num_vertices,
+                               int32_t batch, float damping, int32_t iters, double *part, double *sums, int bp,
+                               hipStream_t s);   // part: 8 * 64 * 2 doubles of scratch
 hrag_status launch_ppr_sv_reset(const float *reset, int64_t n, int32_t batch, float *tele, int bp,
                                 hipStream_t s);
 // partial: 256 * bp doubles

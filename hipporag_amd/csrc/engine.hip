@@ -34,7 +34,8 @@ void free_engine(hrag_engine *e) {
                     e->d_ssum, e->d_tele_sv, e->d_partial_sv, e->d_topk_ws, e->d_deg,
                     e->d_pinvdeg, e->d_R8, e->d_rho8, e->d_partial8, e->d_fused_ws, e->d_mn_f, e->d_mx_f, e->d_fused_sel,
                     e->d_xp8, e->d_row_ptele, e->d_iso, e->d_piso, e->d_colmask_static, e->d_colmask,
-                    e->d_stagep, e->d_pool8[0], e->d_pool8[1], e->d_pool8[2], e->d_zmax_bits, e->d_zmax,
+                    e->d_stagep, e->d_pool8[0], e->d_pool8[1], e->d_pool8[2], e->d_sv16[0], e->d_sv16[1],
+                    e->d_sv16[2], e->d_sv16[3], e->d_zmax_bits, e->d_zmax,
                     e->d_mass, e->d_prior_part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -244,29 +245,82 @@ inline bool use_f16(const hrag_engine *e, int batch, int iters) {
 inline bool use_sv(const hrag_engine *e, int batch) { return e->sell_ready && batch <= kSvMaxBatch; }
 inline int sv_width(int batch) { return batch <= 1 ? 1 : batch <= 2 ? 2 : batch <= 4 ? 4 : 8; }
 
-PprSvArgs ppr_sv_args(const hrag_engine *e, const float *x, float *y, const int32_t *row_slot,
+PprSvArgs ppr_sv_args(const hrag_engine *e, const Sell8Store &m, const void *x, void *y, const int32_t *row_slot,
                       const float *tele, float damping) {
     PprSvArgs a;
-    a.pairs = e->sell.pairs; a.pairs_bytes = e->sell.pairs_bytes(); a.chunk_meta = e->sell.chunk_meta;
-    a.vrow = e->sell.vrow; a.n_chunks = e->sell.n_chunks;
-    a.lrow_row = e->sell.lrow_row; a.lrow_first = e->sell.lrow_first; a.lrow_cnt = e->sell.lrow_cnt;
-    a.n_lrow = e->sell.n_lrow; a.partial = e->d_partial_sv; a.num_vertices = e->V;
+    a.pairs = m.pairs; a.pairs_bytes = m.pairs_bytes(); a.chunk_meta = m.chunk_meta;
+    a.vrow = m.vrow; a.n_chunks = m.n_chunks;
+    a.lrow_row = m.lrow_row; a.lrow_first = m.lrow_first; a.lrow_cnt = m.lrow_cnt;
+    a.n_lrow = m.n_lrow; a.partial = e->d_partial_sv; a.num_vertices = e->V;
     a.x = x; a.y = y; a.row_slot = row_slot; a.tele = tele;
     a.alpha = damping; a.beta = 1.0f - damping;
     a.nt = (e->opt_flags & HRAG_OPT_NT_CSR) ? 1 : 0;   // measured: nt loads are 25 % slower at B = 1
     return a;
 }
 
-// x_0 = v, `iters` sweeps; the final state ends in e->d_x ([V][bp] fp32)
-hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tele, int bp, float damping,
-                       int iters, hipStream_t s) {
+// the two-stage fp16 state of the small-batch path needs K1 >= 8 sweeps before the residual sweep
+inline bool use_sv_half(const hrag_engine *e, int iters) { return e->d_sv16[0] != nullptr && iters >= 16; }
+
+// hrag_ppr (all rows wanted): x_0 = v, `iters` plain sweeps; the final state ends in e->d_x ([V][bp] fp32)
+hrag_status ppr_sv_run_full(hrag_engine *e, const int32_t *row_slot, const float *tele, int bp, float damping,
+                            int iters, hipStream_t s) {
     float *x = e->d_x, *y = e->d_y;
-    HRAG_TRY(launch_ppr_sv_init(ppr_sv_args(e, nullptr, x, row_slot, tele, damping), bp, s));
+    HRAG_TRY(launch_ppr_sv_init(ppr_sv_args(e, e->sell, nullptr, x, row_slot, tele, damping), bp, s));
     for (int it = 0; it < iters; ++it) {
-        HRAG_TRY(launch_ppr_sv_sweep(ppr_sv_args(e, x, y, row_slot, tele, damping), bp, false, s));
+        HRAG_TRY(launch_ppr_sv_sweep(ppr_sv_args(e, e->sell, x, y, row_slot, tele, damping), bp, false, s));
         std::swap(x, y);
     }
     if (x != e->d_x) std::swap(e->d_x, e->d_y);
+    return HRAG_OK;
+}
+
+// hrag_retrieve, batch <= 8 (ppr_sv.hip header): x_0 = v; the first sweep gathers only the passage / seed columns
+// (d_colmask), the last one runs over the passage rows only and leaves x (fp32 [V][bp], passage rows valid) in
+// e->d_x; with >= 16 sweeps the state in between is the two-stage fp16 one (v must carry the per-query scale).
+hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tele, int bp, float damping,
+                       int iters, hipStream_t s) {
+    if (iters < 1) return ppr_sv_run_full(e, row_slot, tele, bp, damping, iters, s);
+    if (!use_sv_half(e, iters)) {
+        float *x = e->d_x, *y = e->d_y;
+        HRAG_TRY(launch_ppr_sv_init(ppr_sv_args(e, e->sell, nullptr, x, row_slot, tele, damping), bp, s));
+        for (int it = 0; it < iters; ++it) {
+            PprSvArgs a = ppr_sv_args(e, it + 1 == iters ? e->fsell : e->sell, x, y, row_slot, tele, damping);
+            a.colmask = it == 0 ? e->d_colmask : nullptr;
+            HRAG_TRY(launch_ppr_sv_sweep(a, bp, false, s));
+            std::swap(x, y);
+        }
+        if (x != e->d_x) std::swap(e->d_x, e->d_y);
+        return HRAG_OK;
+    }
+    const int k1 = iters / 2, k2 = iters - k1 - 1;
+    uint16_t *h = e->d_sv16[0], *hn = e->d_sv16[1], *r = e->d_sv16[2];
+    {
+        PprSvArgs a = ppr_sv_args(e, e->sell, nullptr, h, row_slot, tele, damping);
+        a.half_state = 1;
+        HRAG_TRY(launch_ppr_sv_init(a, bp, s));
+    }
+    for (int it = 0; it < k1; ++it) {
+        PprSvArgs a = ppr_sv_args(e, e->sell, h, hn, row_slot, tele, damping);
+        a.half_state = 1; a.mode = 0; a.colmask = it == 0 ? e->d_colmask : nullptr;
+        HRAG_TRY(launch_ppr_sv_sweep(a, bp, false, s));
+        std::swap(h, hn);
+    }
+    {
+        PprSvArgs a = ppr_sv_args(e, e->sell, h, r, row_slot, tele, damping);
+        a.half_state = 1; a.mode = 1; a.cscale = kPpr16CScale;
+        HRAG_TRY(launch_ppr_sv_sweep(a, bp, false, s));
+    }
+    const uint16_t *c = r;                 // c_{K1+1} = r
+    uint16_t *cn = hn, *cn2 = e->d_sv16[3];
+    for (int j = 0; j < k2; ++j) {
+        const bool last = j + 1 == k2;
+        PprSvArgs a = ppr_sv_args(e, last ? e->fsell : e->sell, c, cn, row_slot, tele, damping);
+        a.half_state = 1; a.mode = last ? 3 : 2; a.aux16 = r; a.cscale = kPpr16CScale;
+        a.h16 = h; a.xout = e->d_x;
+        HRAG_TRY(launch_ppr_sv_sweep(a, bp, false, s));
+        c = cn;
+        std::swap(cn, cn2);
+    }
     return HRAG_OK;
 }
 
@@ -457,29 +511,26 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         }
         E_TRY(build_sell8(e, h_row_ptr, h_col.data(), h_val.data(), want_f8 ? h_deg.data() : nullptr, nullptr,
                           want_sell, &e->sell));
-        if (want_f8) {
-            // the last sweep only needs the passage rows (HippoRAG.py:1745 reads nothing else)
-            std::vector<int32_t> prow_list;
-            std::vector<int32_t> ptele((size_t)e->n_rows, -1);
-            for (int64_t r = 0; r < e->n_rows; ++r)
-                if (h_r2t[(size_t)r] >= 0) {
-                    prow_list.push_back((int32_t)r);
-                    ptele[(size_t)r] = h_r2t[(size_t)r] - (int32_t)e->p_offset;
-                }
-            E_TRY(build_sell8(e, h_row_ptr, h_col.data(), h_val.data(), h_deg.data(), &prow_list, false, &e->fsell));
-            E_TRY(dev_upload(&e->d_row_ptele, ptele.data(), e->n_rows));
-            std::vector<float> f_deg((size_t)e->V);
-            for (int64_t i = 0; i < e->V; ++i) f_deg[(size_t)i] = (float)h_deg[(size_t)i];
-            E_TRY(dev_upload(&e->d_deg, f_deg.data(), e->V));
-            E_TRY(dev_upload(&e->d_iso, h_iso.data(), e->V));
-            std::vector<float> pinv((size_t)e->p_rows);
-            std::vector<uint8_t> piso((size_t)e->p_rows);
-            for (int64_t q = 0; q < e->p_rows; ++q) {
-                const int64_t v = h_pv[(size_t)(e->p_offset + q)];
-                pinv[(size_t)q] = 1.0f / f_deg[(size_t)v];
-                piso[(size_t)q] = h_iso[(size_t)v];
+        // the last sweep only needs the passage rows (HippoRAG.py:1745 reads nothing else): a second matrix
+        std::vector<int32_t> prow_list;
+        std::vector<int32_t> ptele((size_t)e->n_rows, -1);
+        for (int64_t r = 0; r < e->n_rows; ++r)
+            if (h_r2t[(size_t)r] >= 0) {
+                prow_list.push_back((int32_t)r);
+                ptele[(size_t)r] = h_r2t[(size_t)r] - (int32_t)e->p_offset;
             }
-            E_TRY(dev_upload(&e->d_pinvdeg, pinv.data(), e->p_rows));
+        E_TRY(build_sell8(e, h_row_ptr, h_col.data(), h_val.data(), want_f8 ? h_deg.data() : nullptr, &prow_list,
+                          want_sell, &e->fsell));
+        if (!want_f8) {
+            // isolated vertices (the closed-form mass of the small-batch path): no row entries <=> no edges (symmetric)
+            h_iso.assign((size_t)e->V, 0);
+            for (int64_t r = 0; r < e->n_rows; ++r)
+                if (h_row_ptr[(size_t)r + 1] == h_row_ptr[(size_t)r]) h_iso[(size_t)(e->row_offset + r)] = 1;
+        }
+        {
+            E_TRY(dev_upload(&e->d_iso, h_iso.data(), e->V));
+            std::vector<uint8_t> piso((size_t)e->p_rows);
+            for (int64_t q = 0; q < e->p_rows; ++q) piso[(size_t)q] = h_iso[(size_t)h_pv[(size_t)(e->p_offset + q)]];
             E_TRY(dev_upload(&e->d_piso, piso.data(), e->p_rows));
             // column bitmap of the passage vertices (ALL passages: the columns are global)
             e->colmask_words = ceil_div(e->V + 1, 32);
@@ -487,6 +538,16 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
             for (int64_t q = 0; q < e->n_passages; ++q) mask[(size_t)(h_pv[(size_t)q] >> 5)] |= 1u << (h_pv[(size_t)q] & 31);
             E_TRY(dev_upload(&e->d_colmask_static, mask.data(), e->colmask_words));
             E_TRY(dev_alloc(&e->d_colmask, e->colmask_words));
+        }
+        if (want_f8) {
+            E_TRY(dev_upload(&e->d_row_ptele, ptele.data(), e->n_rows));
+            std::vector<float> f_deg((size_t)e->V);
+            for (int64_t i = 0; i < e->V; ++i) f_deg[(size_t)i] = (float)h_deg[(size_t)i];
+            E_TRY(dev_upload(&e->d_deg, f_deg.data(), e->V));
+            std::vector<float> pinv((size_t)e->p_rows);
+            for (int64_t q = 0; q < e->p_rows; ++q)
+                pinv[(size_t)q] = 1.0f / f_deg[(size_t)h_pv[(size_t)(e->p_offset + q)]];
+            E_TRY(dev_upload(&e->d_pinvdeg, pinv.data(), e->p_rows));
             e->f8_ready = true;   // buffers follow with the workspace
         }
     }
@@ -507,7 +568,11 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     e->state_elems = unsharded ? (int64_t)lay.n_slabs * e->V * lay.bc : 0;   // d_x / d_y: hrag_retrieve, hrag_ppr
     if (want_sell) {
         E_TRY(dev_alloc(&e->d_tele_sv, (e->n_passages + (int64_t)kSvMaxBatch * kMaxSeeds) * kSvMaxBatch));
-        E_TRY(dev_alloc(&e->d_partial_sv, (int64_t)std::max(e->sell.n_partial, 1) * kSvMaxBatch));
+        E_TRY(dev_alloc(&e->d_partial_sv, (int64_t)std::max({e->sell.n_partial, e->fsell.n_partial, 1}) * kSvMaxBatch));
+        for (auto &p : e->d_sv16) {   // two-stage fp16 state of the small-batch path: h ping / pong, r, c
+            E_TRY(dev_alloc(&p, e->V * (int64_t)kSvMaxBatch));
+            E_HIP(hipMemset(p, 0, (size_t)e->V * kSvMaxBatch * sizeof(uint16_t)));
+        }
         e->sell_ready = true;
     }
     if (want_sell || e->f8_ready) {
@@ -515,6 +580,10 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         E_TRY(dev_alloc(&e->d_row_slot, e->n_rows));
         E_HIP(hipMemcpy(e->d_row_slot, e->f8_ready ? e->d_row_ptele : e->d_row_to_tele,
                         (size_t)e->n_rows * sizeof(int32_t), hipMemcpyDeviceToDevice));
+    }
+    if (want_sell && !(want_f16 || e->f8_ready)) {   // small-batch-only engine: per-query scale of the fp16 state
+        E_TRY(dev_alloc(&e->d_qscale, B));
+        E_TRY(dev_alloc(&e->d_ssum, B));
     }
     if (want_f16 || e->f8_ready) {
         // teleport rows of the fp16 and fp8 paths: the owned passages, then the seed rows (fp32, 64-query slabs)
@@ -788,8 +857,9 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_START], s));
     // dense_passage_retrieval: raw scores + min / max (HippoRAG.py:1496-1498)
     HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
+    const bool sv_half = sv && use_sv_half(e, ppr_iters);
     HRAG_TRY(launch_row_minmax(e->d_spass, batch, e->n_passages, e->ld_p, e->d_mn_p, e->d_mx_p, s,
-                               f16 ? e->d_ssum : nullptr));   // fp8 path: d_ssum is the z-max scratch
+                               (f16 || sv_half) ? e->d_ssum : nullptr));
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SIM], s));
     // reset vector: entity seeds + passage prior (HippoRAG.py:1574-1638)
     if (e->d_subj) {
@@ -824,15 +894,26 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
         HRAG_TRY(launch_ppr16_seed_rows(e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt, e->d_qscale, batch,
                                         e->n_passages, e->V, e->d_row_slot, e->d_tele16, e->tele16_rows, 64, s));
     } else if (sv) {
-        // small batch (ppr_sv.hip): v = [Np + seed rows][bp] fp32, same "seeds are teleport rows" form
+        // small batch (ppr_sv.hip): v = [Np + seed rows][bp] fp32, same "seeds are teleport rows" form; with the
+        // fp16 state v carries the per-query power-of-two scale of ppr16.hip (every iterate fits fp16)
+        const float *qs = nullptr;
+        if (sv_half) {
+            HRAG_TRY(launch_ppr16_scale(e->d_mn_p, e->d_mx_p, e->d_ssum, e->n_passages, passage_node_weight,
+                                        e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, e->d_qscale, s));
+            qs = e->d_qscale;
+        }
         HRAG_TRY(launch_ppr_sv_tele(e->d_spass, e->ld_p, e->n_passages, batch, e->d_mn_p, e->d_mx_p,
-                                    passage_node_weight, e->d_flags, e->d_tele_sv, bp, s));
+                                    passage_node_weight, e->d_flags, e->d_tele_sv, bp, s, qs));
         HRAG_HIP_TRY(hipMemsetAsync(e->d_tele_sv + (size_t)e->n_passages * bp, 0,
                                     (size_t)batch * kMaxSeeds * bp * sizeof(float), s));
         HRAG_HIP_TRY(hipMemcpyAsync(e->d_row_slot, e->d_row_to_tele, (size_t)e->V * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, s));
-        HRAG_TRY(launch_ppr16_seed_rows(e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt, nullptr, batch,
+        HRAG_TRY(launch_ppr16_seed_rows(e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt, qs, batch,
                                         e->n_passages, e->V, e->d_row_slot, e->d_tele_sv, 0, bp, s));
+        // columns where x_0 = v can be non-zero: the passage vertices + this batch's seeds (first sweep)
+        HRAG_HIP_TRY(hipMemcpyAsync(e->d_colmask, e->d_colmask_static, (size_t)e->colmask_words * sizeof(uint32_t),
+                                    hipMemcpyDeviceToDevice, s));
+        HRAG_TRY(launch_ppr8_mask_seeds(e->d_seed_vtx, e->d_seed_cnt, batch, e->V, e->d_colmask, s));
     } else {
         HRAG_TRY(hrag_stage_teleport(e, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, passage_node_weight,
                                      e->d_flags, batch, e->d_tele, stream));
@@ -859,7 +940,11 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_PPR], s));
     // doc scores + ranking (HippoRAG.py:1745-1747, :503)
     if (sv) {
-        HRAG_TRY(launch_ppr_sv_colsum(e->d_x, e->V, bp, e->d_colsum_partial, e->d_sums, s));
+        // normalisation: the closed-form mass of the K-sweep iterate (the last sweep only produced the passage rows)
+        HRAG_TRY(launch_ppr_sv_mass(e->d_tele_sv, e->n_passages, e->n_passages + (int64_t)batch * kMaxSeeds, e->d_piso,
+                                    e->d_iso, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt,
+                                    sv_half ? e->d_qscale : nullptr, e->V, batch, damping, ppr_iters, e->d_colsum_partial,
+                                    e->d_sums, bp, s));
         HRAG_TRY(launch_ppr_sv_rows(e->d_x, e->d_passage_vertex, e->n_passages, batch, e->d_sums, e->d_doc,
                                     e->ld_p, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, e->d_flags, bp, s));
     } else if (f8) {
@@ -909,7 +994,7 @@ hrag_status hrag_ppr(hrag_engine *e, const float *reset, int32_t batch, float da
     if (use_sv(e, batch)) {   // run_ppr seam at B = 1 (ppr_sv.hip), v dense over all vertices
         const int bp = sv_width(batch);
         HRAG_TRY(launch_ppr_sv_reset(reset, e->V, batch, e->d_tele_dense, bp, s));
-        HRAG_TRY(ppr_sv_run(e, nullptr, e->d_tele_dense, bp, damping, iters, s));
+        HRAG_TRY(ppr_sv_run_full(e, nullptr, e->d_tele_dense, bp, damping, iters, s));
         HRAG_TRY(launch_ppr_sv_colsum(e->d_x, e->V, bp, e->d_colsum_partial, e->d_sums, s));
         HRAG_TRY(launch_ppr_sv_rows(e->d_x, nullptr, e->V, batch, e->d_sums, x_out, e->V, nullptr, 0, nullptr,
                                     nullptr, nullptr, bp, s));
@@ -949,7 +1034,7 @@ hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damp
         const int bp = sv_width(batch);
         float *x = e->d_x, *y = e->d_y;
         for (int it = 0; it < n; ++it) {
-            HRAG_TRY(launch_ppr_sv_sweep(ppr_sv_args(e, x, y, e->d_row_slot, e->d_tele_sv, damping), bp,
+            HRAG_TRY(launch_ppr_sv_sweep(ppr_sv_args(e, e->sell, x, y, e->d_row_slot, e->d_tele_sv, damping), bp,
                                          (flags & 1) != 0, (hipStream_t)stream));
             std::swap(x, y);
         }

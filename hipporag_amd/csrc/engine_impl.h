@@ -129,6 +129,7 @@ struct hrag_engine {
     int32_t f16_max_batch = 0;  // ... sized for this many queries (64 when the fp8 path serves the larger batches)
     bool sell_ready = false;  // SELL-8 matrix + small-batch buffers present (every unsharded engine)
     float *d_tele_sv = nullptr, *d_partial_sv = nullptr;   // small-batch path (ppr_sv.hip), BP <= 8
+    uint16_t *d_sv16[4] = {nullptr, nullptr, nullptr, nullptr};   // ... its two-stage fp16 state [V][8]: h ping / pong, r, c
     float *d_partial16 = nullptr;
     uint16_t *d_h16[4] = {nullptr, nullptr, nullptr, nullptr};  // hA, hB, r, cA
     int64_t state16_elems = 0;

@@ -15,6 +15,16 @@
 //   * rows longer than 64 entries are the same <= 64 segments as in ppr16.hip (partials + reduce).
 // v (passage prior + seed rows) is one fp32 array [tele_rows][BP] addressed through row_slot, like
 // on the fp16 path; row_slot == nullptr means "dense v" (slot = vertex), used by hrag_ppr.
+//
+// Round 2 (hrag_retrieve with >= 16 sweeps; hrag_ppr keeps the plain fp32 iteration over all rows):
+//   * TWO-STAGE fp16 STATE, the scheme of ppr16.hip at [V][BP] halfs: h <- f16(a P h + b v) for K/2 sweeps,
+//     one residual sweep r = f16(64 ((a P h + b v) - h)) in fp32 arithmetic, then c <- f16(a P c + r),
+//     x = h + c / 64.  At 1 M vertices x and y are 2 MB each instead of 4 MB: the gathers stay in the 4 MB
+//     L2 (the fp32 state missed 30 % of them and the sweep ran on the miss traffic: 0.86 GB per sweep).
+//   * the FIRST sweep gathers only where x_0 = v is non-zero (passage and seed columns, column bitmap);
+//   * the LAST sweep runs over the passage rows only (a second SELL-8 matrix) and writes x = h + c / 64 in
+//     fp32 there -- nothing else is read afterwards (HippoRAG.py:1745) -- and the normalisation is the closed
+//     form of ppr8.hip (mass of the K-sweep iterate from sum(v) and the mass on isolated vertices).
 #include "common.h"
 
 namespace hrag {
@@ -45,6 +55,22 @@ __device__ __forceinline__ XVec<BP> ld_x(const float *x, unsigned col) {
     return r;
 }
 
+// the same for a fp16 state: BP halfs = 2 .. 16 contiguous bytes
+template <int BP>
+__device__ __forceinline__ XVec<BP> ld_x(const _Float16 *x, unsigned col) {
+    typedef _Float16 hvec __attribute__((ext_vector_type(BP < 2 ? 2 : BP)));
+    XVec<BP> r;
+    const _Float16 *p = x + (size_t)col * BP;
+    if constexpr (BP == 1) {
+        r.v[0] = (float)*p;
+    } else {
+        const hvec t = *reinterpret_cast<const hvec *>(p);
+#pragma unroll
+        for (int b = 0; b < BP; ++b) r.v[b] = (float)t[b];
+    }
+    return r;
+}
+
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 
 // non-temporal buffer load (aux = 2): the stream must not evict x from L2; see ppr16.hip on why a
@@ -55,17 +81,35 @@ __device__ __forceinline__ int2 ld_pair_nt(__amdgpu_buffer_rsrc_t rsrc, unsigned
     return make_int2(v.x, v.y);
 }
 
+constexpr float kSvHalfMax = 65504.f;
+__device__ __forceinline__ _Float16 to_half(float v) { return (_Float16)fminf(fmaxf(v, -kSvHalfMax), kSvHalfMax); }
+
+// Sweep modes.  fp32 state: kSvPlain only.  fp16 state: H = kSvPlain, then kSvResid, kSvCorr; kSvFinal = the last
+// correction sweep, over the passage rows, writing x = h + c / cscale in fp32.
+enum SvMode { kSvPlain = 0, kSvResid = 1, kSvCorr = 2, kSvFinal = 3 };
+
 // lane gl (< BP) of the group finishes column gl of the row
-template <int BP>
+template <int BP, int MODE, typename T>
 __device__ __forceinline__ void sv_finish(const PprSvArgs &a, int row, int gl, float sum) {
     if (gl >= BP) return;
-    float t = 0.f;
-    const int64_t slot = a.row_slot ? (int64_t)a.row_slot[row] : (int64_t)row;
-    if (slot >= 0) t = a.tele[(size_t)slot * BP + gl];
-    a.y[(size_t)row * BP + gl] = fmaf(a.alpha, sum, a.beta * t);
+    const size_t at = (size_t)row * BP + gl;
+    if constexpr (MODE == kSvPlain || MODE == kSvResid) {
+        float t = 0.f;
+        const int64_t slot = a.row_slot ? (int64_t)a.row_slot[row] : (int64_t)row;
+        if (slot >= 0) t = a.tele[(size_t)slot * BP + gl];
+        float out = fmaf(a.alpha, sum, a.beta * t);
+        if constexpr (MODE == kSvResid) out = (out - (float)static_cast<const T *>(a.x)[at]) * a.cscale;
+        if constexpr (sizeof(T) == 2) static_cast<_Float16 *>(a.y)[at] = to_half(out);
+        else static_cast<float *>(a.y)[at] = out;
+    } else {
+        const float c = fmaf(a.alpha, sum, (float)reinterpret_cast<const _Float16 *>(a.aux16)[at]);
+        if constexpr (MODE == kSvCorr) static_cast<_Float16 *>(a.y)[at] = to_half(c);
+        else a.xout[at] = fmaf(c, 1.0f / a.cscale, (float)reinterpret_cast<const _Float16 *>(a.h16)[at]);
+    }
 }
 
-template <int BP, bool NT>
+// MASK: the gathers of columns whose bit is clear in a.colmask are skipped (first sweep: x_0 = v is zero there)
+template <int BP, bool NT, int MODE, typename T, bool MASK>
 __global__ __launch_bounds__(256) void ppr_sv_kernel(const PprSvArgs a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
@@ -76,6 +120,7 @@ __global__ __launch_bounds__(256) void ppr_sv_kernel(const PprSvArgs a) {
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int2 *>(a.pairs), 0, (int)a.pairs_bytes, 0x00020000);
     const unsigned pbase = (unsigned)meta.x * 512u, poff = (unsigned)lane * 8u;
+    const T *xs = static_cast<const T *>(a.x);
     float acc[BP];
 #pragma unroll
     for (int b = 0; b < BP; ++b) acc[b] = 0.f;
@@ -86,8 +131,18 @@ __global__ __launch_bounds__(256) void ppr_sv_kernel(const PprSvArgs a) {
         const int2 p2 = ld_pair_nt<NT>(prs, poff + (unsigned)(s + 2) * 512u, pbase);
         const int2 p3 = ld_pair_nt<NT>(prs, poff + (unsigned)(s + 3) * 512u, pbase);
         const bool tail = s + 1 >= n_steps;      // wave-uniform
-        const XVec<BP> xa = ld_x<BP>(a.x, (unsigned)p0.x);
-        const XVec<BP> xb = ld_x<BP>(a.x, tail ? 0u : (unsigned)p1.x);
+        XVec<BP> xa, xb;
+        if constexpr (MASK) {
+            const bool ona = (a.colmask[(unsigned)p0.x >> 5] >> (p0.x & 31)) & 1u;
+            const bool onb = !tail && ((a.colmask[(unsigned)p1.x >> 5] >> (p1.x & 31)) & 1u);
+#pragma unroll
+            for (int b = 0; b < BP; ++b) xa.v[b] = xb.v[b] = 0.f;
+            if (ona) xa = ld_x<BP>(xs, (unsigned)p0.x);
+            if (onb) xb = ld_x<BP>(xs, (unsigned)p1.x);
+        } else {
+            xa = ld_x<BP>(xs, (unsigned)p0.x);
+            xb = ld_x<BP>(xs, tail ? 0u : (unsigned)p1.x);
+        }
         const float wa = __int_as_float(p0.y), wb = tail ? 0.f : __int_as_float(p1.y);
 #pragma unroll
         for (int b = 0; b < BP; ++b) acc[b] = fmaf(wa, xa.v[b], acc[b]);
@@ -106,14 +161,14 @@ __global__ __launch_bounds__(256) void ppr_sv_kernel(const PprSvArgs a) {
     for (int b = 1; b < BP; ++b) mine = gl == b ? acc[b] : mine;
     const int tgt = a.vrow[chunk * 8 + grp];
     if (tgt >= 0) {
-        sv_finish<BP>(a, tgt, gl, mine);
+        sv_finish<BP, MODE, T>(a, tgt, gl, mine);
     } else if (tgt != kVrowNone && gl < BP) {
         a.partial[(size_t)(-(tgt + 1)) * BP + gl] = mine;
     }
 }
 
 // one thread per (long row, column): <= 64 partial sums, added in segment order
-template <int BP>
+template <int BP, int MODE, typename T>
 __global__ __launch_bounds__(256) void ppr_sv_reduce_kernel(const PprSvArgs a) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int m = t / BP, gl = t % BP;
@@ -121,11 +176,11 @@ __global__ __launch_bounds__(256) void ppr_sv_reduce_kernel(const PprSvArgs a) {
     const int first = a.lrow_first[m], cnt = a.lrow_cnt[m];
     float s = 0.f;
     for (int i = 0; i < cnt; ++i) s += a.partial[(size_t)(first + i) * BP + gl];
-    sv_finish<BP>(a, a.lrow_row[m], gl, s);
+    sv_finish<BP, MODE, T>(a, a.lrow_row[m], gl, s);
 }
 
-// x_0 = v
-template <int BP>
+// x_0 = v  (fp32 or fp16 state)
+template <int BP, typename T>
 __global__ __launch_bounds__(256) void ppr_sv_init_kernel(const PprSvArgs a) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = t / BP;
@@ -134,7 +189,59 @@ __global__ __launch_bounds__(256) void ppr_sv_init_kernel(const PprSvArgs a) {
     float v = 0.f;
     const int64_t slot = a.row_slot ? (int64_t)a.row_slot[row] : row;
     if (slot >= 0) v = a.tele[(size_t)slot * BP + gl];
-    a.y[(size_t)row * BP + gl] = v;
+    if constexpr (sizeof(T) == 2) static_cast<_Float16 *>(a.y)[(size_t)row * BP + gl] = to_half(v);
+    else static_cast<float *>(a.y)[(size_t)row * BP + gl] = v;
+}
+
+// The mass of the `iters`-sweep iterate in closed form (see ppr8_scale_kernel): M = sum over ALL teleport rows
+// (passages with the seeds that are passages folded in, then the seed rows), S = the part on isolated vertices.
+// Pass 1: grid (kSvMassSplit, batch) partial sums in double; pass 2: one thread per query adds them in a fixed order.
+constexpr int kSvMassSplit = 64;
+template <int BP>
+__global__ __launch_bounds__(256) void ppr_sv_mass_kernel(const float *__restrict__ tele, int64_t n_passages,
+                                                          int64_t tele_rows, const uint8_t *__restrict__ piso,
+                                                          double *__restrict__ part) {
+    __shared__ double rm[256], rs[256];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    double m = 0.0, si = 0.0;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + tid; r < tele_rows; r += (int64_t)kSvMassSplit * 256) {
+        const double v = (double)tele[(size_t)r * BP + b];
+        m += v;
+        if (r < n_passages && piso[r]) si += v;
+    }
+    rm[tid] = m; rs[tid] = si;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { rm[tid] += rm[tid + o]; rs[tid] += rs[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        part[((size_t)b * kSvMassSplit + blockIdx.x) * 2 + 0] = rm[0];
+        part[((size_t)b * kSvMassSplit + blockIdx.x) * 2 + 1] = rs[0];
+    }
+}
+__global__ void ppr_sv_mass_final_kernel(const double *__restrict__ part, const uint8_t *__restrict__ iso,
+                                         const int32_t *__restrict__ passage_of_vertex,
+                                         const int32_t *__restrict__ seed_vtx, const float *__restrict__ seed_w,
+                                         const int32_t *__restrict__ seed_cnt, const float *__restrict__ qscale,
+                                         int64_t num_vertices, int32_t batch, float damping, int32_t iters,
+                                         double *sums) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double M = 0.0, S = 0.0;
+    for (int i = 0; i < kSvMassSplit; ++i) {
+        M += part[((size_t)b * kSvMassSplit + i) * 2 + 0];
+        S += part[((size_t)b * kSvMassSplit + i) * 2 + 1];
+    }
+    const double qs = qscale ? (double)qscale[b] : 1.0;
+    for (int j = 0; j < seed_cnt[b]; ++j) {       // isolated seed vertices that are not passages (own seed row)
+        const int64_t v = seed_vtx[b * kMaxSeeds + j];
+        if (v >= 0 && v < num_vertices && iso[v] && passage_of_vertex[v] < 0) S += (double)(seed_w[b * kMaxSeeds + j]) * qs;
+    }
+    const double al = (double)damping, be = (double)(1.0f - damping);
+    double mk = M;
+    for (int k = 0; k < iters; ++k) mk = al * (mk - (k == 0 ? S : be * S)) + be * M;
+    sums[b] = mk;
 }
 
 __device__ __forceinline__ float sv_minmax_norm(float s, float mn, float mx) {
@@ -146,14 +253,17 @@ __device__ __forceinline__ float sv_minmax_norm(float s, float mn, float mx) {
 template <int BP>
 __global__ __launch_bounds__(256) void ppr_sv_tele_kernel(const float *scores, int64_t ld, int64_t n,
                                                           int32_t batch, const float *mn, const float *mx,
-                                                          float weight, const int32_t *flags, float *tele) {
+                                                          float weight, const int32_t *flags, float *tele,
+                                                          const float *qscale) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
 #pragma unroll
     for (int b = 0; b < BP; ++b) {
         float v = 0.f;
-        if (b < batch && !(flags && (flags[b] & 1)))
+        if (b < batch && !(flags && (flags[b] & 1))) {
             v = sv_minmax_norm(scores[(size_t)b * ld + p], mn[b], mx[b]) * weight;
+            if (qscale) v *= qscale[b];      // a power of two: exact
+        }
         tele[(size_t)p * BP + b] = v;
     }
 }
@@ -234,20 +344,39 @@ __global__ __launch_bounds__(256) void ppr_sv_rows_kernel(const float *x, const 
     }
 }
 
-template <int BP>
-hrag_status sv_sweep(const PprSvArgs &a, bool main_only, hipStream_t s) {
+template <int BP, int MODE, typename T, bool MASK>
+hrag_status sv_sweep_one(const PprSvArgs &a, bool main_only, hipStream_t s) {
     if (a.n_chunks > 0) {
         const dim3 grid((unsigned)ceil_div(a.n_chunks, 4));
-        if (a.nt) hipLaunchKernelGGL((ppr_sv_kernel<BP, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((ppr_sv_kernel<BP, false>), grid, dim3(256), 0, s, a);
+        if (a.nt) hipLaunchKernelGGL((ppr_sv_kernel<BP, true, MODE, T, MASK>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((ppr_sv_kernel<BP, false, MODE, T, MASK>), grid, dim3(256), 0, s, a);
         HRAG_LAUNCH_CHECK();
     }
     if (!main_only && a.n_lrow > 0) {
-        hipLaunchKernelGGL(ppr_sv_reduce_kernel<BP>, dim3((unsigned)ceil_div((int64_t)a.n_lrow * BP, 256)),
+        hipLaunchKernelGGL((ppr_sv_reduce_kernel<BP, MODE, T>), dim3((unsigned)ceil_div((int64_t)a.n_lrow * BP, 256)),
                            dim3(256), 0, s, a);
         HRAG_LAUNCH_CHECK();
     }
     return HRAG_OK;
+}
+
+template <int BP>
+hrag_status sv_sweep(const PprSvArgs &a, bool main_only, hipStream_t s) {
+    const bool mask = a.colmask != nullptr;
+    if (!a.half_state) {
+        HRAG_REQUIRE(a.mode == kSvPlain, "the fp32 small-batch state only has the plain sweep");
+        return mask ? sv_sweep_one<BP, kSvPlain, float, true>(a, main_only, s)
+                    : sv_sweep_one<BP, kSvPlain, float, false>(a, main_only, s);
+    }
+    switch (a.mode) {
+        case kSvPlain:
+            return mask ? sv_sweep_one<BP, kSvPlain, _Float16, true>(a, main_only, s)
+                        : sv_sweep_one<BP, kSvPlain, _Float16, false>(a, main_only, s);
+        case kSvResid: return sv_sweep_one<BP, kSvResid, _Float16, false>(a, main_only, s);
+        case kSvCorr: return sv_sweep_one<BP, kSvCorr, _Float16, false>(a, main_only, s);
+        case kSvFinal: return sv_sweep_one<BP, kSvFinal, _Float16, false>(a, main_only, s);
+        default: set_error("bad small-batch sweep mode %d", a.mode); return HRAG_EINVAL;
+    }
 }
 
 }  // namespace
@@ -272,7 +401,9 @@ hrag_status launch_ppr_sv_sweep(const PprSvArgs &a, int bp, bool main_only, hipS
 
 hrag_status launch_ppr_sv_init(const PprSvArgs &a, int bp, hipStream_t s) {
     const dim3 grid((unsigned)ceil_div(a.num_vertices * bp, 256));
-#define CALL(BP) hipLaunchKernelGGL(ppr_sv_init_kernel<BP>, grid, dim3(256), 0, s, a)
+#define CALL(BP)                                                                                  \
+    if (a.half_state) hipLaunchKernelGGL((ppr_sv_init_kernel<BP, _Float16>), grid, dim3(256), 0, s, a); \
+    else hipLaunchKernelGGL((ppr_sv_init_kernel<BP, float>), grid, dim3(256), 0, s, a)
     HRAG_DISPATCH_BP(bp, CALL)
 #undef CALL
     HRAG_LAUNCH_CHECK();
@@ -281,10 +412,10 @@ hrag_status launch_ppr_sv_init(const PprSvArgs &a, int bp, hipStream_t s) {
 
 hrag_status launch_ppr_sv_tele(const float *scores, int64_t ld, int64_t n, int32_t batch, const float *mn,
                                const float *mx, float weight, const int32_t *flags, float *tele, int bp,
-                               hipStream_t s) {
+                               hipStream_t s, const float *qscale) {
     if (n == 0) return HRAG_OK;
     const dim3 grid((unsigned)ceil_div(n, 256));
-#define CALL(BP) hipLaunchKernelGGL(ppr_sv_tele_kernel<BP>, grid, dim3(256), 0, s, scores, ld, n, batch, mn, mx, weight, flags, tele)
+#define CALL(BP) hipLaunchKernelGGL(ppr_sv_tele_kernel<BP>, grid, dim3(256), 0, s, scores, ld, n, batch, mn, mx, weight, flags, tele, qscale)
     HRAG_DISPATCH_BP(bp, CALL)
 #undef CALL
     HRAG_LAUNCH_CHECK();
@@ -308,6 +439,23 @@ hrag_status launch_ppr_sv_colsum(const float *x, int64_t n, int bp, double *part
     hipLaunchKernelGGL(ppr_sv_colsum_final_kernel<BP>, dim3(1), dim3(64), 0, s, partial, kSvSumBlocks, sums)
     HRAG_DISPATCH_BP(bp, CALL)
 #undef CALL
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr_sv_mass(const float *tele, int64_t n_passages, int64_t tele_rows, const uint8_t *piso,
+                               const uint8_t *iso, const int32_t *passage_of_vertex, const int32_t *seed_vtx,
+                               const float *seed_w, const int32_t *seed_cnt, const float *qscale, int64_t num_vertices,
+                               int32_t batch, float damping, int32_t iters, double *part, double *sums, int bp,
+                               hipStream_t s) {
+#define CALL(BP)                                                                                             \
+    hipLaunchKernelGGL(ppr_sv_mass_kernel<BP>, dim3(kSvMassSplit, (unsigned)batch), dim3(256), 0, s, tele, n_passages, \
+                       tele_rows, piso, part)
+    HRAG_DISPATCH_BP(bp, CALL)
+#undef CALL
+    HRAG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ppr_sv_mass_final_kernel, dim3(1), dim3(64), 0, s, part, iso, passage_of_vertex, seed_vtx, seed_w,
+                       seed_cnt, qscale, num_vertices, batch, damping, iters, sums);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

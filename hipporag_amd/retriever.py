@@ -134,8 +134,8 @@ class RetrievalConfig:
     ppr_iters: Optional[int] = None      # None: derived from damping (sweeps_for_damping: 20 at 0.5)
     max_batch: int = 256
     slab_width: int = 0
-    fp8_margin: bool = True              # HRAG_OPT_FP8_MARGIN: +2 sweeps on the fp8 PPR state (accuracy margin on
-                                         # bipartite-hub graphs, +8 % PPR time); benchmarks run the raw engine
+    fp8_margin: bool = False             # HRAG_OPT_FP8_MARGIN: +2 sweeps on the fp8 PPR state (+8 % PPR time; measured
+                                         # gain on the star forest only 1.5x: the error there is rounding, not truncation)
 
 
 def identity_rerank_filter(query, candidate_items, candidate_indices, len_after_rerank=None):

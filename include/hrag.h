@@ -116,10 +116,10 @@ typedef struct hrag_fact_desc {
 #define HRAG_OPT_SLABS_PER_WG_1 256   /* fp8 sweep: one slab per workgroup (4 chunks) instead of the wavefronts of a   */
                                       /* workgroup sharing a chunk's (col, val) stream across 2 / 4 slabs             */
 
-#define HRAG_OPT_FP8_MARGIN 512       /* the fp8-state PPR runs ppr_iters + 2 sweeps (when that is <= 30): on graphs   */
-                                      /* whose spectrum makes the truncation bound of the sweep count tight (bipartite  */
-                                      /* hubs) the staged scheme sits up to ~5x above the plain iteration; two sweeps   */
-                                      /* more (factor 4 at damping 0.5) restore the margin for +8 % PPR time            */
+#define HRAG_OPT_FP8_MARGIN 512       /* the fp8-state PPR runs ppr_iters + 2 sweeps (when that is <= 30), +8 % PPR    */
+                                      /* time.  Removes the truncation part of the error (factor 4 at damping 0.5); on */
+                                      /* the star forest, where the scheme sits at the 1e-5 bar, the measured gain is  */
+                                      /* only 1.5x -- the error there is the fp8 rounding of the smallest scores        */
 
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */

@@ -107,10 +107,11 @@ hrag_status launch_colsum(const float *x, int64_t num_vertices, int64_t row_offs
 // ppr16.hip : two-stage fp16-state PPR (64 queries per 128-byte line), SELL-8 matrix
 enum Ppr16Mode { kPprModeH = 0, kPprModeR = 1, kPprModeC = 2 };
 constexpr int32_t kVrowNone = (int32_t)0x80000000;  // padding virtual row (no output)
-// rows above this are cut into <= 64 segments.  Rows are sorted by length, so the 8 rows of a wavefront
-// have similar trip counts and the longest start first: only real hubs need cutting (at 64 the reduce
-// kernels of cfg 3 handled 13.6k rows and cost 0.4 ms per batch).
+// rows above this (large graphs; engine.hip sell8_seg_len picks 64 .. 256 on small ones) are cut into segments.
+// Rows are sorted by length, so the 8 rows of a wavefront have similar trip counts and the longest start first:
+// only real hubs need cutting.
 constexpr int kSell8SegLen = 512;
+constexpr int kSell8MaxSegs = 1024;
 struct Ppr16Args {
     const int2 *pairs;         // [total_steps * 64] (col, fp32 bits of val), step-major per chunk
     uint32_t pairs_bytes;      // size of the pairs array incl. the read-ahead padding (< 2^31)
@@ -120,6 +121,9 @@ struct Ppr16Args {
     const int32_t *lrow_row, *lrow_first, *lrow_cnt;  // [n_lrow] long rows and their partial slots
     int32_t n_lrow;
     int32_t n_partial;
+    const int32_t *seg_lrow;   // [n_partial] long row of a partial slot
+    int32_t *lcount;           // [n_slabs][n_lrow] arrival counters (zero between launches): the LAST segment of a long
+                               // row to arrive adds the row's partial sums up and finishes it -- no second kernel
     float *partial;            // [n_slabs][n_partial][64] fp32
     int64_t num_vertices;
     const uint16_t *x;         // gather source, fp16 [n_slabs][V][64]
@@ -162,6 +166,8 @@ struct Sell8Dev {
     const int32_t *lrow_row, *lrow_first, *lrow_cnt;  // [n_lrow] long rows and their partial slots
     int32_t n_lrow;
     int32_t n_partial;
+    const int32_t *seg_lrow;   // [n_partial] long row of a partial slot
+    int32_t *lcount;           // [n_slabs][n_lrow] arrival counters (see Ppr16Args)
 };
 // State buffers: e4m3 [n_groups][V + 1][spg][128]; slab s lives in group s / spg, column block s % spg;
 // row V of every group is all-zero (the target of masked-out gathers in mode B0).  An owner's rows
@@ -234,6 +240,8 @@ struct PprSvArgs {
     int32_t n_chunks;
     const int32_t *lrow_row, *lrow_first, *lrow_cnt;
     int32_t n_lrow;
+    const int32_t *seg_lrow;   // [n_partial] long row of a partial slot
+    int32_t *lcount;           // [n_lrow] arrival counters (see Ppr16Args)
     float *partial;            // [n_partial][BP]
     int64_t num_vertices;
     const void *x;             // [V][BP] fp32, or fp16 when half_state

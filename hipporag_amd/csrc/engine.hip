@@ -6,6 +6,7 @@
 // afterwards only enqueues kernels on the caller's stream (no allocation, no synchronisation).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -16,7 +17,8 @@
 namespace {
 
 void free_store(Sell8Store &m) {
-    void *ptrs[] = {m.pairs, m.pairs_at, m.chunk_meta, m.vrow, m.lrow_row, m.lrow_first, m.lrow_cnt};
+    void *ptrs[] = {m.pairs, m.pairs_at, m.chunk_meta, m.vrow, m.lrow_row, m.lrow_first, m.lrow_cnt, m.seg_lrow,
+                    m.lcount};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     m = Sell8Store();
@@ -78,6 +80,24 @@ hrag_status ppr_step(hrag_engine *e, const float *tele, int64_t tele_rows, const
     return HRAG_OK;
 }
 
+// Longest (virtual) row of the SELL-8 matrix.  The wavefront that owns a row of n entries runs n / 8 dependent
+// gather steps (~0.9 us each): a sweep cannot end before its longest row does, and rows are cut into segments of
+// at most this many entries (the last-arriving segment adds the partial sums up inside the sweep kernel).
+// Measured (profiles/r02k_segment_length.json): on the 2 M-entry graph of cfg 2 a 64-query sweep moves its
+// 256 MB in ~38 us, and 512-entry rows (64 steps = 57 us) WERE the sweep: 41.3k queries/s at 512, 52.8k at 256,
+// 60.0k at 128, 62.5k at 64, 51.8k at 32 (more virtual rows, partial sums and arrivals), 37.0k at 16; the same
+// graph at 256 queries (two fp8 slabs) peaks at 128; 20 M entries x 2 slabs (cfg 3, 800 us sweeps) are flat from
+// 256 to 1024 and 1 % slower at 128.  Hence a rule in the work of one sweep, entries x 128-query slabs.
+// HRAG_SELL8_SEG_LEN overrides (experiments).
+int32_t sell8_seg_len(int64_t nnz_owned, int max_batch) {
+    if (const char *env = std::getenv("HRAG_SELL8_SEG_LEN")) {
+        const int v = std::atoi(env);
+        if (v >= 8 && v <= 1 << 20) return (int32_t)round_up(v, 8);
+    }
+    const int64_t work = nnz_owned * (int64_t)n_slabs128(max_batch);
+    return work <= (int64_t)3 << 20 ? 64 : work <= (int64_t)12 << 20 ? 128 : work <= (int64_t)30 << 20 ? 256 : kSell8SegLen;
+}
+
 // SELL-8 form of (a subset of) the owned CSR rows for ppr16.hip / ppr8.hip (see the header comments there).
 // rows (may be null = all): LOCAL rows to include.  want_p: the (col, P value) pairs of ppr16 / ppr_sv.
 // deg (may be null): weighted degrees by GLOBAL vertex id; when given, the pairs with the row-normalised
@@ -89,24 +109,27 @@ hrag_status build_sell8(const hrag_engine *e, const std::vector<int32_t> &row_pt
     std::vector<VRow> vr;
     const int64_t n_sel = rows ? (int64_t)rows->size() : e->n_rows;
     vr.reserve((size_t)n_sel + 1024);
-    std::vector<int32_t> lrow_row, lrow_first, lrow_cnt;
+    std::vector<int32_t> lrow_row, lrow_first, lrow_cnt, seg_lrow;
     int32_t n_partial = 0;
+    const int32_t max_len = sell8_seg_len(row_ptr[(size_t)e->n_rows], e->max_batch);
     for (int64_t k = 0; k < n_sel; ++k) {
         const int64_t r = rows ? (*rows)[(size_t)k] : k;
         const int32_t b0 = row_ptr[(size_t)r], len = row_ptr[(size_t)r + 1] - b0;
-        if (len <= kSell8SegLen) {
+        if (len <= max_len) {
             vr.push_back({len, b0, (int32_t)r, (int32_t)r});
             continue;
         }
-        // at most 64 segments per row, each a multiple of 8 entries
-        int32_t nseg = std::min<int32_t>((len + kSell8SegLen - 1) / kSell8SegLen, 64);
+        // at most kSell8MaxSegs segments per row, each a multiple of 8 entries
+        int32_t nseg = std::min<int32_t>((len + max_len - 1) / max_len, kSell8MaxSegs);
         const int32_t seg_len = (int32_t)round_up((len + nseg - 1) / nseg, 8);
         nseg = (len + seg_len - 1) / seg_len;
         lrow_row.push_back((int32_t)r);
         lrow_first.push_back(n_partial);
         lrow_cnt.push_back(nseg);
-        for (int32_t i = 0; i < nseg; ++i)
+        for (int32_t i = 0; i < nseg; ++i) {
+            seg_lrow.push_back((int32_t)lrow_row.size() - 1);
             vr.push_back({std::min(seg_len, len - i * seg_len), b0 + i * seg_len, -(n_partial++ + 1), (int32_t)r});
+        }
     }
     // longest first (stable => deterministic); a chunk = 8 consecutive virtual rows
     std::stable_sort(vr.begin(), vr.end(), [](const VRow &a, const VRow &b) { return a.len > b.len; });
@@ -197,6 +220,10 @@ hrag_status build_sell8(const hrag_engine *e, const std::vector<int32_t> &row_pt
     HRAG_TRY(dev_upload(&out->lrow_row, lrow_row.data(), (int64_t)lrow_row.size()));
     HRAG_TRY(dev_upload(&out->lrow_first, lrow_first.data(), (int64_t)lrow_first.size()));
     HRAG_TRY(dev_upload(&out->lrow_cnt, lrow_cnt.data(), (int64_t)lrow_cnt.size()));
+    HRAG_TRY(dev_upload(&out->seg_lrow, seg_lrow.data(), (int64_t)seg_lrow.size()));
+    const int64_t n_cnt = (int64_t)n_slabs64(e->max_batch) * (int64_t)lrow_row.size();
+    HRAG_TRY(dev_alloc(&out->lcount, n_cnt));
+    if (n_cnt > 0) HRAG_HIP_TRY(hipMemset(out->lcount, 0, (size_t)n_cnt * sizeof(int32_t)));
     return HRAG_OK;
 }
 
@@ -207,6 +234,7 @@ Ppr16Args ppr16_args(const hrag_engine *e, const uint16_t *x, uint16_t *y, const
     a.chunk_meta = e->sell.chunk_meta; a.vrow = e->sell.vrow; a.n_chunks = e->sell.n_chunks;
     a.lrow_row = e->sell.lrow_row; a.lrow_first = e->sell.lrow_first; a.lrow_cnt = e->sell.lrow_cnt;
     a.n_lrow = e->sell.n_lrow; a.n_partial = e->sell.n_partial; a.partial = e->d_partial16;
+    a.seg_lrow = e->sell.seg_lrow; a.lcount = e->sell.lcount;
     a.num_vertices = e->V; a.x = x; a.y = y; a.aux = aux; a.row_slot = e->d_row_slot;
     a.tele = e->d_tele16; a.tele_rows = e->tele16_rows;
     a.alpha = damping; a.beta = 1.0f - damping; a.cscale = kPpr16CScale;
@@ -252,6 +280,7 @@ PprSvArgs ppr_sv_args(const hrag_engine *e, const Sell8Store &m, const void *x, 
     a.vrow = m.vrow; a.n_chunks = m.n_chunks;
     a.lrow_row = m.lrow_row; a.lrow_first = m.lrow_first; a.lrow_cnt = m.lrow_cnt;
     a.n_lrow = m.n_lrow; a.partial = e->d_partial_sv; a.num_vertices = e->V;
+    a.seg_lrow = m.seg_lrow; a.lcount = m.lcount;
     a.x = x; a.y = y; a.row_slot = row_slot; a.tele = tele;
     a.alpha = damping; a.beta = 1.0f - damping;
     a.nt = (e->opt_flags & HRAG_OPT_NT_CSR) ? 1 : 0;   // measured: nt loads are 25 % slower at B = 1

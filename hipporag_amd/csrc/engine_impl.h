@@ -53,6 +53,8 @@ struct Sell8Store {
     int2 *pairs_at = nullptr;   // (col, At value = p_ij d_j / d_i)    -- ppr8
     int2 *chunk_meta = nullptr;
     int32_t *vrow = nullptr, *lrow_row = nullptr, *lrow_first = nullptr, *lrow_cnt = nullptr;
+    int32_t *seg_lrow = nullptr;   // [n_partial] long row of a partial slot
+    int32_t *lcount = nullptr;     // [n_slabs64(max_batch)][n_lrow] arrival counters, zero between launches
     int32_t n_chunks = 0, n_lrow = 0, n_partial = 0;
     int64_t steps = 0;
     uint32_t pairs_bytes() const { return (uint32_t)((steps + 4) * 512); }
@@ -60,7 +62,7 @@ struct Sell8Store {
         Sell8Dev d;
         d.pairs = pairs_at; d.pairs_bytes = pairs_bytes(); d.chunk_meta = chunk_meta; d.vrow = vrow;
         d.n_chunks = n_chunks; d.lrow_row = lrow_row; d.lrow_first = lrow_first; d.lrow_cnt = lrow_cnt;
-        d.n_lrow = n_lrow; d.n_partial = n_partial;
+        d.n_lrow = n_lrow; d.n_partial = n_partial; d.seg_lrow = seg_lrow; d.lcount = lcount;
         return d;
     }
 };

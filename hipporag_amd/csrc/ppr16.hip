@@ -22,8 +22,9 @@
 //
 // Storage: x is [n_slabs][V][64] fp16 -- one gather = one 128-byte line = 64 queries.
 // Matrix: SELL-8 ("sliced ELLPACK", slice = the 8 rows of one wavefront): rows sorted by length,
-// rows longer than kSell8SegLen (512) entries cut into <= 64 segments ("virtual rows" whose partial sums are
-// combined by ppr16_reduce_kernel in a fixed order -- no atomics, bit-reproducible), 8 virtual
+// rows longer than 64 .. 512 entries (engine.hip sell8_seg_len) cut into segments ("virtual rows" whose partial sums are
+// combined in a fixed order by the wavefront of the segment that arrives last -- no atomics on the data, one
+// arrival counter per row; bit-reproducible, no second kernel), 8 virtual
 // rows per wavefront, entries stored step-major as (col, val) pairs so that a wavefront's CSR
 // read is ONE coalesced 512-byte load per 8-gather step and every fetched byte is used once.
 #include <hip/hip_fp16.h>
@@ -79,6 +80,18 @@ template <bool NT>
 __device__ __forceinline__ int2 ld_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
     const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, NT ? 2 : 0);
     return make_int2(v.x, v.y);
+}
+
+// 16-byte store / load with sc1 (aux bit 4): write-through to memory / served past the CU's L1 -- the forms that
+// make data written by one workgroup readable by another INSIDE a launch (per-XCD L2s are not coherent)
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, float a, float b, float c, float d) {
+    const v4u_t v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 16);
+}
+__device__ __forceinline__ f32x4_t ld_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 16);
+    return f32x4_t{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }
 
 __device__ __forceinline__ float clamp_half(float v) { return fminf(fmaxf(v, -kHalfMax), kHalfMax); }
@@ -148,40 +161,52 @@ __global__ __launch_bounds__(256, 6) void ppr16_kernel(const Ppr16Args a) {
         p1 = p2;
     }
     const int tgt = a.vrow[chunk * 8 + grp];
+    const bool seg = tgt < 0 && tgt != kVrowNone;
+    // partial sums travel write-through / L1-bypassing (sc1): writer and reader may sit on different XCDs
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+        a.partial + (size_t)slab * a.n_partial * 64, 0, a.n_partial * 256, 0x00020000);
     if (tgt >= 0) {
         finish_row<MODE, NT_ST>(a, slab, tgt, gl, acc);
-    } else if (tgt != kVrowNone) {
-        f32x4_t *pp4 = reinterpret_cast<f32x4_t *>(
-            a.partial + ((size_t)slab * a.n_partial + (size_t)(-(tgt + 1))) * 64 + (size_t)gl * 8);
-        f32x4_t v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
-        pp4[0] = v0;
-        pp4[1] = v1;
+    } else if (seg) {
+        const unsigned at = (unsigned)(-(tgt + 1)) * 256u + (unsigned)gl * 32u;
+        st_sc1(qrs, at, acc[0], acc[1], acc[2], acc[3]);
+        st_sc1(qrs, at + 16u, acc[4], acc[5], acc[6], acc[7]);
     }
-}
-
-// One wavefront per long row: the 8 lane groups stride over the row's partial sums, then the 8
-// group totals are added with xor-shuffles -- a fixed summation order.
-template <int MODE>
-__global__ __launch_bounds__(256) void ppr16_reduce_kernel(const Ppr16Args a) {
-    const int lane = threadIdx.x & 63;
-    const int gl = lane & 7, grp = lane >> 3;
-    const int slab = blockIdx.y;
-    const int m = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (m >= a.n_lrow) return;
-    const int first = a.lrow_first[m], cnt = a.lrow_cnt[m];
-    const float *base = a.partial + ((size_t)slab * a.n_partial + (size_t)first) * 64 + (size_t)gl * 8;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = grp; s < cnt; s += 8) {
-        const f32x4_t *p = reinterpret_cast<const f32x4_t *>(base + (size_t)s * 64);
-        const f32x4_t v0 = p[0], v1 = p[1];
-        acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
-        acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+    // Long rows arrive as segments in different wavefronts; the segment that arrives LAST (agent-scope
+    // counter) lends its whole wavefront to the row: the 8 lane groups stride over the row's partial sums, the 8
+    // group totals are added with xor-shuffles -- a fixed summation order, whoever comes last -- and the row is
+    // finished.  No second kernel per sweep.
+    if (__builtin_amdgcn_ballot_w64(seg) == 0) return;   // wave-uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's partial sums have left the CU
+    int m = -1;
+    bool last = false;
+    int32_t *cnts = a.lcount + (size_t)slab * a.n_lrow;
+    if (seg && gl == 0) {
+        m = a.seg_lrow[-(tgt + 1)];
+        const int before = __hip_atomic_fetch_add(cnts + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = before == a.lrow_cnt[m] - 1;
     }
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(last);
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int mm = __builtin_amdgcn_readlane(m, l);
+        const int first = a.lrow_first[mm], cnt = a.lrow_cnt[mm];
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1)
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int sg = grp; sg < cnt; sg += 8) {
+            const unsigned at = (unsigned)(first + sg) * 256u + (unsigned)gl * 32u;
+            const f32x4_t v0 = ld_sc1(qrs, at), v1 = ld_sc1(qrs, at + 16u);
+            acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
+            acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
-    if (grp == 0) finish_row<MODE>(a, slab, a.lrow_row[m], gl, acc);
+        for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+        if (grp == 0) finish_row<MODE>(a, slab, a.lrow_row[mm], gl, acc);
+        if (lane == 0) __hip_atomic_store(cnts + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // h_0 = f16(v): every vertex row of every slab
@@ -288,11 +313,7 @@ hrag_status sweep_mode(const Ppr16Args &a, int n_slabs, int nt, bool main_only, 
         }
         HRAG_LAUNCH_CHECK();
     }
-    if (!main_only && a.n_lrow > 0) {
-        dim3 grid((unsigned)ceil_div(a.n_lrow, 4), (unsigned)n_slabs);
-        hipLaunchKernelGGL(ppr16_reduce_kernel<MODE>, grid, dim3(256), 0, s, a);
-        HRAG_LAUNCH_CHECK();
-    }
+    (void)main_only;   // long rows are finished inside the sweep kernel (last-arriving segment)
     return HRAG_OK;
 }
 

@@ -201,6 +201,25 @@ __device__ __forceinline__ void st16i(float *row, int gl, const f32x2_t (&f)[8])
         __builtin_nontemporal_store(v, p4 + 8 * i);
     }
 }
+// the same rows with sc1 (aux bit 4): write-through to memory / served past the CU's L1 -- the forms that make
+// data written by one workgroup readable by another INSIDE a launch (per-XCD L2s are not coherent)
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ld16i_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned row_off, int gl, f32x2_t (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row_off + (unsigned)(8 * i + gl) * 16u, 0, 16);
+        f[2 * i] = f32x2_t{__uint_as_float(v.x), __uint_as_float(v.y)};
+        f[2 * i + 1] = f32x2_t{__uint_as_float(v.z), __uint_as_float(v.w)};
+    }
+}
+__device__ __forceinline__ void st16i_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned row_off, int gl, const f32x2_t (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const v4u_t v = {__float_as_uint(f[2 * i].x), __float_as_uint(f[2 * i].y), __float_as_uint(f[2 * i + 1].x),
+                         __float_as_uint(f[2 * i + 1].y)};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, row_off + (unsigned)(8 * i + gl) * 16u, 0, 16);
+    }
+}
 // natural order (caller-facing arrays): lane owns 16 consecutive floats
 __device__ __forceinline__ void st16f(float *p, const f32x2_t (&f)[8]) {
     f32x4_t *p4 = reinterpret_cast<f32x4_t *>(p);
@@ -421,41 +440,53 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
         }
     }
     const int tgt = a.m.vrow[chunk * 8 + grp];
+    const bool seg = tgt < 0 && tgt != kVrowNone;
+    // partial sums travel write-through / L1-bypassing (sc1): writer and reader may sit on different XCDs
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+        a.partial + (size_t)slab * a.m.n_partial * 128, 0, a.m.n_partial * 512, 0x00020000);
     if (tgt >= 0) {
         finish_row<MODE, RIO>(a, slab, tgt, gl, acc);
-    } else if (tgt != kVrowNone) {
-        st16i(a.partial + ((size_t)slab * a.m.n_partial + (size_t)(-(tgt + 1))) * 128, gl, acc);
+    } else if (seg) {
+        st16i_sc1(qrs, (unsigned)(-(tgt + 1)) * 512u, gl, acc);
     }
-}
-
-// One wavefront per long row: the 8 lane groups stride over the row's partial sums, then the 8
-// group totals are added with xor-shuffles -- a fixed summation order.
-template <int MODE, int RIO>
-__global__ __launch_bounds__(256) void ppr8_reduce_kernel(const Ppr8Args a) {
-    const int lane = threadIdx.x & 63;
-    const int gl = lane & 7, grp = lane >> 3;
-    const int slab = a.slab0 + blockIdx.y;
-    const int m = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (m >= a.m.n_lrow) return;
-    const int first = a.m.lrow_first[m], cnt = a.m.lrow_cnt[m];
-    const float *base = a.partial + ((size_t)slab * a.m.n_partial + (size_t)first) * 128;
-    f32x2_t acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = f32x2_t{0.f, 0.f};
-    for (int s = grp; s < cnt; s += 8) {
-        f32x2_t v[8];
-        ld16i(base + (size_t)s * 128, gl, v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    // Long rows arrive as segments in different wavefronts; the segment that arrives LAST (agent-scope
+    // counter) lends its whole wavefront to the row: the 8 lane groups stride over the row's partial sums, the 8
+    // group totals are added with xor-shuffles -- a fixed summation order, whoever comes last -- and the row is
+    // finished.  No second kernel per sweep.
+    if (__builtin_amdgcn_ballot_w64(seg) == 0) return;   // wave-uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's partial sums have left the CU
+    int m = -1;
+    bool last = false;
+    int32_t *cnts = a.m.lcount + (size_t)slab * a.m.n_lrow;
+    if (seg && gl == 0) {
+        m = a.m.seg_lrow[-(tgt + 1)];
+        const int before = __hip_atomic_fetch_add(cnts + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = before == a.m.lrow_cnt[m] - 1;
     }
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(last);
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int mm = __builtin_amdgcn_readlane(m, l);
+        const int first = a.m.lrow_first[mm], cnt = a.m.lrow_cnt[mm];
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1)
+        for (int j = 0; j < 8; ++j) acc[j] = f32x2_t{0.f, 0.f};
+        for (int sg = grp; sg < cnt; sg += 8) {
+            f32x2_t v[8];
+            ld16i_sc1(qrs, (unsigned)(first + sg) * 512u, gl, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            acc[j].x += __shfl_xor(acc[j].x, o, 64);
-            acc[j].y += __shfl_xor(acc[j].y, o, 64);
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
         }
-    if (grp == 0) finish_row<MODE, RIO>(a, slab, a.m.lrow_row[m], gl, acc);
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j].x += __shfl_xor(acc[j].x, o, 64);
+                acc[j].y += __shfl_xor(acc[j].y, o, 64);
+            }
+        if (grp == 0) finish_row<MODE, RIO>(a, slab, a.m.lrow_row[mm], gl, acc);
+        if (lane == 0) __hip_atomic_store(cnts + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // c_0 = Q(v/d * c0_scale) for every OWNED row of the launch's slabs (R_0 = b v/d is formed on the fly by
@@ -606,11 +637,7 @@ hrag_status sweep_mode(const Ppr8Args &a, bool main_only, hipStream_t s) {
                            dim3(256), 0, s, b);
         HRAG_LAUNCH_CHECK();
     }
-    if (!main_only && a.m.n_lrow > 0) {
-        dim3 grid((unsigned)ceil_div(a.m.n_lrow, 4), (unsigned)a.n_slabs);
-        hipLaunchKernelGGL((ppr8_reduce_kernel<MODE, RIO>), grid, dim3(256), 0, s, a);
-        HRAG_LAUNCH_CHECK();
-    }
+    (void)main_only;   // long rows are finished inside the sweep kernel (last-arriving segment)
     return HRAG_OK;
 }
 

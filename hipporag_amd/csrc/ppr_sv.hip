@@ -12,7 +12,8 @@
 //     wavefront step; here every lane keeps its own (col, val) pair -- lane l of an 8-lane group
 //     walks entries l, l+8, ... of the group's row -- and the 8 partial sums are combined with a
 //     fixed xor-butterfly.  No atomics; bit-reproducible.
-//   * rows longer than 64 entries are the same <= 64 segments as in ppr16.hip (partials + reduce).
+//   * rows longer than kSell8SegLen entries are the same segments as in ppr16.hip; the segment that arrives
+//     last adds the partial sums up (fixed order) and finishes the row.
 // v (passage prior + seed rows) is one fp32 array [tele_rows][BP] addressed through row_slot, like
 // on the fp16 path; row_slot == nullptr means "dense v" (slot = vertex), used by hrag_ppr.
 //
@@ -160,23 +161,44 @@ __global__ __launch_bounds__(256) void ppr_sv_kernel(const PprSvArgs a) {
 #pragma unroll
     for (int b = 1; b < BP; ++b) mine = gl == b ? acc[b] : mine;
     const int tgt = a.vrow[chunk * 8 + grp];
+    const bool seg = tgt < 0 && tgt != kVrowNone;
     if (tgt >= 0) {
         sv_finish<BP, MODE, T>(a, tgt, gl, mine);
-    } else if (tgt != kVrowNone && gl < BP) {
-        a.partial[(size_t)(-(tgt + 1)) * BP + gl] = mine;
+    } else if (seg && gl < BP) {
+        // write-through (sc1): another XCD's reader must find the value in memory, not in this XCD's L2
+        __hip_atomic_store(&a.partial[(size_t)(-(tgt + 1)) * BP + gl], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-// one thread per (long row, column): <= 64 partial sums, added in segment order
-template <int BP, int MODE, typename T>
-__global__ __launch_bounds__(256) void ppr_sv_reduce_kernel(const PprSvArgs a) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int m = t / BP, gl = t % BP;
-    if (m >= a.n_lrow) return;
-    const int first = a.lrow_first[m], cnt = a.lrow_cnt[m];
-    float s = 0.f;
-    for (int i = 0; i < cnt; ++i) s += a.partial[(size_t)(first + i) * BP + gl];
-    sv_finish<BP, MODE, T>(a, a.lrow_row[m], gl, s);
+    // Long rows (> kSell8SegLen entries) arrive as segments in different wavefronts.  The segment that
+    // arrives LAST (agent-scope counter) adds the partial sums up -- always in segment order, with the whole
+    // wavefront -- and finishes the row: no second kernel, and the result does not depend on who came last.
+    if (__builtin_amdgcn_ballot_w64(seg) == 0) return;   // wave-uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's partial sums have left the CU
+    int m = -1;
+    bool last = false;
+    if (seg && gl == 0) {
+        m = a.seg_lrow[-(tgt + 1)];
+        const int before = __hip_atomic_fetch_add(a.lcount + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = before == a.lrow_cnt[m] - 1;
+    }
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(last);
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int mm = __builtin_amdgcn_readlane(m, l);
+        const int first = a.lrow_first[mm], cnt = a.lrow_cnt[mm];
+        float tot = 0.f;
+#pragma unroll
+        for (int b = 0; b < BP; ++b) {
+            float v = 0.f;
+            for (int i = lane; i < cnt; i += 64)
+                v += __hip_atomic_load(&a.partial[(size_t)(first + i) * BP + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            tot = gl == b ? v : tot;
+        }
+        if (grp == 0) sv_finish<BP, MODE, T>(a, a.lrow_row[mm], gl, tot);
+        if (lane == 0) __hip_atomic_store(a.lcount + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // x_0 = v  (fp32 or fp16 state)
@@ -352,11 +374,7 @@ hrag_status sv_sweep_one(const PprSvArgs &a, bool main_only, hipStream_t s) {
         else hipLaunchKernelGGL((ppr_sv_kernel<BP, false, MODE, T, MASK>), grid, dim3(256), 0, s, a);
         HRAG_LAUNCH_CHECK();
     }
-    if (!main_only && a.n_lrow > 0) {
-        hipLaunchKernelGGL((ppr_sv_reduce_kernel<BP, MODE, T>), dim3((unsigned)ceil_div((int64_t)a.n_lrow * BP, 256)),
-                           dim3(256), 0, s, a);
-        HRAG_LAUNCH_CHECK();
-    }
+    (void)main_only;   // long rows are finished inside the sweep kernel (last-arriving segment)
     return HRAG_OK;
 }
 

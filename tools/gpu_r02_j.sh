@@ -1,0 +1,20 @@
+#!/bin/bash
+# round 2: long rows finished inside the sweep kernels (no reduce launches) -- parity + timings
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/${1:-r02j}
+mkdir -p "$OUT"
+cd "$REPO"
+timeout 600 python -m pytest tests/test_gpu_long_rows.py -q -m gpu --tb=short > "$OUT/long_rows.log" 2>&1
+tail -8 "$OUT/long_rows.log"
+timeout 1500 python -m pytest tests -q -m gpu --maxfail=8 --tb=short > "$OUT/gpu_tests.log" 2>&1
+tail -8 "$OUT/gpu_tests.log"
+timeout 600 python tools/sweep_smallb.py --batches 1,2,4,8 --out "$OUT/sweep_smallb.json" > "$OUT/sweep_smallb.log" 2> "$OUT/sweep_smallb.err"
+cut -c1-330 "$OUT/sweep_smallb.log"
+for C in cfg2 cfg3; do
+  timeout 600 python bench.py --config $C --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_$C.json" 2> "$OUT/bench_$C.err"
+  python - <<PY
+import json
+d=json.load(open("$OUT/bench_$C.json")); print("$C", round(d["value"]), round(d["ms_per_step"],3), d["phases_ms"], d["roofline"]["frac"])
+PY
+done

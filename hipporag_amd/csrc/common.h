@@ -105,7 +105,7 @@ hrag_status launch_colsum(const float *x, int64_t num_vertices, int64_t row_offs
                           hipStream_t s);
 
 // ppr16.hip : two-stage fp16-state PPR (64 queries per 128-byte line), SELL-8 matrix
-enum Ppr16Mode { kPprModeH = 0, kPprModeR = 1, kPprModeC = 2 };
+enum Ppr16Mode { kPprModeH = 0, kPprModeR = 1, kPprModeC = 2, kPprModeF = 3 };   // F: last C sweep, passage rows
 constexpr int32_t kVrowNone = (int32_t)0x80000000;  // padding virtual row (no output)
 // rows above this (large graphs; engine.hip sell8_seg_len picks 64 .. 256 on small ones) are cut into segments.
 // Rows are sorted by length, so the 8 rows of a wavefront have similar trip counts and the longest start first:
@@ -133,13 +133,18 @@ struct Ppr16Args {
     const float *tele;         // fp32 [n_slabs][tele_rows][64]
     int64_t tele_rows;
     float alpha, beta, cscale;
+    // mode H, first sweep: only columns whose bit is set are gathered (h_0 = f16(v) is zero elsewhere); nullptr: all
+    const uint32_t *colmask = nullptr;
+    uint32_t colmask_bytes = 0;
+    // mode F (the matrix holds the passage rows only): x = h + c / cscale, fp32 [n_slabs][p_rows][64], passage order
+    const uint16_t *hfin = nullptr;
+    float *out = nullptr;
+    int64_t p_rows = 0;
 };
 // nt: bit0 non-temporal (col, val) loads, bit1 non-temporal state stores
 hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, int nt, bool main_only,
                                hipStream_t s);
 hrag_status launch_ppr16_init(const Ppr16Args &a, int n_slabs, hipStream_t s);  // y = f16(v)
-hrag_status launch_ppr16_combine(const uint16_t *h, const uint16_t *c, float inv_cscale, int64_t elems,
-                                 float *out, hipStream_t s);
 hrag_status launch_ppr16_scale(const float *mn, const float *mx, const float *ssum, int64_t n_passages,
                                float passage_weight, const float *seed_w, const int32_t *seed_cnt,
                                const int32_t *flags, int32_t batch, float *qscale, hipStream_t s);
@@ -263,13 +268,15 @@ hrag_status launch_ppr_sv_init(const PprSvArgs &a, int bp, hipStream_t s);
 hrag_status launch_ppr_sv_tele(const float *scores, int64_t ld, int64_t n, int32_t batch, const float *mn,
                                const float *mx, float weight, const int32_t *flags, float *tele, int bp,
                                hipStream_t s, const float *qscale = nullptr);
-// sums[b] = mass of the `iters`-sweep iterate, closed form (tele: [tele_rows][bp]; piso / iso: isolated flags of the
-// passages / of all vertices; passage_of_vertex: [V] passage number or -1)
-hrag_status launch_ppr_sv_mass(const float *tele, int64_t n_passages, int64_t tele_rows, const uint8_t *piso,
-                               const uint8_t *iso, const int32_t *passage_of_vertex, const int32_t *seed_vtx,
-                               const float *seed_w, const int32_t *seed_cnt, const float *qscale, int64_t num_vertices,
-                               int32_t batch, float damping, int32_t iters, double *part, double *sums, int bp,
-                               hipStream_t s);   // part: 8 * 64 * 2 doubles of scratch
+// sums[b] = mass of the `iters`-sweep iterate, closed form.  tele: [slab][slab_rows][stride], query b in slab
+// b / stride, column b % stride (ppr_sv: one slab, stride = bp; ppr16: stride 64); the first tele_rows rows of a slab
+// are summed; piso / iso: isolated flags of the passages / of all vertices; passage_of_vertex: [V] passage number or
+// -1; part: batch * 64 * 2 doubles of scratch
+hrag_status launch_ppr_sv_mass(const float *tele, int stride, int64_t slab_rows, int64_t n_passages, int64_t tele_rows,
+                               const uint8_t *piso, const uint8_t *iso, const int32_t *passage_of_vertex,
+                               const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt, const float *qscale,
+                               int64_t num_vertices, int32_t batch, float damping, int32_t iters, double *part,
+                               double *sums, hipStream_t s);
 hrag_status launch_ppr_sv_reset(const float *reset, int64_t n, int32_t batch, float *tele, int bp,
                                 hipStream_t s);
 // partial: 256 * bp doubles

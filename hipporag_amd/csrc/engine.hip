@@ -241,8 +241,10 @@ Ppr16Args ppr16_args(const hrag_engine *e, const uint16_t *x, uint16_t *y, const
     return a;
 }
 
-// h_0 = f16(v); K1 sweeps on h; the residual sweep; K2 sweeps on the correction; d_x = h + c / cs.
-// Buffers: d_h16[0], [1] ping-pong for h; [2] = r; the free h buffer and [3] ping-pong for c.
+// h_0 = f16(v); K1 sweeps on h (the first one gathers only the columns where h_0 is non-zero: d_colmask); the
+// residual sweep; K2 sweeps on the correction, the last of them over the passage rows only (fsell), writing
+// x = h + c / cs in fp32 at the passages (d_xp8, passage order) -- nothing else is read afterwards
+// (HippoRAG.py:1745).  Buffers: d_h16[0], [1] ping-pong for h; [2] = r; the free h buffer and [3] ping-pong for c.
 hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipStream_t s) {
     const int ns = n_slabs64(batch);
     const int nt = (e->opt_flags & HRAG_OPT_TEMPORAL16) ? 0 : 3;
@@ -250,18 +252,28 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
     uint16_t *h = e->d_h16[0], *hn = e->d_h16[1], *r = e->d_h16[2];
     HRAG_TRY(launch_ppr16_init(ppr16_args(e, nullptr, h, nullptr, damping), ns, s));
     for (int it = 0; it < k1; ++it) {
-        HRAG_TRY(launch_ppr16_sweep(ppr16_args(e, h, hn, nullptr, damping), kPprModeH, ns, nt, false, s));
+        Ppr16Args a = ppr16_args(e, h, hn, nullptr, damping);
+        if (it == 0) { a.colmask = e->d_colmask; a.colmask_bytes = (uint32_t)(e->colmask_words * 4); }
+        HRAG_TRY(launch_ppr16_sweep(a, kPprModeH, ns, nt, false, s));
         std::swap(h, hn);
     }
     HRAG_TRY(launch_ppr16_sweep(ppr16_args(e, h, r, nullptr, damping), kPprModeR, ns, nt, false, s));
     const uint16_t *c = r;            // c_{K1+1} = r
     uint16_t *cn = hn, *cn2 = e->d_h16[3];
     for (int it = 0; it < k2; ++it) {
-        HRAG_TRY(launch_ppr16_sweep(ppr16_args(e, c, cn, r, damping), kPprModeC, ns, nt, false, s));
+        const bool last = it + 1 == k2;
+        Ppr16Args a = ppr16_args(e, c, cn, r, damping);
+        if (last) {
+            const Sell8Store &m = e->fsell;
+            a.pairs = m.pairs; a.pairs_bytes = m.pairs_bytes(); a.chunk_meta = m.chunk_meta; a.vrow = m.vrow;
+            a.n_chunks = m.n_chunks; a.lrow_row = m.lrow_row; a.lrow_first = m.lrow_first; a.lrow_cnt = m.lrow_cnt;
+            a.n_lrow = m.n_lrow; a.n_partial = m.n_partial; a.seg_lrow = m.seg_lrow; a.lcount = m.lcount;
+            a.hfin = h; a.out = e->d_xp8; a.p_rows = e->p_rows;
+        }
+        HRAG_TRY(launch_ppr16_sweep(a, last ? kPprModeF : kPprModeC, ns, nt, false, s));
         c = cn;
         std::swap(cn, cn2);
     }
-    HRAG_TRY(launch_ppr16_combine(h, c, 1.0f / kPpr16CScale, (int64_t)ns * e->V * 64, e->d_x, s));
     if (h != e->d_h16[0]) std::swap(e->d_h16[0], e->d_h16[1]);  // keep h in [0] for hrag_ppr_sweeps
     return HRAG_OK;
 }
@@ -632,6 +644,7 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         for (auto &p : e->d_h16) E_TRY(dev_alloc(&p, e->state16_elems));
         E_TRY(dev_alloc(&e->d_partial16, (int64_t)ns * std::max(e->sell.n_partial, 1) * 64));
         for (auto &p : e->d_h16) E_HIP(hipMemset(p, 0, (size_t)e->state16_elems * sizeof(uint16_t)));
+        if (!e->f8_ready) E_TRY(dev_alloc(&e->d_xp8, (int64_t)ns * std::max<int64_t>(e->p_rows, 1) * 64));
         e->f16_ready = true;
     }
     if (e->f8_ready) {
@@ -922,6 +935,10 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
                                     hipMemcpyDeviceToDevice, s));
         HRAG_TRY(launch_ppr16_seed_rows(e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt, e->d_qscale, batch,
                                         e->n_passages, e->V, e->d_row_slot, e->d_tele16, e->tele16_rows, 64, s));
+        // columns where h_0 = f16(v) can be non-zero: the passage vertices + this batch's seeds (first sweep)
+        HRAG_HIP_TRY(hipMemcpyAsync(e->d_colmask, e->d_colmask_static, (size_t)e->colmask_words * sizeof(uint32_t),
+                                    hipMemcpyDeviceToDevice, s));
+        HRAG_TRY(launch_ppr8_mask_seeds(e->d_seed_vtx, e->d_seed_cnt, batch, e->V, e->d_colmask, s));
     } else if (sv) {
         // small batch (ppr_sv.hip): v = [Np + seed rows][bp] fp32, same "seeds are teleport rows" form; with the
         // fp16 state v carries the per-query power-of-two scale of ppr16.hip (every iterate fits fp16)
@@ -970,14 +987,21 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     // doc scores + ranking (HippoRAG.py:1745-1747, :503)
     if (sv) {
         // normalisation: the closed-form mass of the K-sweep iterate (the last sweep only produced the passage rows)
-        HRAG_TRY(launch_ppr_sv_mass(e->d_tele_sv, e->n_passages, e->n_passages + (int64_t)batch * kMaxSeeds, e->d_piso,
-                                    e->d_iso, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt,
-                                    sv_half ? e->d_qscale : nullptr, e->V, batch, damping, ppr_iters, e->d_colsum_partial,
-                                    e->d_sums, bp, s));
+        HRAG_TRY(launch_ppr_sv_mass(e->d_tele_sv, bp, 0, e->n_passages, e->n_passages + (int64_t)batch * kMaxSeeds,
+                                    e->d_piso, e->d_iso, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt,
+                                    sv_half ? e->d_qscale : nullptr, e->V, batch, damping, ppr_iters,
+                                    e->d_colsum_partial, e->d_sums, s));
         HRAG_TRY(launch_ppr_sv_rows(e->d_x, e->d_passage_vertex, e->n_passages, batch, e->d_sums, e->d_doc,
                                     e->ld_p, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, e->d_flags, bp, s));
     } else if (f8) {
         HRAG_TRY(ppr8_doc_scores(e, e->d_mn_p, e->d_mx_p, e->d_flags, batch, s));   // d_sums: the analytic mass
+    } else if (f16) {
+        // the same tail as the fp8 path: closed-form mass, x at the passages already in passage order
+        HRAG_TRY(launch_ppr_sv_mass(e->d_tele16, 64, e->tele16_rows, e->n_passages,
+                                    e->n_passages + (int64_t)batch * kMaxSeeds, e->d_piso, e->d_iso, e->d_row_to_tele,
+                                    e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt, e->d_qscale, e->V, batch, damping,
+                                    ppr_iters, e->d_colsum_partial, e->d_sums, s));
+        HRAG_TRY(ppr8_doc_scores(e, e->d_mn_p, e->d_mx_p, e->d_flags, batch, s));
     } else {
         HRAG_TRY(launch_colsum(e->d_x, e->V, 0, e->V, batch, lay, e->d_colsum_partial, e->d_sums, s));
         HRAG_TRY(launch_slab_to_rows(e->d_x, e->V, e->d_passage_vertex, e->n_passages, batch, e->d_sums,

@@ -13,7 +13,11 @@
 //   sweep  K1+1       r       = (alpha P h + beta v) - h   in fp32, stored f16(r * cs)   (mode R)
 //                     -- this IS sweep K1+1 of the iteration started at x_K1 = h: x_{K1+1} = h + r
 //   sweeps K1+2..K    c_{k+1} = f16(alpha P c_k + r),  c_{K1+1} = r               (mode C)
-//   result            x_K     = h + c_K / cs           (fp32, ppr16_combine_kernel)
+//   sweep  K          the last C sweep runs over the passage rows only (a second SELL-8 matrix) and writes
+//                     x_K = h + c_K / cs in fp32 at the passages, in passage order           (mode F)
+//                     -- nothing else is read afterwards (HippoRAG.py:1745); the normalising mass of x_K is the
+//                     closed form of ppr8.hip / ppr_sv.hip (sum(v) and the mass on isolated vertices)
+//   sweep  1          gathers only the columns where h_0 = f16(v) is non-zero (passages, seeds: column bitmap)
 //
 // x_k = h + c_k obeys exactly the recurrence of the fp32 iteration from x_K1 = h, so the truncation
 // error after K sweeps is that of K ordinary sweeps; the rounding of h is removed by r (computed
@@ -71,6 +75,31 @@ struct Gather8 {
     }
 };
 
+// First sweep: h_0 = f16(v) is zero outside the passage / seed vertices; the gather of a column whose bit is clear in
+// the column bitmap is not issued (its lanes are masked off for the load), ~6 % of the entries remain.
+template <int K>
+struct Gather8M {
+    __device__ __forceinline__ static void load(v4i_t (&xv)[8], float (&wk)[8], int c, int wbits, int on, const char *xs,
+                                                unsigned lane_off) {
+        const unsigned ck = (unsigned)bcast8<K>(c);
+        wk[K] = __int_as_float(bcast8<K>(wbits));
+        v4i_t v = {0, 0, 0, 0};
+        if (bcast8<K>(on)) v = *reinterpret_cast<const v4i_t *>(xs + (size_t)(ck * 128u + lane_off));
+        xv[K] = v;
+        if constexpr (K + 1 < 8) Gather8M<K + 1>::load(xv, wk, c, wbits, on, xs, lane_off);
+    }
+};
+// all (predicated) loads of a step are issued before the first FMA
+__device__ __forceinline__ void gather_step_masked(float (&acc)[8], int c, int wbits, int on, const char *xs,
+                                                   unsigned lane_off) {
+    v4i_t xv[8];
+    float wk[8];
+    Gather8M<0>::load(xv, wk, c, wbits, on, xs, lane_off);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fma8(acc, wk[k], xv[k]);
+}
+
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 
 // (col, val) pairs are read through a buffer descriptor: hipcc keeps raw buffer loads where they are
@@ -96,33 +125,70 @@ __device__ __forceinline__ f32x4_t ld_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 
 __device__ __forceinline__ float clamp_half(float v) { return fminf(fmaxf(v, -kHalfMax), kHalfMax); }
 
-// Finish one output row: lane gl of its group owns queries 8*gl .. 8*gl+7 of the slab.
-template <int MODE, bool NT_ST = false>
-__device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row, int gl,
-                                           const float (&acc)[8]) {
-    float out[8];
+// What a row's finish reads besides the accumulated sums: its teleport row (modes H, R), its own h (R, F), the
+// right-hand side r (C, F) and its slot.  Loaded by the wavefront BEFORE the gather loop (the row is known from the
+// start), so that the vrow -> row_slot -> tele chain of dependent loads overlaps with the gathers instead of
+// following them: on small graphs (cfg 2: 12.5k wavefronts, ~3 gather steps each) that chain was a third of the sweep.
+struct RowIn {
+    f32x4_t t0, t1;     // H, R: teleport row (zero without one)
+    half8_t h;          // R: a.x own row; F: a.hfin own row
+    half8_t r;          // C, F: a.aux own row
+    int slot;           // F: passage number
+};
+template <int MODE>
+__device__ __forceinline__ void load_row_in(const Ppr16Args &a, int slab, int row, int gl, RowIn &in) {
     const size_t state_off = ((size_t)slab * a.num_vertices + (size_t)row) * 64 + (size_t)gl * 8;
+    in.t0 = in.t1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    in.slot = -1;
     if constexpr (MODE == kPprModeH || MODE == kPprModeR) {
-        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int slot = a.row_slot[row];
         if (slot >= 0) {
             const f32x4_t *tp = reinterpret_cast<const f32x4_t *>(
                 a.tele + ((size_t)slab * a.tele_rows + (size_t)slot) * 64 + (size_t)gl * 8);
-            const f32x4_t t0 = tp[0], t1 = tp[1];
-            t[0] = t0.x; t[1] = t0.y; t[2] = t0.z; t[3] = t0.w;
-            t[4] = t1.x; t[5] = t1.y; t[6] = t1.z; t[7] = t1.w;
+            in.t0 = tp[0];
+            in.t1 = tp[1];
         }
+        if constexpr (MODE == kPprModeR) in.h = *reinterpret_cast<const half8_t *>(a.x + state_off);
+    } else {
+        in.r = *reinterpret_cast<const half8_t *>(a.aux + state_off);
+        if constexpr (MODE == kPprModeF) {
+            in.h = *reinterpret_cast<const half8_t *>(a.hfin + state_off);
+            in.slot = a.row_slot[row];
+        }
+    }
+}
+
+// Finish one output row: lane gl of its group owns queries 8*gl .. 8*gl+7 of the slab.
+template <int MODE, bool NT_ST = false>
+__device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row, int gl,
+                                           const float (&acc)[8], const RowIn &in) {
+    float out[8];
+    const size_t state_off = ((size_t)slab * a.num_vertices + (size_t)row) * 64 + (size_t)gl * 8;
+    if constexpr (MODE == kPprModeH || MODE == kPprModeR) {
+        const float t[8] = {in.t0.x, in.t0.y, in.t0.z, in.t0.w, in.t1.x, in.t1.y, in.t1.z, in.t1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[j] = fmaf(a.alpha, acc[j], a.beta * t[j]);
         if constexpr (MODE == kPprModeR) {
-            const half8_t h = *reinterpret_cast<const half8_t *>(a.x + state_off);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) out[j] = (out[j] - (float)h[j]) * a.cscale;
+            for (int j = 0; j < 8; ++j) out[j] = (out[j] - (float)in.h[j]) * a.cscale;
         }
     } else {
-        const half8_t r = *reinterpret_cast<const half8_t *>(a.aux + state_off);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) out[j] = fmaf(a.alpha, acc[j], (float)r[j]);
+        for (int j = 0; j < 8; ++j) out[j] = fmaf(a.alpha, acc[j], (float)in.r[j]);
+        if constexpr (MODE == kPprModeF) {
+            // last correction sweep, passage rows only: x = h + c / cscale in fp32, passage order
+            // [n_slabs][p_rows][64] -- the layout slab_to_rows reads without a gather
+            const float ics = 1.0f / a.cscale;
+            f32x4_t *op = reinterpret_cast<f32x4_t *>(
+                a.out + ((size_t)slab * a.p_rows + (size_t)in.slot) * 64 + (size_t)gl * 8);
+            const f32x4_t v0 = {fmaf(out[0], ics, (float)in.h[0]), fmaf(out[1], ics, (float)in.h[1]),
+                                fmaf(out[2], ics, (float)in.h[2]), fmaf(out[3], ics, (float)in.h[3])};
+            const f32x4_t v1 = {fmaf(out[4], ics, (float)in.h[4]), fmaf(out[5], ics, (float)in.h[5]),
+                                fmaf(out[6], ics, (float)in.h[6]), fmaf(out[7], ics, (float)in.h[7])};
+            op[0] = v0;
+            op[1] = v1;
+            return;
+        }
     }
     half8_t o;
 #pragma unroll
@@ -134,7 +200,7 @@ __device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row
     }
 }
 
-template <int MODE, bool NT, bool NT_ST>
+template <int MODE, bool NT, bool NT_ST, bool MASK = false>
 __global__ __launch_bounds__(256, 6) void ppr16_kernel(const Ppr16Args a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
@@ -150,23 +216,39 @@ __global__ __launch_bounds__(256, 6) void ppr16_kernel(const Ppr16Args a) {
     const unsigned poff = (unsigned)lane * 8u;
     const unsigned lane_off = (unsigned)gl * 16u;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int tgt = a.vrow[chunk * 8 + grp];
+    RowIn in;
+    if (tgt >= 0) load_row_in<MODE>(a, slab, tgt, gl, in);
     // the pair stream is read two steps ahead, unconditionally (the array carries two steps of
     // padding), so that the loop body is branch-free and the compiler can wait with vmcnt(N > 0)
     int2 p0 = ld_pair<NT>(prs, poff, pbase);
     int2 p1 = ld_pair<NT>(prs, poff + 512u, pbase);
-    for (int s = 0; s < n_steps; ++s) {
-        const int2 p2 = ld_pair<NT>(prs, poff + (unsigned)(s + 2) * 512u, pbase);
-        Gather8<0>::run(acc, p0.x, p0.y, xs, lane_off);
-        p0 = p1;
-        p1 = p2;
+    if constexpr (MASK) {
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t *>(a.colmask), 0, (int)a.colmask_bytes, 0x00020000);
+        int m0 = __builtin_amdgcn_raw_buffer_load_b32(mrs, ((unsigned)p0.x >> 5) * 4u, 0, 0);
+        for (int s = 0; s < n_steps; ++s) {
+            const int2 p2 = ld_pair<NT>(prs, poff + (unsigned)(s + 2) * 512u, pbase);
+            const int m1 = __builtin_amdgcn_raw_buffer_load_b32(mrs, ((unsigned)p1.x >> 5) * 4u, 0, 0);
+            gather_step_masked(acc, p0.x, p0.y, (m0 >> (p0.x & 31)) & 1, xs, lane_off);
+            p0 = p1;
+            p1 = p2;
+            m0 = m1;
+        }
+    } else {
+        for (int s = 0; s < n_steps; ++s) {
+            const int2 p2 = ld_pair<NT>(prs, poff + (unsigned)(s + 2) * 512u, pbase);
+            Gather8<0>::run(acc, p0.x, p0.y, xs, lane_off);
+            p0 = p1;
+            p1 = p2;
+        }
     }
-    const int tgt = a.vrow[chunk * 8 + grp];
     const bool seg = tgt < 0 && tgt != kVrowNone;
     // partial sums travel write-through / L1-bypassing (sc1): writer and reader may sit on different XCDs
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
         a.partial + (size_t)slab * a.n_partial * 64, 0, a.n_partial * 256, 0x00020000);
     if (tgt >= 0) {
-        finish_row<MODE, NT_ST>(a, slab, tgt, gl, acc);
+        finish_row<MODE, NT_ST>(a, slab, tgt, gl, acc, in);
     } else if (seg) {
         const unsigned at = (unsigned)(-(tgt + 1)) * 256u + (unsigned)gl * 32u;
         st_sc1(qrs, at, acc[0], acc[1], acc[2], acc[3]);
@@ -204,7 +286,11 @@ __global__ __launch_bounds__(256, 6) void ppr16_kernel(const Ppr16Args a) {
         for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
-        if (grp == 0) finish_row<MODE>(a, slab, a.lrow_row[mm], gl, acc);
+        if (grp == 0) {
+            const int row = a.lrow_row[mm];
+            load_row_in<MODE>(a, slab, row, gl, in);
+            finish_row<MODE>(a, slab, row, gl, acc, in);
+        }
         if (lane == 0) __hip_atomic_store(cnts + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -228,27 +314,6 @@ __global__ __launch_bounds__(256) void ppr16_init_kernel(const Ppr16Args a) {
         o[6] = (_Float16)clamp_half(t1.z); o[7] = (_Float16)clamp_half(t1.w);
     }
     *reinterpret_cast<half8_t *>(a.y + ((size_t)slab * a.num_vertices + (size_t)row) * 64 + (size_t)gl * 8) = o;
-}
-
-// x32[slab][v][64] = h + c * inv_cscale   (c may be null: x = h)
-__global__ __launch_bounds__(256) void ppr16_combine_kernel(const _Float16 *h, const _Float16 *c,
-                                                            float inv_cscale, int64_t n8,
-                                                            float *out) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n8) return;
-    const half8_t hv = reinterpret_cast<const half8_t *>(h)[t];
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (float)hv[j];
-    if (c) {
-        const half8_t cv = reinterpret_cast<const half8_t *>(c)[t];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = fmaf((float)cv[j], inv_cscale, o[j]);
-    }
-    f32x4_t *op = reinterpret_cast<f32x4_t *>(out) + t * 2;
-    f32x4_t v0 = {o[0], o[1], o[2], o[3]}, v1 = {o[4], o[5], o[6], o[7]};
-    op[0] = v0;
-    op[1] = v1;
 }
 
 // Per-query scale s_q (a power of two) such that sum(v_q) * s_q is in (2^14, 2^15]: every entry of
@@ -303,17 +368,24 @@ __global__ void ppr16_seed_rows_kernel(const int32_t *seed_vtx, const float *see
 
 template <int MODE>
 hrag_status sweep_mode(const Ppr16Args &a, int n_slabs, int nt, bool main_only, hipStream_t s) {
-    if (a.n_chunks > 0) {
-        dim3 grid((unsigned)ceil_div(a.n_chunks, 4), (unsigned)n_slabs);
-        switch (nt & 3) {   // bit0: non-temporal pair loads, bit1: non-temporal state stores
-            case 0: hipLaunchKernelGGL((ppr16_kernel<MODE, false, false>), grid, dim3(256), 0, s, a); break;
-            case 1: hipLaunchKernelGGL((ppr16_kernel<MODE, true, false>), grid, dim3(256), 0, s, a); break;
-            case 2: hipLaunchKernelGGL((ppr16_kernel<MODE, false, true>), grid, dim3(256), 0, s, a); break;
-            default: hipLaunchKernelGGL((ppr16_kernel<MODE, true, true>), grid, dim3(256), 0, s, a); break;
-        }
-        HRAG_LAUNCH_CHECK();
-    }
     (void)main_only;   // long rows are finished inside the sweep kernel (last-arriving segment)
+    if (a.n_chunks <= 0) return HRAG_OK;
+    dim3 grid((unsigned)ceil_div(a.n_chunks, 4), (unsigned)n_slabs);
+    if constexpr (MODE == kPprModeH) {
+        if (a.colmask) {   // first sweep
+            if (nt & 2) hipLaunchKernelGGL((ppr16_kernel<MODE, true, true, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((ppr16_kernel<MODE, true, false, true>), grid, dim3(256), 0, s, a);
+            HRAG_LAUNCH_CHECK();
+            return HRAG_OK;
+        }
+    }
+    switch (nt & 3) {   // bit0: non-temporal pair loads, bit1: non-temporal state stores
+        case 0: hipLaunchKernelGGL((ppr16_kernel<MODE, false, false>), grid, dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((ppr16_kernel<MODE, true, false>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((ppr16_kernel<MODE, false, true>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((ppr16_kernel<MODE, true, true>), grid, dim3(256), 0, s, a); break;
+    }
+    HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }
 
@@ -325,6 +397,7 @@ hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, int nt
         case kPprModeH: return sweep_mode<kPprModeH>(a, n_slabs, nt_pairs, main_only, s);
         case kPprModeR: return sweep_mode<kPprModeR>(a, n_slabs, nt_pairs, main_only, s);
         case kPprModeC: return sweep_mode<kPprModeC>(a, n_slabs, nt_pairs, main_only, s);
+        case kPprModeF: return sweep_mode<kPprModeF>(a, n_slabs, nt_pairs, main_only, s);
         default: set_error("bad ppr16 mode %d", mode); return HRAG_EINVAL;
     }
 }
@@ -332,17 +405,6 @@ hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, int nt
 hrag_status launch_ppr16_init(const Ppr16Args &a, int n_slabs, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(a.num_vertices * 8, 256), (unsigned)n_slabs);
     hipLaunchKernelGGL(ppr16_init_kernel, grid, dim3(256), 0, s, a);
-    HRAG_LAUNCH_CHECK();
-    return HRAG_OK;
-}
-
-hrag_status launch_ppr16_combine(const uint16_t *h, const uint16_t *c, float inv_cscale, int64_t elems,
-                                 float *out, hipStream_t s) {
-    const int64_t n8 = elems / 8;
-    if (n8 == 0) return HRAG_OK;
-    hipLaunchKernelGGL(ppr16_combine_kernel, dim3((unsigned)ceil_div(n8, 256)), dim3(256), 0, s,
-                       reinterpret_cast<const _Float16 *>(h), reinterpret_cast<const _Float16 *>(c),
-                       inv_cscale, n8, out);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

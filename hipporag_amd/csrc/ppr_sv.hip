@@ -219,15 +219,16 @@ __global__ __launch_bounds__(256) void ppr_sv_init_kernel(const PprSvArgs a) {
 // (passages with the seeds that are passages folded in, then the seed rows), S = the part on isolated vertices.
 // Pass 1: grid (kSvMassSplit, batch) partial sums in double; pass 2: one thread per query adds them in a fixed order.
 constexpr int kSvMassSplit = 64;
-template <int BP>
-__global__ __launch_bounds__(256) void ppr_sv_mass_kernel(const float *__restrict__ tele, int64_t n_passages,
-                                                          int64_t tele_rows, const uint8_t *__restrict__ piso,
-                                                          double *__restrict__ part) {
+// tele: [slab][slab_rows][stride] with query b in slab b / stride, column b % stride (small batches: one slab)
+__global__ __launch_bounds__(256) void ppr_sv_mass_kernel(const float *__restrict__ tele, int stride, int64_t slab_rows,
+                                                          int64_t n_passages, int64_t tele_rows,
+                                                          const uint8_t *__restrict__ piso, double *__restrict__ part) {
     __shared__ double rm[256], rs[256];
     const int b = blockIdx.y, tid = threadIdx.x;
+    const float *col = tele + (size_t)(b / stride) * (size_t)slab_rows * stride + (b % stride);
     double m = 0.0, si = 0.0;
     for (int64_t r = (int64_t)blockIdx.x * 256 + tid; r < tele_rows; r += (int64_t)kSvMassSplit * 256) {
-        const double v = (double)tele[(size_t)r * BP + b];
+        const double v = (double)col[(size_t)r * stride];
         m += v;
         if (r < n_passages && piso[r]) si += v;
     }
@@ -461,19 +462,16 @@ hrag_status launch_ppr_sv_colsum(const float *x, int64_t n, int bp, double *part
     return HRAG_OK;
 }
 
-hrag_status launch_ppr_sv_mass(const float *tele, int64_t n_passages, int64_t tele_rows, const uint8_t *piso,
-                               const uint8_t *iso, const int32_t *passage_of_vertex, const int32_t *seed_vtx,
-                               const float *seed_w, const int32_t *seed_cnt, const float *qscale, int64_t num_vertices,
-                               int32_t batch, float damping, int32_t iters, double *part, double *sums, int bp,
-                               hipStream_t s) {
-#define CALL(BP)                                                                                             \
-    hipLaunchKernelGGL(ppr_sv_mass_kernel<BP>, dim3(kSvMassSplit, (unsigned)batch), dim3(256), 0, s, tele, n_passages, \
-                       tele_rows, piso, part)
-    HRAG_DISPATCH_BP(bp, CALL)
-#undef CALL
+hrag_status launch_ppr_sv_mass(const float *tele, int stride, int64_t slab_rows, int64_t n_passages, int64_t tele_rows,
+                               const uint8_t *piso, const uint8_t *iso, const int32_t *passage_of_vertex,
+                               const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt, const float *qscale,
+                               int64_t num_vertices, int32_t batch, float damping, int32_t iters, double *part,
+                               double *sums, hipStream_t s) {
+    hipLaunchKernelGGL(ppr_sv_mass_kernel, dim3(kSvMassSplit, (unsigned)batch), dim3(256), 0, s, tele, stride, slab_rows,
+                       n_passages, tele_rows, piso, part);
     HRAG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ppr_sv_mass_final_kernel, dim3(1), dim3(64), 0, s, part, iso, passage_of_vertex, seed_vtx, seed_w,
-                       seed_cnt, qscale, num_vertices, batch, damping, iters, sums);
+    hipLaunchKernelGGL(ppr_sv_mass_final_kernel, dim3((unsigned)ceil_div(batch, 64)), dim3(64), 0, s, part, iso,
+                       passage_of_vertex, seed_vtx, seed_w, seed_cnt, qscale, num_vertices, batch, damping, iters, sums);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -321,8 +321,11 @@ hrag_status launch_sim_gemm256(const uint16_t *emb, int64_t rows, int32_t dim, c
                                float *out, int64_t ld, float *tmax, float *tmin, hipStream_t s, int32_t dtype);
 
 // fused similarity + top-k for k <= 16 (no [B, rows] score matrix; bit-identical to the two-step path)
-//   ws: 2 * sim_fused_tiles(rows) * batch floats; sel: batch * 16 ints; mn / mx: batch floats
+//   ws: 2 * sim_fused_tiles(rows) * batch floats; sel: sim_fused_sel_ints(batch) ints, zeroed ONCE at allocation
+//   (per-query records: selected tiles, arrival counter, candidate keys); mn / mx: batch floats
 int64_t sim_fused_tiles(int64_t rows);
+int64_t sim_fused_sel_ints(int32_t batch);
+int64_t sim_fused_sel_ints(int32_t batch);   // ints of the `sel` workspace (zero it once, at allocation)
 hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
                                   int32_t batch, int32_t k, int32_t idx_offset, int32_t normalize,
                                   float *ws, int32_t *sel, float *mn, float *mx, int32_t *idx_out,

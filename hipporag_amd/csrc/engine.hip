@@ -678,7 +678,8 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     if (facts) E_TRY(dev_alloc(&e->d_sfact, (int64_t)B * e->ld_f));
     if (facts && B > 16) {
         E_TRY(dev_alloc(&e->d_fused_ws, 2 * sim_fused_tiles(std::max<int64_t>(e->f_rows, 1)) * B));
-        E_TRY(dev_alloc(&e->d_fused_sel, (int64_t)B * 16));
+        E_TRY(dev_alloc(&e->d_fused_sel, sim_fused_sel_ints(B)));
+        E_HIP(hipMemset(e->d_fused_sel, 0, (size_t)sim_fused_sel_ints(B) * sizeof(int32_t)));
         E_TRY(dev_alloc(&e->d_mn_f, B));
         E_TRY(dev_alloc(&e->d_mx_f, B));
     }

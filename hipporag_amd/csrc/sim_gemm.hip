@@ -240,6 +240,7 @@ __device__ __forceinline__ uint64_t block_max_u64(uint64_t v, uint64_t *red, int
 // read ONCE into registers (kSelRegs per thread covers 8192 tiles = 1M rows; beyond that the rounds
 // re-read memory) and the k selection rounds run on the registers.
 constexpr int kSelRegs = 32;
+constexpr int kSelRecInts = 32 + 16 * 128 * 2;   // = kSelRec below: ints per query record of the `sel` workspace
 __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restrict__ tmax,
                                                           const float *__restrict__ tmin, int32_t n_tiles,
                                                           int32_t batch, int32_t k, int32_t *__restrict__ sel,
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restric
         }
         best = block_max_u64(best, red, tid);
         if (tid == 0) {
-            sel[b * kFusedMaxK + r] = best ? (int32_t)(uint32_t)best : -1;
+            sel[(size_t)b * kSelRecInts + r] = best ? (int32_t)(uint32_t)best : -1;
             if (r == 0) {
                 mx_out[b] = best ? ordered_to_f32((uint32_t)(best >> 32)) : -INFINITY;
                 mn_out[b] = mn;
@@ -290,10 +291,19 @@ __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restric
     }
 }
 
+// Per-query record in the `sel` workspace (ints): [0, 16) the selected tiles, [16] the arrival counter of pass 3
+// (zero between launches), then kFusedMaxK * BM 64-bit candidate keys.  The record stride does not depend on the
+// batch, so the counters zeroed at allocation stay where every launch expects them.
+constexpr int kSelRec = 32 + kFusedMaxK * BM * 2;
+
+// Pass 3, one workgroup per (selected tile, query) -- round 1 ran the k tiles of a query one after the other in one
+// workgroup, a chain of ~240 dependent loads (0.10 ms at cfg 3, 69 us at cfg 2); now the k tiles are k workgroups, and
+// the one that arrives LAST (agent-scope counter; candidate keys travel as sc1 stores / loads: the workgroups sit on
+// different XCDs) selects the exact top-k of the k x 128 keys.  Same MFMA fragments in the same k order as pass 1.
 template <bool F16>
 __global__ __launch_bounds__(256) void tile_rescore_kernel(const uint16_t *__restrict__ emb, int64_t rows,
                                                            int32_t dim, const uint16_t *__restrict__ q,
-                                                           const int32_t *__restrict__ sel,
+                                                           int32_t *__restrict__ rec,
                                                            const float *__restrict__ mn_in,
                                                            const float *__restrict__ mx_in, int32_t k,
                                                            int32_t idx_offset, int32_t normalize,
@@ -301,45 +311,62 @@ __global__ __launch_bounds__(256) void tile_rescore_kernel(const uint16_t *__res
                                                            float *__restrict__ val_out) {
     __shared__ uint64_t cand[kFusedMaxK * BM];
     __shared__ uint64_t red[4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_last;
+    const int r = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t *my = rec + (size_t)b * kSelRec;
+    unsigned long long *gc = reinterpret_cast<unsigned long long *>(my + 32);
     const uint16_t *qrow = q + (size_t)b * dim;
-    int n_cand = 0;
-    for (int r = 0; r < k; ++r) {
-        const int t = sel[b * kFusedMaxK + r];
-        if (t < 0) break;
+    const int t = my[r];
+    if (t >= 0) {
+        const int64_t row0 = (int64_t)t * BM + wave * 32;
+        const int64_t arow0 = row0 + (lane & 15), arow1 = arow0 + 16;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // the k order of sim_gemm_kernel: BK = 64 steps, two 32-wide MFMAs each, 8-element zero fill
+        for (int k0 = 0; k0 < dim; k0 += BK) {
+            uint4 ua0[BK / 32], ua1[BK / 32], ub[BK / 32];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const int64_t row0 = (int64_t)t * BM + wave * 32 + f * 16;
-            const int64_t arow = row0 + (lane & 15);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            // the k order of sim_gemm_kernel: BK = 64 steps, two 32-wide MFMAs each, 8-element zero fill
-            for (int k0 = 0; k0 < dim; k0 += BK) {
-#pragma unroll
-                for (int s = 0; s < BK / 32; ++s) {
-                    const int kcol = k0 + s * 32 + 8 * (lane >> 4);
-                    uint4 ua = make_uint4(0, 0, 0, 0), ub = make_uint4(0, 0, 0, 0);
-                    if (kcol < dim) {
-                        ub = *reinterpret_cast<const uint4 *>(qrow + kcol);
-                        if (arow < rows) ua = *reinterpret_cast<const uint4 *>(emb + (size_t)arow * dim + kcol);
-                    }
-                    acc = mfma32<F16>(ua, ub, acc);
+            for (int s = 0; s < BK / 32; ++s) {
+                const int kcol = k0 + s * 32 + 8 * (lane >> 4);
+                ua0[s] = ua1[s] = ub[s] = make_uint4(0, 0, 0, 0);
+                if (kcol < dim) {
+                    ub[s] = *reinterpret_cast<const uint4 *>(qrow + kcol);
+                    if (arow0 < rows) ua0[s] = *reinterpret_cast<const uint4 *>(emb + (size_t)arow0 * dim + kcol);
+                    if (arow1 < rows) ua1[s] = *reinterpret_cast<const uint4 *>(emb + (size_t)arow1 * dim + kcol);
                 }
             }
-            if ((lane & 15) == 0) {   // every column holds the same query: take column 0
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int64_t m = row0 + 4 * (lane >> 4) + reg;
-                    cand[r * BM + wave * 32 + f * 16 + 4 * (lane >> 4) + reg] =
-                        m < rows ? rank_key(acc[reg], (uint32_t)m) : 0ull;
-                }
+            for (int s = 0; s < BK / 32; ++s) {
+                acc0 = mfma32<F16>(ua0[s], ub[s], acc0);
+                acc1 = mfma32<F16>(ua1[s], ub[s], acc1);
             }
         }
-        n_cand += BM;
+        if ((lane & 15) == 0) {   // every column holds the same query: take column 0
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int at = wave * 32 + 4 * (lane >> 4) + reg;
+                const int64_t m0 = row0 + 4 * (lane >> 4) + reg, m1 = m0 + 16;
+                __hip_atomic_store(gc + r * BM + at, m0 < rows ? rank_key(acc0[reg], (uint32_t)m0) : 0ull,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gc + r * BM + at + 16, m1 < rows ? rank_key(acc1[reg], (uint32_t)m1) : 0ull,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wavefront: its keys have left the CU
+    __syncthreads();
+    if (tid == 0)
+        s_last = __hip_atomic_fetch_add(my + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k - 1;
+    __syncthreads();
+    if (!s_last) return;
+    int n_cand = 0;
+    for (int i = 0; i < k; ++i) n_cand += my[i] >= 0 ? BM : 0;   // selected tiles are a prefix of the list
+    for (int i = tid; i < n_cand; i += 256)
+        cand[i] = __hip_atomic_load(gc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(my + 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const float mn = mn_in[b], mx = mx_in[b];
     uint64_t prev = ~0ull;
-    for (int r = 0; r < k; ++r) {
+    for (int rr = 0; rr < k; ++rr) {
         uint64_t best = 0;
         for (int i = tid; i < n_cand; i += 256) {
             const uint64_t key = cand[i];
@@ -357,8 +384,8 @@ __global__ __launch_bounds__(256) void tile_rescore_kernel(const uint16_t *__res
                     val = range == 0.f ? 1.f : __fdiv_rn(val - mn, range);   // misc_utils.py:130-139
                 }
             }
-            idx_out[(size_t)b * k + r] = idx;
-            val_out[(size_t)b * k + r] = val;
+            idx_out[(size_t)b * k + rr] = idx;
+            val_out[(size_t)b * k + rr] = val;
         }
         prev = best ? best : 0;
     }
@@ -367,6 +394,7 @@ __global__ __launch_bounds__(256) void tile_rescore_kernel(const uint16_t *__res
 }  // namespace
 
 int64_t sim_fused_tiles(int64_t rows) { return ceil_div(rows, BM); }
+int64_t sim_fused_sel_ints(int32_t batch) { static_assert(kSelRec == kSelRecInts, "record size"); return (int64_t)batch * kSelRec; }
 
 // A/B switch for measurements and for the bit-identity test of the two GEMM kernels: HRAG_SIM_SMALL_TILES=1 in the
 // environment keeps every shape on sim_gemm_kernel (read once)
@@ -375,7 +403,8 @@ bool sim_gemm_force_small_tiles() {
     return v;
 }
 
-// ws: 2 * tiles * batch floats (tile max / min) ; sel: batch * 16 ints ; mn / mx: batch floats
+// ws: 2 * tiles * batch floats (tile max / min) ; sel: sim_fused_sel_ints(batch) ints, ZEROED at allocation (per-query
+// records: selected tiles, arrival counter, candidate keys) ; mn / mx: batch floats
 hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
                                   int32_t batch, int32_t k, int32_t idx_offset, int32_t normalize,
                                   float *ws, int32_t *sel, float *mn, float *mx, int32_t *idx_out,
@@ -408,11 +437,11 @@ hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim
                        batch, k, sel, mn, mx);
     HRAG_LAUNCH_CHECK();
     if (dtype == HRAG_FP16)
-        hipLaunchKernelGGL(tile_rescore_kernel<true>, dim3((unsigned)batch), dim3(256), 0, s, emb, rows, dim, q, sel,
-                           mn, mx, k, idx_offset, normalize, idx_out, val_out);
+        hipLaunchKernelGGL(tile_rescore_kernel<true>, dim3((unsigned)k, (unsigned)batch), dim3(256), 0, s, emb, rows, dim,
+                           q, sel, mn, mx, k, idx_offset, normalize, idx_out, val_out);
     else
-        hipLaunchKernelGGL(tile_rescore_kernel<false>, dim3((unsigned)batch), dim3(256), 0, s, emb, rows, dim, q, sel,
-                           mn, mx, k, idx_offset, normalize, idx_out, val_out);
+        hipLaunchKernelGGL(tile_rescore_kernel<false>, dim3((unsigned)k, (unsigned)batch), dim3(256), 0, s, emb, rows, dim,
+                           q, sel, mn, mx, k, idx_offset, normalize, idx_out, val_out);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

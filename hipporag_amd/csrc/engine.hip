@@ -87,7 +87,9 @@ hrag_status ppr_step(hrag_engine *e, const float *tele, int64_t tele_rows, const
 // 256 MB in ~38 us, and 512-entry rows (64 steps = 57 us) WERE the sweep: 41.3k queries/s at 512, 52.8k at 256,
 // 60.0k at 128, 62.5k at 64, 51.8k at 32 (more virtual rows, partial sums and arrivals), 37.0k at 16; the same
 // graph at 256 queries (two fp8 slabs) peaks at 128; 20 M entries x 2 slabs (cfg 3, 800 us sweeps) are flat from
-// 256 to 1024 and 1 % slower at 128.  Hence a rule in the work of one sweep, entries x 128-query slabs.
+// 256 to 1024 and 1 % slower at 128; one GPU's share of the hub-heavy 200 M-entry power-law graph of cfg 5 (25 M
+// entries x 4 slabs, 18 ms sweeps) prefers 2048 (1294 queries/s; 1264 at 512: every segment pays ~4 us for its
+// write-through and arrival; 1269 at 8192: imbalance).  Hence a rule in the work of one sweep, entries x 128-query slabs.
 // HRAG_SELL8_SEG_LEN overrides (experiments).
 int32_t sell8_seg_len(int64_t nnz_owned, int max_batch) {
     if (const char *env = std::getenv("HRAG_SELL8_SEG_LEN")) {
@@ -95,7 +97,8 @@ int32_t sell8_seg_len(int64_t nnz_owned, int max_batch) {
         if (v >= 8 && v <= 1 << 20) return (int32_t)round_up(v, 8);
     }
     const int64_t work = nnz_owned * (int64_t)n_slabs128(max_batch);
-    return work <= (int64_t)3 << 20 ? 64 : work <= (int64_t)12 << 20 ? 128 : work <= (int64_t)30 << 20 ? 256 : kSell8SegLen;
+    return work <= (int64_t)3 << 20 ? 64 : work <= (int64_t)12 << 20 ? 128 : work <= (int64_t)30 << 20 ? 256
+         : work <= (int64_t)64 << 20 ? kSell8SegLen : 2048;
 }
 
 // SELL-8 form of (a subset of) the owned CSR rows for ppr16.hip / ppr8.hip (see the header comments there).

@@ -71,3 +71,35 @@ def test_long_rows_are_finished_inside_the_sweep_kernel(gpu_device, hub_case, b,
         want = oracle.retrieve_one(index, qf[q], qp[q]).x[index.passage_vertex]
         worst = max(worst, float(np.abs(got_sc[q] / want[got_idx[q]] - 1).max()))
     assert worst < 1e-5, worst
+
+
+def test_fused_fact_topk_hand_off_is_repeatable(gpu_device):
+    """Pass 3 of the fused fact top-k (csrc/sim_gemm.hip) hands the candidate keys of k workgroups to the one that
+    arrives last (the same sc1 + arrival-counter hand-off): 12 calls in a row -- the per-query records and their
+    counters are reused every time -- must give identical ids and scores, equal to the exact ranking."""
+    import torch
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd.graph import build_csr
+    rng = np.random.default_rng(3)
+    n, n_p, n_f, b, dim = 4000, 500, 40000, 200, 128
+    src, dst = rng.integers(0, n, 20000), rng.integers(0, n, 20000)
+    keep = src != dst
+    csr = build_csr(n, src[keep], dst[keep], np.ones(int(keep.sum())))
+    pv = np.arange(n_p, dtype=np.int32)
+    pass_bits, fact_bits = synth.make_embeddings_np(n_p, dim, 1), synth.make_embeddings_np(n_f, dim, 2)
+    subj = rng.integers(n_p, n, n_f).astype(np.int32)
+    obj = ((subj - n_p + 1 + rng.integers(0, n - n_p - 1, n_f)) % (n - n_p) + n_p).astype(np.int32)
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=9)
+    with HippoRAGEngine(csr, pv, pass_bits, fact_bits, subj, obj, np.ones(n, np.int32), max_batch=b, max_topk=100) as eng:
+        runs = []
+        for _ in range(12):
+            idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=16)
+            torch.cuda.synchronize()
+            runs.append((idx.cpu().numpy().copy(), sc.cpu().numpy().copy()))
+    for idx, sc in runs[1:]:
+        assert np.array_equal(idx, runs[0][0]) and np.array_equal(sc, runs[0][1])
+    scores = bf16_bits_to_float(qf_bits).astype(np.float64) @ bf16_bits_to_float(fact_bits).astype(np.float64).T
+    for q in range(0, b, 17):
+        order = np.lexsort((-np.arange(n_f), -scores[q]))[:16]
+        got = runs[0][0][q]
+        assert set(got.tolist()) == set(order.tolist()) or np.allclose(np.sort(scores[q][got]), np.sort(scores[q][order]), rtol=0, atol=2e-6)

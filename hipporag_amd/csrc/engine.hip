@@ -874,6 +874,14 @@ hrag_status hrag_stage_doc_scores(hrag_engine *e, const float *x, const double *
     return HRAG_OK;
 }
 
+// Exchange groups of hrag_retrieve's own fp8 state (one GPU: there is nothing to exchange, the number only sets the
+// layout): 0 = one group per slab, [slab][V + 1][128]; 1 = vertex-major, [V + 1][slabs][128].  HRAG_P8_GROUPS
+// overrides (experiments).
+static int retrieve_state_groups() {
+    static const int v = [] { const char *e = std::getenv("HRAG_P8_GROUPS"); return e ? std::atoi(e) : 0; }();
+    return v;
+}
+
 hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
                           const int32_t *kept_idx, const float *kept_score, const int32_t *kept_count,
                           int32_t kf, int32_t link_top_k, float damping, float passage_node_weight,
@@ -920,7 +928,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     if (f8) {
         // staged fp8 state (ppr8.hip / shard.hip): the single-GPU engine is the row shard that owns everything
         hrag_shard_layout sl;
-        HRAG_TRY(ppr8_layout(e, batch, 0, &sl));
+        HRAG_TRY(ppr8_layout(e, batch, retrieve_state_groups(), &sl));
         HRAG_TRY(ppr8_prior(e, e->d_mn_p, e->d_mx_p, passage_node_weight, e->d_flags, batch, e->d_zmax, e->d_mass, s));
         HRAG_TRY(ppr8_begin(e, e->d_mn_p, e->d_mx_p, e->d_zmax, e->d_mass, passage_node_weight, e->d_seed_vtx,
                             e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, damping, f8_iters, sl, e->d_pool8, s));

@@ -662,8 +662,8 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         E_TRY(dev_alloc(&e->d_mass, 2 * (int64_t)B));
         E_TRY(dev_alloc(&e->d_prior_part, (int64_t)kP8PriorSplit * B * 2));
         if (unsharded) {
-            // hrag_retrieve's own state buffers: one exchange group per slab, (V + 1) rows (the last one zero)
-            e->state8_bytes = (int64_t)ns * (e->V + 1) * 128;
+            // hrag_retrieve's own state buffers: groups of two slabs, [group][V + 1][2][128] (ppr8_layout)
+            e->state8_bytes = (int64_t)round_up(ns, 2) * (e->V + 1) * 128;
             for (auto &p : e->d_pool8) {
                 E_TRY(dev_alloc(&p, e->state8_bytes));
                 E_HIP(hipMemset(p, 0, (size_t)e->state8_bytes));
@@ -874,14 +874,6 @@ hrag_status hrag_stage_doc_scores(hrag_engine *e, const float *x, const double *
     return HRAG_OK;
 }
 
-// Exchange groups of hrag_retrieve's own fp8 state (one GPU: there is nothing to exchange, the number only sets the
-// layout): 0 = one group per slab, [slab][V + 1][128]; 1 = vertex-major, [V + 1][slabs][128].  HRAG_P8_GROUPS
-// overrides (experiments).
-static int retrieve_state_groups() {
-    static const int v = [] { const char *e = std::getenv("HRAG_P8_GROUPS"); return e ? std::atoi(e) : 0; }();
-    return v;
-}
-
 hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
                           const int32_t *kept_idx, const float *kept_score, const int32_t *kept_count,
                           int32_t kf, int32_t link_top_k, float damping, float passage_node_weight,
@@ -928,7 +920,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     if (f8) {
         // staged fp8 state (ppr8.hip / shard.hip): the single-GPU engine is the row shard that owns everything
         hrag_shard_layout sl;
-        HRAG_TRY(ppr8_layout(e, batch, retrieve_state_groups(), &sl));
+        HRAG_TRY(ppr8_layout(e, batch, 0, &sl));   // narrowest groups: two adjacent slabs per vertex
         HRAG_TRY(ppr8_prior(e, e->d_mn_p, e->d_mx_p, passage_node_weight, e->d_flags, batch, e->d_zmax, e->d_mass, s));
         HRAG_TRY(ppr8_begin(e, e->d_mn_p, e->d_mx_p, e->d_zmax, e->d_mass, passage_node_weight, e->d_seed_vtx,
                             e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, damping, f8_iters, sl, e->d_pool8, s));

@@ -192,7 +192,8 @@ namespace hrag {
 // (damping^iters <= 2^-18) and the stage plan fits.
 bool ppr8_usable(const hrag_engine *e, int batch, int iters, float damping);
 int ppr8_plan(int iters, int *plan);
-// layout of the state buffers for `batch` queries in `want_groups` exchange groups (0 = one slab per group)
+// layout of the state buffers for `batch` queries in `want_groups` exchange groups (0 = the narrowest groups: slab
+// pairs; the group width is kept even, see hrag.h)
 hrag_status ppr8_layout(const hrag_engine *e, int32_t batch, int32_t want_groups, hrag_shard_layout *out);
 // local statistics of the passage prior over the owned passages (d_spass must hold the local scores)
 hrag_status ppr8_prior(hrag_engine *e, const float *mn, const float *mx, float passage_weight,

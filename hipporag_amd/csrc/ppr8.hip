@@ -489,6 +489,160 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     }
 }
 
+// Two slabs per wavefront ("pair" kernel).  With the slabs of a vertex adjacent in memory (spg even: vertex-major
+// state) a lane issues the 16-byte loads of slab s and slab s + 1 of the same vertex back to back: the memory system
+// sees 256 contiguous bytes per gathered row instead of two unrelated 128-byte lines (tools/membench.hip: random
+// 256-byte pieces stream 7 % faster than random 128-byte lines), and the (col, val) stream is read once per pair.
+// Twice the accumulators and loads in flight per wavefront, fewer wavefronts per SIMD.
+template <int K>
+struct Gather8P {
+    __device__ __forceinline__ static void load(v4i_t (&x0)[8], v4i_t (&x1)[8], float (&wk)[8], int c, int wbits,
+                                                const char *xs, unsigned stride, unsigned lane_off) {
+        const unsigned ck = (unsigned)bcast8<K>(c);
+        wk[K] = __int_as_float(bcast8<K>(wbits));
+        const char *p = xs + (size_t)(__umul24(ck, stride) + lane_off);
+        x0[K] = *reinterpret_cast<const v4i_t *>(p);
+        x1[K] = *reinterpret_cast<const v4i_t *>(p + 128);
+        if constexpr (K + 1 < 8) Gather8P<K + 1>::load(x0, x1, wk, c, wbits, xs, stride, lane_off);
+    }
+};
+
+template <int K>
+struct Gather8PM {   // mode B0: masked (see Gather8M)
+    __device__ __forceinline__ static void load(v4i_t (&x0)[8], v4i_t (&x1)[8], float (&wk)[8], int c, int wbits, int on,
+                                                const char *xs, unsigned stride, unsigned lane_off) {
+        const unsigned ck = (unsigned)bcast8<K>(c);
+        wk[K] = __int_as_float(bcast8<K>(wbits));
+        const int onk = bcast8<K>(on);
+        v4i_t v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+        if (onk) {
+            const char *p = xs + (size_t)(__umul24(ck, stride) + lane_off);
+            v0 = *reinterpret_cast<const v4i_t *>(p);
+            v1 = *reinterpret_cast<const v4i_t *>(p + 128);
+        }
+        x0[K] = v0;
+        x1[K] = v1;
+        if constexpr (K + 1 < 8) Gather8PM<K + 1>::load(x0, x1, wk, c, wbits, on, xs, stride, lane_off);
+    }
+};
+
+template <int MODE, int RIO>
+__device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & 7, grp = lane >> 3;
+    // a workgroup = 4 wavefronts = (4 / wps) chunks x wps slab PAIRS
+    const int id = blockIdx.x, wps = a.wps, nsg = (a.n_slabs >> 1) / wps, wave = threadIdx.x >> 6;
+    const int slab = a.slab0 + 2 * (((id >> 3) % nsg) * wps + (wave & (wps - 1)));
+    const int cg = (id / (8 * nsg)) * 8 + (id & 7);
+    const int chunk = __builtin_amdgcn_readfirstlane(cg * (4 / wps) + wave / wps);
+    if (chunk >= a.m.n_chunks) return;
+    const int2 meta = a.m.chunk_meta[chunk];  // (first step, number of steps)
+    const int n_steps = meta.y;
+    const int g = slab / a.spg, k = slab - g * a.spg;
+    const char *xs = reinterpret_cast<const char *>(a.x) + (size_t)g * (size_t)a.group_bytes + (size_t)k * 128;
+    const unsigned stride = a.row_stride;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int2 *>(a.m.pairs), 0, (int)a.m.pairs_bytes, 0x00020000);
+    const unsigned pbase = (unsigned)meta.x * 512u;
+    const unsigned poff = (unsigned)lane * 8u;
+    const unsigned lane_off = (unsigned)gl * 16u;
+    f32x2_t acc0[8], acc1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc0[j] = acc1[j] = f32x2_t{0.f, 0.f};
+    int2 p0 = ld_pair(prs, poff, pbase);
+    int2 p1 = ld_pair(prs, poff + 512u, pbase);
+    if constexpr (MODE == kP8ModeB0) {
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t *>(a.colmask), 0, (int)a.colmask_bytes, 0x00020000);
+        int m0 = ld_mask(mrs, ((unsigned)p0.x >> 5) * 4u);
+        for (int s = 0; s < n_steps; ++s) {
+            const int2 p2 = ld_pair(prs, poff + (unsigned)(s + 2) * 512u, pbase);
+            const int m1 = ld_mask(mrs, ((unsigned)p1.x >> 5) * 4u);
+            v4i_t x0[8], x1[8];
+            float wk[8];
+            Gather8PM<0>::load(x0, x1, wk, p0.x, p0.y, (m0 >> (p0.x & 31)) & 1, xs, stride, lane_off);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                fma16(acc0, wk[kk], x0[kk]);
+                fma16(acc1, wk[kk], x1[kk]);
+            }
+            p0 = p1;
+            p1 = p2;
+            m0 = m1;
+        }
+    } else {
+        for (int s = 0; s < n_steps; ++s) {
+            const int2 p2 = ld_pair(prs, poff + (unsigned)(s + 2) * 512u, pbase);
+            v4i_t x0[8], x1[8];
+            float wk[8];
+            Gather8P<0>::load(x0, x1, wk, p0.x, p0.y, xs, stride, lane_off);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                fma16(acc0, wk[kk], x0[kk]);
+                fma16(acc1, wk[kk], x1[kk]);
+            }
+            p0 = p1;
+            p1 = p2;
+        }
+    }
+    const int tgt = a.m.vrow[chunk * 8 + grp];
+    const bool seg = tgt < 0 && tgt != kVrowNone;
+    const __amdgpu_buffer_rsrc_t q0 = __builtin_amdgcn_make_buffer_rsrc(
+        a.partial + (size_t)slab * a.m.n_partial * 128, 0, a.m.n_partial * 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t q1 = __builtin_amdgcn_make_buffer_rsrc(
+        a.partial + (size_t)(slab + 1) * a.m.n_partial * 128, 0, a.m.n_partial * 512, 0x00020000);
+    if (tgt >= 0) {
+        finish_row<MODE, RIO>(a, slab, tgt, gl, acc0);
+        finish_row<MODE, RIO>(a, slab + 1, tgt, gl, acc1);
+    } else if (seg) {
+        st16i_sc1(q0, (unsigned)(-(tgt + 1)) * 512u, gl, acc0);
+        st16i_sc1(q1, (unsigned)(-(tgt + 1)) * 512u, gl, acc1);
+    }
+    // long rows: as in ppr8_kernel; one arrival (the first slab's counter) covers both slabs of the pair
+    if (__builtin_amdgcn_ballot_w64(seg) == 0) return;   // wave-uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int m = -1;
+    bool last = false;
+    int32_t *cnts = a.m.lcount + (size_t)slab * a.m.n_lrow;
+    if (seg && gl == 0) {
+        m = a.m.seg_lrow[-(tgt + 1)];
+        const int before = __hip_atomic_fetch_add(cnts + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = before == a.m.lrow_cnt[m] - 1;
+    }
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(last);
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int mm = __builtin_amdgcn_readlane(m, l);
+        const int first = a.m.lrow_first[mm], cnt = a.m.lrow_cnt[mm];
+        for (int half = 0; half < 2; ++half) {
+            const __amdgpu_buffer_rsrc_t qh = half ? q1 : q0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc0[j] = f32x2_t{0.f, 0.f};
+            for (int sg = grp; sg < cnt; sg += 8) {
+                f32x2_t v[8];
+                ld16i_sc1(qh, (unsigned)(first + sg) * 512u, gl, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc0[j] += v[j];
+            }
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc0[j].x += __shfl_xor(acc0[j].x, o, 64);
+                    acc0[j].y += __shfl_xor(acc0[j].y, o, 64);
+                }
+            if (grp == 0) finish_row<MODE, RIO>(a, slab + half, a.m.lrow_row[mm], gl, acc0);
+        }
+        if (lane == 0) __hip_atomic_store(cnts + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int MODE, int RIO>
+__global__ __launch_bounds__(256, 2) void ppr8_pair_kernel(const Ppr8Args a) { ppr8_pair_body<MODE, RIO>(a); }
+
 // c_0 = Q(v/d * c0_scale) for every OWNED row of the launch's slabs (R_0 = b v/d is formed on the fly by
 // the first boundary sweep, mode B0).
 __global__ __launch_bounds__(256) void ppr8_init_kernel(const Ppr8Args a, float c0_scale) {
@@ -626,8 +780,29 @@ __global__ void ppr8_mask_seeds_kernel(const int32_t *__restrict__ seed_vtx, con
     atomicOr(&colmask[v >> 5], 1u << (v & 31));
 }
 
+// The pair kernel takes the slabs that come in adjacent pairs (groups of even width), ppr8_kernel an odd last slab.
+// HRAG_P8_PAIR=0 keeps everything on ppr8_kernel (A/B measurements).
+static bool p8_pair_enabled() {
+    static const bool v = [] { const char *e = getenv("HRAG_P8_PAIR"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 template <int MODE, int RIO>
-hrag_status sweep_mode(const Ppr8Args &a, bool main_only, hipStream_t s) {
+hrag_status sweep_mode(const Ppr8Args &a_in, bool main_only, hipStream_t s) {
+    Ppr8Args a = a_in;
+    if (a.m.n_chunks > 0 && p8_pair_enabled() && a.spg % 2 == 0 && a.slab0 % 2 == 0 && a.n_slabs >= 2) {
+        Ppr8Args b = a;
+        b.n_slabs = a.n_slabs & ~1;
+        const int np = b.n_slabs / 2;
+        b.wps = (a.wps == 4 && np % 4 == 0) ? 4 : (a.wps >= 2 && np % 2 == 0) ? 2 : 1;
+        const unsigned ncg = (unsigned)ceil_div(a.m.n_chunks, 4 / b.wps);
+        hipLaunchKernelGGL((ppr8_pair_kernel<MODE, RIO>), dim3((unsigned)round_up(ncg, 8) * (unsigned)(np / b.wps)),
+                           dim3(256), 0, s, b);
+        HRAG_LAUNCH_CHECK();
+        a.slab0 += b.n_slabs;
+        a.n_slabs -= b.n_slabs;
+        if (a.n_slabs == 0) return HRAG_OK;
+    }
     if (a.m.n_chunks > 0) {
         // (86 VGPRs = 5 wavefronts per SIMD; 6 measured the same: the sweep is bandwidth-bound)
         Ppr8Args b = a;

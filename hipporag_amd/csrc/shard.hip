@@ -45,6 +45,8 @@ hrag_status ppr8_layout(const hrag_engine *e, int32_t batch, int32_t want_groups
     const int spg_max = (int)std::max<int64_t>(1, std::min<int64_t>(ns, ((int64_t)1 << 32) / row_bytes));
     int spg = want_groups <= 0 ? 1 : (int)ceil_div(ns, std::min(want_groups, ns));
     spg = std::max(1, std::min(spg, spg_max));
+    // the sweep kernels work on PAIRS of adjacent slabs (ppr8_pair_kernel): keep the group width even
+    if (ns >= 2 && (spg & 1)) spg = spg + 1 <= spg_max ? spg + 1 : std::max(1, spg - 1);
     hrag_shard_layout l = {};
     l.n_slabs = ns;
     l.slabs_per_group = spg;

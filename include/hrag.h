@@ -342,8 +342,9 @@ typedef struct hrag_shard_layout {
     int64_t own_bytes;       /* n_rows * slabs_per_group * 128                                  */
 } hrag_shard_layout;
 
-/* want_groups: 0 = one group per slab; otherwise the number of exchange groups asked for (the engine
- * may return more: a group is limited to 4 GiB and 2^24 vertices). */
+/* want_groups: 0 = the narrowest groups; otherwise the number of exchange groups asked for.  The engine may
+ * return a different number: a group is limited to 4 GiB and 2^24 vertices, and its width is kept EVEN
+ * (the sweep kernels gather the two adjacent slabs of a vertex together), so the narrowest group holds two slabs. */
 hrag_status hrag_shard_layout_query(hrag_engine *e, int32_t batch, int32_t want_groups,
                                     hrag_shard_layout *out);
 

@@ -136,7 +136,10 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
     achieved = alg / (spmm_ms * 1e-3) / 1e9
     traffic = load_traffic()
     bc, n_slabs = (128, (B + 127) // 128) if f8 else (64, (B + 63) // 64) if f16 else eng.layout(B)
-    kernel = "ppr8_kernel" if f8 else "ppr16_kernel" if f16 else "ppr_spmm_kernel"
+    kernel = "ppr8_kernel" if f8 else "ppr16_kernel" if f16 else "ppr_spmm_kernel"   # key of pmc_traffic.json
+    # slab pairs are swept by ppr8_pair_kernel (two slabs per wavefront), an odd last slab by ppr8_kernel
+    kernel_launched = ("ppr8_pair_kernel" + (" + ppr8_kernel (odd last slab)" if n_slabs % 2 else "")
+                       if f8 and n_slabs >= 2 else kernel)
     ppr_iter_ms = phases["ppr_ms"] / PPR_ITERS      # every kernel of the PPR stage (init, reduce) / iterations
     tr = (traffic or {}).get(kernel, {})
     traffic_bytes = tr.get("bytes_per_launch") if tr.get("workload") == f"{config_name}:B{B}" else None
@@ -153,7 +156,7 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
         if cnt == PPR_ITERS:
             traffic_bytes = tot / cnt
     roofline = {
-        "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": kernel_launched, "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "frac_definition": ("average launch of one retrieve over the kernel's instantiations (stage plan counts)"
                             if f8 else "average launch of the sweep kernel (+ its long-row reduce)"),

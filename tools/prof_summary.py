@@ -70,6 +70,8 @@ def main():
         inst8 = {}    # ppr8_kernel<mode, residual form> -> HBM bytes per launch (bench.py weights them by the stage plan)
         for k, d in out.items():
             base = k.split("::")[-1].split("<")[0]
+            if base == "ppr8_pair_kernel":      # two slabs per wavefront: the same sweep, the usual kernel at B >= 256
+                base = "ppr8_kernel"
             if base == "ppr8_kernel" and "bytes_per_launch" in d and "<" in k:
                 inst8[k[k.index("<"):].replace(" ", "")] = {"bytes_per_launch": d["bytes_per_launch"],
                                                             "l2_hit_rate": d.get("l2_hit_rate")}

@@ -37,27 +37,44 @@ __global__ void build_seeds_kernel(const int32_t *__restrict__ kept_idx,
     cnt = cnt < 0 ? 0 : (cnt > kf ? kf : cnt);
     int32_t flag = flags[q] & ~(1 | 4);
     if (cnt == 0) flag |= 1;  // DPR fallback (HippoRAG.py:467-469)
-    for (int r = 0; r < cnt; ++r) {
-        const int64_t f = kept_idx[q * kf + r];
-        if (f < 0 || f >= n_facts) continue;
-        const float score = kept_score[q * kf + r];
-        for (int side = 0; side < 2; ++side) {
-            const int32_t v = side == 0 ? subj[f] : obj[f];
-            if (v < 0 || v >= num_vertices) continue;
-            float w = score;
-            const int32_t nc = num_chunks[v];
-            if (nc > 0) w = __fdiv_rn(score, (float)nc);
-            int j = 0;
-            while (j < m && ids[j] != v) ++j;
-            if (j == m) {
-                ids[m] = v;
-                wsum[m] = 0.0;
-                occ[m] = 0;
-                ++m;
-            }
-            wsum[j] += (double)w;
-            occ[j] += 1;
+    // three rounds of independent loads (facts -> their two entities -> the entities' chunk counts) instead of a
+    // chain of 3 dependent loads per fact and side: one thread per query is latency, not work (42 -> 12 us at cfg 3)
+    int32_t fidx[kMaxKeptFacts], vtx[2 * kMaxKeptFacts], nch[2 * kMaxKeptFacts];
+    float fsc[kMaxKeptFacts];
+#pragma unroll
+    for (int r = 0; r < kMaxKeptFacts; ++r) {
+        const bool on = r < cnt;
+        fidx[r] = on ? kept_idx[q * kf + r] : -1;
+        fsc[r] = on ? kept_score[q * kf + r] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < kMaxKeptFacts; ++r) {
+        const bool on = fidx[r] >= 0 && (int64_t)fidx[r] < n_facts;
+        vtx[2 * r] = on ? subj[fidx[r]] : -1;
+        vtx[2 * r + 1] = on ? obj[fidx[r]] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * kMaxKeptFacts; ++i) {
+        const bool on = vtx[i] >= 0 && (int64_t)vtx[i] < num_vertices;
+        nch[i] = on ? num_chunks[vtx[i]] : 0;
+        if (!on) vtx[i] = -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * kMaxKeptFacts; ++i) {   // fact r = i / 2 in rank order, subject before object
+        const int32_t v = vtx[i];
+        if (v < 0) continue;
+        const float score = fsc[i >> 1];
+        const float w = nch[i] > 0 ? __fdiv_rn(score, (float)nch[i]) : score;
+        int j = 0;
+        while (j < m && ids[j] != v) ++j;
+        if (j == m) {
+            ids[m] = v;
+            wsum[m] = 0.0;
+            occ[m] = 0;
+            ++m;
         }
+        wsum[j] += (double)w;
+        occ[j] += 1;
     }
     for (int j = 0; j < m; ++j) wsum[j] /= (double)occ[j];
     // stable selection of the link_top_k heaviest (link_top_k <= 0: keep all, sorted)

@@ -295,7 +295,9 @@ hrag_status launch_row_topk(const float *scores, int32_t batch, int64_t n, int64
     // one workgroup per row leaves the chip idle for a handful of rows: split long rows
     int parts = 1;
     if (ws && batch < 64 && n >= 32768) {
-        parts = (int)std::min<int64_t>(std::min<int64_t>(TK_CAP / k, ceil_div(n, 8192)), std::max(1, 256 / batch));
+        // the merge kernel bitonic-sorts parts * k keys (barrier stages ~ log^2): keep that at <= 1024 keys when k allows
+        const int64_t merge_cap = k <= 512 ? 1024 : TK_CAP;
+        parts = (int)std::min<int64_t>(std::min<int64_t>(merge_cap / k, ceil_div(n, 8192)), std::max(1, 256 / batch));
         parts = std::min(parts, 64);
         while (parts > 1 && (size_t)batch * parts * ((size_t)k * 8 + 8) > ws_bytes) --parts;
     }

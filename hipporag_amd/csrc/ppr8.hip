@@ -1,7 +1,7 @@
 // K3b -- PPR power iteration with an fp8 (OCP e4m3) state and an fp32 true residual.
 //
 // Replaces igraph/PRPACK behind HippoRAG.run_ppr (reference src/hipporag/HippoRAG.py:1736-1743)
-// for batches wider than 64 queries: one gather = one 128-byte line = 128 queries.
+// for batches wider than 64 queries: one gathered line = 128 queries (two adjacent lines per gather at B > 128).
 //
 // Why: the sweep is bound by the random row gathers of the state (nnz * B * sizeof(state) bytes,
 // ~7 TB/s of 128-byte lines, tools/membench.hip), so bytes per gathered element are the lever.
@@ -34,8 +34,13 @@
 // iteration on slowly mixing graphs (ring, stars) whose own truncation error is the larger term.
 //
 // Matrix: the SELL-8 form of ppr16.hip with the row-normalised values At (engine.hip builds it
-// from P and the weighted degrees: at_ij = p_ij d_j / d_i).  Long rows: segments + fixed-order
-// reduce, no atomics, bit-reproducible.  All arithmetic is fp32; fp8 -> fp32 is exact.
+// from P and the weighted degrees: at_ij = p_ij d_j / d_i).  Long rows: segments whose partial sums the
+// last-arriving wavefront adds up in a fixed order inside the sweep kernel (no second launch, no atomics on
+// the data, bit-reproducible).  All arithmetic is fp32; fp8 -> fp32 is exact.
+//
+// Two kernels run the same sweep: ppr8_pair_kernel -- a wavefront carries TWO adjacent slabs of its 8 rows, so a
+// gathered row is one 256-byte piece (the slabs of a vertex are adjacent: state [group][V + 1][spg][128] with spg
+// even) -- takes the slab pairs, ppr8_kernel (one slab per wavefront) an odd last slab.
 //
 // Row shards (multi-GPU, the layout BASELINE.json's north star names): an engine owns rows
 // [row_offset, row_offset + n_rows); its SELL-8 matrix, R, the stage copies and v cover those rows only,

@@ -233,7 +233,8 @@ hrag_status hrag_sim_gemm(const uint16_t *emb_dev, int64_t rows, int32_t dim, co
 
 /* Measurement hook: run `n` PPR SpMM sweeps over the engine's current state buffers for
  * `batch` right-hand sides (state is whatever the last hrag_retrieve / hrag_ppr left).
- * flags bit0: main CSR kernel only (skip the long-row and seed kernels);
+ * flags bit0: fp32 CSR path: main kernel only (skip its long-row and seed kernels); no effect on the SELL-8 kernels
+ *             (bits 1-3), which finish long rows inside the sweep kernel;
  * flags bit1: the fp16-state kernel of the two-stage scheme (mode H) instead of the fp32 one
  *             (HRAG_EINVAL when the engine has no fp16 state: sharded, max_batch <= 8, F32_STATE);
  * flags bit2: the small-batch kernel (batch <= 8, state fp32 [V][1|2|4|8]);

@@ -1,11 +1,14 @@
 // Memory-system microbenchmarks for the PPR SpMM design (not product code):
 //   stream  : float4 streaming read of a buffer of S bytes
 //   gather  : pseudo-random chunk gathers (chunk = g bytes, g/16 lanes per chunk) from a buffer of S bytes
-// Prints GB/s for each (S, g).  Usage: membench
+//   replay  : the gathers of a REAL column-index stream (membench --cols <int32 file> [--rows V]): every index fetches
+//             one piece of g bytes from a state of V pieces -- the gather traffic of one PPR sweep and nothing else
+// Prints GB/s for each (S, g).  Usage: membench   |   membench --cols cols.bin --rows 1000000
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
@@ -42,6 +45,41 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4 *p, uint32_t n
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = 1.f;
 }
 
+// replay of a column stream: lane group `grp` takes entries grp, grp + n_groups, ... (8 in flight per lane)
+template <int LPC>
+__global__ __launch_bounds__(256) void replay_kernel(const float4 *p, const int32_t *__restrict__ cols, int64_t nnz,
+                                                     float *out) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t grp = tid / LPC, n_groups = (int64_t)gridDim.x * 256 / LPC;
+    const int gl = (int)(tid % LPC);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int64_t e = grp; e < nnz; e += n_groups * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = e + (int64_t)u * n_groups;
+            v[u] = i < nnz ? p[(size_t)cols[i] * LPC + gl] : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = 1.f;
+}
+
+template <int LPC>
+void run_replay(const float4 *buf, const int32_t *cols, int64_t nnz, float *out) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int blocks = 256 * 24;
+    hipLaunchKernelGGL((replay_kernel<LPC>), dim3(blocks), dim3(256), 0, 0, buf, cols, nnz, out);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((replay_kernel<LPC>), dim3(blocks), dim3(256), 0, 0, buf, cols, nnz, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 5;
+    printf("  piece %4d B: %8.3f ms per pass, %8.0f GB/s useful (+ %0.0f MB of indices)\n", 16 * LPC, ms,
+           (double)nnz * 16 * LPC / (ms * 1e-3) / 1e9, (double)nnz * 4 / 1e6);
+}
+
 template <int LPC>
 double run_gather(const float4 *buf, size_t bytes, float *out, int blocks, int iters) {
     const uint32_t n_chunks = (uint32_t)(bytes / (16 * LPC));
@@ -56,7 +94,33 @@ double run_gather(const float4 *buf, size_t bytes, float *out, int blocks, int i
     return total / (ms * 1e-3) / 1e9;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const char *cols_path = nullptr;
+    int64_t rows = 0;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "--cols")) cols_path = argv[i + 1];
+        if (!strcmp(argv[i], "--rows")) rows = atoll(argv[i + 1]);
+    }
+    if (cols_path) {
+        FILE *f = fopen(cols_path, "rb");
+        if (!f) { printf("cannot open %s\n", cols_path); return 1; }
+        fseek(f, 0, SEEK_END);
+        const int64_t nnz = ftell(f) / 4;
+        fseek(f, 0, SEEK_SET);
+        std::vector<int32_t> h((size_t)nnz);
+        if (fread(h.data(), 4, (size_t)nnz, f) != (size_t)nnz) { printf("short read\n"); return 1; }
+        fclose(f);
+        if (rows <= 0) for (int32_t c : h) rows = std::max<int64_t>(rows, (int64_t)c + 1);
+        int32_t *dcols; float4 *state; float *o;
+        CK(hipMalloc(&dcols, (size_t)nnz * 4)); CK(hipMemcpy(dcols, h.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&state, (size_t)rows * 1024)); CK(hipMemset(state, 0, (size_t)rows * 1024)); CK(hipMalloc(&o, 64));
+        printf("replay of %lld column indices over %lld state rows (gathers only: no streams, no arithmetic)\n",
+               (long long)nnz, (long long)rows);
+        run_replay<8>(state, dcols, nnz, o);
+        run_replay<16>(state, dcols, nnz, o);
+        run_replay<32>(state, dcols, nnz, o);
+        return 0;
+    }
     const size_t maxb = (size_t)4 << 30;
     float4 *buf; float *out;
     CK(hipMalloc(&buf, maxb)); CK(hipMalloc(&out, 64));

@@ -66,6 +66,36 @@ __global__ __launch_bounds__(256) void replay_kernel(const float4 *p, const int3
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = 1.f;
 }
 
+// the small-batch shape: every lane owns its entries and fetches ES bytes (2 = one fp16 value, B = 1) per entry
+template <typename T>
+__global__ __launch_bounds__(256) void replay_lane_kernel(const T *p, const int32_t *__restrict__ cols, int64_t nnz, float *out) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, n = (int64_t)gridDim.x * 256;
+    float acc = 0.f;
+    for (int64_t e = tid; e < nnz; e += n * 8) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = e + (int64_t)u * n;
+            v[u] = i < nnz ? p[cols[i]] : T{};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (float)v[u];
+    }
+    if (acc == 123.456f) out[0] = 1.f;
+}
+template <typename T>
+void run_replay_lane(const void *buf, const int32_t *cols, int64_t nnz, float *out) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int blocks = 256 * 16;
+    hipLaunchKernelGGL(replay_lane_kernel<T>, dim3(blocks), dim3(256), 0, 0, (const T *)buf, cols, nnz, out);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(replay_lane_kernel<T>, dim3(blocks), dim3(256), 0, 0, (const T *)buf, cols, nnz, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 5;
+    printf("  per-lane %zu-byte gathers: %8.3f ms per pass, %6.1f G gathers/s\n", sizeof(T), ms, (double)nnz / (ms * 1e-3) / 1e9);
+}
+
 template <int LPC>
 void run_replay(const float4 *buf, const int32_t *cols, int64_t nnz, float *out) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -119,6 +149,8 @@ int main(int argc, char **argv) {
         run_replay<8>(state, dcols, nnz, o);
         run_replay<16>(state, dcols, nnz, o);
         run_replay<32>(state, dcols, nnz, o);
+        run_replay_lane<_Float16>(state, dcols, nnz, o);
+        run_replay_lane<float>(state, dcols, nnz, o);
         return 0;
     }
     const size_t maxb = (size_t)4 << 30;

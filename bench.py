@@ -87,7 +87,7 @@ def _time_launches(fn, n_l):
 def fp8_mode_counts(iters, damping=None):
     """Launches of one retrieve by kernel instantiation "<mode>" or "<mode>/<residual form>": ppr8_plan and the
     residual-form schedule of ppr8_begin in csrc/shard.hip (stages 1, 2, 3.., remainder; the residual travels in
-    its 3-byte form once damping^k <= 2^-9)."""
+    its 3-byte form once damping^k <= 2^-6)."""
     damping = DAMPING if damping is None else damping
     left = iters - 3
     stages = [1, 2] + [3] * (left // 3) + ([left % 3] if left % 3 else [])
@@ -98,7 +98,7 @@ def fp8_mode_counts(iters, damping=None):
         if si == 0:
             continue
         if si + 1 < len(stages):
-            out16 = damping ** k <= 1.0 / 512.0
+            out16 = damping ** k <= 1.0 / 64.0
             key = f"B/{(1 if r16 else 0) | (2 if out16 else 0)}"
             counts[key] = counts.get(key, 0) + 1
             r16 = out16

@@ -297,8 +297,9 @@ __device__ __forceinline__ size_t state_off(const Ppr8Args &a, int slab, int64_t
 //          buffer: it is only ever read at the own row) plus the fp16 remainder rho = f16(R cs - rt) that
 //          the previous boundary stored: 3 bytes instead of 4, |error| <= 2^-11 |rho| <= 2^-15 |R|;
 //   bit 1: R_out is stored in that form (rho only: the new rt is written anyway).
-// The host switches a boundary to this form once damping^k <= 2^-9 (k = sweeps done), where 2^-15 |R| is
-// below 1e-7 of the solution (csrc/shard.hip); the early boundaries keep the fp32 R.
+// The host switches a boundary to this form once damping^k <= 2^-6 (k = sweeps done), where 2^-15 |R| is
+// below 5e-7 of the solution (csrc/shard.hip; emulation: 2.5e-7 -> 3.9e-7 on the benchmark graph against 2^-9,
+// 4e-6 at 2^-3); the early boundaries keep the fp32 R.
 template <int MODE, int RIO>
 __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow, int gl,
                                            const f32x2_t (&acc)[8]) {

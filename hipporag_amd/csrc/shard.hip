@@ -147,9 +147,9 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
             // the new right-hand side overwrites the old one in place (row by row: a row only ever reads its own
             // rt): R, or its fp16 remainder next to rt, carries everything else
             const int y = (rt >= 0 && c != rt) ? rt : (c + 1) % 3;
-            // residual form: fp32 while it is large; (rt + fp16 remainder) once damping^k <= 2^-9, where the
-            // 2^-15 relative error of that form is below 1e-7 of the solution (ppr8.hip finish_row)
-            const bool out16 = si > 0 && std::pow(al, k_done) <= 1.0 / 512.0;
+            // residual form: fp32 while it is large; (rt + fp16 remainder) once damping^k <= 2^-6, where the
+            // 2^-15 relative error of that form is below 5e-7 of the solution (ppr8.hip finish_row)
+            const bool out16 = si > 0 && std::pow(al, k_done) <= 1.0 / 64.0;
             const int rio = (r16 ? 1 : 0) | (out16 ? 2 : 0);
             p.steps[n++] = Ppr8Step{si == 0 ? kP8ModeB0 : kP8ModeB, si, c, y, rt, 1.0f / cs, cs_next, rio};
             r16 = out16;

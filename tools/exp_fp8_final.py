@@ -29,7 +29,7 @@ def plan_for(iters):
 
 def ppr8(at32, d1, v, alpha, plan, rho_form=True):
     """Mirror of ppr8_begin / ppr8_sweep (csrc/shard.hip) + the kernels of csrc/ppr8.hip, fp32 arithmetic.
-    rho_form: the true residual travels as (rt + fp16 remainder) once damping^k <= 2^-9, like the device."""
+    rho_form: the true residual travels as (rt + fp16 remainder) once damping^k <= 2^-6, like the device."""
     import math
     al, be = np.float32(alpha), np.float32(1 - alpha)
     zv = (v / d1[:, None])
@@ -63,7 +63,7 @@ def ppr8(at32, d1, v, alpha, plan, rho_form=True):
         if si + 1 < len(plan):
             q = (R * cs_next).astype(np.float32)
             rt = q8(q)
-            r16 = rho_form and si > 0 and alpha ** k_done <= 1.0 / 512.0
+            r16 = rho_form and si > 0 and alpha ** k_done <= 1.0 / 64.0
             if r16:
                 rho = (q - rt).astype(np.float16).astype(np.float32)
     z = X + R

@@ -11,11 +11,11 @@ LIB_PATH = os.path.join(_HERE, "libhrag.so")
 
 HRAG_OK, HRAG_EINVAL, HRAG_ENOMEM, HRAG_EHIP, HRAG_EZERO_RESET, HRAG_ECAPACITY = range(6)
 SEED_STRIDE = 32
-HRAG_VERSION = 3      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
-FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, FLAG_FP8_SATURATED = 1, 2, 4, 8
+HRAG_VERSION = 4      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
+FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, FLAG_FP8_SATURATED, FLAG_NOT_CONVERGED = 1, 2, 4, 8, 16
 # hrag_opts.flags (include/hrag.h HRAG_OPT_*)
 OPT_NATURAL_ROW_ORDER, OPT_NT_CSR, OPT_NT_STORE, OPT_F32_STATE, OPT_TEMPORAL16, OPT_NO_FP8 = 1, 2, 4, 8, 16, 32
-OPT_ROWS_BY_MINCOL, OPT_ROWS_BFS, OPT_SLABS_PER_WG_1, OPT_FP8_MARGIN = 64, 128, 256, 512
+OPT_ROWS_BY_MINCOL, OPT_ROWS_BFS, OPT_SLABS_PER_WG_1, OPT_NO_F16 = 64, 128, 256, 1024
 
 
 class HragError(RuntimeError):
@@ -71,7 +71,8 @@ SIGNATURES = {
                                      C.POINTER(FactDesc), C.POINTER(Opts), C.POINTER(_P)]),
     "hrag_engine_destroy": (C.c_int, [_P]),
     "hrag_score_facts": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),
-    "hrag_retrieve": (C.c_int, [_P, _P, _I32, _P, _P, _P, _I32, _I32, _F32, _F32, _I32, _I32, _P, _P, _P, _P]),
+    "hrag_retrieve": (C.c_int, [_P, _P, _I32, _P, _P, _P, _I32, _I32, _F32, _F32, _I32, _I32, _F32, _I32, _P, _P, _P,
+                                _P, _P, _P]),
     "hrag_dense_retrieve": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),
     "hrag_sim_scores": (C.c_int, [_P, _I32, _P, _I32, _P, _P]),
     "hrag_ppr": (C.c_int, [_P, _P, _I32, _F32, _I32, _P, _P, _P]),
@@ -123,9 +124,11 @@ def load(build_if_missing: bool = True):
         # digest-stamped: a no-op when neither a source nor a header changed, so a stale library can never
         # be loaded against newer ctypes struct layouts.  Without hipcc (a deployment box that received the
         # built library) the existing file is used and the version check below is the guard.
+        # A compile error propagates (never load a stale library over a source that no longer builds).
+        from .csrc.build import ToolchainMissing
         try:
             build_library()
-        except Exception:
+        except ToolchainMissing:
             if not os.path.exists(LIB_PATH):
                 raise
     if not os.path.exists(LIB_PATH):

@@ -8,6 +8,7 @@ snapshot to the GPU box.  hipcc cross-compiles for gfx950 without a GPU present.
 
 from __future__ import annotations
 
+import fcntl
 import hashlib
 import os
 import shutil
@@ -28,10 +29,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-I" + INCLUDE, "-I" + HERE]
 
 
+class ToolchainMissing(RuntimeError):
+    """No hipcc on this machine (a deployment box that received the built library)."""
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
-        raise RuntimeError("hipcc not found: libhrag.so cannot be built (ROCm toolchain required)")
+        raise ToolchainMissing("hipcc not found: libhrag.so cannot be built (ROCm toolchain required)")
     return exe
 
 
@@ -45,8 +50,21 @@ def _digest(paths) -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile what changed and relink.  Safe under concurrent callers (the N ranks of a torchrun job all import
+    the package): the whole build runs under an exclusive file lock, objects and the library are written to a
+    temporary name and renamed into place, so a peer never dlopens a half-written file and the ranks that waited
+    find everything up to date."""
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(hipcc, force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(hipcc: str, force: bool, verbose: bool) -> str:
     hdr_digest = _digest(HEADERS)
 
     def compile_one(src: str):
@@ -56,10 +74,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         want = _digest([src_path]) + hdr_digest
         if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
             return obj, False
-        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src_path, "-o", obj]
+        tmp = obj + f".tmp{os.getpid()}"
+        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src_path, "-o", tmp]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        os.replace(tmp, obj)
         with open(stamp, "w") as f:
             f.write(want)
         return obj, True
@@ -68,10 +88,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         results = list(ex.map(compile_one, SOURCES))
     objs = [o for o, _ in results]
     if force or any(changed for _, changed in results) or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        tmp = LIB + f".tmp{os.getpid()}"
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
     return LIB
 
 

@@ -140,6 +140,10 @@ struct Ppr16Args {
     const uint16_t *hfin = nullptr;
     float *out = nullptr;
     int64_t p_rows = 0;
+    // mode F, convergence contract: est[q] = max over the passage rows of |x_new - x_old| / x_new as float bits
+    // (atomicMax; x_old from the own row of the gather source); nullptr: not measured
+    int32_t *est = nullptr;
+    int32_t batch = 0;
 };
 // nt: bit0 non-temporal (col, val) loads, bit1 non-temporal state stores
 hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, int nt, bool main_only,
@@ -162,6 +166,8 @@ enum Ppr8Mode { kP8ModeC = 0, kP8ModeB = 1, kP8ModeF = 2, kP8ModeB0 = 3 };   // 
 constexpr int kP8MaxStages = 12;      // stage lengths 1,2,3,..,3,(1|2) => <= 11 stages for ppr_iters <= 30
 constexpr float kP8C0Scale = 128.f;   // c_0 = Q(v/d * 2^7),  max(v/d) in (1/2, 1]
 constexpr int32_t kFlagFp8Saturated = 8;   // flags bit 3 (HRAG_FLAG_FP8_SATURATED)
+constexpr int32_t kFlagNotConverged = 16;  // flags bit 4 (HRAG_FLAG_NOT_CONVERGED)
+constexpr int kP8MaxExt = 4;          // extension stages (3 sweeps each) the convergence contract may add
 struct Sell8Dev {
     const int2 *pairs;         // (col, fp32 bits of the value), step-major per chunk (ppr16.hip layout)
     uint32_t pairs_bytes;      // incl. the read-ahead padding (< 2^31)
@@ -211,6 +217,15 @@ struct Ppr8Args {
     int32_t batch;
     int32_t slab0, n_slabs;    // 128-query slabs covered by this launch
     int32_t wps;               // slabs handled inside one workgroup (1, 2 or 4 wavefronts per chunk); 0 / 1 = one
+    // convergence contract (csrc/shard.hip, ppr8_begin): a launch whose gate word differs from gate_want returns at
+    // once -- the extension stages and the alternative final sweeps are enqueued unconditionally and the DEVICE
+    // decides which of them run (no host synchronisation, graph-capture safe)
+    const int32_t *gate = nullptr;
+    int32_t gate_want = 0;
+    // modes B / F: est[q] = max over the owned passage rows of |R_p| / z_p as float bits (atomicMax), the relative
+    // size of the last update of the passage scores; nullptr: not computed.  Mode B then needs stage / stage_inv /
+    // n_stage like mode F (z_p = sum of the stage copies + c / cs + R).
+    int32_t *est = nullptr;
 };
 hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, bool main_only, hipStream_t s);
 // c_0 = Q(v/d * c0_scale) on the owned rows of slabs [slab0, slab0 + n_slabs)
@@ -231,7 +246,14 @@ hrag_status launch_ppr8_scale(const float *zmax, const double *mass, float passa
                               const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
                               const float *deg, const uint8_t *iso, int64_t num_vertices, const int32_t *flags,
                               int32_t batch, float damping, int32_t iters, float *qscale, double *sums,
-                              hipStream_t s);
+                              hipStream_t s, int32_t n_tab = 1, int64_t tab_stride = 0);
+// the convergence contract's two tiny kernels (ppr8.hip): decision j after a checkpoint boundary; the per-query
+// results after the last step
+hrag_status launch_ppr8_decide(int32_t *est_ck, const int32_t *flags, int32_t batch, float kappa, float g, float tol,
+                               int32_t j, int32_t e_max, int32_t *ctl, int32_t n_ctl, hipStream_t s);
+hrag_status launch_ppr8_finalize(const int32_t *est_f, int32_t *flags, int32_t batch, float g, float tol,
+                                 int32_t iters, const int32_t *ctl, int32_t e_max, const double *mass_tab,
+                                 int64_t tab_stride, double *sums, float *resid, int32_t *iters_used, hipStream_t s);
 // colmask |= bits of the seed vertices
 hrag_status launch_ppr8_mask_seeds(const int32_t *seed_vtx, const int32_t *seed_cnt, int32_t batch,
                                    int64_t num_vertices, uint32_t *colmask, hipStream_t s);
@@ -262,6 +284,10 @@ struct PprSvArgs {
     float *xout = nullptr;             // mode 3: x = h + c / cscale, fp32 [V][BP], written at the matrix' rows only
     float cscale = 64.f;
     const uint32_t *colmask = nullptr; // first sweep: bit = column may be non-zero in x_0 (nullptr: gather everything)
+    // last sweep (kSvFinal, or the plain fp32 sweep over the passage rows), convergence contract: est[q] = max over
+    // the rows of |x_new - x_old| / x_new as float bits (atomicMax); nullptr: not measured
+    int32_t *est = nullptr;
+    int32_t batch = 0;
 };
 hrag_status launch_ppr_sv_sweep(const PprSvArgs &a, int bp, bool main_only, hipStream_t s);
 hrag_status launch_ppr_sv_init(const PprSvArgs &a, int bp, hipStream_t s);
@@ -306,6 +332,9 @@ hrag_status launch_gather_rows(const void *emb, const void *fresh, const int32_t
 hrag_status launch_fill_i32(int32_t *dst, int32_t value, int64_t n, hipStream_t s);
 hrag_status launch_flag_zero_mass(const double *sums, int32_t batch, int32_t *flags, int32_t bit,
                                   hipStream_t s);
+// convergence contract, fp32 slab state: est[q] = max over the passages of |x - x_prev| / x (float bits, atomicMax)
+hrag_status launch_passage_delta(const float *x, const float *x_prev, int64_t slab_rows, const int32_t *passage_vertex,
+                                 int64_t n_passages, int32_t batch, SlabLayout lay, int32_t *est, hipStream_t s);
 
 // sim_gemm.hip : S[b][m] = sum_k Q[b][k] * E[m][k]   (bf16 in, fp32 out, ld in elements)
 // dtype: HRAG_BF16 | HRAG_FP16 element type of emb AND q (16-bit patterns)

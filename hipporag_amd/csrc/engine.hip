@@ -38,7 +38,8 @@ void free_engine(hrag_engine *e) {
                     e->d_xp8, e->d_row_ptele, e->d_iso, e->d_piso, e->d_colmask_static, e->d_colmask,
                     e->d_stagep, e->d_pool8[0], e->d_pool8[1], e->d_pool8[2], e->d_sv16[0], e->d_sv16[1],
                     e->d_sv16[2], e->d_sv16[3], e->d_zmax_bits, e->d_zmax,
-                    e->d_mass, e->d_prior_part};
+                    e->d_mass, e->d_prior_part, e->d_est_ck, e->d_est_f, e->d_ctl, e->d_iters_used, e->d_resid,
+                    e->d_mass_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_store(e->sell);
@@ -248,7 +249,7 @@ Ppr16Args ppr16_args(const hrag_engine *e, const uint16_t *x, uint16_t *y, const
 // residual sweep; K2 sweeps on the correction, the last of them over the passage rows only (fsell), writing
 // x = h + c / cs in fp32 at the passages (d_xp8, passage order) -- nothing else is read afterwards
 // (HippoRAG.py:1745).  Buffers: d_h16[0], [1] ping-pong for h; [2] = r; the free h buffer and [3] ping-pong for c.
-hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipStream_t s) {
+hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipStream_t s, int32_t *est = nullptr) {
     const int ns = n_slabs64(batch);
     const int nt = (e->opt_flags & HRAG_OPT_TEMPORAL16) ? 0 : 3;
     const int k1 = iters / 2, k2 = iters - k1 - 1;
@@ -272,6 +273,7 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
             a.n_chunks = m.n_chunks; a.lrow_row = m.lrow_row; a.lrow_first = m.lrow_first; a.lrow_cnt = m.lrow_cnt;
             a.n_lrow = m.n_lrow; a.n_partial = m.n_partial; a.seg_lrow = m.seg_lrow; a.lcount = m.lcount;
             a.hfin = h; a.out = e->d_xp8; a.p_rows = e->p_rows;
+            a.est = est; a.batch = batch;
         }
         HRAG_TRY(launch_ppr16_sweep(a, last ? kPprModeF : kPprModeC, ns, nt, false, s));
         c = cn;
@@ -283,7 +285,8 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
 
 // The fp16 two-stage scheme needs K1 >= 8 sweeps before the residual sweep (error ~ 2^-(11+K1)).
 inline bool use_f16(const hrag_engine *e, int batch, int iters) {
-    return e->f16_ready && batch > kSvMaxBatch && batch <= e->f16_max_batch && iters >= 16;
+    return e->f16_ready && !(e->opt_flags & HRAG_OPT_NO_F16) && batch > kSvMaxBatch && batch <= e->f16_max_batch &&
+           iters >= 16;
 }
 inline bool use_sv(const hrag_engine *e, int batch) { return e->sell_ready && batch <= kSvMaxBatch; }
 inline int sv_width(int batch) { return batch <= 1 ? 1 : batch <= 2 ? 2 : batch <= 4 ? 4 : 8; }
@@ -303,7 +306,9 @@ PprSvArgs ppr_sv_args(const hrag_engine *e, const Sell8Store &m, const void *x, 
 }
 
 // the two-stage fp16 state of the small-batch path needs K1 >= 8 sweeps before the residual sweep
-inline bool use_sv_half(const hrag_engine *e, int iters) { return e->d_sv16[0] != nullptr && iters >= 16; }
+inline bool use_sv_half(const hrag_engine *e, int iters) {
+    return e->d_sv16[0] != nullptr && !(e->opt_flags & HRAG_OPT_NO_F16) && iters >= 16;
+}
 
 // hrag_ppr (all rows wanted): x_0 = v, `iters` plain sweeps; the final state ends in e->d_x ([V][bp] fp32)
 hrag_status ppr_sv_run_full(hrag_engine *e, const int32_t *row_slot, const float *tele, int bp, float damping,
@@ -322,7 +327,7 @@ hrag_status ppr_sv_run_full(hrag_engine *e, const int32_t *row_slot, const float
 // (d_colmask), the last one runs over the passage rows only and leaves x (fp32 [V][bp], passage rows valid) in
 // e->d_x; with >= 16 sweeps the state in between is the two-stage fp16 one (v must carry the per-query scale).
 hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tele, int bp, float damping,
-                       int iters, hipStream_t s) {
+                       int iters, hipStream_t s, int32_t *est = nullptr, int batch = 0) {
     if (iters < 1) return ppr_sv_run_full(e, row_slot, tele, bp, damping, iters, s);
     if (!use_sv_half(e, iters)) {
         float *x = e->d_x, *y = e->d_y;
@@ -330,6 +335,7 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
         for (int it = 0; it < iters; ++it) {
             PprSvArgs a = ppr_sv_args(e, it + 1 == iters ? e->fsell : e->sell, x, y, row_slot, tele, damping);
             a.colmask = it == 0 ? e->d_colmask : nullptr;
+            if (it + 1 == iters) { a.est = est; a.batch = batch; }
             HRAG_TRY(launch_ppr_sv_sweep(a, bp, false, s));
             std::swap(x, y);
         }
@@ -361,6 +367,7 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
         PprSvArgs a = ppr_sv_args(e, last ? e->fsell : e->sell, c, cn, row_slot, tele, damping);
         a.half_state = 1; a.mode = last ? 3 : 2; a.aux16 = r; a.cscale = kPpr16CScale;
         a.h16 = h; a.xout = e->d_x;
+        if (last) { a.est = est; a.batch = batch; }
         HRAG_TRY(launch_ppr_sv_sweep(a, bp, false, s));
         c = cn;
         std::swap(cn, cn2);
@@ -695,6 +702,12 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     // colsum partials: worst case is the narrowest slab (most slabs * bc stays ~B, padded)
     E_TRY(dev_alloc(&e->d_colsum_partial, (int64_t)kColsumBlocks * (round_up(B, 4) + 64)));
     E_TRY(dev_alloc(&e->d_sums, B));
+    E_TRY(dev_alloc(&e->d_est_ck, B));
+    E_TRY(dev_alloc(&e->d_est_f, B));
+    E_TRY(dev_alloc(&e->d_ctl, 2 * (kP8MaxExt + 1)));
+    E_TRY(dev_alloc(&e->d_iters_used, B));
+    E_TRY(dev_alloc(&e->d_resid, B));
+    E_TRY(dev_alloc(&e->d_mass_tab, (int64_t)(kP8MaxExt + 1) * B));
     {
         char *ws = nullptr;
         E_TRY(dev_alloc(&ws, (int64_t)kTopkWsBytes));
@@ -877,9 +890,12 @@ hrag_status hrag_stage_doc_scores(hrag_engine *e, const float *x, const double *
 hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
                           const int32_t *kept_idx, const float *kept_score, const int32_t *kept_count,
                           int32_t kf, int32_t link_top_k, float damping, float passage_node_weight,
-                          int32_t ppr_iters, int32_t k, int32_t *doc_idx_out, float *doc_score_out,
-                          int32_t *flags_out, hrag_stream stream) {
+                          int32_t ppr_iters, int32_t ppr_max_iters, float ppr_tol, int32_t k, int32_t *doc_idx_out,
+                          float *doc_score_out, int32_t *flags_out, float *residual_out, int32_t *iters_out,
+                          hrag_stream stream) {
     HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(ppr_tol >= 0.f && ppr_tol == ppr_tol, "ppr_tol must be >= 0");
+    HRAG_REQUIRE(ppr_tol == 0.f || ppr_max_iters >= ppr_iters, "ppr_max_iters=%d < ppr_iters=%d", ppr_max_iters, ppr_iters);
     HRAG_REQUIRE(q_pass && kept_idx && kept_score && kept_count && doc_idx_out && doc_score_out, "NULL argument");
     HRAG_REQUIRE(e->n_rows == e->V && e->p_rows == e->n_passages,
                  "hrag_retrieve needs an unsharded engine; sharded engines use the hrag_stage_* operators");
@@ -890,8 +906,7 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     hipStream_t s = (hipStream_t)stream;
     const bool sv = use_sv(e, batch);
     const bool f8 = !sv && batch > 64 && e->d_pool8[0] && ppr8_usable(e, batch, ppr_iters, damping);
-    // HRAG_OPT_FP8_MARGIN: two sweeps more than asked for on the fp8 state (accuracy margin, see hrag.h)
-    const int f8_iters = (f8 && (e->opt_flags & HRAG_OPT_FP8_MARGIN) && ppr_iters + 2 <= 30) ? ppr_iters + 2 : ppr_iters;
+    const int f8_iters = ppr_iters;
     const bool f16 = !sv && !f8 && use_f16(e, batch, ppr_iters);
     const int bp = sv_width(batch);
     SlabLayout lay = e->layout(batch);
@@ -900,6 +915,11 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     const bool prof = e->profiling;
 
     HRAG_HIP_TRY(hipMemsetAsync(e->d_flags, 0, (size_t)batch * sizeof(int32_t), s));
+    // convergence contract on the fp16 / small-batch / fp32 states: the fixed count runs, the last sweep measures the
+    // relative update of the passage scores (residual_out, flags bit 4); only the fp8 state extends on the device
+    const bool want_est = residual_out != nullptr || ppr_tol > 0.f;
+    int32_t *est = (want_est && !f8 && ppr_iters >= 1) ? e->d_est_f : nullptr;
+    if (est) HRAG_HIP_TRY(hipMemsetAsync(est, 0, (size_t)batch * sizeof(int32_t), s));
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_START], s));
     // dense_passage_retrieval: raw scores + min / max (HippoRAG.py:1496-1498)
     HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
@@ -923,7 +943,8 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
         HRAG_TRY(ppr8_layout(e, batch, 0, &sl));   // narrowest groups: two adjacent slabs per vertex
         HRAG_TRY(ppr8_prior(e, e->d_mn_p, e->d_mx_p, passage_node_weight, e->d_flags, batch, e->d_zmax, e->d_mass, s));
         HRAG_TRY(ppr8_begin(e, e->d_mn_p, e->d_mx_p, e->d_zmax, e->d_mass, passage_node_weight, e->d_seed_vtx,
-                            e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, damping, f8_iters, sl, e->d_pool8, s));
+                            e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, damping, f8_iters, sl, e->d_pool8, s,
+                            ppr_max_iters, ppr_tol, residual_out != nullptr));
     } else if (f16) {
         // v is scaled per query by a power of two so that every iterate fits fp16 (ppr16.hip); the seeds
         // become extra teleport rows, i.e. v is one array that every sweep reads identically
@@ -971,11 +992,15 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SEED], s));
     // PPR (HippoRAG.py:1736-1743): fixed-count leaky power iteration
     if (f8) {
-        for (int it = 0; it < f8_iters; ++it) HRAG_TRY(ppr8_sweep(e, it, -1, nullptr, s));
+        // `f8_iters` sweeps + the conditional steps of the convergence contract (their gate words decide on the device)
+        for (int it = 0; it < e->p8.n_steps; ++it) {
+            HRAG_TRY(ppr8_sweep(e, it, -1, nullptr, s));
+            HRAG_TRY(ppr8_decide(e, it, s));
+        }
     } else if (f16) {
-        HRAG_TRY(ppr16_run(e, batch, damping, ppr_iters, s));
+        HRAG_TRY(ppr16_run(e, batch, damping, ppr_iters, s, est));
     } else if (sv) {
-        HRAG_TRY(ppr_sv_run(e, e->d_row_slot, e->d_tele_sv, bp, damping, ppr_iters, s));
+        HRAG_TRY(ppr_sv_run(e, e->d_row_slot, e->d_tele_sv, bp, damping, ppr_iters, s, est, batch));
     } else {
         float *x = e->d_x, *y = e->d_y;
         HRAG_TRY(ppr_init(e, e->d_tele, e->n_passages, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w,
@@ -985,7 +1010,8 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
                               e->d_seed_cnt, batch, damping, x, y, lay, false, s));
             std::swap(x, y);
         }
-        if (x != e->d_x) std::swap(e->d_x, e->d_y);  // keep the final state in d_x
+        if (x != e->d_x) std::swap(e->d_x, e->d_y);  // keep the final state in d_x (d_y: the sweep before)
+        if (est) HRAG_TRY(launch_passage_delta(e->d_x, e->d_y, e->V, e->d_passage_vertex, e->n_passages, batch, lay, est, s));
     }
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_PPR], s));
     // doc scores + ranking (HippoRAG.py:1745-1747, :503)
@@ -998,14 +1024,14 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
         HRAG_TRY(launch_ppr_sv_rows(e->d_x, e->d_passage_vertex, e->n_passages, batch, e->d_sums, e->d_doc,
                                     e->ld_p, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, e->d_flags, bp, s));
     } else if (f8) {
-        HRAG_TRY(ppr8_doc_scores(e, e->d_mn_p, e->d_mx_p, e->d_flags, batch, s));   // d_sums: the analytic mass
+        HRAG_TRY(ppr8_doc_scores(e, e->d_mn_p, e->d_mx_p, e->d_flags, batch, s, true));   // d_sums: the analytic mass
     } else if (f16) {
         // the same tail as the fp8 path: closed-form mass, x at the passages already in passage order
         HRAG_TRY(launch_ppr_sv_mass(e->d_tele16, 64, e->tele16_rows, e->n_passages,
                                     e->n_passages + (int64_t)batch * kMaxSeeds, e->d_piso, e->d_iso, e->d_row_to_tele,
                                     e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt, e->d_qscale, e->V, batch, damping,
                                     ppr_iters, e->d_colsum_partial, e->d_sums, s));
-        HRAG_TRY(ppr8_doc_scores(e, e->d_mn_p, e->d_mx_p, e->d_flags, batch, s));
+        HRAG_TRY(ppr8_doc_scores(e, e->d_mn_p, e->d_mx_p, e->d_flags, batch, s, false));
     } else {
         HRAG_TRY(launch_colsum(e->d_x, e->V, 0, e->V, batch, lay, e->d_colsum_partial, e->d_sums, s));
         HRAG_TRY(launch_slab_to_rows(e->d_x, e->V, e->d_passage_vertex, e->n_passages, batch, e->d_sums,
@@ -1015,8 +1041,23 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     HRAG_TRY(launch_flag_zero_mass(e->d_sums, batch, e->d_flags, 2, s));
     HRAG_TRY(launch_row_topk(e->d_doc, batch, e->n_passages, e->ld_p, k, 0, kNormNone, doc_idx_out,
                              doc_score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
+    if (!f8) {
+        if (est) {
+            HRAG_HIP_TRY(hipMemsetAsync(e->d_ctl, 0, (size_t)2 * (kP8MaxExt + 1) * sizeof(int32_t), s));
+            HRAG_TRY(launch_ppr8_finalize(est, e->d_flags, batch, damping / (1.0f - damping), ppr_tol, ppr_iters, e->d_ctl,
+                                          0, nullptr, 0, e->d_sums, e->d_resid, e->d_iters_used, s));
+        } else {
+            HRAG_TRY(launch_fill_i32(reinterpret_cast<int32_t *>(e->d_resid), (int32_t)0xbf800000u, batch, s));   // -1: not measured
+            HRAG_TRY(launch_fill_i32(e->d_iters_used, ppr_iters, batch, s));
+        }
+    }
     if (flags_out)
         HRAG_HIP_TRY(hipMemcpyAsync(flags_out, e->d_flags, (size_t)batch * sizeof(int32_t),
+                                    hipMemcpyDeviceToDevice, s));
+    if (residual_out)
+        HRAG_HIP_TRY(hipMemcpyAsync(residual_out, e->d_resid, (size_t)batch * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (iters_out)
+        HRAG_HIP_TRY(hipMemcpyAsync(iters_out, e->d_iters_used, (size_t)batch * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, s));
     if (prof) {
         HRAG_HIP_TRY(hipEventRecord(e->ev[EV_RANK], s));

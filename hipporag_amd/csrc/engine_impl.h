@@ -75,6 +75,12 @@ struct Ppr8Step {
     int32_t x, y, rt;    // state buffer indices (y: written = to be exchanged, -1 for mode F; rt: the stage's rhs)
     float inv_cs, cs_next;
     int32_t rio;         // residual form of a boundary / final step (Ppr8Args.rio)
+    // convergence contract: gate = index of the control word the launch is conditional on (-1: always runs),
+    // ckpt = this boundary measures est (the relative update of the passage scores) and is followed by decision
+    // number `decide` (-1: none), kappa = the contraction predicted for the stage that follows
+    int32_t gate = -1, gate_want = 1;
+    int32_t ckpt = 0, decide = -1;
+    float kappa = 0.f;
 };
 struct Ppr8Session {
     bool active = false;
@@ -84,8 +90,12 @@ struct Ppr8Session {
     float damping = 0.f;
     uint8_t *buf[3] = {nullptr, nullptr, nullptr};
     const int32_t *flags = nullptr;      // the batch's flag words (bit 3: fp8 saturation)
-    Ppr8Step steps[40];
+    Ppr8Step steps[64];
     float stage_inv[kP8MaxStages];
+    // convergence contract (ppr8_begin): sweeps always run / extension stages allowed / tolerance on est
+    int32_t e_max = 0;
+    bool want_est = false;
+    float tol = 0.f;
 };
 
 }  // namespace hrag
@@ -160,6 +170,12 @@ struct hrag_engine {
     float *d_zmax = nullptr;
     double *d_mass = nullptr, *d_prior_part = nullptr;
     Ppr8Session p8;
+    // convergence contract of the PPR solve (every state type): est = max over the passages of the relative size of the
+    // last update, as float bits (atomicMax) -- at the last checkpoint boundary / at the final sweep; control words
+    // [0 .. kP8MaxExt]: extension stage j + 1 runs, [kP8MaxExt + 1 ..]: final sweep variant j runs; the results
+    int32_t *d_est_ck = nullptr, *d_est_f = nullptr, *d_ctl = nullptr, *d_iters_used = nullptr;
+    float *d_resid = nullptr;
+    double *d_mass_tab = nullptr;   // [kP8MaxExt + 1][max_batch]: mass of the (iters + 3 j)-sweep iterate
     // timing
     hipEvent_t ev[EV_COUNT] = {};
     bool profiling = false, have_retrieve_ev = false, have_fact_ev = false;
@@ -199,15 +215,24 @@ hrag_status ppr8_layout(const hrag_engine *e, int32_t batch, int32_t want_groups
 hrag_status ppr8_prior(hrag_engine *e, const float *mn, const float *mx, float passage_weight,
                        const int32_t *flags, int32_t batch, float *zmax_out, double *mass_out, hipStream_t s);
 // scale, teleport rows, seed rows, column mask, stage plan, c_0 on the owned rows of buf[0]
+// max_iters / tol / want_est: the convergence contract (include/hrag.h, hrag_retrieve): tol > 0 lets the DEVICE add
+// up to (max_iters - iters) / 3 stages of 3 sweeps; the session then has more steps than `iters` (p8.n_steps)
 hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const float *zmax, const double *mass,
                        float passage_weight, const int32_t *seed_vtx, const float *seed_w,
                        const int32_t *seed_cnt, int32_t *flags, int32_t batch, float damping, int32_t iters,
-                       const hrag_shard_layout &lay, uint8_t *const bufs[3], hipStream_t s);
-// sweep `i` (0-based) on exchange group `group` (-1: every group); *exchange = buffer written (-1: none)
+                       const hrag_shard_layout &lay, uint8_t *const bufs[3], hipStream_t s,
+                       int32_t max_iters = 0, float tol = 0.f, bool want_est = false);
+// step `i` (0-based, < p8.n_steps) on exchange group `group` (-1: every group); *exchange = buffer written (-1: none)
 hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchange, hipStream_t s);
+// after the checkpoint step `i` ran on every group: decide whether the next stage is the last (one tiny launch)
+hrag_status ppr8_decide(hrag_engine *e, int32_t i, hipStream_t s);
+// residual / sweeps used / NOT_CONVERGED flag / the mass of the iterate actually computed -> d_resid, d_iters_used,
+// flags, d_sums (every session, after its last step)
+hrag_status ppr8_finalize(hrag_engine *e, int32_t *flags, hipStream_t s);
 // d_doc[q][p_local] = x / mass, or the normalised DPR score on the fallback; flags bit 1 on zero mass
+// fp8_session: the scores come from the active fp8 session (ppr8_finalize runs first: mass, residual, flag)
 hrag_status ppr8_doc_scores(hrag_engine *e, const float *mn, const float *mx, int32_t *flags, int32_t batch,
-                            hipStream_t s);
+                            hipStream_t s, bool fp8_session);
 // measurement hook: one launch of kernel mode `mode` over the buffers of the active session (it: parity of
 // the ping-pong); results are garbage, the memory traffic is that of a real sweep of that mode
 hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int rio, int it, bool main_only, hipStream_t s);

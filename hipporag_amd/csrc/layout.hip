@@ -206,4 +206,31 @@ hrag_status launch_flag_zero_mass(const double *sums, int32_t batch, int32_t *fl
     return HRAG_OK;
 }
 
+
+namespace {
+// one thread per (passage, query): slab layout [n_slabs][slab_rows][bc]
+__global__ __launch_bounds__(256) void passage_delta_kernel(const float *__restrict__ x, const float *__restrict__ xp,
+                                                            int64_t slab_rows, const int32_t *__restrict__ pv,
+                                                            int64_t n_passages, int32_t batch, int32_t bc, int32_t *est) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t p = t / batch;
+    const int q = (int)(t - p * batch);
+    if (p >= n_passages) return;
+    const size_t at = ((size_t)(q / bc) * slab_rows + (size_t)pv[p]) * bc + (size_t)(q % bc);
+    const float a = x[at];
+    const float r = a > 0.f ? fabsf(a - xp[at]) / a : 0.f;
+    const int bits = __float_as_int(r);
+    if (bits > est[q]) atomicMax(&est[q], bits);
+}
+}  // namespace
+
+hrag_status launch_passage_delta(const float *x, const float *x_prev, int64_t slab_rows, const int32_t *passage_vertex,
+                                 int64_t n_passages, int32_t batch, SlabLayout lay, int32_t *est, hipStream_t s) {
+    if (n_passages <= 0 || batch <= 0) return HRAG_OK;
+    hipLaunchKernelGGL(passage_delta_kernel, dim3((unsigned)ceil_div(n_passages * batch, 256)), dim3(256), 0, s, x,
+                       x_prev, slab_rows, passage_vertex, n_passages, batch, lay.bc, est);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
 }  // namespace hrag

@@ -187,6 +187,17 @@ __device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row
                                 fmaf(out[6], ics, (float)in.h[6]), fmaf(out[7], ics, (float)in.h[7])};
             op[0] = v0;
             op[1] = v1;
+            if (a.est) {   // the relative size of this (last) sweep's update of the passage score
+                const half8_t cold = *reinterpret_cast<const half8_t *>(a.x + state_off);
+                const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = slab * 64 + gl * 8 + j;
+                    const float r = xs[j] > 0.f ? fabsf(out[j] - (float)cold[j]) * ics / xs[j] : 0.f;
+                    const int bits = __float_as_int(r);
+                    if (q < a.batch && bits > a.est[q]) atomicMax(&a.est[q], bits);
+                }
+            }
             return;
         }
     }

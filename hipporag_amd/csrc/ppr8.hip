@@ -300,9 +300,11 @@ __device__ __forceinline__ size_t state_off(const Ppr8Args &a, int slab, int64_t
 // The host switches a boundary to this form once damping^k <= 2^-6 (k = sweeps done), where 2^-15 |R| is
 // below 5e-7 of the solution (csrc/shard.hip; emulation: 2.5e-7 -> 3.9e-7 on the benchmark graph against 2^-9,
 // 4e-6 at 2^-3); the early boundaries keep the fp32 R.
-template <int MODE, int RIO>
+// er (modes B / F with a.est): on return |R_p| / z_p of this lane's 16 queries when the row is an owned passage
+// (the relative size of the update the boundary applies to the passage score), untouched otherwise.
+template <int MODE, int RIO, bool EST>
 __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow, int gl,
-                                           const f32x2_t (&acc)[8]) {
+                                           const f32x2_t (&acc)[8], f32x2_t (&er)[8]) {
     const int64_t grow = a.row_offset + lrow;
     const size_t off = state_off(a, slab, grow, gl);
     f32x2_t out[8];
@@ -357,8 +359,30 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow
                 st16i(rrow, gl, out);
             }
             // the final combine needs every stage's c at the passage rows only: keep a compact copy
-            if (is_passage)
-                *reinterpret_cast<v4i_t *>(a.stage_out + ((size_t)slab * a.p_rows + (size_t)slot) * 128 + (size_t)gl * 16) = cv;
+            if (is_passage) {
+                const size_t poff = ((size_t)slab * a.p_rows + (size_t)slot) * 128 + (size_t)gl * 16;
+                *reinterpret_cast<v4i_t *>(a.stage_out + poff) = cv;
+                if constexpr (MODE == kP8ModeB && EST) {
+                    {   // checkpoint boundary: z_p = X_p + R_p, X_p = the stages' c / cs summed (as mode F does)
+                        f32x2_t z[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) z[j] = f32x2_t{0.f, 0.f};
+                        for (int s = 0; s + 1 < a.n_stage; ++s) {
+                            f32x2_t cs[8];
+                            decode16(*reinterpret_cast<const v4i_t *>(a.stage[s] + poff), cs);
+                            const f32x2_t si = {a.stage_inv[s], a.stage_inv[s]};
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) z[j] = __builtin_elementwise_fma(cs[j], si, z[j]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const f32x2_t zz = __builtin_elementwise_fma(c[j], inv, z[j]) + out[j];
+                            er[j].x = zz.x > 0.f ? fabsf(out[j].x) / zz.x : 0.f;
+                            er[j].y = zz.y > 0.f ? fabsf(out[j].y) / zz.y : 0.f;
+                        }
+                    }
+                }
+            }
         } else {   // kP8ModeF: z = R' + sum_s c_s / cs_s (earliest stage first), x = d z
             if (!is_passage) return;
             const size_t poff = ((size_t)slab * a.p_rows + (size_t)slot) * 128 + (size_t)gl * 16;
@@ -378,13 +402,42 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 z[j] = __builtin_elementwise_fma(c[j], sl, z[j]);
-                xs[j] = (z[j] + out[j]) * dg;
+                const f32x2_t zz = z[j] + out[j];
+                xs[j] = zz * dg;
+                if constexpr (EST) {
+                    er[j].x = zz.x > 0.f ? fabsf(out[j].x) / zz.x : 0.f;
+                    er[j].y = zz.y > 0.f ? fabsf(out[j].y) / zz.y : 0.f;
+                }
             }
             // passage order: xp is [n_slabs64][p_rows][64] fp32, the layout slab_to_rows reads without a gather
             const int slab64 = 2 * slab + (gl >> 2);
             if (slab64 < a.n_slabs64)
                 st16f(a.out + ((size_t)slab64 * a.p_rows + (size_t)slot) * 64 + (size_t)(gl & 3) * 16, xs);
         }
+    }
+}
+
+// est[q] = max(est[q], er) for the 16 queries of lane gl.  WAVE: the 8 row groups of the wavefront are reduced
+// first (every lane must call; lanes without a passage row pass zeros), then group 0 commits.  The plain load
+// may be stale (another XCD's update): a stale value only costs a redundant atomic, the maximum is order-free.
+template <bool WAVE>
+__device__ __forceinline__ void est_commit(const Ppr8Args &a, int slab, int gl, int grp, f32x2_t (&er)[8]) {
+    if constexpr (WAVE) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                er[j].x = fmaxf(er[j].x, __shfl_xor(er[j].x, o, 64));
+                er[j].y = fmaxf(er[j].y, __shfl_xor(er[j].y, o, 64));
+            }
+        if (grp != 0) return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = slab * 128 + gl * 16 + 2 * j;
+        const int b0 = __float_as_int(er[j].x), b1 = __float_as_int(er[j].y);
+        if (q < a.batch && b0 > a.est[q]) atomicMax(&a.est[q], b0);
+        if (q + 1 < a.batch && b1 > a.est[q + 1]) atomicMax(&a.est[q + 1], b1);
     }
 }
 
@@ -396,8 +449,9 @@ __device__ __forceinline__ int ld_mask(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 // on the same XCD.  They are given the SAME chunk group for consecutive slabs: the second reader of
 // a (col, val) block then finds it in that XCD's L2 (measured: C sweep 0.822 -> 0.802 ms at cfg 3;
 // with non-temporal pair loads the remap alone changes nothing).
-template <int MODE, int RIO>
+template <int MODE, int RIO, bool EST>
 __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
+    if (a.gate && *a.gate != a.gate_want) return;   // a conditional step the device decided not to run
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
     // a workgroup = 4 wavefronts = (4 / wps) chunks x wps slabs: the wavefronts that work on the same chunk for
@@ -450,11 +504,16 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     // partial sums travel write-through / L1-bypassing (sc1): writer and reader may sit on different XCDs
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
         a.partial + (size_t)slab * a.m.n_partial * 128, 0, a.m.n_partial * 512, 0x00020000);
+    constexpr bool kEst = EST && (MODE == kP8ModeB || MODE == kP8ModeF);
+    f32x2_t er[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) er[j] = f32x2_t{0.f, 0.f};
     if (tgt >= 0) {
-        finish_row<MODE, RIO>(a, slab, tgt, gl, acc);
+        finish_row<MODE, RIO, EST>(a, slab, tgt, gl, acc, er);
     } else if (seg) {
         st16i_sc1(qrs, (unsigned)(-(tgt + 1)) * 512u, gl, acc);
     }
+    if constexpr (kEst) est_commit<true>(a, slab, gl, grp, er);   // every lane takes part in the reduction
     // Long rows arrive as segments in different wavefronts; the segment that arrives LAST (agent-scope
     // counter) lends its whole wavefront to the row: the 8 lane groups stride over the row's partial sums, the 8
     // group totals are added with xor-shuffles -- a fixed summation order, whoever comes last -- and the row is
@@ -490,7 +549,12 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
                 acc[j].x += __shfl_xor(acc[j].x, o, 64);
                 acc[j].y += __shfl_xor(acc[j].y, o, 64);
             }
-        if (grp == 0) finish_row<MODE, RIO>(a, slab, a.m.lrow_row[mm], gl, acc);
+        if (grp == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) er[j] = f32x2_t{0.f, 0.f};
+            finish_row<MODE, RIO, EST>(a, slab, a.m.lrow_row[mm], gl, acc, er);
+            if constexpr (kEst) est_commit<false>(a, slab, gl, 0, er);
+        }
         if (lane == 0) __hip_atomic_store(cnts + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -532,8 +596,9 @@ struct Gather8PM {   // mode B0: masked (see Gather8M)
     }
 };
 
-template <int MODE, int RIO>
+template <int MODE, int RIO, bool EST>
 __device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
+    if (a.gate && *a.gate != a.gate_want) return;   // a conditional step the device decided not to run
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
     // a workgroup = 4 wavefronts = (4 / wps) chunks x wps slab PAIRS
@@ -599,12 +664,18 @@ __device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
         a.partial + (size_t)slab * a.m.n_partial * 128, 0, a.m.n_partial * 512, 0x00020000);
     const __amdgpu_buffer_rsrc_t q1 = __builtin_amdgcn_make_buffer_rsrc(
         a.partial + (size_t)(slab + 1) * a.m.n_partial * 128, 0, a.m.n_partial * 512, 0x00020000);
-    if (tgt >= 0) {
-        finish_row<MODE, RIO>(a, slab, tgt, gl, acc0);
-        finish_row<MODE, RIO>(a, slab + 1, tgt, gl, acc1);
-    } else if (seg) {
-        st16i_sc1(q0, (unsigned)(-(tgt + 1)) * 512u, gl, acc0);
-        st16i_sc1(q1, (unsigned)(-(tgt + 1)) * 512u, gl, acc1);
+    constexpr bool kEst = EST && (MODE == kP8ModeB || MODE == kP8ModeF);
+    f32x2_t er[8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) er[j] = f32x2_t{0.f, 0.f};
+        if (tgt >= 0) {
+            finish_row<MODE, RIO, EST>(a, slab + half, tgt, gl, half ? acc1 : acc0, er);
+        } else if (seg) {
+            st16i_sc1(half ? q1 : q0, (unsigned)(-(tgt + 1)) * 512u, gl, half ? acc1 : acc0);
+        }
+        if constexpr (kEst) est_commit<true>(a, slab + half, gl, grp, er);
     }
     // long rows: as in ppr8_kernel; one arrival (the first slab's counter) covers both slabs of the pair
     if (__builtin_amdgcn_ballot_w64(seg) == 0) return;   // wave-uniform
@@ -640,14 +711,19 @@ __device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
                     acc0[j].x += __shfl_xor(acc0[j].x, o, 64);
                     acc0[j].y += __shfl_xor(acc0[j].y, o, 64);
                 }
-            if (grp == 0) finish_row<MODE, RIO>(a, slab + half, a.m.lrow_row[mm], gl, acc0);
+            if (grp == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) er[j] = f32x2_t{0.f, 0.f};
+                finish_row<MODE, RIO, EST>(a, slab + half, a.m.lrow_row[mm], gl, acc0, er);
+                if constexpr (kEst) est_commit<false>(a, slab + half, gl, 0, er);
+            }
         }
         if (lane == 0) __hip_atomic_store(cnts + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-template <int MODE, int RIO>
-__global__ __launch_bounds__(256, 2) void ppr8_pair_kernel(const Ppr8Args a) { ppr8_pair_body<MODE, RIO>(a); }
+template <int MODE, int RIO, bool EST>
+__global__ __launch_bounds__(256, 2) void ppr8_pair_kernel(const Ppr8Args a) { ppr8_pair_body<MODE, RIO, EST>(a); }
 
 // c_0 = Q(v/d * c0_scale) for every OWNED row of the launch's slabs (R_0 = b v/d is formed on the fly by
 // the first boundary sweep, mode B0).
@@ -739,7 +815,8 @@ __global__ void ppr8_scale_kernel(const float *__restrict__ zmax, const double *
                                   const float *__restrict__ seed_w, const int32_t *__restrict__ seed_cnt,
                                   const float *__restrict__ deg, const uint8_t *__restrict__ iso,
                                   int64_t num_vertices, const int32_t *__restrict__ flags, int32_t batch,
-                                  float damping, int32_t iters, float *qscale, double *sums) {
+                                  float damping, int32_t iters, float *qscale, double *sums, int32_t n_tab,
+                                  int64_t tab_stride) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= batch) return;
     float bound = 0.f;
@@ -771,9 +848,62 @@ __global__ void ppr8_scale_kernel(const float *__restrict__ zmax, const double *
     M *= (double)s;   // powers of two: exact
     S *= (double)s;
     const double al = (double)damping, be = (double)(1.0f - damping);
+    // sums[j * tab_stride + q] = the mass after iters + 3 j sweeps (j > 0: the extension stages of the convergence
+    // contract, csrc/shard.hip)
     double m = M;
-    for (int k = 0; k < iters; ++k) m = al * (m - (k == 0 ? S : be * S)) + be * M;
-    sums[q] = m;
+    int k = 0;
+    for (int j = 0; j < n_tab; ++j) {
+        for (; k < iters + 3 * j; ++k) m = al * (m - (k == 0 ? S : be * S)) + be * M;
+        sums[(size_t)j * tab_stride + q] = m;
+    }
+}
+
+// Convergence contract, decision number j (after a checkpoint boundary): est_ck[q] holds the relative size of the
+// update that boundary applied to the passage scores (max over the passages, float bits).  kappa = the contraction
+// the next stage is expected to add (damping^m + the e4m3 rounding of its right-hand side), g = damping / (1 -
+// damping) turns an update into the error that is left after it.  ctl[j] = 1: the next stage is closed by another
+// checkpoint boundary and extension stage j + 1 follows; ctl[n_ctl + j] = 1: the next stage is the last, final
+// sweep variant j runs.  A decision whose predecessor stopped leaves both at 0.
+__global__ __launch_bounds__(256) void ppr8_decide_kernel(int32_t *est_ck, const int32_t *__restrict__ flags,
+                                                          int32_t batch, float kappa, float g, float tol, int32_t j,
+                                                          int32_t e_max, int32_t *ctl, int32_t n_ctl) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const bool alive = j == 0 || ctl[j - 1] == 1;
+    float m = 0.f;
+    for (int q = tid; q < batch; q += 256) {
+        if (!(flags[q] & 1)) m = fmaxf(m, __int_as_float(est_ck[q]));
+        est_ck[q] = 0;   // the next checkpoint starts from zero
+    }
+    red[tid] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    if (tid == 0 && alive) {
+        const bool go = tol > 0.f && j < e_max && g * kappa * red[0] > tol;
+        ctl[j] = go ? 1 : 0;
+        ctl[n_ctl + j] = go ? 0 : 1;
+    }
+}
+
+// Results of the contract per query: resid = g * (relative size of the final sweep's update of the passage scores),
+// the sweeps that ran, flags bit 4 when tol > 0 and resid > tol, and the mass of the iterate that was computed.
+__global__ void ppr8_finalize_kernel(const int32_t *__restrict__ est_f, int32_t *flags, int32_t batch, float g,
+                                     float tol, int32_t iters, const int32_t *__restrict__ ctl, int32_t e_max,
+                                     const double *__restrict__ mass_tab, int64_t tab_stride, double *sums,
+                                     float *resid, int32_t *iters_used) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= batch) return;
+    int n_ext = 0;
+    for (int j = 0; j < e_max; ++j) n_ext += ctl[j] == 1 ? 1 : 0;
+    const bool fallback = (flags[q] & 1) != 0;
+    const float r = fallback ? 0.f : g * __int_as_float(est_f[q]);
+    resid[q] = r;
+    iters_used[q] = fallback ? 0 : iters + 3 * n_ext;
+    if (mass_tab) sums[q] = mass_tab[(size_t)n_ext * tab_stride + q];
+    if (tol > 0.f && r > tol) flags[q] |= kFlagNotConverged;
 }
 
 __global__ void ppr8_mask_seeds_kernel(const int32_t *__restrict__ seed_vtx, const int32_t *__restrict__ seed_cnt,
@@ -793,7 +923,7 @@ static bool p8_pair_enabled() {
     return v;
 }
 
-template <int MODE, int RIO>
+template <int MODE, int RIO, bool EST = false>
 hrag_status sweep_mode(const Ppr8Args &a_in, bool main_only, hipStream_t s) {
     Ppr8Args a = a_in;
     if (a.m.n_chunks > 0 && p8_pair_enabled() && a.spg % 2 == 0 && a.slab0 % 2 == 0 && a.n_slabs >= 2) {
@@ -802,7 +932,7 @@ hrag_status sweep_mode(const Ppr8Args &a_in, bool main_only, hipStream_t s) {
         const int np = b.n_slabs / 2;
         b.wps = (a.wps == 4 && np % 4 == 0) ? 4 : (a.wps >= 2 && np % 2 == 0) ? 2 : 1;
         const unsigned ncg = (unsigned)ceil_div(a.m.n_chunks, 4 / b.wps);
-        hipLaunchKernelGGL((ppr8_pair_kernel<MODE, RIO>), dim3((unsigned)round_up(ncg, 8) * (unsigned)(np / b.wps)),
+        hipLaunchKernelGGL((ppr8_pair_kernel<MODE, RIO, EST>), dim3((unsigned)round_up(ncg, 8) * (unsigned)(np / b.wps)),
                            dim3(256), 0, s, b);
         HRAG_LAUNCH_CHECK();
         a.slab0 += b.n_slabs;
@@ -814,7 +944,7 @@ hrag_status sweep_mode(const Ppr8Args &a_in, bool main_only, hipStream_t s) {
         Ppr8Args b = a;
         b.wps = (a.wps == 4 && a.n_slabs % 4 == 0) ? 4 : (a.wps >= 2 && a.n_slabs % 2 == 0) ? 2 : 1;
         const unsigned ncg = (unsigned)ceil_div(a.m.n_chunks, 4 / b.wps);
-        hipLaunchKernelGGL((ppr8_kernel<MODE, RIO>), dim3((unsigned)round_up(ncg, 8) * (unsigned)(a.n_slabs / b.wps)),
+        hipLaunchKernelGGL((ppr8_kernel<MODE, RIO, EST>), dim3((unsigned)round_up(ncg, 8) * (unsigned)(a.n_slabs / b.wps)),
                            dim3(256), 0, s, b);
         HRAG_LAUNCH_CHECK();
     }
@@ -831,11 +961,22 @@ hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, bool main_only, hipSt
         case kP8ModeC: return sweep_mode<kP8ModeC, 0>(a, main_only, s);
         case kP8ModeB0: return sweep_mode<kP8ModeB0, 0>(a, main_only, s);
         case kP8ModeB:
+            if (a.est) {   // checkpoint boundary of the convergence contract
+                if (rio == 0) return sweep_mode<kP8ModeB, 0, true>(a, main_only, s);
+                if (rio == 2) return sweep_mode<kP8ModeB, 2, true>(a, main_only, s);
+                if (rio == 3) return sweep_mode<kP8ModeB, 3, true>(a, main_only, s);
+                break;
+            }
             if (rio == 0) return sweep_mode<kP8ModeB, 0>(a, main_only, s);
             if (rio == 2) return sweep_mode<kP8ModeB, 2>(a, main_only, s);
             if (rio == 3) return sweep_mode<kP8ModeB, 3>(a, main_only, s);
             break;
         case kP8ModeF:
+            if (a.est) {
+                if (rio == 0) return sweep_mode<kP8ModeF, 0, true>(a, main_only, s);
+                if (rio == 1) return sweep_mode<kP8ModeF, 1, true>(a, main_only, s);
+                break;
+            }
             if (rio == 0) return sweep_mode<kP8ModeF, 0>(a, main_only, s);
             if (rio == 1) return sweep_mode<kP8ModeF, 1>(a, main_only, s);
             break;
@@ -871,10 +1012,27 @@ hrag_status launch_ppr8_scale(const float *zmax, const double *mass, float passa
                               const int32_t *seed_vtx, const float *seed_w, const int32_t *seed_cnt,
                               const float *deg, const uint8_t *iso, int64_t num_vertices, const int32_t *flags,
                               int32_t batch, float damping, int32_t iters, float *qscale, double *sums,
-                              hipStream_t s) {
+                              hipStream_t s, int32_t n_tab, int64_t tab_stride) {
     hipLaunchKernelGGL(ppr8_scale_kernel, dim3((unsigned)ceil_div(batch, 64)), dim3(64), 0, s, zmax, mass,
                        passage_weight, seed_vtx, seed_w, seed_cnt, deg, iso, num_vertices, flags, batch, damping,
-                       iters, qscale, sums);
+                       iters, qscale, sums, n_tab, tab_stride);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr8_decide(int32_t *est_ck, const int32_t *flags, int32_t batch, float kappa, float g, float tol,
+                               int32_t j, int32_t e_max, int32_t *ctl, int32_t n_ctl, hipStream_t s) {
+    hipLaunchKernelGGL(ppr8_decide_kernel, dim3(1), dim3(256), 0, s, est_ck, flags, batch, kappa, g, tol, j, e_max,
+                       ctl, n_ctl);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr8_finalize(const int32_t *est_f, int32_t *flags, int32_t batch, float g, float tol,
+                                 int32_t iters, const int32_t *ctl, int32_t e_max, const double *mass_tab,
+                                 int64_t tab_stride, double *sums, float *resid, int32_t *iters_used, hipStream_t s) {
+    hipLaunchKernelGGL(ppr8_finalize_kernel, dim3((unsigned)ceil_div(batch, 64)), dim3(64), 0, s, est_f, flags, batch,
+                       g, tol, iters, ctl, e_max, mass_tab, tab_stride, sums, resid, iters_used);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -100,12 +100,28 @@ __device__ __forceinline__ void sv_finish(const PprSvArgs &a, int row, int gl, f
         if (slot >= 0) t = a.tele[(size_t)slot * BP + gl];
         float out = fmaf(a.alpha, sum, a.beta * t);
         if constexpr (MODE == kSvResid) out = (out - (float)static_cast<const T *>(a.x)[at]) * a.cscale;
+        if constexpr (MODE == kSvPlain && sizeof(T) == 4) {
+            if (a.est && gl < a.batch) {   // last sweep of the fp32 state: relative size of the update
+                const float r = out > 0.f ? fabsf(out - static_cast<const float *>(a.x)[at]) / out : 0.f;
+                const int bits = __float_as_int(r);
+                if (bits > a.est[gl]) atomicMax(&a.est[gl], bits);
+            }
+        }
         if constexpr (sizeof(T) == 2) static_cast<_Float16 *>(a.y)[at] = to_half(out);
         else static_cast<float *>(a.y)[at] = out;
     } else {
         const float c = fmaf(a.alpha, sum, (float)reinterpret_cast<const _Float16 *>(a.aux16)[at]);
-        if constexpr (MODE == kSvCorr) static_cast<_Float16 *>(a.y)[at] = to_half(c);
-        else a.xout[at] = fmaf(c, 1.0f / a.cscale, (float)reinterpret_cast<const _Float16 *>(a.h16)[at]);
+        if constexpr (MODE == kSvCorr) {
+            static_cast<_Float16 *>(a.y)[at] = to_half(c);
+        } else {
+            const float x = fmaf(c, 1.0f / a.cscale, (float)reinterpret_cast<const _Float16 *>(a.h16)[at]);
+            a.xout[at] = x;
+            if (a.est && gl < a.batch) {   // relative size of this (last) sweep's update
+                const float r = x > 0.f ? fabsf(c - (float)static_cast<const _Float16 *>(a.x)[at]) / (a.cscale * x) : 0.f;
+                const int bits = __float_as_int(r);
+                if (bits > a.est[gl]) atomicMax(&a.est[gl], bits);
+            }
+        }
     }
 }
 

@@ -95,12 +95,14 @@ hrag_status ppr8_prior(hrag_engine *e, const float *mn, const float *mx, float p
 hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const float *zmax, const double *mass,
                        float passage_weight, const int32_t *seed_vtx, const float *seed_w,
                        const int32_t *seed_cnt, int32_t *flags, int32_t batch, float damping, int32_t iters,
-                       const hrag_shard_layout &lay, uint8_t *const bufs[3], hipStream_t s) {
+                       const hrag_shard_layout &lay, uint8_t *const bufs[3], hipStream_t s, int32_t max_iters,
+                       float tol, bool want_est) {
     HRAG_REQUIRE(ppr8_usable(e, batch, iters, damping),
                  "the fp8-state PPR does not serve ppr_iters=%d at damping %g (needs 16..30 sweeps and "
                  "damping^ppr_iters <= 2^-20) or the engine has no fp8 state", iters, (double)damping);
     HRAG_REQUIRE(bufs[0] && bufs[1] && bufs[2] && bufs[0] != bufs[1] && bufs[1] != bufs[2] && bufs[0] != bufs[2],
                  "three distinct state buffers are needed");
+    HRAG_REQUIRE(tol >= 0.f, "ppr_tol must be >= 0");
     Ppr8Session &p = e->p8;
     p.active = false;
     p.batch = batch; p.iters = iters; p.damping = damping; p.flags = flags;
@@ -115,6 +117,17 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     const int n_stage = ppr8_plan(iters, plan);
     HRAG_REQUIRE(n_stage >= 2 && n_stage <= kP8MaxStages, "ppr_iters=%d needs %d fp8 stages (2..%d)", iters, n_stage,
                  kP8MaxStages);
+    // ---- convergence contract (reference: PRPACK iterates until its residual is below 1e-10, HippoRAG.py:1736-1743;
+    // here: `iters` sweeps always run, then the DEVICE may add stages of 3 sweeps while the measured update of the
+    // passage scores predicts an error above tol).  Every conditional launch is enqueued; its gate word decides.
+    const bool est = want_est || tol > 0.f;
+    int e_max = 0;
+    if (tol > 0.f && max_iters > iters) {
+        e_max = std::min({(max_iters - iters) / 3, (30 - iters) / 3, kP8MaxExt, kP8MaxStages - n_stage});
+        e_max = std::max(e_max, 0);
+    }
+    for (int j = 0; j < e_max; ++j) plan[n_stage + j] = 3;
+    p.e_max = e_max; p.want_est = est; p.tol = tol;
     const double al = (double)damping;
     double bound = std::max(al, 1.0 - al) + 0.07;
     auto scale_for = [&](int m) {
@@ -123,27 +136,40 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
         ex = std::min(std::max(ex, -60), 60);
         return std::ldexp(1.0f, ex);
     };
+    auto kappa_for = [&](int m) { return (float)(std::pow(al, m) + 1.0 / 16.0); };
     int n = 0, c = 0, rt = -1;   // c_0 lives in buffer 0
     int k_done = 0;              // sweeps completed
     bool r16 = false;            // the stored residual is in the 3-byte form (rt + fp16 remainder)
     float cs = kP8C0Scale, cs_next = scale_for(plan[1]);
-    for (int si = 0; si < n_stage; ++si) {
+    const int n_total = n_stage + e_max;
+    for (int si = 0; si < n_total; ++si) {
         const int m = plan[si];
+        const int ext = si - (n_stage - 1);            // >= 1: extension stage number `ext`, runs iff ctl[ext - 1]
+        const int stage_gate = ext >= 1 ? ext - 1 : -1;
         if (si > 0) {
             cs = cs_next;
             c = rt;
             for (int j = 1; j < m; ++j) {
                 const int dst = c == rt ? (c + 1) % 3 : 3 - c - rt;
-                p.steps[n++] = Ppr8Step{kP8ModeC, si, c, dst, rt, 0.f, 0.f, 0};
+                Ppr8Step st{kP8ModeC, si, c, dst, rt, 0.f, 0.f, 0};
+                st.gate = stage_gate;
+                p.steps[n++] = st;
                 c = dst;
                 ++k_done;
             }
             bound *= std::pow(al, m);
-            cs_next = si + 1 < n_stage ? scale_for(plan[si + 1]) : 1.0f;
+            cs_next = si + 1 < n_total ? scale_for(plan[si + 1]) : 1.0f;
         }
         p.stage_inv[si] = 1.0f / cs;
         ++k_done;
-        if (si + 1 < n_stage) {
+        if (si >= n_stage - 1) {
+            // the stage may be the last one: final sweep variant j (passage rows only), gated on ctl[n_ctl + j]
+            Ppr8Step st{kP8ModeF, si, c, -1, rt, 1.0f / cs, 1.0f, r16 ? 1 : 0};
+            st.gate = est ? (kP8MaxExt + 1) + (si - (n_stage - 1)) : -1;
+            if (e_max == 0) st.gate = -1;
+            p.steps[n++] = st;
+        }
+        if (si + 1 < n_total) {
             // the new right-hand side overwrites the old one in place (row by row: a row only ever reads its own
             // rt): R, or its fp16 remainder next to rt, carries everything else
             const int y = (rt >= 0 && c != rt) ? rt : (c + 1) % 3;
@@ -151,20 +177,30 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
             // 2^-15 relative error of that form is below 5e-7 of the solution (ppr8.hip finish_row)
             const bool out16 = si > 0 && std::pow(al, k_done) <= 1.0 / 64.0;
             const int rio = (r16 ? 1 : 0) | (out16 ? 2 : 0);
-            p.steps[n++] = Ppr8Step{si == 0 ? kP8ModeB0 : kP8ModeB, si, c, y, rt, 1.0f / cs, cs_next, rio};
+            Ppr8Step st{si == 0 ? kP8ModeB0 : kP8ModeB, si, c, y, rt, 1.0f / cs, cs_next, rio};
+            if (si >= n_stage - 1) st.gate = si - (n_stage - 1);   // closes a stage that could have been the last
+            if (e_max > 0 && si >= n_stage - 2) {   // checkpoint: the last regular boundary and the extensions'
+                st.ckpt = 1;
+                st.decide = si - (n_stage - 2);
+                st.kappa = kappa_for(plan[si + 1]);
+            }
+            p.steps[n++] = st;
             r16 = out16;
             rt = y;
-        } else {
-            p.steps[n++] = Ppr8Step{kP8ModeF, si, c, -1, rt, 1.0f / cs, 1.0f, r16 ? 1 : 0};
         }
     }
-    HRAG_REQUIRE(n == iters, "internal: stage plan has %d sweeps for ppr_iters=%d", n, iters);
+    HRAG_REQUIRE(n <= (int)(sizeof(p.steps) / sizeof(p.steps[0])), "internal: %d steps", n);
     p.n_steps = n;
     p.n_stage = n_stage;
+    if (est) {
+        HRAG_HIP_TRY(hipMemsetAsync(e->d_est_ck, 0, (size_t)batch * sizeof(int32_t), s));
+        HRAG_HIP_TRY(hipMemsetAsync(e->d_est_f, 0, (size_t)batch * sizeof(int32_t), s));
+    }
+    HRAG_HIP_TRY(hipMemsetAsync(e->d_ctl, 0, (size_t)2 * (kP8MaxExt + 1) * sizeof(int32_t), s));
 
     // ---- reset vector on the owned rows: per-query scale, passage prior rows, seed rows, column bitmap
     HRAG_TRY(launch_ppr8_scale(zmax, mass, passage_weight, seed_vtx, seed_w, seed_cnt, e->d_deg, e->d_iso, e->V,
-                               flags, batch, damping, iters, e->d_qscale, e->d_sums, s));
+                               flags, batch, damping, iters, e->d_qscale, e->d_mass_tab, s, e_max + 1, e->max_batch));
     SlabLayout l64;
     l64.bc = 64; l64.n_slabs = n_slabs64(batch);
     HRAG_TRY(launch_rows_to_slab(e->d_spass, e->ld_p, e->p_rows, batch, kMinMaxScale, mn, mx, passage_weight,
@@ -195,6 +231,7 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
     HRAG_REQUIRE(group >= -1 && group < p.n_groups, "group %d outside [0, %d)", group, p.n_groups);
     const Ppr8Step &st = p.steps[i];
     Ppr8Args a = base_args(e);
+    if (st.gate >= 0) { a.gate = e->d_ctl + st.gate; a.gate_want = st.gate_want; }
     if (group >= 0) {
         a.slab0 = group * p.spg;
         a.n_slabs = std::min(p.spg, p.n_slabs - a.slab0);
@@ -209,17 +246,42 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
         a.rt = st.rt >= 0 ? p.buf[st.rt] : nullptr;
         a.rio = st.rio;
         a.stage_out = stage_copy(e, st.stage);
-    } else {   // kP8ModeF: the passage rows only
+        if (st.ckpt) {   // z at the passage rows = the stages' c / cs summed + R, like mode F
+            for (int k = 0; k < st.stage; ++k) a.stage[k] = stage_copy(e, k);
+            for (int k = 0; k <= st.stage; ++k) a.stage_inv[k] = p.stage_inv[k];
+            a.n_stage = st.stage + 1;
+            a.est = e->d_est_ck;
+        }
+    } else {   // kP8ModeF: the passage rows only; stage st.stage is the last one
         a.rt = st.rt >= 0 ? p.buf[st.rt] : nullptr;
         a.rio = st.rio;
         a.m = e->fsell.dev_at();
-        for (int k = 0; k + 1 < p.n_stage; ++k) a.stage[k] = stage_copy(e, k);
-        for (int k = 0; k < p.n_stage; ++k) a.stage_inv[k] = p.stage_inv[k];
-        a.n_stage = p.n_stage;
+        for (int k = 0; k < st.stage; ++k) a.stage[k] = stage_copy(e, k);
+        for (int k = 0; k <= st.stage; ++k) a.stage_inv[k] = p.stage_inv[k];
+        a.n_stage = st.stage + 1;
         a.out = e->d_xp8;
+        if (p.want_est) a.est = e->d_est_f;
     }
     if (exchange) *exchange = st.y;
     return launch_ppr8_sweep(a, st.mode, false, s);
+}
+
+hrag_status ppr8_decide(hrag_engine *e, int32_t i, hipStream_t s) {
+    const Ppr8Session &p = e->p8;
+    HRAG_REQUIRE(p.active && i >= 0 && i < p.n_steps, "no such step");
+    const Ppr8Step &st = p.steps[i];
+    if (st.decide < 0) return HRAG_OK;
+    const float g = p.damping / (1.0f - p.damping);
+    return launch_ppr8_decide(e->d_est_ck, p.flags, p.batch, st.kappa, g, p.tol, st.decide, p.e_max, e->d_ctl,
+                              kP8MaxExt + 1, s);
+}
+
+hrag_status ppr8_finalize(hrag_engine *e, int32_t *flags, hipStream_t s) {
+    const Ppr8Session &p = e->p8;
+    HRAG_REQUIRE(p.active, "no fp8 PPR session");
+    const float g = p.damping / (1.0f - p.damping);
+    return launch_ppr8_finalize(e->d_est_f, flags, p.batch, g, p.tol, p.iters, e->d_ctl, p.e_max, e->d_mass_tab,
+                                e->max_batch, e->d_sums, e->d_resid, e->d_iters_used, s);
 }
 
 hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int rio, int it, bool main_only, hipStream_t s) {
@@ -243,9 +305,10 @@ hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int rio, int it, bool mai
 }
 
 hrag_status ppr8_doc_scores(hrag_engine *e, const float *mn, const float *mx, int32_t *flags, int32_t batch,
-                            hipStream_t s) {
+                            hipStream_t s, bool fp8_session) {
     SlabLayout l64;
     l64.bc = 64; l64.n_slabs = n_slabs64(batch);
+    if (fp8_session) HRAG_TRY(ppr8_finalize(e, flags, s));   // d_sums <- the mass of the iterate that was computed
     HRAG_TRY(launch_slab_to_rows(e->d_xp8, e->p_rows, nullptr, e->p_rows, batch, e->d_sums, e->d_doc, e->ld_p,
                                  e->d_spass, e->ld_p, mn, mx, flags, l64, s));
     if (flags) HRAG_TRY(launch_flag_zero_mass(e->d_sums, batch, flags, 2, s));
@@ -356,9 +419,10 @@ hrag_status hrag_shard_finish(hrag_engine *e, const float *mn, const float *mx, 
     if (e->p_rows == 0) {
         HRAG_TRY(launch_fill_i32(idx_out, -1, (int64_t)batch * k, s));
         HRAG_HIP_TRY(hipMemsetAsync(score_out, 0, (size_t)batch * k * sizeof(float), s));
+        HRAG_TRY(ppr8_finalize(e, flags, s));
         return launch_flag_zero_mass(e->d_sums, batch, flags, 2, s);
     }
-    HRAG_TRY(ppr8_doc_scores(e, mn, mx, flags, batch, s));
+    HRAG_TRY(ppr8_doc_scores(e, mn, mx, flags, batch, s, true));
     return launch_row_topk(e->d_doc, batch, e->p_rows, e->ld_p, k, (int32_t)e->p_offset, kNormNone, idx_out,
                            score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes);
 }
@@ -375,8 +439,8 @@ hrag_status hrag_engine_gather_embeddings(hrag_engine *e, int32_t which, const i
 hrag_status hrag_engine_set_flags(hrag_engine *e, int32_t flags, int32_t on) {
     HRAG_REQUIRE(e != nullptr, "engine is NULL");
     const int32_t runtime = HRAG_OPT_NO_FP8 | HRAG_OPT_NT_CSR | HRAG_OPT_NT_STORE | HRAG_OPT_TEMPORAL16 | HRAG_OPT_SLABS_PER_WG_1 |
-                            HRAG_OPT_FP8_MARGIN;
-    HRAG_REQUIRE((flags & ~runtime) == 0, "only HRAG_OPT_NO_FP8 / NT_CSR / NT_STORE / TEMPORAL16 / SLABS_PER_WG_1 / FP8_MARGIN can change after creation");
+                            HRAG_OPT_NO_F16;
+    HRAG_REQUIRE((flags & ~runtime) == 0, "only HRAG_OPT_NO_FP8 / NO_F16 / NT_CSR / NT_STORE / TEMPORAL16 / SLABS_PER_WG_1 can change after creation");
     if (on) e->opt_flags |= flags; else e->opt_flags &= ~flags;
     return HRAG_OK;
 }

@@ -8,6 +8,7 @@ a GPU (or without libhrag.so) constructing an engine raises.
 from __future__ import annotations
 
 import ctypes as C
+import logging
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -65,6 +66,12 @@ class RetrieveOutput:
     doc_idx: "object"     # torch int32 [B, k] passage positions, best first
     doc_score: "object"   # torch fp32  [B, k]
     flags: "object"       # torch int32 [B]
+    residual: "object" = None    # torch fp32 [B]: damping / (1 - damping) * the relative size of the last sweep's update
+                                 # of the passage scores (include/hrag.h, hrag_retrieve); -1 where not measured
+    iters_used: "object" = None  # torch int32 [B]: PPR sweeps that ran
+
+
+logger = logging.getLogger(__name__)
 
 
 class HippoRAGEngine:
@@ -125,6 +132,7 @@ class HippoRAGEngine:
             fdesc = EmbedDesc(f_rows, fact_offset, dim, dt, _ptr(f_obj))
             fd = FactDesc(self.n_facts, _ptr(sv), _ptr(ov), _ptr(nc))
             keep += [f_obj, sv, ov, nc]
+        self.opt_flags = int(flags)      # HRAG_OPT_* bits as set_flags leaves them
         opts = Opts(max_batch, max_topk, slab_width, long_row_nnz, self.device.index, flags, segment_nnz)
         with torch.cuda.device(self.device):
             check(self._lib.hrag_engine_create(C.byref(gd), C.byref(fdesc) if fdesc else None,
@@ -197,8 +205,11 @@ class HippoRAGEngine:
 
     def retrieve(self, q_pass, kept_idx, kept_score, kept_count, *, link_top_k: int = 5,
                  damping: float = 0.5, passage_node_weight: float = 0.05, ppr_iters: int = 20,
-                 k: int = 200) -> RetrieveOutput:
-        """Phase B: seeds + passage prior + PPR + ranking (DPR ranking where kept_count == 0)."""
+                 k: int = 200, ppr_tol: float = 0.0, ppr_max_iters: int = 0,
+                 want_residual: bool = True) -> RetrieveOutput:
+        """Phase B: seeds + passage prior + PPR + ranking (DPR ranking where kept_count == 0).
+        ppr_tol / ppr_max_iters: the convergence contract of include/hrag.h (0 = exactly ppr_iters sweeps);
+        the output carries the per-query residual and the sweeps that ran."""
         torch = _torch()
         q = self._q(q_pass)
         b = q.shape[0]
@@ -211,11 +222,76 @@ class HippoRAGEngine:
         idx = self._empty((b, k), torch.int32)
         sc = self._empty((b, k), torch.float32)
         flags = self._empty((b,), torch.int32)
+        resid = self._empty((b,), torch.float32) if want_residual or ppr_tol > 0 else None
+        used = self._empty((b,), torch.int32) if resid is not None else None
         check(self._lib.hrag_retrieve(self._handle, q.data_ptr(), b, kept_idx.data_ptr(),
                                       kept_score.data_ptr(), kept_count.data_ptr(), kf, link_top_k,
-                                      damping, passage_node_weight, ppr_iters, k, idx.data_ptr(),
-                                      sc.data_ptr(), flags.data_ptr(), _stream()))
-        return RetrieveOutput(idx, sc, flags)
+                                      damping, passage_node_weight, ppr_iters, max(ppr_max_iters, ppr_iters),
+                                      ppr_tol, k, idx.data_ptr(), sc.data_ptr(), flags.data_ptr(),
+                                      resid.data_ptr() if resid is not None else None,
+                                      used.data_ptr() if used is not None else None, _stream()))
+        return RetrieveOutput(idx, sc, flags, resid, used)
+
+    def retrieve_converged(self, q_pass, kept_idx, kept_score, kept_count, *, damping: float = 0.5,
+                           ppr_iters: int = 20, ppr_tol: float = 3e-6, ppr_max_iters: int = 400, **kw) -> RetrieveOutput:
+        """retrieve() + what the host owes the convergence contract (include/hrag.h): a batch whose fp8 state
+        saturated is repeated on the wider state (never clipped scores); queries the engine flags
+        HRAG_FLAG_NOT_CONVERGED -- its sweep budget did not reach ppr_tol: a slowly mixing graph -- are repeated,
+        those queries only, on the wider state with the sweeps their residual asks for (it contracts by `damping`
+        per sweep), up to ppr_max_iters.  The reference's PRPACK does the same thing implicitly: it iterates to
+        1e-10 whatever the graph (HippoRAG.py:1736-1743).  A flag that survives means ppr_max_iters was too small."""
+        torch = _torch()
+        from ._lib import FLAG_FP8_SATURATED, FLAG_NOT_CONVERGED, OPT_NO_F16, OPT_NO_FP8
+        q = self._q(q_pass)
+        kept_idx, kept_score, kept_count = (t.to(self.device) for t in (kept_idx, kept_score, kept_count))
+
+        def run(rows=None, iters=ppr_iters, max_iters=ppr_max_iters):
+            sel = slice(None) if rows is None else rows
+            return self.retrieve(q[sel], kept_idx[sel], kept_score[sel], kept_count[sel], damping=damping,
+                                 ppr_iters=iters, ppr_tol=ppr_tol, ppr_max_iters=max(max_iters, iters), **kw)
+
+        def on_wider_state(fn, bits=OPT_NO_FP8):
+            had = self.opt_flags & bits               # restore what the engine was created with
+            self.set_flags(bits, True)
+            try:
+                return fn()
+            finally:
+                if bits & ~had:
+                    self.set_flags(bits & ~had, False)
+
+        out = run()
+        flags = out.flags.cpu().numpy()
+        if (flags & FLAG_FP8_SATURATED).any():
+            logger.warning("fp8 PPR state saturated for %d queries: repeating the batch on the wider state",
+                           int(((flags & FLAG_FP8_SATURATED) != 0).sum()))
+            out = on_wider_state(run)
+            flags = out.flags.cpu().numpy()
+        if ppr_tol <= 0 or not (flags & FLAG_NOT_CONVERGED).any():
+            return out
+        resid, used = out.residual.cpu().numpy(), out.iters_used.cpu().numpy()
+        for _ in range(6):
+            rows = np.flatnonzero(flags & FLAG_NOT_CONVERGED)
+            if not len(rows):
+                break
+            done = int(used[rows].max())
+            need = done + int(np.ceil(np.log(max(float(resid[rows].max()) / ppr_tol, 1.0)) / -np.log(damping))) + 4
+            need = min(max(need, done + 4), max(ppr_max_iters, ppr_iters))
+            if need <= done:
+                break                                   # ppr_max_iters reached: the flag stays
+            logger.info("PPR not converged for %d queries after %d sweeps (residual %.2g > %.2g): repeating them "
+                        "with %d sweeps", len(rows), done, float(resid[rows].max()), ppr_tol, need)
+            rt = torch.as_tensor(rows, device=self.device)
+            # fp32 state: the scores that converge last are orders of magnitude below the largest one
+            o2 = on_wider_state(lambda: run(rt, need, need), OPT_NO_FP8 | OPT_NO_F16)
+            out.doc_idx[rt], out.doc_score[rt] = o2.doc_idx, o2.doc_score
+            out.flags[rt], out.residual[rt], out.iters_used[rt] = o2.flags, o2.residual, o2.iters_used
+            flags[rows], resid[rows], used[rows] = (o2.flags.cpu().numpy(), o2.residual.cpu().numpy(),
+                                                    o2.iters_used.cpu().numpy())
+        left = (flags & FLAG_NOT_CONVERGED) != 0
+        if left.any():
+            logger.warning("PPR residual above ppr_tol=%.2g for %d queries after ppr_max_iters=%d sweeps (max %.2g)",
+                           ppr_tol, int(left.sum()), ppr_max_iters, float(resid[left].max()))
+        return out
 
     def dense_retrieve(self, q_pass, k: int = 200):
         torch = _torch()
@@ -263,6 +339,7 @@ class HippoRAGEngine:
     def set_flags(self, flags: int, on: bool = True):
         """Set / clear HRAG_OPT_* bits after creation (e.g. _lib.OPT_NO_FP8 to rerun a saturated batch)."""
         check(self._lib.hrag_engine_set_flags(self._handle, flags, 1 if on else 0))
+        self.opt_flags = (self.opt_flags | flags) if on else (self.opt_flags & ~flags)
 
     def gather_embeddings(self, which: str, src_rows, new_rows=None):
         """The embedding matrix of the next engine after an index update, composed ON THE DEVICE:

@@ -101,7 +101,8 @@ def build_engine_from_reference(rag, *, max_batch: int = 256):
     return eng, facts
 
 
-def attach(rag, *, max_batch: int = 256, ppr_iters: Optional[int] = None, batched_retrieve: bool = True):
+def attach(rag, *, max_batch: int = 256, ppr_iters: Optional[int] = None, batched_retrieve: bool = True,
+           ppr_tol: float = 3e-6, ppr_max_iters: int = 400):
     """Patch ``rag`` in place; returns it.  Call again after ``index()`` / ``delete()`` (they change
     the graph and the stores; the reference only resets ``ready_to_retrieve`` on delete, :411)."""
     import torch
@@ -171,7 +172,7 @@ def attach(rag, *, max_batch: int = 256, ppr_iters: Optional[int] = None, batche
                                 linking_top_k=int(cfg.linking_top_k), damping=cfg.damping,
                                 passage_node_weight=cfg.passage_node_weight, ppr_iters=sweeps,
                                 num_to_retrieve=int(num_to_retrieve), n_passages=len(rag.passage_node_keys),
-                                timers=rag)
+                                timers=rag, ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters)
         results = []
         for q, (d_idx, d_sc, seeds) in zip(queries, rows):
             r = build_result(q, d_idx, d_sc, num_to_retrieve, seeds)

@@ -132,10 +132,16 @@ class RetrievalConfig:
     is_directed_graph: bool = False      # :176
     # engine-only knobs (no reference analogue)
     ppr_iters: Optional[int] = None      # None: derived from damping (sweeps_for_damping: 20 at 0.5)
+    # convergence contract (include/hrag.h, hrag_retrieve; the reference's PRPACK iterates to 1e-10,
+    # HippoRAG.py:1736-1743): the engine measures the relative update of the passage scores and keeps sweeping
+    # while it predicts an error above ppr_tol.  3e-6 keeps every passage score within the 1e-5 relative parity
+    # bar on the graphs this repository tests (the measure is within 3.5x of the true error wherever that is above
+    # the fp32 noise floor); 0 = exactly ppr_iters sweeps
+    ppr_tol: float = 3e-6
+    ppr_max_iters: int = 400             # bound on the sweeps a slowly mixing graph may cost (fp8 state: 30, then
+                                         # the flagged queries are repeated on the wider state)
     max_batch: int = 256
     slab_width: int = 0
-    fp8_margin: bool = False             # HRAG_OPT_FP8_MARGIN: +2 sweeps on the fp8 PPR state (+8 % PPR time; measured
-                                         # gain on the star forest only 1.5x: the error there is rounding, not truncation)
 
 
 def identity_rerank_filter(query, candidate_items, candidate_indices, len_after_rerank=None):
@@ -146,14 +152,17 @@ def identity_rerank_filter(query, candidate_items, candidate_indices, len_after_
 
 def batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Sequence, rerank_filter: Callable, *,
                      linking_top_k: int, damping: float, passage_node_weight: float, ppr_iters: int,
-                     num_to_retrieve: int, n_passages: int, timers=None):
+                     num_to_retrieve: int, n_passages: int, timers=None, ppr_tol: float = 0.0,
+                     ppr_max_iters: int = 0):
     """The body of retrieve() (HippoRAG.py:459-480) for all queries at once, shared by the mirror class below
     and by reference_adapter.attach(): phase A on the device, the recognition-memory filter on the host
     (rerank_facts :1659-1707), phase B on the device.  Returns one (doc ids, doc scores, kept facts) per
     query; raises where the reference's asserts would (:1541, :1644).  timers: object whose rerank_time /
-    ppr_time attributes are advanced like the reference's accumulators (:184-186)."""
+    ppr_time attributes are advanced like the reference's accumulators (:184-186).
+    ppr_tol / ppr_max_iters: the convergence contract (RetrievalConfig): queries the engine flags as not converged
+    within its sweep budget are repeated -- those queries only -- on the wider state with the sweeps their
+    residual asks for, so a slowly mixing graph costs time, never accuracy."""
     import torch
-    from ._lib import FLAG_FP8_SATURATED, OPT_NO_FP8
     k_f = int(linking_top_k)
     want = max(1, min(int(num_to_retrieve), n_passages))
     k_docs = min(want, eng.max_topk)
@@ -189,24 +198,11 @@ def batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Sequenc
             timers.rerank_time = getattr(timers, "rerank_time", 0.0) + time.time() - t_r
         t_p = time.time()
 
-        def phase_b():
-            return eng.retrieve(q_tensor(qs, "passage"), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc),
-                                torch.from_numpy(kept_cnt), link_top_k=k_f, damping=damping,
-                                passage_node_weight=passage_node_weight, ppr_iters=ppr_iters, k=k_docs)
-
-        out = phase_b()
+        out = eng.retrieve_converged(q_tensor(qs, "passage"), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc),
+                                     torch.from_numpy(kept_cnt), link_top_k=k_f, damping=damping,
+                                     passage_node_weight=passage_node_weight, ppr_iters=ppr_iters, k=k_docs,
+                                     ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters)
         flags = out.flags.cpu().numpy()
-        if (flags & FLAG_FP8_SATURATED).any():
-            # a static scale bound of the fp8-state PPR was violated (include/hrag.h): never return clipped
-            # scores -- repeat the batch on the fp16 / fp32 state
-            logger.warning("fp8 PPR state saturated for %d queries: repeating the batch on the wider state",
-                           int(((flags & FLAG_FP8_SATURATED) != 0).sum()))
-            eng.set_flags(OPT_NO_FP8, True)
-            try:
-                out = phase_b()
-            finally:
-                eng.set_flags(OPT_NO_FP8, False)
-            flags = out.flags.cpu().numpy()
         d_idx, d_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
         if timers is not None:
             timers.ppr_time = getattr(timers, "ppr_time", 0.0) + time.time() - t_p
@@ -454,7 +450,6 @@ class HippoRAG:
         engine already holds are gathered device-side into the new matrices (hrag_engine_gather_embeddings):
         only the rows that are new cross PCIe, the graph (CSR -> SELL-8) is recompiled from the edge list."""
         from .engine import HippoRAGEngine
-        from ._lib import OPT_FP8_MARGIN
         if self._arrays is None:
             raise RuntimeError("nothing indexed yet")
         a = self._arrays
@@ -482,7 +477,7 @@ class HippoRAG:
                                 max_batch=self.global_config.max_batch,
                                 max_topk=min(2048, max(self.global_config.retrieval_top_k, 1)),
                                 slab_width=self.global_config.slab_width,
-                                flags=OPT_FP8_MARGIN if self.global_config.fp8_margin else 0)
+                                flags=0)
         if old is not None:
             old.close()
         self.engine = engine
@@ -574,6 +569,7 @@ class HippoRAG:
         rows = batched_retrieve(self.engine, queries, self._q_tensor, self.facts if self.fact_node_keys else [],
                                 self.rerank_filter, linking_top_k=cfg.linking_top_k, damping=cfg.damping,
                                 passage_node_weight=cfg.passage_node_weight, ppr_iters=self._ppr_iters(),
+                                ppr_tol=cfg.ppr_tol, ppr_max_iters=cfg.ppr_max_iters,
                                 num_to_retrieve=num_to_retrieve, n_passages=len(self.passage_node_keys), timers=self)
         results: List[QuerySolution] = []
         for q, (d_idx, d_sc, seeds) in zip(queries, rows):

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define HRAG_VERSION_MAJOR 0
-#define HRAG_VERSION_MINOR 3
+#define HRAG_VERSION_MINOR 4
 
 typedef enum hrag_status {
     HRAG_OK = 0,
@@ -116,10 +116,14 @@ typedef struct hrag_fact_desc {
 #define HRAG_OPT_SLABS_PER_WG_1 256   /* fp8 sweep: one slab per workgroup (4 chunks) instead of the wavefronts of a   */
                                       /* workgroup sharing a chunk's (col, val) stream across 2 / 4 slabs             */
 
-#define HRAG_OPT_FP8_MARGIN 512       /* the fp8-state PPR runs ppr_iters + 2 sweeps (when that is <= 30), +8 % PPR    */
-                                      /* time.  Removes the truncation part of the error (factor 4 at damping 0.5); on */
-                                      /* the star forest, where the scheme sits at the 1e-5 bar, the measured gain is  */
-                                      /* only 1.5x -- the error there is the fp8 rounding of the smallest scores        */
+/* 512: was HRAG_OPT_FP8_MARGIN (two extra sweeps on the fp8 state); superseded by the convergence contract of   */
+/* hrag_retrieve (ppr_tol / ppr_max_iters), which adds sweeps only where the measured residual asks for them    */
+
+#define HRAG_OPT_NO_F16 1024          /* never take the fp16-state PPR either (two-stage fp16 state of batches 9..64 and of  */
+                                      /* batches <= 8): the fp32 state serves.  Its values carry a relative precision of     */
+                                      /* 2^-24 whatever their size, which passage scores many orders of magnitude below the */
+                                      /* largest one need (a query on a slowly mixing graph that is being repeated for      */
+                                      /* HRAG_FLAG_NOT_CONVERGED); runtime-switchable like HRAG_OPT_NO_FP8                    */
 
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */
@@ -183,13 +187,35 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q_fact_dev, int32_t
  *                                       range (a static scale bound was violated): this query's scores are
  *                                       not trustworthy; rerun the batch after
  *                                       hrag_engine_set_flags(e, HRAG_OPT_NO_FP8, 1)
- *   ppr_iters: fixed number of power iterations (20 in BASELINE.json). */
+ *                                 bit4: HRAG_FLAG_NOT_CONVERGED -- ppr_tol > 0 and this query's residual (below)
+ *                                       is still above it after ppr_max_iters sweeps: rerun with more sweeps
+ *
+ * Convergence contract of the PPR solve.  The reference hands the solve to PRPACK, which iterates until its
+ * residual is below 1e-10 (HippoRAG.py:1736-1743); a fixed sweep count is only as accurate as the graph mixes.
+ *   ppr_iters       sweeps that always run (20 in BASELINE.json)
+ *   ppr_tol         0: exactly ppr_iters sweeps.  > 0: the engine measures, per query, the relative size of the
+ *                   update its last sweep applied to the passage scores,
+ *                       residual = damping / (1 - damping) * max over passages p of |x_p(K) - x_p(K-1)| / x_p(K)
+ *                   (the error a contraction with factor `damping` has left after an update of that size), and
+ *                   keeps sweeping -- decided ON THE DEVICE from the same measure at a checkpoint sweep, no host
+ *                   synchronisation -- while the prediction for the batch is above ppr_tol and fewer than
+ *                   ppr_max_iters sweeps ran.  The fp8-state path (batch > 64) extends in stages of 3 sweeps up
+ *                   to 30; the other state types run the fixed count and report.
+ *   ppr_max_iters   upper bound on the sweeps (>= ppr_iters; ignored when ppr_tol == 0)
+ *   residual_out_dev fp32 [B] (may be NULL): the residual above for the sweeps that ran (0 on the DPR fallback)
+ *   iters_out_dev   int32 [B] (may be NULL): sweeps that ran for the query's batch
+ * The measure sees the passage rows only: on a bipartite graph whose reset vector lives on one side the passage
+ * rows change on alternate sweeps only and a single sweep's update can read 0 (HippoRAG graphs hold a triangle
+ * passage - subject - object for every fact, so they are not bipartite where it matters). */
+#define HRAG_FLAG_NOT_CONVERGED 16
 hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass_dev, int32_t batch,
                           const int32_t *kept_idx_dev, const float *kept_score_dev,
                           const int32_t *kept_count_dev, int32_t kf, int32_t link_top_k,
-                          float damping, float passage_node_weight, int32_t ppr_iters, int32_t k,
+                          float damping, float passage_node_weight, int32_t ppr_iters,
+                          int32_t ppr_max_iters, float ppr_tol, int32_t k,
                           int32_t *doc_idx_out_dev, float *doc_score_out_dev,
-                          int32_t *flags_out_dev, hrag_stream stream);
+                          int32_t *flags_out_dev, float *residual_out_dev, int32_t *iters_out_dev,
+                          hrag_stream stream);
 
 /* == dense_passage_retrieval (HippoRAG.py:1467-1502, StandardRAG.py:393-429), top-k only. */
 hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass_dev, int32_t batch,

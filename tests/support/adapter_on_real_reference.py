@@ -52,8 +52,10 @@ class OracleEngine:
             idx[i, :len(top)], sc[i, :len(top)] = top, s[top]
         return torch.from_numpy(idx), torch.from_numpy(sc)
 
+    opt_flags = 0
+
     def retrieve(self, q_pass, kept_idx, kept_score, kept_count, *, link_top_k, damping, passage_node_weight,
-                 ppr_iters, k):
+                 ppr_iters, k, ppr_tol=0.0, ppr_max_iters=0):
         import dataclasses
         ix = dataclasses.replace(self.index, linking_top_k=link_top_k, damping=damping,
                                  passage_node_weight=passage_node_weight)
@@ -77,6 +79,8 @@ class OracleEngine:
                 ids, sc, _ = oracle.run_ppr(ix, oracle.reset_vector(ix, sid, sw, by_p), damping, "power", ppr_iters)
             d_idx[i, :min(k, len(ids))], d_sc[i, :min(k, len(ids))] = ids[:k], sc[:k]
         return engine_mod.RetrieveOutput(torch.from_numpy(d_idx), torch.from_numpy(d_sc), torch.from_numpy(flags))
+
+    retrieve_converged = retrieve
 
     def sim_scores(self, which, q):
         emb = self.index.fact_emb if which == "facts" else self.index.passage_emb

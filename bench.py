@@ -201,15 +201,17 @@ def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, bu
     qp = qp_t.float().cpu().numpy()
     n_done, t0 = 0, time.perf_counter()
     ids_equal, max_rel = True, 0.0
+    exact_pos = n_pos = exact_rows = 0
+    from tests.helpers import tie_aware_report
     while n_done < min(max_queries, qf.shape[0]):
         ids, scores = ref.retrieve_one(qf[n_done], qp[n_done])
         k = gpu_idx.shape[1]
         g_ids = gpu_idx[n_done]
-        if not np.array_equal(g_ids, ids[:k]):
-            # tolerate permutations inside near-tie classes only
-            sys.path.insert(0, os.path.join(ROOT))
-            from tests.helpers import tie_aware_equal
-            ids_equal = ids_equal and bool(tie_aware_equal(g_ids, ids[:k], scores[:k], rel_gap=2e-5))
+        # permutations are tolerated inside near-tie classes only (reference scores closer than twice the score
+        # bar); how many ranks needed that is reported beside the verdict
+        rep = tie_aware_report(g_ids, ids[:k], scores[:k], rel_gap=2e-5)
+        ids_equal = ids_equal and rep["equal"]
+        exact_pos += rep["exact_positions"]; n_pos += rep["n"]; exact_rows += int(rep["exact_positions"] == rep["n"])
         full = np.empty(len(ids)); full[ids] = scores
         rel = np.abs(gpu_scores[n_done] - full[g_ids]) / np.maximum(full[g_ids], 1e-300)
         max_rel = max(max_rel, float(rel.max()))
@@ -225,7 +227,11 @@ def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, bu
         "sim_s_per_query": ref.sim_time / max(n_done, 1), "ppr_s_per_query": ref.ppr_time / max(n_done, 1),
         "host_cpus": os.cpu_count(), "cpu_model": _cpu_model(),
     }
-    parity = {"queries_checked": n_done, "topk_ids_equal": bool(ids_equal), "max_rel_score_err": max_rel}
+    parity = {"queries_checked": n_done, "topk_ids_equal": bool(ids_equal),
+              "topk_ids_equal_definition": "identical ranked ids; a permutation is accepted only inside a run of "
+                                           "oracle scores closer than 2e-5 relative (tie class)",
+              "exact_id_fraction": exact_pos / max(n_pos, 1), "queries_with_identical_id_lists": exact_rows,
+              "max_rel_score_err": max_rel}
     # ---- "vectorised" leg: batched sgemm + argpartition + OpenMP SpMM over all host cores, the
     # same algorithm and sweep count as the GPU path -- the ratio against THIS number is the one free of the
     # reference's Python overhead
@@ -377,6 +383,10 @@ def main():
     ap.add_argument("--no-rowshard", action="store_true", help="N > 1: skip the secondary row-sharded leg")
     ap.add_argument("--rowshard-timeout-s", type=float, default=240.0,
                     help="N > 1: abandon the row-sharded leg after this long (the primary line still prints)")
+    ap.add_argument("--ppr-tol", type=float, default=3e-6,
+                    help="tolerance of the secondary leg that runs under the convergence contract (the headline runs "
+                         "BASELINE.json's fixed 20 sweeps and reports the residual they leave)")
+    ap.add_argument("--ppr-max-iters", type=int, default=29)
     args = ap.parse_args()
 
     import torch
@@ -412,22 +422,37 @@ def main():
     cnt = torch.full((B,), K_F, dtype=torch.int32, device=dev)
     setup_s = time.perf_counter() - t_setup
 
-    def step(i):
+    def step(i, tol=0.0, max_iters=0):
         idx, sc = eng.score_facts(qf[i], k=K_F)                         # phase A
         # identity "recognition memory" filter: all K_F candidates kept, device-side, no host sync
         return eng.retrieve(qp[i], idx, sc, cnt, link_top_k=K_F, damping=DAMPING,
-                            passage_node_weight=PASSAGE_W, ppr_iters=PPR_ITERS, k=K_P)
+                            passage_node_weight=PASSAGE_W, ppr_iters=PPR_ITERS, k=K_P, ppr_tol=tol,
+                            ppr_max_iters=max_iters)
 
-    for i in range(args.warmup):
-        out = step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_batches):
-        out = step(i)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    def timed(tol=0.0, max_iters=0):
+        for i in range(args.warmup):
+            o = step(i, tol, max_iters)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res, used, flg = [], [], []
+        for i in range(args.warmup, n_batches):
+            o = step(i, tol, max_iters)
+            res.append(o.residual); used.append(o.iters_used); flg.append(o.flags)     # device tensors: no sync
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        contract = {"ppr_tol": tol, "ppr_max_iters": max(max_iters, PPR_ITERS) if tol > 0 else PPR_ITERS,
+                    "ppr_residual_max": float(torch.stack(res).max()),
+                    "ppr_residual_definition": "damping / (1 - damping) * max over passages of the relative update of "
+                                               "the passage score in the last sweep (include/hrag.h, hrag_retrieve)",
+                    "sweeps_used_min": int(torch.stack(used).min()), "sweeps_used_max": int(torch.stack(used).max()),
+                    "queries_flagged_not_converged": int((torch.stack(flg) & 16).ne(0).sum())}
+        return o, el, contract
+
+    out, elapsed, contract = timed()                                    # BASELINE.json: exactly 20 PPR iterations
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     qps = B * args.steps / elapsed
+    _, el_c, contract_c = timed(args.ppr_tol, args.ppr_max_iters)       # the mirror's default: the convergence contract
+    contract_c.update({"value": B * args.steps / el_c, "unit": "queries/s", "ms_per_step": el_c * 1e3 / max(args.steps, 1)})
 
     # phase breakdown of one more step (HIP events inside the library, same stream)
     eng.set_profiling(True)
@@ -451,6 +476,7 @@ def main():
                                        "f16 hi + f16 correction (fp32 arithmetic)" if f16 else "f32"),
                    "parallelism": "1gpu"},
         "roofline": roofline,
+        "ppr_contract": contract, "with_convergence_contract": contract_c,
         "phases_ms": {k: phases[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")},
         "sim_algorithmic_bytes": sim_algorithmic_bytes(kg.n_facts, kg.n_passages, D, B),
         "n_long_rows": phases["n_long_rows"], "setup_s": setup_s,

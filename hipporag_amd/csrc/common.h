@@ -55,6 +55,14 @@ __device__ __forceinline__ uint64_t rank_key(float score, uint32_t idx) {
     return ((uint64_t)f32_to_ordered(score) << 32) | (uint64_t)idx;
 }
 
+// Convergence contract: the running per-query maximum est[q] (float bits) is raised with atomicMax by whoever holds a
+// larger value.  The pre-check must see the other workgroups' updates -- a cached plain load keeps reading the
+// initial 0 and every lane of every wavefront would issue its atomic (measured: +0.3 ms on a 1 ms sweep) -- so it is
+// an agent-scope load; a stale value would only cost a redundant atomic, the maximum itself is order-free.
+__device__ __forceinline__ int32_t est_peek(const int32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // seeds.hip limits
 constexpr int kMaxKeptFacts = 16; // kf upper bound
 constexpr int kMaxSeeds = 32;     // 2 * kMaxKeptFacts
@@ -143,6 +151,7 @@ struct Ppr16Args {
     // mode F, convergence contract: est[q] = max over the passage rows of |x_new - x_old| / x_new as float bits
     // (atomicMax; x_old from the own row of the gather source); nullptr: not measured
     int32_t *est = nullptr;
+    float *est_ws = nullptr;   // scratch [n_slabs][n_chunks][64]: every wavefront's maximum (reduced by launch_est_reduce)
     int32_t batch = 0;
 };
 // nt: bit0 non-temporal (col, val) loads, bit1 non-temporal state stores
@@ -167,7 +176,11 @@ constexpr int kP8MaxStages = 12;      // stage lengths 1,2,3,..,3,(1|2) => <= 11
 constexpr float kP8C0Scale = 128.f;   // c_0 = Q(v/d * 2^7),  max(v/d) in (1/2, 1]
 constexpr int32_t kFlagFp8Saturated = 8;   // flags bit 3 (HRAG_FLAG_FP8_SATURATED)
 constexpr int32_t kFlagNotConverged = 16;  // flags bit 4 (HRAG_FLAG_NOT_CONVERGED)
-constexpr int kP8MaxExt = 4;          // extension stages (3 sweeps each) the convergence contract may add
+constexpr int kP8MaxExt = 4;          // extension stages the convergence contract may add: 1, 2, 3, 3 sweeps -- a
+                                      // prediction just above the tolerance costs one sweep, a slowly mixing graph gets 9
+__host__ __device__ inline int p8_ext_sweeps(int n_ext) {   // sweeps of the first n_ext extension stages
+    return n_ext <= 0 ? 0 : n_ext == 1 ? 1 : 3 * (n_ext - 1);
+}
 struct Sell8Dev {
     const int2 *pairs;         // (col, fp32 bits of the value), step-major per chunk (ppr16.hip layout)
     uint32_t pairs_bytes;      // incl. the read-ahead padding (< 2^31)
@@ -179,6 +192,8 @@ struct Sell8Dev {
     int32_t n_partial;
     const int32_t *seg_lrow;   // [n_partial] long row of a partial slot
     int32_t *lcount;           // [n_slabs][n_lrow] arrival counters (see Ppr16Args)
+    const int32_t *pslot;      // [n_chunks] dense number of a chunk that holds a passage row (else -1): its row of the
+    int32_t n_pchunks;         // est scratch [n_slabs][n_pchunks][128] (convergence contract)
 };
 // State buffers: e4m3 [n_groups][V + 1][spg][128]; slab s lives in group s / spg, column block s % spg;
 // row V of every group is all-zero (the target of masked-out gathers in mode B0).  An owner's rows
@@ -226,6 +241,7 @@ struct Ppr8Args {
     // size of the last update of the passage scores; nullptr: not computed.  Mode B then needs stage / stage_inv /
     // n_stage like mode F (z_p = sum of the stage copies + c / cs + R).
     int32_t *est = nullptr;
+    float *est_ws = nullptr;   // scratch [n_slabs][m.n_pchunks][128]: the maximum of every wavefront that holds a passage row
 };
 hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, bool main_only, hipStream_t s);
 // c_0 = Q(v/d * c0_scale) on the owned rows of slabs [slab0, slab0 + n_slabs)
@@ -249,8 +265,12 @@ hrag_status launch_ppr8_scale(const float *zmax, const double *mass, float passa
                               hipStream_t s, int32_t n_tab = 1, int64_t tab_stride = 0);
 // the convergence contract's two tiny kernels (ppr8.hip): decision j after a checkpoint boundary; the per-query
 // results after the last step
-hrag_status launch_ppr8_decide(int32_t *est_ck, const int32_t *flags, int32_t batch, float kappa, float g, float tol,
-                               int32_t j, int32_t e_max, int32_t *ctl, int32_t n_ctl, hipStream_t s);
+// est[slab * w + col] = max(itself, column maxima of ws[slab][chunk][w]) for slabs [slab0, slab0 + n_slabs)
+hrag_status launch_est_reduce(const float *ws, int32_t n_chunks, int32_t w, int32_t slab0, int32_t n_slabs, int32_t batch,
+                              int32_t *est, const int32_t *gate, int32_t gate_want, hipStream_t s);
+hrag_status launch_ppr8_decide(int32_t *est_ck, float *est_prev, const int32_t *flags, int32_t batch, float kappa,
+                               float expo, float g, float tol, int32_t j, int32_t e_max, int32_t *ctl, int32_t n_ctl,
+                               hipStream_t s);
 hrag_status launch_ppr8_finalize(const int32_t *est_f, int32_t *flags, int32_t batch, float g, float tol,
                                  int32_t iters, const int32_t *ctl, int32_t e_max, const double *mass_tab,
                                  int64_t tab_stride, double *sums, float *resid, int32_t *iters_used, hipStream_t s);
@@ -287,6 +307,7 @@ struct PprSvArgs {
     // last sweep (kSvFinal, or the plain fp32 sweep over the passage rows), convergence contract: est[q] = max over
     // the rows of |x_new - x_old| / x_new as float bits (atomicMax); nullptr: not measured
     int32_t *est = nullptr;
+    float *est_ws = nullptr;   // scratch [n_chunks][BP]: every wavefront's maximum (reduced by launch_est_reduce)
     int32_t batch = 0;
 };
 hrag_status launch_ppr_sv_sweep(const PprSvArgs &a, int bp, bool main_only, hipStream_t s);

@@ -18,7 +18,7 @@ namespace {
 
 void free_store(Sell8Store &m) {
     void *ptrs[] = {m.pairs, m.pairs_at, m.chunk_meta, m.vrow, m.lrow_row, m.lrow_first, m.lrow_cnt, m.seg_lrow,
-                    m.lcount};
+                    m.lcount, m.pslot};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     m = Sell8Store();
@@ -39,7 +39,7 @@ void free_engine(hrag_engine *e) {
                     e->d_stagep, e->d_pool8[0], e->d_pool8[1], e->d_pool8[2], e->d_sv16[0], e->d_sv16[1],
                     e->d_sv16[2], e->d_sv16[3], e->d_zmax_bits, e->d_zmax,
                     e->d_mass, e->d_prior_part, e->d_est_ck, e->d_est_f, e->d_ctl, e->d_iters_used, e->d_resid,
-                    e->d_mass_tab};
+                    e->d_mass_tab, e->d_est_prev, e->d_est_ws};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_store(e->sell);
@@ -106,9 +106,11 @@ int32_t sell8_seg_len(int64_t nnz_owned, int max_batch) {
 // rows (may be null = all): LOCAL rows to include.  want_p: the (col, P value) pairs of ppr16 / ppr_sv.
 // deg (may be null): weighted degrees by GLOBAL vertex id; when given, the pairs with the row-normalised
 // values at_ij = p_ij d_j / d_i (the degree-scaled iteration of ppr8.hip) are built.
+// row_passage (may be null): per LOCAL row, >= 0 when the row is a passage vertex -- the chunks that hold such a row get
+// a dense slot number (Sell8Store::pslot): the scratch rows of the convergence contract's est measure.
 hrag_status build_sell8(const hrag_engine *e, const std::vector<int32_t> &row_ptr, const int32_t *col,
                         const float *val, const double *deg, const std::vector<int32_t> *rows, bool want_p,
-                        Sell8Store *out) {
+                        Sell8Store *out, const int32_t *row_passage = nullptr) {
     struct VRow { int32_t len, begin, target, row; };
     std::vector<VRow> vr;
     const int64_t n_sel = rows ? (int64_t)rows->size() : e->n_rows;
@@ -213,6 +215,19 @@ hrag_status build_sell8(const hrag_engine *e, const std::vector<int32_t> &row_pt
             }
         }
     }
+    if (row_passage) {
+        // rows are sorted by length with ties in vertex order and the passages are the last vertices, so the passage
+        // rows of a length class sit together: ~ Np / 8 chunks, not all of them
+        std::vector<int32_t> pslot((size_t)n_chunks, -1);
+        int32_t n_p = 0;
+        for (int64_t c = 0; c < n_chunks; ++c)
+            for (int g = 0; g < 8; ++g) {
+                const int32_t t = vrow[(size_t)c * 8 + g];
+                if (t >= 0 && row_passage[(size_t)t] >= 0) { pslot[(size_t)c] = n_p++; break; }
+            }
+        out->n_pchunks = n_p;
+        HRAG_TRY(dev_upload(&out->pslot, pslot.data(), (int64_t)pslot.size()));
+    }
     out->n_chunks = (int32_t)n_chunks;
     out->n_lrow = (int32_t)lrow_row.size();
     out->n_partial = n_partial;
@@ -273,7 +288,7 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
             a.n_chunks = m.n_chunks; a.lrow_row = m.lrow_row; a.lrow_first = m.lrow_first; a.lrow_cnt = m.lrow_cnt;
             a.n_lrow = m.n_lrow; a.n_partial = m.n_partial; a.seg_lrow = m.seg_lrow; a.lcount = m.lcount;
             a.hfin = h; a.out = e->d_xp8; a.p_rows = e->p_rows;
-            a.est = est; a.batch = batch;
+            a.est = est; a.est_ws = e->d_est_ws; a.batch = batch;
         }
         HRAG_TRY(launch_ppr16_sweep(a, last ? kPprModeF : kPprModeC, ns, nt, false, s));
         c = cn;
@@ -335,7 +350,7 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
         for (int it = 0; it < iters; ++it) {
             PprSvArgs a = ppr_sv_args(e, it + 1 == iters ? e->fsell : e->sell, x, y, row_slot, tele, damping);
             a.colmask = it == 0 ? e->d_colmask : nullptr;
-            if (it + 1 == iters) { a.est = est; a.batch = batch; }
+            if (it + 1 == iters) { a.est = est; a.est_ws = e->d_est_ws; a.batch = batch; }
             HRAG_TRY(launch_ppr_sv_sweep(a, bp, false, s));
             std::swap(x, y);
         }
@@ -367,7 +382,7 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
         PprSvArgs a = ppr_sv_args(e, last ? e->fsell : e->sell, c, cn, row_slot, tele, damping);
         a.half_state = 1; a.mode = last ? 3 : 2; a.aux16 = r; a.cscale = kPpr16CScale;
         a.h16 = h; a.xout = e->d_x;
-        if (last) { a.est = est; a.batch = batch; }
+        if (last) { a.est = est; a.est_ws = e->d_est_ws; a.batch = batch; }
         HRAG_TRY(launch_ppr_sv_sweep(a, bp, false, s));
         c = cn;
         std::swap(cn, cn2);
@@ -561,7 +576,7 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
             }
         }
         E_TRY(build_sell8(e, h_row_ptr, h_col.data(), h_val.data(), want_f8 ? h_deg.data() : nullptr, nullptr,
-                          want_sell, &e->sell));
+                          want_sell, &e->sell, h_r2t.data()));
         // the last sweep only needs the passage rows (HippoRAG.py:1745 reads nothing else): a second matrix
         std::vector<int32_t> prow_list;
         std::vector<int32_t> ptele((size_t)e->n_rows, -1);
@@ -571,7 +586,7 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
                 ptele[(size_t)r] = h_r2t[(size_t)r] - (int32_t)e->p_offset;
             }
         E_TRY(build_sell8(e, h_row_ptr, h_col.data(), h_val.data(), want_f8 ? h_deg.data() : nullptr, &prow_list,
-                          want_sell, &e->fsell));
+                          want_sell, &e->fsell, h_r2t.data()));
         if (!want_f8) {
             // isolated vertices (the closed-form mass of the small-batch path): no row entries <=> no edges (symmetric)
             h_iso.assign((size_t)e->V, 0);
@@ -707,6 +722,16 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     E_TRY(dev_alloc(&e->d_ctl, 2 * (kP8MaxExt + 1)));
     E_TRY(dev_alloc(&e->d_iters_used, B));
     E_TRY(dev_alloc(&e->d_resid, B));
+    E_TRY(dev_alloc(&e->d_est_prev, B));
+    {
+        // every wavefront of a sweep that measures est writes one row of (queries per slab row) floats; the widest
+        // user is the checkpoint boundary of the fp8 state (all chunks of the main matrix, 128 queries per row)
+        const int64_t c_p = std::max<int64_t>(e->sell.n_pchunks, e->fsell.n_pchunks), c_f = e->fsell.n_chunks;
+        int64_t n = c_f * 8;                                                   // small batches (last sweep: passage rows)
+        if (e->f8_ready) n = std::max(n, (int64_t)n_slabs128(B) * c_p * 128);   // the chunks that hold passage rows
+        if (e->f16_ready) n = std::max(n, (int64_t)n_slabs64(e->f16_max_batch) * c_f * 64);
+        E_TRY(dev_alloc(&e->d_est_ws, std::max<int64_t>(n, 1)));
+    }
     E_TRY(dev_alloc(&e->d_mass_tab, (int64_t)(kP8MaxExt + 1) * B));
     {
         char *ws = nullptr;

@@ -55,7 +55,8 @@ struct Sell8Store {
     int32_t *vrow = nullptr, *lrow_row = nullptr, *lrow_first = nullptr, *lrow_cnt = nullptr;
     int32_t *seg_lrow = nullptr;   // [n_partial] long row of a partial slot
     int32_t *lcount = nullptr;     // [n_slabs64(max_batch)][n_lrow] arrival counters, zero between launches
-    int32_t n_chunks = 0, n_lrow = 0, n_partial = 0;
+    int32_t *pslot = nullptr;      // [n_chunks] dense number of a chunk that holds a passage row, else -1
+    int32_t n_chunks = 0, n_lrow = 0, n_partial = 0, n_pchunks = 0;
     int64_t steps = 0;
     uint32_t pairs_bytes() const { return (uint32_t)((steps + 4) * 512); }
     Sell8Dev dev_at() const {
@@ -63,6 +64,7 @@ struct Sell8Store {
         d.pairs = pairs_at; d.pairs_bytes = pairs_bytes(); d.chunk_meta = chunk_meta; d.vrow = vrow;
         d.n_chunks = n_chunks; d.lrow_row = lrow_row; d.lrow_first = lrow_first; d.lrow_cnt = lrow_cnt;
         d.n_lrow = n_lrow; d.n_partial = n_partial; d.seg_lrow = seg_lrow; d.lcount = lcount;
+        d.pslot = pslot; d.n_pchunks = n_pchunks;
         return d;
     }
 };
@@ -79,8 +81,8 @@ struct Ppr8Step {
     // ckpt = this boundary measures est (the relative update of the passage scores) and is followed by decision
     // number `decide` (-1: none), kappa = the contraction predicted for the stage that follows
     int32_t gate = -1, gate_want = 1;
-    int32_t ckpt = 0, decide = -1;
-    float kappa = 0.f;
+    int32_t ckpt = 0, decide = -1;   // decide: -1 none, -2 probe (remember the values for the next decision), >= 0
+    float kappa = 0.f, expo = 1.f;   // expo = sweeps of the next stage / sweeps since the previous checkpoint
 };
 struct Ppr8Session {
     bool active = false;
@@ -174,7 +176,8 @@ struct hrag_engine {
     // last update, as float bits (atomicMax) -- at the last checkpoint boundary / at the final sweep; control words
     // [0 .. kP8MaxExt]: extension stage j + 1 runs, [kP8MaxExt + 1 ..]: final sweep variant j runs; the results
     int32_t *d_est_ck = nullptr, *d_est_f = nullptr, *d_ctl = nullptr, *d_iters_used = nullptr;
-    float *d_resid = nullptr;
+    float *d_resid = nullptr, *d_est_prev = nullptr;
+    float *d_est_ws = nullptr;      // per-wavefront maxima of a sweep that measures est: [slabs][chunks][queries per slab row]
     double *d_mass_tab = nullptr;   // [kP8MaxExt + 1][max_batch]: mass of the (iters + 3 j)-sweep iterate
     // timing
     hipEvent_t ev[EV_COUNT] = {};
@@ -216,7 +219,7 @@ hrag_status ppr8_prior(hrag_engine *e, const float *mn, const float *mx, float p
                        const int32_t *flags, int32_t batch, float *zmax_out, double *mass_out, hipStream_t s);
 // scale, teleport rows, seed rows, column mask, stage plan, c_0 on the owned rows of buf[0]
 // max_iters / tol / want_est: the convergence contract (include/hrag.h, hrag_retrieve): tol > 0 lets the DEVICE add
-// up to (max_iters - iters) / 3 stages of 3 sweeps; the session then has more steps than `iters` (p8.n_steps)
+// up to kP8MaxExt stages of 1, 2, 3, 3 sweeps; the session then has more steps than `iters` (p8.n_steps)
 hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const float *zmax, const double *mass,
                        float passage_weight, const int32_t *seed_vtx, const float *seed_w,
                        const int32_t *seed_cnt, int32_t *flags, int32_t batch, float damping, int32_t iters,

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void passage_delta_kernel(const float *__restr
     const float a = x[at];
     const float r = a > 0.f ? fabsf(a - xp[at]) / a : 0.f;
     const int bits = __float_as_int(r);
-    if (bits > est[q]) atomicMax(&est[q], bits);
+    if (bits > est_peek(est + q)) atomicMax(&est[q], bits);   // rare path (fp32 slab state): a coherent pre-check is fine
 }
 }  // namespace
 

@@ -159,9 +159,10 @@ __device__ __forceinline__ void load_row_in(const Ppr16Args &a, int slab, int ro
 }
 
 // Finish one output row: lane gl of its group owns queries 8*gl .. 8*gl+7 of the slab.
+// er (mode F with a.est): the relative size of this (last) sweep's update of the lane's 8 queries
 template <int MODE, bool NT_ST = false>
 __device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row, int gl,
-                                           const float (&acc)[8], const RowIn &in) {
+                                           const float (&acc)[8], const RowIn &in, float (&er)[8]) {
     float out[8];
     const size_t state_off = ((size_t)slab * a.num_vertices + (size_t)row) * 64 + (size_t)gl * 8;
     if constexpr (MODE == kPprModeH || MODE == kPprModeR) {
@@ -191,12 +192,8 @@ __device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row
                 const half8_t cold = *reinterpret_cast<const half8_t *>(a.x + state_off);
                 const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int q = slab * 64 + gl * 8 + j;
-                    const float r = xs[j] > 0.f ? fabsf(out[j] - (float)cold[j]) * ics / xs[j] : 0.f;
-                    const int bits = __float_as_int(r);
-                    if (q < a.batch && bits > a.est[q]) atomicMax(&a.est[q], bits);
-                }
+                for (int j = 0; j < 8; ++j)
+                    er[j] = xs[j] > 0.f ? fabsf(out[j] - (float)cold[j]) * ics / xs[j] : 0.f;
             }
             return;
         }
@@ -258,8 +255,9 @@ __global__ __launch_bounds__(256, 6) void ppr16_kernel(const Ppr16Args a) {
     // partial sums travel write-through / L1-bypassing (sc1): writer and reader may sit on different XCDs
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
         a.partial + (size_t)slab * a.n_partial * 64, 0, a.n_partial * 256, 0x00020000);
+    float er[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (tgt >= 0) {
-        finish_row<MODE, NT_ST>(a, slab, tgt, gl, acc, in);
+        finish_row<MODE, NT_ST>(a, slab, tgt, gl, acc, in, er);
     } else if (seg) {
         const unsigned at = (unsigned)(-(tgt + 1)) * 256u + (unsigned)gl * 32u;
         st_sc1(qrs, at, acc[0], acc[1], acc[2], acc[3]);
@@ -269,6 +267,20 @@ __global__ __launch_bounds__(256, 6) void ppr16_kernel(const Ppr16Args a) {
     // counter) lends its whole wavefront to the row: the 8 lane groups stride over the row's partial sums, the 8
     // group totals are added with xor-shuffles -- a fixed summation order, whoever comes last -- and the row is
     // finished.  No second kernel per sweep.
+    if constexpr (MODE == kPprModeF) {
+        if (a.est) {   // wave-uniform.  The wavefront's maximum per query -> its slot of est_ws[slab][chunk][64] (plain
+                       // stores; launch_est_reduce takes the column maxima: no atomics per row)
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) er[j] = fmaxf(er[j], __shfl_xor(er[j], o, 64));
+            if (grp == 0) {
+                f32x4_t *wp = reinterpret_cast<f32x4_t *>(a.est_ws + ((size_t)slab * a.n_chunks + (size_t)chunk) * 64 + (size_t)gl * 8);
+                wp[0] = f32x4_t{er[0], er[1], er[2], er[3]};
+                wp[1] = f32x4_t{er[4], er[5], er[6], er[7]};
+            }
+        }
+    }
     if (__builtin_amdgcn_ballot_w64(seg) == 0) return;   // wave-uniform
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's partial sums have left the CU
     int m = -1;
@@ -300,7 +312,18 @@ __global__ __launch_bounds__(256, 6) void ppr16_kernel(const Ppr16Args a) {
         if (grp == 0) {
             const int row = a.lrow_row[mm];
             load_row_in<MODE>(a, slab, row, gl, in);
-            finish_row<MODE>(a, slab, row, gl, acc, in);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) er[j] = 0.f;
+            finish_row<MODE>(a, slab, row, gl, acc, in, er);
+            if constexpr (MODE == kPprModeF) {
+                if (a.est) {   // a handful of rows
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int q = slab * 64 + gl * 8 + j;
+                        if (q < a.batch && er[j] > 0.f) atomicMax(&a.est[q], __float_as_int(er[j]));
+                    }
+                }
+            }
         }
         if (lane == 0) __hip_atomic_store(cnts + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -408,7 +431,11 @@ hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, int nt
         case kPprModeH: return sweep_mode<kPprModeH>(a, n_slabs, nt_pairs, main_only, s);
         case kPprModeR: return sweep_mode<kPprModeR>(a, n_slabs, nt_pairs, main_only, s);
         case kPprModeC: return sweep_mode<kPprModeC>(a, n_slabs, nt_pairs, main_only, s);
-        case kPprModeF: return sweep_mode<kPprModeF>(a, n_slabs, nt_pairs, main_only, s);
+        case kPprModeF:
+            HRAG_TRY(sweep_mode<kPprModeF>(a, n_slabs, nt_pairs, main_only, s));
+            if (a.est && a.n_chunks > 0)
+                return launch_est_reduce(a.est_ws, a.n_chunks, 64, 0, n_slabs, a.batch, a.est, nullptr, 0, s);
+            return HRAG_OK;
         default: set_error("bad ppr16 mode %d", mode); return HRAG_EINVAL;
     }
 }

@@ -54,6 +54,8 @@
 //     sweep by sweep, so the mass of the K-sweep iterate is a closed form of sum(v) (ppr8_scale_kernel);
 //   * c_0 = Q(v/d) is zero outside the passage and seed vertices, so the first sweep (mode B0) tests a
 //     column bitmap and issues only the gathers of those columns.
+#include <algorithm>
+
 #include "common.h"
 
 namespace hrag {
@@ -417,12 +419,17 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow
     }
 }
 
-// est[q] = max(est[q], er) for the 16 queries of lane gl.  WAVE: the 8 row groups of the wavefront are reduced
-// first (every lane must call; lanes without a passage row pass zeros), then group 0 commits.  The plain load
-// may be stale (another XCD's update): a stale value only costs a redundant atomic, the maximum is order-free.
+// The wavefront's maximum of er over its 8 rows, 128 queries, goes to its own 512-byte row of the scratch array
+// est_ws[slab][pslot[chunk]][128] with plain stores (every wavefront whose chunk holds a passage row writes, zeros
+// included: nothing to initialise; the other chunks have no row -- the rows are sorted by length with the passages
+// last inside a length class, so ~ Np / 8 of the chunks do); est_reduce_kernel takes the column maxima afterwards.  No atomics on this path: 4 M atomicMax on 256 addresses cost
+// 0.3 ms per sweep when tried, and a pre-check needs a coherent (memory-latency) load per value.
+// WAVE = false (a long row finished by the last-arriving wavefront, group 0 only; a handful of rows): atomicMax.
 template <bool WAVE>
-__device__ __forceinline__ void est_commit(const Ppr8Args &a, int slab, int gl, int grp, f32x2_t (&er)[8]) {
+__device__ __forceinline__ void est_commit(const Ppr8Args &a, int slab, int chunk, int gl, int grp, f32x2_t (&er)[8]) {
     if constexpr (WAVE) {
+        const int slot = a.m.pslot[chunk];   // wave-uniform
+        if (slot < 0) return;
 #pragma unroll
         for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
@@ -431,13 +438,14 @@ __device__ __forceinline__ void est_commit(const Ppr8Args &a, int slab, int gl, 
                 er[j].y = fmaxf(er[j].y, __shfl_xor(er[j].y, o, 64));
             }
         if (grp != 0) return;
-    }
+        st16f(a.est_ws + ((size_t)slab * a.m.n_pchunks + (size_t)slot) * 128 + (size_t)gl * 16, er);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int q = slab * 128 + gl * 16 + 2 * j;
-        const int b0 = __float_as_int(er[j].x), b1 = __float_as_int(er[j].y);
-        if (q < a.batch && b0 > a.est[q]) atomicMax(&a.est[q], b0);
-        if (q + 1 < a.batch && b1 > a.est[q + 1]) atomicMax(&a.est[q + 1], b1);
+        for (int j = 0; j < 8; ++j) {
+            const int q = slab * 128 + gl * 16 + 2 * j;
+            if (q < a.batch && er[j].x > 0.f) atomicMax(&a.est[q], __float_as_int(er[j].x));
+            if (q + 1 < a.batch && er[j].y > 0.f) atomicMax(&a.est[q + 1], __float_as_int(er[j].y));
+        }
     }
 }
 
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     } else if (seg) {
         st16i_sc1(qrs, (unsigned)(-(tgt + 1)) * 512u, gl, acc);
     }
-    if constexpr (kEst) est_commit<true>(a, slab, gl, grp, er);   // every lane takes part in the reduction
+    if constexpr (kEst) est_commit<true>(a, slab, chunk, gl, grp, er);   // every lane takes part in the reduction
     // Long rows arrive as segments in different wavefronts; the segment that arrives LAST (agent-scope
     // counter) lends its whole wavefront to the row: the 8 lane groups stride over the row's partial sums, the 8
     // group totals are added with xor-shuffles -- a fixed summation order, whoever comes last -- and the row is
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) er[j] = f32x2_t{0.f, 0.f};
             finish_row<MODE, RIO, EST>(a, slab, a.m.lrow_row[mm], gl, acc, er);
-            if constexpr (kEst) est_commit<false>(a, slab, gl, 0, er);
+            if constexpr (kEst) est_commit<false>(a, slab, chunk, gl, 0, er);
         }
         if (lane == 0) __hip_atomic_store(cnts + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -675,7 +683,7 @@ __device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
         } else if (seg) {
             st16i_sc1(half ? q1 : q0, (unsigned)(-(tgt + 1)) * 512u, gl, half ? acc1 : acc0);
         }
-        if constexpr (kEst) est_commit<true>(a, slab + half, gl, grp, er);
+        if constexpr (kEst) est_commit<true>(a, slab + half, chunk, gl, grp, er);
     }
     // long rows: as in ppr8_kernel; one arrival (the first slab's counter) covers both slabs of the pair
     if (__builtin_amdgcn_ballot_w64(seg) == 0) return;   // wave-uniform
@@ -715,7 +723,7 @@ __device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) er[j] = f32x2_t{0.f, 0.f};
                 finish_row<MODE, RIO, EST>(a, slab + half, a.m.lrow_row[mm], gl, acc0, er);
-                if constexpr (kEst) est_commit<false>(a, slab + half, gl, 0, er);
+                if constexpr (kEst) est_commit<false>(a, slab + half, chunk, gl, 0, er);
             }
         }
         if (lane == 0) __hip_atomic_store(cnts + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -848,32 +856,68 @@ __global__ void ppr8_scale_kernel(const float *__restrict__ zmax, const double *
     M *= (double)s;   // powers of two: exact
     S *= (double)s;
     const double al = (double)damping, be = (double)(1.0f - damping);
-    // sums[j * tab_stride + q] = the mass after iters + 3 j sweeps (j > 0: the extension stages of the convergence
-    // contract, csrc/shard.hip)
+    // sums[j * tab_stride + q] = the mass after iters + p8_ext_sweeps(j) sweeps (j > 0: the extension stages of the
+    // convergence contract, csrc/shard.hip)
     double m = M;
     int k = 0;
     for (int j = 0; j < n_tab; ++j) {
-        for (; k < iters + 3 * j; ++k) m = al * (m - (k == 0 ? S : be * S)) + be * M;
+        for (; k < iters + p8_ext_sweeps(j); ++k) m = al * (m - (k == 0 ? S : be * S)) + be * M;
         sums[(size_t)j * tab_stride + q] = m;
     }
 }
 
+// est[slab * W + w] = max(est[...], max over the chunks of ws[slab][chunk][w]): the column maxima of the per-wavefront
+// scratch a sweep with est left behind (W = queries per slab row: 128 fp8 state, 64 fp16 state, bp small batches).
+// Grid (kEstSplit, n_slabs); one atomicMax per (block, query).  gate: the sweep it follows was conditional.
+constexpr int kEstSplit = 128;
+__global__ __launch_bounds__(256) void est_reduce_kernel(const float *__restrict__ ws, int32_t n_chunks, int32_t w,
+                                                         int32_t slab0, int32_t batch, int32_t *est,
+                                                         const int32_t *gate, int32_t gate_want) {
+    if (gate && *gate != gate_want) return;
+    __shared__ float red[256];
+    const int slab = slab0 + blockIdx.y, tid = threadIdx.x;
+    const int col = tid % w, sub = tid / w, nsub = 256 / w;      // w divides 256
+    const float *base = ws + (size_t)slab * n_chunks * w;
+    float m = 0.f;
+    for (int64_t c = (int64_t)blockIdx.x * nsub + sub; c < n_chunks; c += (int64_t)gridDim.x * nsub)
+        m = fmaxf(m, base[(size_t)c * w + col]);
+    red[tid] = m;
+    __syncthreads();
+    if (tid < w) {
+        for (int k = 1; k < nsub; ++k) m = fmaxf(m, red[tid + k * w]);
+        const int q = slab * w + tid;
+        if (q < batch && m > 0.f) atomicMax(&est[q], __float_as_int(m));
+    }
+}
+
 // Convergence contract, decision number j (after a checkpoint boundary): est_ck[q] holds the relative size of the
-// update that boundary applied to the passage scores (max over the passages, float bits).  kappa = the contraction
-// the next stage is expected to add (damping^m + the e4m3 rounding of its right-hand side), g = damping / (1 -
-// damping) turns an update into the error that is left after it.  ctl[j] = 1: the next stage is closed by another
-// checkpoint boundary and extension stage j + 1 follows; ctl[n_ctl + j] = 1: the next stage is the last, final
-// sweep variant j runs.  A decision whose predecessor stopped leaves both at 0.
-__global__ __launch_bounds__(256) void ppr8_decide_kernel(int32_t *est_ck, const int32_t *__restrict__ flags,
-                                                          int32_t batch, float kappa, float g, float tol, int32_t j,
-                                                          int32_t e_max, int32_t *ctl, int32_t n_ctl) {
+// update that boundary applied to the passage scores (max over the passages, float bits).  The update the NEXT stage's
+// closing sweep will apply is predicted per query as est * kappa_q, kappa_q = min(kappa, 1.5 * rho_q^expo): kappa is
+// the model bound (damping^m + the e4m3 rounding of the stage's right-hand side), rho_q the contraction MEASURED
+// between the previous checkpoint (est_prev) and this one, expo = sweeps of the next stage / sweeps since the previous
+// checkpoint -- a graph that mixes well contracts much faster than damping per sweep, and the model bound alone would
+// buy it a stage it does not need.  g = damping / (1 - damping) turns an update into the error left after it.
+// ctl[j] = 1: the next stage is closed by another checkpoint boundary and extension stage j + 1 follows;
+// ctl[n_ctl + j] = 1: the next stage is the last, final sweep variant j runs.  A decision whose predecessor stopped
+// leaves both at 0.  j < 0: probe only (remember this checkpoint's values for the next decision).
+// A prediction that turns out optimistic is caught by the final sweep's own measurement (flags bit 4).
+__global__ __launch_bounds__(256) void ppr8_decide_kernel(int32_t *est_ck, float *est_prev,
+                                                          const int32_t *__restrict__ flags, int32_t batch, float kappa,
+                                                          float expo, float g, float tol, int32_t j, int32_t e_max,
+                                                          int32_t *ctl, int32_t n_ctl) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
-    const bool alive = j == 0 || ctl[j - 1] == 1;
+    const bool alive = j <= 0 || ctl[j - 1] == 1;
     float m = 0.f;
-    for (int q = tid; q < batch; q += 256) {
-        if (!(flags[q] & 1)) m = fmaxf(m, __int_as_float(est_ck[q]));
-        est_ck[q] = 0;   // the next checkpoint starts from zero
+    if (alive) {
+        for (int q = tid; q < batch; q += 256) {
+            const float cur = __int_as_float(est_ck[q]), prev = est_prev[q];
+            float kq = kappa;
+            if (prev > 0.f && cur < prev) kq = fminf(kappa, fmaxf(1.5f * powf(cur / prev, expo), 0.02f));
+            if (!(flags[q] & 1)) m = fmaxf(m, cur * kq);
+            est_prev[q] = cur;
+            est_ck[q] = 0;   // the next checkpoint starts from zero
+        }
     }
     red[tid] = m;
     __syncthreads();
@@ -881,8 +925,8 @@ __global__ __launch_bounds__(256) void ppr8_decide_kernel(int32_t *est_ck, const
         if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
         __syncthreads();
     }
-    if (tid == 0 && alive) {
-        const bool go = tol > 0.f && j < e_max && g * kappa * red[0] > tol;
+    if (tid == 0 && alive && j >= 0) {
+        const bool go = tol > 0.f && j < e_max && g * red[0] > tol;
         ctl[j] = go ? 1 : 0;
         ctl[n_ctl + j] = go ? 0 : 1;
     }
@@ -901,7 +945,7 @@ __global__ void ppr8_finalize_kernel(const int32_t *__restrict__ est_f, int32_t 
     const bool fallback = (flags[q] & 1) != 0;
     const float r = fallback ? 0.f : g * __int_as_float(est_f[q]);
     resid[q] = r;
-    iters_used[q] = fallback ? 0 : iters + 3 * n_ext;
+    iters_used[q] = fallback ? 0 : iters + p8_ext_sweeps(n_ext);
     if (mass_tab) sums[q] = mass_tab[(size_t)n_ext * tab_stride + q];
     if (tol > 0.f && r > tol) flags[q] |= kFlagNotConverged;
 }
@@ -954,8 +998,17 @@ hrag_status sweep_mode(const Ppr8Args &a_in, bool main_only, hipStream_t s) {
 
 }  // namespace
 
+static hrag_status sweep_dispatch(const Ppr8Args &a, int mode, bool main_only, hipStream_t s);
+
 hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, bool main_only, hipStream_t s) {
     if (a.n_slabs <= 0) return HRAG_OK;
+    HRAG_TRY(sweep_dispatch(a, mode, main_only, s));
+    if (a.est && (mode == kP8ModeB || mode == kP8ModeF))   // column maxima of the per-wavefront scratch
+        return launch_est_reduce(a.est_ws, a.m.n_pchunks, 128, a.slab0, a.n_slabs, a.batch, a.est, a.gate, a.gate_want, s);
+    return HRAG_OK;
+}
+
+static hrag_status sweep_dispatch(const Ppr8Args &a, int mode, bool main_only, hipStream_t s) {
     const int rio = a.rio & 3;
     switch (mode) {
         case kP8ModeC: return sweep_mode<kP8ModeC, 0>(a, main_only, s);
@@ -1020,10 +1073,25 @@ hrag_status launch_ppr8_scale(const float *zmax, const double *mass, float passa
     return HRAG_OK;
 }
 
-hrag_status launch_ppr8_decide(int32_t *est_ck, const int32_t *flags, int32_t batch, float kappa, float g, float tol,
-                               int32_t j, int32_t e_max, int32_t *ctl, int32_t n_ctl, hipStream_t s) {
-    hipLaunchKernelGGL(ppr8_decide_kernel, dim3(1), dim3(256), 0, s, est_ck, flags, batch, kappa, g, tol, j, e_max,
-                       ctl, n_ctl);
+hrag_status launch_est_reduce(const float *ws, int32_t n_chunks, int32_t w, int32_t slab0, int32_t n_slabs, int32_t batch,
+                              int32_t *est, const int32_t *gate, int32_t gate_want, hipStream_t s) {
+    if (n_chunks <= 0 || n_slabs <= 0) return HRAG_OK;
+    if (!(w == 128 || w == 64 || w == 8 || w == 4 || w == 2 || w == 1)) {
+        set_error("est_reduce: unsupported row width %d", w);
+        return HRAG_EINVAL;
+    }
+    const unsigned split = (unsigned)std::min<int64_t>(kEstSplit, std::max<int64_t>(1, (int64_t)n_chunks * w / 4096));
+    hipLaunchKernelGGL(est_reduce_kernel, dim3(split, (unsigned)n_slabs), dim3(256), 0, s, ws, n_chunks, w, slab0,
+                       batch, est, gate, gate_want);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr8_decide(int32_t *est_ck, float *est_prev, const int32_t *flags, int32_t batch, float kappa,
+                               float expo, float g, float tol, int32_t j, int32_t e_max, int32_t *ctl, int32_t n_ctl,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(ppr8_decide_kernel, dim3(1), dim3(256), 0, s, est_ck, est_prev, flags, batch, kappa, expo, g,
+                       tol, j, e_max, ctl, n_ctl);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

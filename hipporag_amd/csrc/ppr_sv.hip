@@ -90,9 +90,11 @@ __device__ __forceinline__ _Float16 to_half(float v) { return (_Float16)fminf(fm
 enum SvMode { kSvPlain = 0, kSvResid = 1, kSvCorr = 2, kSvFinal = 3 };
 
 // lane gl (< BP) of the group finishes column gl of the row
+// returns the relative size of the update when a.est asks for it (last sweep), else 0
 template <int BP, int MODE, typename T>
-__device__ __forceinline__ void sv_finish(const PprSvArgs &a, int row, int gl, float sum) {
-    if (gl >= BP) return;
+__device__ __forceinline__ float sv_finish(const PprSvArgs &a, int row, int gl, float sum) {
+    float er = 0.f;
+    if (gl >= BP) return er;
     const size_t at = (size_t)row * BP + gl;
     if constexpr (MODE == kSvPlain || MODE == kSvResid) {
         float t = 0.f;
@@ -101,11 +103,8 @@ __device__ __forceinline__ void sv_finish(const PprSvArgs &a, int row, int gl, f
         float out = fmaf(a.alpha, sum, a.beta * t);
         if constexpr (MODE == kSvResid) out = (out - (float)static_cast<const T *>(a.x)[at]) * a.cscale;
         if constexpr (MODE == kSvPlain && sizeof(T) == 4) {
-            if (a.est && gl < a.batch) {   // last sweep of the fp32 state: relative size of the update
-                const float r = out > 0.f ? fabsf(out - static_cast<const float *>(a.x)[at]) / out : 0.f;
-                const int bits = __float_as_int(r);
-                if (bits > a.est[gl]) atomicMax(&a.est[gl], bits);
-            }
+            if (a.est && gl < a.batch)    // last sweep of the fp32 state: relative size of the update
+                er = out > 0.f ? fabsf(out - static_cast<const float *>(a.x)[at]) / out : 0.f;
         }
         if constexpr (sizeof(T) == 2) static_cast<_Float16 *>(a.y)[at] = to_half(out);
         else static_cast<float *>(a.y)[at] = out;
@@ -116,13 +115,11 @@ __device__ __forceinline__ void sv_finish(const PprSvArgs &a, int row, int gl, f
         } else {
             const float x = fmaf(c, 1.0f / a.cscale, (float)reinterpret_cast<const _Float16 *>(a.h16)[at]);
             a.xout[at] = x;
-            if (a.est && gl < a.batch) {   // relative size of this (last) sweep's update
-                const float r = x > 0.f ? fabsf(c - (float)static_cast<const _Float16 *>(a.x)[at]) / (a.cscale * x) : 0.f;
-                const int bits = __float_as_int(r);
-                if (bits > a.est[gl]) atomicMax(&a.est[gl], bits);
-            }
+            if (a.est && gl < a.batch)    // relative size of this (last) sweep's update
+                er = x > 0.f ? fabsf(c - (float)static_cast<const _Float16 *>(a.x)[at]) / (a.cscale * x) : 0.f;
         }
     }
+    return er;
 }
 
 // MASK: the gathers of columns whose bit is clear in a.colmask are skipped (first sweep: x_0 = v is zero there)
@@ -178,8 +175,9 @@ __global__ __launch_bounds__(256) void ppr_sv_kernel(const PprSvArgs a) {
     for (int b = 1; b < BP; ++b) mine = gl == b ? acc[b] : mine;
     const int tgt = a.vrow[chunk * 8 + grp];
     const bool seg = tgt < 0 && tgt != kVrowNone;
+    float er = 0.f;
     if (tgt >= 0) {
-        sv_finish<BP, MODE, T>(a, tgt, gl, mine);
+        er = sv_finish<BP, MODE, T>(a, tgt, gl, mine);
     } else if (seg && gl < BP) {
         // write-through (sc1): another XCD's reader must find the value in memory, not in this XCD's L2
         __hip_atomic_store(&a.partial[(size_t)(-(tgt + 1)) * BP + gl], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -187,6 +185,12 @@ __global__ __launch_bounds__(256) void ppr_sv_kernel(const PprSvArgs a) {
     // Long rows (> kSell8SegLen entries) arrive as segments in different wavefronts.  The segment that
     // arrives LAST (agent-scope counter) adds the partial sums up -- always in segment order, with the whole
     // wavefront -- and finishes the row: no second kernel, and the result does not depend on who came last.
+    if (a.est) {   // wave-uniform.  The wavefront's maximum per column -> its slot of est_ws[chunk][BP] (plain stores;
+                   // launch_est_reduce takes the column maxima: no atomics per row)
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) er = fmaxf(er, __shfl_xor(er, o, 64));
+        if (grp == 0 && gl < BP) a.est_ws[(size_t)chunk * BP + gl] = er;
+    }
     if (__builtin_amdgcn_ballot_w64(seg) == 0) return;   // wave-uniform
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's partial sums have left the CU
     int m = -1;
@@ -212,7 +216,10 @@ __global__ __launch_bounds__(256) void ppr_sv_kernel(const PprSvArgs a) {
             for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
             tot = gl == b ? v : tot;
         }
-        if (grp == 0) sv_finish<BP, MODE, T>(a, a.lrow_row[mm], gl, tot);
+        if (grp == 0) {
+            const float e2 = sv_finish<BP, MODE, T>(a, a.lrow_row[mm], gl, tot);
+            if (a.est && gl < a.batch && e2 > 0.f) atomicMax(&a.est[gl], __float_as_int(e2));   // a handful of rows
+        }
         if (lane == 0) __hip_atomic_store(a.lcount + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -390,6 +397,7 @@ hrag_status sv_sweep_one(const PprSvArgs &a, bool main_only, hipStream_t s) {
         if (a.nt) hipLaunchKernelGGL((ppr_sv_kernel<BP, true, MODE, T, MASK>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((ppr_sv_kernel<BP, false, MODE, T, MASK>), grid, dim3(256), 0, s, a);
         HRAG_LAUNCH_CHECK();
+        if (a.est) HRAG_TRY(launch_est_reduce(a.est_ws, a.n_chunks, BP, 0, 1, a.batch, a.est, nullptr, 0, s));
     }
     (void)main_only;   // long rows are finished inside the sweep kernel (last-arriving segment)
     return HRAG_OK;

@@ -118,15 +118,15 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     HRAG_REQUIRE(n_stage >= 2 && n_stage <= kP8MaxStages, "ppr_iters=%d needs %d fp8 stages (2..%d)", iters, n_stage,
                  kP8MaxStages);
     // ---- convergence contract (reference: PRPACK iterates until its residual is below 1e-10, HippoRAG.py:1736-1743;
-    // here: `iters` sweeps always run, then the DEVICE may add stages of 3 sweeps while the measured update of the
+    // here: `iters` sweeps always run, then the DEVICE may add stages of 1, 2, 3, 3 sweeps while the measured update of the
     // passage scores predicts an error above tol).  Every conditional launch is enqueued; its gate word decides.
     const bool est = want_est || tol > 0.f;
     int e_max = 0;
-    if (tol > 0.f && max_iters > iters) {
-        e_max = std::min({(max_iters - iters) / 3, (30 - iters) / 3, kP8MaxExt, kP8MaxStages - n_stage});
-        e_max = std::max(e_max, 0);
-    }
-    for (int j = 0; j < e_max; ++j) plan[n_stage + j] = 3;
+    if (tol > 0.f && max_iters > iters)
+        while (e_max < std::min(kP8MaxExt, kP8MaxStages - n_stage) &&
+               iters + p8_ext_sweeps(e_max + 1) <= std::min(max_iters, 30))
+            ++e_max;
+    for (int j = 0; j < e_max; ++j) plan[n_stage + j] = p8_ext_sweeps(j + 1) - p8_ext_sweeps(j);   // 1, 2, 3, 3
     p.e_max = e_max; p.want_est = est; p.tol = tol;
     const double al = (double)damping;
     double bound = std::max(al, 1.0 - al) + 0.07;
@@ -179,10 +179,13 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
             const int rio = (r16 ? 1 : 0) | (out16 ? 2 : 0);
             Ppr8Step st{si == 0 ? kP8ModeB0 : kP8ModeB, si, c, y, rt, 1.0f / cs, cs_next, rio};
             if (si >= n_stage - 1) st.gate = si - (n_stage - 1);   // closes a stage that could have been the last
-            if (e_max > 0 && si >= n_stage - 2) {   // checkpoint: the last regular boundary and the extensions'
+            if (e_max > 0 && si >= n_stage - 3 && si > 0) {
+                // checkpoints: the two last regular boundaries (the first one only probes: the decisions work with
+                // the contraction measured between two checkpoints) and the extensions' boundaries
                 st.ckpt = 1;
-                st.decide = si - (n_stage - 2);
+                st.decide = si == n_stage - 3 ? -2 : si - (n_stage - 2);
                 st.kappa = kappa_for(plan[si + 1]);
+                st.expo = (float)plan[si + 1] / (float)plan[si];
             }
             p.steps[n++] = st;
             r16 = out16;
@@ -193,6 +196,7 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     p.n_steps = n;
     p.n_stage = n_stage;
     if (est) {
+        HRAG_HIP_TRY(hipMemsetAsync(e->d_est_prev, 0, (size_t)batch * sizeof(float), s));
         HRAG_HIP_TRY(hipMemsetAsync(e->d_est_ck, 0, (size_t)batch * sizeof(int32_t), s));
         HRAG_HIP_TRY(hipMemsetAsync(e->d_est_f, 0, (size_t)batch * sizeof(int32_t), s));
     }
@@ -250,7 +254,7 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
             for (int k = 0; k < st.stage; ++k) a.stage[k] = stage_copy(e, k);
             for (int k = 0; k <= st.stage; ++k) a.stage_inv[k] = p.stage_inv[k];
             a.n_stage = st.stage + 1;
-            a.est = e->d_est_ck;
+            a.est = e->d_est_ck; a.est_ws = e->d_est_ws;
         }
     } else {   // kP8ModeF: the passage rows only; stage st.stage is the last one
         a.rt = st.rt >= 0 ? p.buf[st.rt] : nullptr;
@@ -260,7 +264,7 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
         for (int k = 0; k <= st.stage; ++k) a.stage_inv[k] = p.stage_inv[k];
         a.n_stage = st.stage + 1;
         a.out = e->d_xp8;
-        if (p.want_est) a.est = e->d_est_f;
+        if (p.want_est) { a.est = e->d_est_f; a.est_ws = e->d_est_ws; }
     }
     if (exchange) *exchange = st.y;
     return launch_ppr8_sweep(a, st.mode, false, s);
@@ -270,10 +274,10 @@ hrag_status ppr8_decide(hrag_engine *e, int32_t i, hipStream_t s) {
     const Ppr8Session &p = e->p8;
     HRAG_REQUIRE(p.active && i >= 0 && i < p.n_steps, "no such step");
     const Ppr8Step &st = p.steps[i];
-    if (st.decide < 0) return HRAG_OK;
+    if (st.decide == -1) return HRAG_OK;
     const float g = p.damping / (1.0f - p.damping);
-    return launch_ppr8_decide(e->d_est_ck, p.flags, p.batch, st.kappa, g, p.tol, st.decide, p.e_max, e->d_ctl,
-                              kP8MaxExt + 1, s);
+    return launch_ppr8_decide(e->d_est_ck, e->d_est_prev, p.flags, p.batch, st.kappa, st.expo, g, p.tol, st.decide,
+                              p.e_max, e->d_ctl, kP8MaxExt + 1, s);
 }
 
 hrag_status ppr8_finalize(hrag_engine *e, int32_t *flags, hipStream_t s) {

@@ -199,7 +199,7 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q_fact_dev, int32_t
  *                   (the error a contraction with factor `damping` has left after an update of that size), and
  *                   keeps sweeping -- decided ON THE DEVICE from the same measure at a checkpoint sweep, no host
  *                   synchronisation -- while the prediction for the batch is above ppr_tol and fewer than
- *                   ppr_max_iters sweeps ran.  The fp8-state path (batch > 64) extends in stages of 3 sweeps up
+ *                   ppr_max_iters sweeps ran.  The fp8-state path (batch > 64) extends in stages of 1, 2, 3, 3 sweeps up
  *                   to 30; the other state types run the fixed count and report.
  *   ppr_max_iters   upper bound on the sweeps (>= ppr_iters; ignored when ppr_tol == 0)
  *   residual_out_dev fp32 [B] (may be NULL): the residual above for the sweeps that ran (0 on the DPR fallback)

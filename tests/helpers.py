@@ -44,3 +44,14 @@ def tie_aware_equal(got_ids, ref_ids, ref_scores, rel_gap=4e-6, abs_gap=0.0):
             return False
         start = end
     return True
+
+
+def tie_aware_report(got_ids, ref_ids, ref_scores, rel_gap=4e-6, abs_gap=0.0):
+    """tie_aware_equal plus HOW MUCH of the agreement is exact: {"equal": the tie-class-aware verdict,
+    "exact_positions": ranks at which the two id lists agree outright, "n": ranks compared}.  The ranks that
+    only agree as members of a tie class are n - exact_positions."""
+    got = np.asarray(got_ids)
+    ref = np.asarray(ref_ids)
+    same = int((got == ref).sum()) if got.shape == ref.shape else 0
+    return {"equal": bool(tie_aware_equal(got, ref, ref_scores, rel_gap=rel_gap, abs_gap=abs_gap)),
+            "exact_positions": same, "n": int(ref.size)}

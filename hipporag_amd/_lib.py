@@ -44,7 +44,7 @@ class FactDesc(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("max_batch", C.c_int32), ("max_topk", C.c_int32), ("slab_width", C.c_int32),
                 ("long_row_nnz", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32),
-                ("segment_nnz", C.c_int32), ("reserved", C.c_int32 * 9)]
+                ("segment_nnz", C.c_int32), ("sell_seg_len", C.c_int32), ("reserved", C.c_int32 * 8)]
 
 
 class Timings(C.Structure):

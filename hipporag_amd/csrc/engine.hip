@@ -92,7 +92,8 @@ hrag_status ppr_step(hrag_engine *e, const float *tele, int64_t tele_rows, const
 // entries x 4 slabs, 18 ms sweeps) prefers 2048 (1294 queries/s; 1264 at 512: every segment pays ~4 us for its
 // write-through and arrival; 1269 at 8192: imbalance).  Hence a rule in the work of one sweep, entries x 128-query slabs.
 // HRAG_SELL8_SEG_LEN overrides (experiments).
-int32_t sell8_seg_len(int64_t nnz_owned, int max_batch) {
+int32_t sell8_seg_len(int64_t nnz_owned, int max_batch, int32_t asked = 0) {
+    if (asked >= 8 && asked <= 1 << 20) return (int32_t)round_up(asked, 8);   // hrag_opts.sell_seg_len
     if (const char *env = std::getenv("HRAG_SELL8_SEG_LEN")) {
         const int v = std::atoi(env);
         if (v >= 8 && v <= 1 << 20) return (int32_t)round_up(v, 8);
@@ -117,7 +118,7 @@ hrag_status build_sell8(const hrag_engine *e, const std::vector<int32_t> &row_pt
     vr.reserve((size_t)n_sel + 1024);
     std::vector<int32_t> lrow_row, lrow_first, lrow_cnt, seg_lrow;
     int32_t n_partial = 0;
-    const int32_t max_len = sell8_seg_len(row_ptr[(size_t)e->n_rows], e->max_batch);
+    const int32_t max_len = sell8_seg_len(row_ptr[(size_t)e->n_rows], e->max_batch, e->sell_seg_len);
     for (int64_t k = 0; k < n_sel; ++k) {
         const int64_t r = rows ? (*rows)[(size_t)k] : k;
         const int32_t b0 = row_ptr[(size_t)r], len = row_ptr[(size_t)r + 1] - b0;
@@ -438,6 +439,7 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     // a short row is walked by G lanes in deg/G dependent gather rounds: cap it at 8 rounds
     e->short_thresh = opts->long_row_nnz > 0 ? opts->long_row_nnz : 8 * (e->slab_cap / 4);
     e->seg_len = opts->segment_nnz > 0 ? (int)round_up(opts->segment_nnz, 64) : 512;
+    e->sell_seg_len = opts->sell_seg_len;
     e->opt_flags = opts->flags;
 
     // ---- CSR to the device; row lists on the host (copy row_ptr back if it came from the device)

@@ -124,7 +124,7 @@ struct hrag_engine {
     uint16_t *d_pemb = nullptr, *d_femb = nullptr;
     int32_t *d_subj = nullptr, *d_obj = nullptr, *d_num_chunks = nullptr;
     // options
-    int32_t max_batch = 0, max_topk = 0, slab_cap = 32, short_thresh = 0, seg_len = 0, opt_flags = 0;
+    int32_t max_batch = 0, max_topk = 0, slab_cap = 32, short_thresh = 0, seg_len = 0, opt_flags = 0, sell_seg_len = 0;
     // workspace
     int64_t state_elems = 0;  // floats in each of d_x / d_y
     float *d_x = nullptr, *d_y = nullptr, *d_tele = nullptr, *d_tele_dense = nullptr;

@@ -289,7 +289,7 @@ def shard_index(csr, passage_vertex, world: int, subj_vertex=None, obj_vertex=No
 
 
 def build_shard_engine(sidx: ShardedIndex, pass_emb, fact_emb, rank: int, max_batch: int, max_topk: int,
-                       flags: int = 0):
+                       flags: int = 0, sell_seg_len: int = 0):
     """The engine of shard `rank` of a ShardedIndex (full embedding matrices are sliced here)."""
     from .engine import HippoRAGEngine
     rps = sidx.rows_per_shard
@@ -301,7 +301,7 @@ def build_shard_engine(sidx: ShardedIndex, pass_emb, fact_emb, rank: int, max_ba
                           sidx.obj_vertex if has_facts else None, sidx.num_chunks if has_facts else None,
                           max_batch=max_batch, max_topk=max_topk, row_offset=rank * rps, passage_offset=p_lo,
                           fact_offset=f_lo, n_passages=len(sidx.passage_vertex),
-                          n_facts=sidx.facts[-1][1] if has_facts else None, flags=flags)
+                          n_facts=sidx.facts[-1][1] if has_facts else None, flags=flags, sell_seg_len=sell_seg_len)
 
 
 class TorchComm:
@@ -335,6 +335,10 @@ class TorchComm:
             return None
         if lay.own_offset != self.rank * lay.own_bytes:
             raise ValueError("state exchange needs equal-sized row shards in rank order (dist.shard_index)")
+        if self.world * lay.own_bytes + lay.slabs_per_group * 128 > lay.group_bytes:
+            # the gathered region must end before the group's last row (row V, which stays zero: the target of the
+            # masked-out gathers of the first sweep)
+            raise ValueError("state exchange would overwrite the zero row: shards do not tile [0, V)")
         base = g * lay.group_bytes
         out = buf[base: base + self.world * lay.own_bytes]
         inp = buf[base + lay.own_offset: base + lay.own_offset + lay.own_bytes]
@@ -470,6 +474,60 @@ class ShardedRetriever:
         sat = (flags & 8).contiguous()               # raised on the shard that owns the row that saturated
         c.all_reduce(sat, "max")
         return top_idx, top_val, flags | sat
+
+
+def run_local_shards(world: int, sidx: "ShardedIndex", pass_emb, fact_emb, q_fact, q_pass, retrieve_kw: dict,
+                     groups: int, device, max_topk: int, filter_fn=None, timings: Optional[dict] = None,
+                     sell_seg_len: int = 0):
+    """All `world` shards of `sidx` as threads of THIS process on ONE device, meeting at barriers (LocalComm) and
+    sharing the three e4m3 state buffers: the emulated gather SURVEY.md 8(e) prescribes.  Returns rank 0's
+    (fact idx, fact score, doc idx, doc score, flags) as numpy arrays after checking that every rank computed the
+    same replicated result.  Used by tests/test_gpu_shard.py and by `bench.py --config cfg4local` (the parity-checked
+    form of BASELINE configs[3] when only one GPU is at hand)."""
+    import threading
+    torch = _td()[0]
+    from .engine import ShardStages
+    shared, results, errors = {}, [None] * world, []
+    b = q_fact.shape[0]
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(device)
+            eng = build_shard_engine(sidx, pass_emb, fact_emb, rank, max_batch=b, max_topk=max_topk,
+                                     sell_seg_len=sell_seg_len)
+            rs = ShardedRetriever(ShardStages(eng), LocalComm(rank, world, shared), groups=groups)
+            torch.cuda.synchronize()
+            shared["_barrier"].wait()
+            t0 = time.perf_counter()
+            idx, sc = rs.score_facts(q_fact, k=5)
+            cnt = torch.full((b,), 5, dtype=torch.int32, device=device)
+            if filter_fn is not None:
+                idx, sc, cnt = filter_fn(idx, sc)
+            d_idx, d_sc, flags = rs.retrieve(q_pass, idx, sc, cnt, **retrieve_kw)
+            torch.cuda.synchronize()
+            if timings is not None and rank == 0:
+                timings["wall_s_all_shards_on_one_device"] = time.perf_counter() - t0
+            results[rank] = tuple(t.cpu().numpy() for t in (idx, sc, d_idx, d_sc, flags))
+            shared["_barrier"].wait()          # nobody frees its engine while another shard still runs
+            eng.close()
+        except Exception as exc:               # a dead shard must not leave the others at a barrier for ever
+            errors.append((rank, exc))
+            try:
+                shared["_barrier"].abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=1200)
+    if errors:
+        raise RuntimeError(f"shard threads failed: {errors}")
+    for r in range(1, world):
+        for a, w in zip(results[r], results[0]):
+            np.testing.assert_array_equal(a, w)
+    return results[0]
 
 
 # --------------------------------------------------------------------------------------------

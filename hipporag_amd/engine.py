@@ -87,7 +87,7 @@ class HippoRAGEngine:
                  max_topk: int = 200, slab_width: int = 0, long_row_nnz: int = 0,
                  row_offset: int = 0, passage_offset: int = 0, fact_offset: int = 0,
                  n_passages: Optional[int] = None, n_facts: Optional[int] = None,
-                 device: Optional[int] = None, flags: int = 0, segment_nnz: int = 0):
+                 device: Optional[int] = None, flags: int = 0, segment_nnz: int = 0, sell_seg_len: int = 0):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("HippoRAGEngine needs an MI355X-class GPU: no HIP device is visible "
@@ -133,7 +133,7 @@ class HippoRAGEngine:
             fd = FactDesc(self.n_facts, _ptr(sv), _ptr(ov), _ptr(nc))
             keep += [f_obj, sv, ov, nc]
         self.opt_flags = int(flags)      # HRAG_OPT_* bits as set_flags leaves them
-        opts = Opts(max_batch, max_topk, slab_width, long_row_nnz, self.device.index, flags, segment_nnz)
+        opts = Opts(max_batch, max_topk, slab_width, long_row_nnz, self.device.index, flags, segment_nnz, sell_seg_len)
         with torch.cuda.device(self.device):
             check(self._lib.hrag_engine_create(C.byref(gd), C.byref(fdesc) if fdesc else None,
                                                C.byref(pd), C.byref(fd) if fd else None,

@@ -134,7 +134,12 @@ typedef struct hrag_opts {
     int32_t device;       /* HIP device ordinal, -1 = current                                    */
     int32_t flags;        /* tuning bits, 0 = defaults: HRAG_OPT_*                                  */
     int32_t segment_nnz;  /* entries per long-row segment (multiple of 64); 0 = auto (512)          */
-    int32_t reserved[9];
+    int32_t sell_seg_len; /* SELL-8 matrices (fp8 / fp16 / small-batch sweeps): rows longer than this are cut into */
+                          /* segments whose partial sums are added in a fixed order.  0 = auto, from the work of one */
+                          /* sweep of THIS engine (64 .. 2048).  The cut decides the summation order of long rows, so */
+                          /* engines whose results must agree bit for bit (the row shards of a graph and the unsharded */
+                          /* engine on it) have to be created with the same explicit value                            */
+    int32_t reserved[8];
 } hrag_opts;
 
 /* Phase timings of the last hrag_retrieve / hrag_score_facts on an engine, measured

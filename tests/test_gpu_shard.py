@@ -5,8 +5,6 @@ sweep is computed by exactly one shard from the same replicated iterate, in the 
 additions as the single-GPU kernel, so the result must be BIT-IDENTICAL to the unsharded engine on the
 same (relabelled) index, and within the 1e-5 parity bar of the oracle on the original index."""
 
-import threading
-
 import numpy as np
 import pytest
 
@@ -24,45 +22,10 @@ def _bf16(bits, device):
 
 
 def _run_shards(world, sidx, pass_bits, fact_bits, qf, qp, kw, groups, device, max_topk, filter_fn=None):
-    """All shards of `sidx` as threads on one device; returns rank 0's (fact idx, fact score, doc idx,
-    doc score, flags) and asserts that every rank computed the same replicated result."""
-    import torch
+    """All shards of `sidx` as threads on one device (dist.run_local_shards); returns rank 0's (fact idx, fact
+    score, doc idx, doc score, flags) after asserting that every rank computed the same replicated result."""
     from hipporag_amd import dist as hd
-    from hipporag_amd.engine import ShardStages
-    shared, results, errors = {}, [None] * world, []
-    b = qf.shape[0]
-
-    def worker(rank):
-        try:
-            torch.cuda.set_device(device)
-            eng = hd.build_shard_engine(sidx, pass_bits, fact_bits, rank, max_batch=b, max_topk=max_topk)
-            rs = hd.ShardedRetriever(ShardStages(eng), hd.LocalComm(rank, world, shared), groups=groups)
-            idx, sc = rs.score_facts(qf, k=5)
-            cnt = torch.full((b,), 5, dtype=torch.int32, device=device)
-            if filter_fn is not None:
-                idx, sc, cnt = filter_fn(idx, sc)
-            d_idx, d_sc, flags = rs.retrieve(qp, idx, sc, cnt, **kw)
-            torch.cuda.synchronize()
-            results[rank] = tuple(t.cpu().numpy() for t in (idx, sc, d_idx, d_sc, flags))
-            shared["_barrier"].wait()          # nobody frees its engine while another shard still runs
-            eng.close()
-        except Exception as exc:               # a dead shard must not leave the others at a barrier for ever
-            errors.append((rank, exc))
-            try:
-                shared["_barrier"].abort()
-            except Exception:
-                pass
-
-    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(timeout=600)
-    assert not errors, errors
-    for r in range(1, world):
-        for a, w in zip(results[r], results[0]):
-            np.testing.assert_array_equal(a, w)
-    return results[0]
+    return hd.run_local_shards(world, sidx, pass_bits, fact_bits, qf, qp, kw, groups, device, max_topk, filter_fn)
 
 
 @pytest.mark.parametrize("world,b,groups,iters", [(8, 130, 2, 20), (8, 256, 1, 20), (3, 70, 0, 24), (2, 40, 2, 20)])

@@ -398,6 +398,9 @@ hrag_status launch_row_topk(const float *scores, int32_t batch, int64_t n, int64
 hrag_status launch_row_minmax(const float *scores, int32_t batch, int64_t n, int64_t ld,
                               float *mn_out, float *mx_out, hipStream_t s, float *sum_out = nullptr);
 
+// knn.hip : fp32 rows -> the 3 * dim bf16 layout of HRAG_F32_SPLIT engines ([hi | lo | hi]; queries [hi | hi | lo])
+hrag_status launch_split3(const float *x, int64_t rows, int32_t dim, int32_t as_query, uint16_t *out, hipStream_t s);
+
 // seeds.hip
 hrag_status launch_build_seeds(const int32_t *kept_idx, const float *kept_score,
                                const int32_t *kept_count, int32_t kf, int32_t link_top_k,

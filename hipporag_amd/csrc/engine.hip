@@ -39,7 +39,7 @@ void free_engine(hrag_engine *e) {
                     e->d_stagep, e->d_pool8[0], e->d_pool8[1], e->d_pool8[2], e->d_sv16[0], e->d_sv16[1],
                     e->d_sv16[2], e->d_sv16[3], e->d_zmax_bits, e->d_zmax,
                     e->d_mass, e->d_prior_part, e->d_est_ck, e->d_est_f, e->d_ctl, e->d_iters_used, e->d_resid,
-                    e->d_mass_tab, e->d_est_prev, e->d_est_ws};
+                    e->d_mass_tab, e->d_est_prev, e->d_est_ws, e->d_qsplit};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_store(e->sell);
@@ -407,8 +407,11 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     HRAG_REQUIRE(g->nnz >= 0 && g->nnz < (int64_t)0x7fffffff, "nnz must fit int32");
     HRAG_REQUIRE(g->row_ptr && (g->nnz == 0 || (g->col_idx && g->val)), "CSR arrays missing");
     HRAG_REQUIRE(g->n_passages >= 0 && (g->n_passages == 0 || g->passage_vertex), "passage_vertex missing");
-    HRAG_REQUIRE(passages->dtype == HRAG_BF16 || passages->dtype == HRAG_FP16, "embeddings must be bf16 or fp16");
-    HRAG_REQUIRE(!facts || facts->dtype == passages->dtype, "fact / passage embedding dtypes differ");
+    auto split_dt = [](int dt) { return dt == HRAG_F32_SPLIT || dt == HRAG_F32_SPLIT_ROWS; };
+    HRAG_REQUIRE(passages->dtype == HRAG_BF16 || passages->dtype == HRAG_FP16 || split_dt(passages->dtype),
+                 "embeddings must be bf16, fp16 or fp32 (HRAG_F32_SPLIT / HRAG_F32_SPLIT_ROWS)");
+    HRAG_REQUIRE(!facts || facts->dtype == passages->dtype || (split_dt(facts->dtype) && split_dt(passages->dtype)),
+                 "fact / passage embedding dtypes differ");
     HRAG_REQUIRE(passages->dim > 0 && passages->dim % 8 == 0, "embedding dim must be a multiple of 8");
     HRAG_REQUIRE(!facts || facts->dim == passages->dim, "fact / passage dims differ");
     HRAG_REQUIRE((facts == nullptr) == (fd == nullptr), "facts and fact_desc go together");
@@ -621,11 +624,27 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     }
     // ---- embeddings + fact lookup arrays
     e->dim = passages->dim;
-    e->emb_dtype = passages->dtype;
-    E_TRY(dev_upload(&e->d_pemb, static_cast<const uint16_t *>(passages->data), e->p_rows * e->dim));
+    e->split = split_dt(passages->dtype);
+    e->emb_dtype = e->split ? (int32_t)HRAG_FP16 : (int32_t)passages->dtype;   // the halves of a split vector are fp16
+    e->kdim = e->split ? 3 * e->dim : e->dim;
+    // fp32 rows are split on the device into [hi | lo | hi] (knn.hip); the fp32 copy is transient
+    auto upload_emb = [&](uint16_t **dst, const void *data, int64_t rows, int dt) -> hrag_status {
+        if (!e->split) return dev_upload(dst, static_cast<const uint16_t *>(data), rows * e->dim);
+        if (dt == HRAG_F32_SPLIT_ROWS) return dev_upload(dst, static_cast<const uint16_t *>(data), rows * e->kdim);
+        HRAG_TRY(dev_alloc(dst, rows * e->kdim));
+        float *tmp = nullptr;
+        HRAG_TRY(dev_upload(&tmp, static_cast<const float *>(data), rows * e->dim));
+        hrag_status st = launch_split3(tmp, rows, e->dim, 0, *dst, nullptr);
+        hipError_t err = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (st == HRAG_OK && err != hipSuccess) { set_error("split of the fp32 embeddings failed: %s", hipGetErrorString(err)); st = HRAG_EHIP; }
+        return st;
+    };
+    E_TRY(upload_emb(&e->d_pemb, passages->data, e->p_rows, passages->dtype));
+    if (e->split) E_TRY(dev_alloc(&e->d_qsplit, (int64_t)opts->max_batch * e->kdim));
     if (facts) {
         e->f_rows = facts->rows; e->f_offset = facts->row_offset; e->n_facts = fd->n_facts;
-        E_TRY(dev_upload(&e->d_femb, static_cast<const uint16_t *>(facts->data), e->f_rows * e->dim));
+        E_TRY(upload_emb(&e->d_femb, facts->data, e->f_rows, facts->dtype));
         E_TRY(dev_upload(&e->d_subj, fd->subj_vertex, e->n_facts));
         E_TRY(dev_upload(&e->d_obj, fd->obj_vertex, e->n_facts));
         E_TRY(dev_upload(&e->d_num_chunks, fd->num_chunks, e->V));
@@ -801,11 +820,12 @@ hrag_status hrag_sim_scores(hrag_engine *e, int32_t which, const uint16_t *q, in
     HRAG_REQUIRE(e && q && out, "NULL argument");
     HRAG_REQUIRE(batch >= 1, "batch must be >= 1");
     HRAG_REQUIRE(which == 0 || which == 1, "which must be 0 (facts) or 1 (passages)");
+    HRAG_TRY(prep_query(e, q, batch, (hipStream_t)stream, &q));
     if (which == 0) {
         HRAG_REQUIRE(e->d_femb != nullptr || e->f_rows == 0, "engine has no fact embeddings");
-        return launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, out, e->f_rows, (hipStream_t)stream, 0, e->emb_dtype);
+        return launch_sim_gemm(e->d_femb, e->f_rows, e->kdim, q, batch, out, e->f_rows, (hipStream_t)stream, 0, e->emb_dtype);
     }
-    return launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q, batch, out, e->p_rows, (hipStream_t)stream, 0, e->emb_dtype);
+    return launch_sim_gemm(e->d_pemb, e->p_rows, e->kdim, q, batch, out, e->p_rows, (hipStream_t)stream, 0, e->emb_dtype);
 }
 
 hrag_status hrag_row_minmax(const float *scores, int32_t batch, int64_t n, int64_t ld, float *mn,
@@ -831,13 +851,14 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q, int32_t batch, i
                  "engine goes through hrag_sim_scores + hrag_topk_rows + an all-gather");
     hipStream_t s = (hipStream_t)stream;
     if (e->profiling) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_FACT0], s));
+    HRAG_TRY(prep_query(e, q, batch, s, &q));
     if (batch > 16 && k <= 16 && e->f_rows > 0 && e->d_fused_ws) {
         // no [B, F] score matrix: tile maxima -> k tiles per query -> exact top-k of k * 128 recomputed
         // scores (bit-identical to the two-step path below; sim_gemm.hip)
-        HRAG_TRY(launch_sim_topk_fused(e->d_femb, e->f_rows, e->dim, q, batch, k, 0, 1, e->d_fused_ws,
+        HRAG_TRY(launch_sim_topk_fused(e->d_femb, e->f_rows, e->kdim, q, batch, k, 0, 1, e->d_fused_ws,
                                        e->d_fused_sel, e->d_mn_f, e->d_mx_f, idx_out, score_out, s, e->emb_dtype));
     } else {
-        HRAG_TRY(launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, e->d_sfact, e->ld_f, s, 0, e->emb_dtype));
+        HRAG_TRY(launch_sim_gemm(e->d_femb, e->f_rows, e->kdim, q, batch, e->d_sfact, e->ld_f, s, 0, e->emb_dtype));
         // get_fact_scores' min_max_normalize + rerank_facts' argsort prefix in one kernel
         HRAG_TRY(launch_row_topk(e->d_sfact, batch, e->f_rows, e->ld_f, k, 0, kNormMinMax, idx_out, score_out,
                                  nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
@@ -949,7 +970,8 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     if (est) HRAG_HIP_TRY(hipMemsetAsync(est, 0, (size_t)batch * sizeof(int32_t), s));
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_START], s));
     // dense_passage_retrieval: raw scores + min / max (HippoRAG.py:1496-1498)
-    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
+    HRAG_TRY(prep_query(e, q_pass, batch, s, &q_pass));
+    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->kdim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
     const bool sv_half = sv && use_sv_half(e, ppr_iters);
     HRAG_TRY(launch_row_minmax(e->d_spass, batch, e->n_passages, e->ld_p, e->d_mn_p, e->d_mx_p, s,
                                (f16 || sv_half) ? e->d_ssum : nullptr));
@@ -1103,7 +1125,8 @@ hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t 
     HRAG_REQUIRE(e->p_rows == e->n_passages, "hrag_dense_retrieve needs the whole passage matrix");
     HRAG_REQUIRE(k >= 1 && k <= e->max_topk, "k=%d outside [1, max_topk=%d]", k, e->max_topk);
     hipStream_t s = (hipStream_t)stream;
-    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
+    HRAG_TRY(prep_query(e, q_pass, batch, s, &q_pass));
+    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->kdim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
     return launch_row_topk(e->d_spass, batch, e->n_passages, e->ld_p, k, 0, kNormMinMax, doc_idx_out,
                            doc_score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes);
 }

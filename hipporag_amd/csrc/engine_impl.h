@@ -119,7 +119,10 @@ struct hrag_engine {
     int32_t *d_passage_vertex = nullptr;  // [Np] global vertex ids
     int32_t *d_row_to_tele = nullptr;     // [n_rows] global passage index of an owned row, or -1
     // embeddings (owned rows)
-    int32_t dim = 0, emb_dtype = HRAG_BF16;
+    int32_t dim = 0, emb_dtype = HRAG_BF16;   // emb_dtype: what the similarity kernels see (fp16 on a split engine)
+    int32_t kdim = 0;              // elements per stored row / per query as the kernels see them: dim, or 3 * dim (split)
+    bool split = false;            // HRAG_F32_SPLIT: rows [hi | lo | hi], queries arrive as fp32 and become [hi | hi | lo]
+    uint16_t *d_qsplit = nullptr;  // [max_batch][3 * dim] the current call's queries in that layout
     int64_t p_rows = 0, p_offset = 0, f_rows = 0, f_offset = 0, n_facts = 0;
     uint16_t *d_pemb = nullptr, *d_femb = nullptr;
     int32_t *d_subj = nullptr, *d_obj = nullptr, *d_num_chunks = nullptr;
@@ -206,6 +209,19 @@ struct hrag_engine {
 };
 
 namespace hrag {
+// the query matrix as the similarity kernels take it: the caller's pointer, or (HRAG_F32_SPLIT) its fp32 rows split
+// into [hi | hi | lo] in the engine's buffer (one call in flight per engine: include/hrag.h)
+inline hrag_status prep_query(hrag_engine *e, const uint16_t *q, int32_t batch, hipStream_t s, const uint16_t **out) {
+    *out = q;
+    if (!e->split) return HRAG_OK;
+    if (batch < 1 || batch > e->max_batch) {
+        set_error("batch %d outside [1, max_batch=%d]", batch, e->max_batch);
+        return HRAG_ECAPACITY;
+    }
+    HRAG_TRY(launch_split3(reinterpret_cast<const float *>(q), batch, e->dim, 1, e->d_qsplit, s));
+    *out = e->d_qsplit;
+    return HRAG_OK;
+}
 // ---- shared between engine.hip and shard.hip
 // The fp8 path serves a batch when the truncation error of `iters` sweeps is below the parity bar
 // (damping^iters <= 2^-18) and the stage plan fits.

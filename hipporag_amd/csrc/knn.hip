@@ -43,7 +43,38 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float *__res
     }
 }
 
+// fp32-faithful similarity (HRAG_F32_SPLIT): a vector x = hi + lo, both IEEE fp16 (11 + 11 significant bits: x to
+// 2^-22 |x|; components are <= 1 in magnitude, unit vectors), is laid out over 3 * dim fp16 elements so that ONE fp16
+// MFMA dot product of a stored row with a query is  hi.qhi + lo.qhi + hi.qlo  -- every partial product is exact in
+// the fp32 accumulator, the dropped lo.qlo term is <= 2^-22 |x||q| -- through every similarity kernel unchanged:
+//   embedding row: [hi | lo | hi]        query: [qhi | qhi | qlo]
+// (bf16 halves, 8 + 8 bits, were tried first: 1.5e-6 off the reference's fp32 scores, enough to move the prior of
+// the lowest-ranked passages by 1e-3 relative.)  One wavefront per row.
+__global__ __launch_bounds__(256) void split3_kernel(const float *__restrict__ x, int64_t rows, int32_t dim,
+                                                     int32_t as_query, uint16_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * dim;
+    _Float16 *o = reinterpret_cast<_Float16 *>(out) + (size_t)row * dim * 3;
+    for (int k = lane; k < dim; k += 64) {
+        const float v = xr[k];
+        const _Float16 h = (_Float16)v;                 // round to nearest even
+        const _Float16 l = (_Float16)(v - (float)h);
+        o[k] = h;
+        o[dim + k] = as_query ? h : l;
+        o[2 * dim + k] = as_query ? l : h;
+    }
+}
+
 }  // namespace
+
+hrag_status launch_split3(const float *x, int64_t rows, int32_t dim, int32_t as_query, uint16_t *out, hipStream_t s) {
+    if (rows <= 0) return HRAG_OK;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, x, rows, dim, as_query, out);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
 }  // namespace hrag
 
 using namespace hrag;
@@ -58,6 +89,12 @@ hrag_status hrag_normalize_split_bf16(const float *x_dev, int64_t rows, int32_t 
                        (hipStream_t)stream, x_dev, rows, dim, normalize, hi_dev, lo_dev);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
+}
+
+hrag_status hrag_split_f32(const float *x_dev, int64_t rows, int32_t dim, int32_t as_query, uint16_t *out_dev,
+                           hrag_stream stream) {
+    HRAG_REQUIRE(x_dev && out_dev && rows >= 0 && dim > 0, "bad argument");
+    return launch_split3(x_dev, rows, dim, as_query, out_dev, (hipStream_t)stream);
 }
 
 hrag_status hrag_sim_gemm(const uint16_t *emb_dev, int64_t rows, int32_t dim, const uint16_t *q_dev,

@@ -361,10 +361,11 @@ hrag_status hrag_shard_score_facts(hrag_engine *e, const uint16_t *q, int32_t ba
         HRAG_HIP_TRY(hipMemsetAsync(score_out, 0, (size_t)batch * k * sizeof(float), s));
         return fill_minmax_neutral(mn_out, mx_out, batch, s);
     }
+    HRAG_TRY(prep_query(e, q, batch, s, &q));
     if (batch > 16 && k <= 16 && e->d_fused_ws)
-        return launch_sim_topk_fused(e->d_femb, e->f_rows, e->dim, q, batch, k, (int32_t)e->f_offset, 0, e->d_fused_ws,
+        return launch_sim_topk_fused(e->d_femb, e->f_rows, e->kdim, q, batch, k, (int32_t)e->f_offset, 0, e->d_fused_ws,
                                      e->d_fused_sel, mn_out, mx_out, idx_out, score_out, s, e->emb_dtype);
-    HRAG_TRY(launch_sim_gemm(e->d_femb, e->f_rows, e->dim, q, batch, e->d_sfact, e->ld_f, s, 0, e->emb_dtype));
+    HRAG_TRY(launch_sim_gemm(e->d_femb, e->f_rows, e->kdim, q, batch, e->d_sfact, e->ld_f, s, 0, e->emb_dtype));
     return launch_row_topk(e->d_sfact, batch, e->f_rows, e->ld_f, k, (int32_t)e->f_offset, kNormNone, idx_out,
                            score_out, mn_out, mx_out, s, e->d_topk_ws, kTopkWsBytes);
 }
@@ -376,7 +377,8 @@ hrag_status hrag_shard_passage_scores(hrag_engine *e, const uint16_t *q, int32_t
     HRAG_REQUIRE(e->shard_aligned, "the passage embedding shard must hold exactly the passages of the owned rows");
     hipStream_t s = (hipStream_t)stream;
     if (e->p_rows == 0) return fill_minmax_neutral(mn_out, mx_out, batch, s);
-    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->dim, q, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
+    HRAG_TRY(prep_query(e, q, batch, s, &q));
+    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->kdim, q, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
     return launch_row_minmax(e->d_spass, batch, e->p_rows, e->ld_p, mn_out, mx_out, s);
 }
 
@@ -437,7 +439,7 @@ hrag_status hrag_engine_gather_embeddings(hrag_engine *e, int32_t which, const i
     HRAG_REQUIRE(which == 0 || which == 1, "which must be 0 (facts) or 1 (passages)");
     const void *emb = which == 0 ? (const void *)e->d_femb : (const void *)e->d_pemb;
     HRAG_REQUIRE(emb != nullptr || (which == 0 ? e->f_rows : e->p_rows) == 0, "engine holds no such embeddings");
-    return launch_gather_rows(emb, new_rows, src_rows, n, e->dim * 2, out, (hipStream_t)stream);
+    return launch_gather_rows(emb, new_rows, src_rows, n, e->kdim * 2, out, (hipStream_t)stream);
 }
 
 hrag_status hrag_engine_set_flags(hrag_engine *e, int32_t flags, int32_t on) {

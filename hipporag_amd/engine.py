@@ -42,23 +42,44 @@ def _stream() -> int:
     return _torch().cuda.current_stream().cuda_stream
 
 
+class SplitRows:
+    """Embedding rows already in an HRAG_F32_SPLIT engine's layout (fp16 [rows, 3 * dim] on the device): what
+    gather_embeddings returns on such an engine, accepted by the constructor (HRAG_F32_SPLIT_ROWS)."""
+
+    def __init__(self, tensor, dim: int):
+        self.tensor, self.dim = tensor, int(dim)
+        self.shape = (tensor.shape[0], self.dim)
+
+    def __getitem__(self, rows):        # row slices (dist.build_shard_engine)
+        return SplitRows(self.tensor[rows], self.dim)
+
+
 def _as_16bit(emb):
-    """Accept a torch bf16 / fp16 tensor, a numpy float16 array, or uint16 bf16 bit patterns (numpy /
-    torch); return (obj, rows, dim, dtype) with dtype 0 = bf16, 1 = fp16 (hrag_dtype)."""
+    """Accept a torch bf16 / fp16 tensor, a numpy float16 array, uint16 bf16 bit patterns (numpy / torch), or fp32
+    (numpy / torch: the fp32-faithful HRAG_F32_SPLIT engine); return (obj, rows, dim, dtype) with dtype 0 = bf16,
+    1 = fp16, 2 = fp32 split (hrag_dtype)."""
     torch = _torch()
+    if isinstance(emb, SplitRows):
+        return emb.tensor.contiguous(), emb.tensor.shape[0], emb.dim, 3
     if isinstance(emb, np.ndarray):
+        if emb.dtype == np.float32:
+            emb = np.ascontiguousarray(emb)
+            return emb, emb.shape[0], emb.shape[1], 2
         if emb.dtype == np.float16:
             emb = np.ascontiguousarray(emb)
             return emb, emb.shape[0], emb.shape[1], 1
         if emb.dtype != np.uint16:
-            raise TypeError("numpy embeddings must be float16, or uint16 bf16 bit patterns "
-                            "(hipporag_amd.graph.float_to_bf16_bits)")
+            raise TypeError("numpy embeddings must be float32 (fp32-faithful engine), float16, or uint16 bf16 bit "
+                            "patterns (hipporag_amd.graph.float_to_bf16_bits)")
         emb = np.ascontiguousarray(emb)
         return emb, emb.shape[0], emb.shape[1], 0
-    if emb.dtype not in (torch.bfloat16, torch.float16, torch.uint16, torch.int16):
-        raise TypeError("tensor embeddings must be torch.bfloat16 or torch.float16 (or raw bf16 bit patterns)")
+    if emb.dtype not in (torch.bfloat16, torch.float16, torch.uint16, torch.int16, torch.float32):
+        raise TypeError("tensor embeddings must be torch.float32, torch.bfloat16 or torch.float16 (or raw bf16 bit patterns)")
     emb = emb.contiguous()
-    return emb, emb.shape[0], emb.shape[1], 1 if emb.dtype == torch.float16 else 0
+    return emb, emb.shape[0], emb.shape[1], 2 if emb.dtype == torch.float32 else 1 if emb.dtype == torch.float16 else 0
+
+
+_TORCH_DTYPE_OF = {0: "bfloat16", 1: "float16", 2: "float32", 3: "float32"}
 
 
 @dataclass
@@ -99,7 +120,8 @@ class HippoRAGEngine:
         pv = np.ascontiguousarray(passage_vertex, dtype=np.int32)
         self.n_passages = int(pv.shape[0]) if n_passages is None else int(n_passages)
         p_obj, p_rows, dim, dt = _as_16bit(passage_emb)
-        self.emb_dtype = torch.float16 if dt == 1 else torch.bfloat16
+        self.emb_dtype = getattr(torch, _TORCH_DTYPE_OF[dt])    # the dtype queries travel in (fp32 on a split engine)
+        self.f32_split = dt in (2, 3)
         row_ptr = np.ascontiguousarray(graph.row_ptr, dtype=np.int32)
         col_idx = np.ascontiguousarray(graph.col_idx, dtype=np.int32)
         val = np.ascontiguousarray(graph.val, dtype=np.float32)
@@ -119,7 +141,7 @@ class HippoRAGEngine:
         self.n_facts = 0
         if fact_emb is not None:
             f_obj, f_rows, f_dim, f_dt = _as_16bit(fact_emb)
-            if f_dim != dim or f_dt != dt:
+            if f_dim != dim or (f_dt != dt and not (f_dt in (2, 3) and dt in (2, 3))):
                 raise ValueError("fact / passage embedding dims or dtypes differ")
             sv = np.ascontiguousarray(subj_vertex, dtype=np.int32)
             ov = np.ascontiguousarray(obj_vertex, dtype=np.int32)
@@ -129,7 +151,7 @@ class HippoRAGEngine:
             self.n_facts = int(sv.shape[0]) if n_facts is None else int(n_facts)
             if sv.shape[0] != self.n_facts or ov.shape[0] != self.n_facts:
                 raise ValueError("subj_vertex / obj_vertex must cover all (global) facts")
-            fdesc = EmbedDesc(f_rows, fact_offset, dim, dt, _ptr(f_obj))
+            fdesc = EmbedDesc(f_rows, fact_offset, dim, f_dt, _ptr(f_obj))
             fd = FactDesc(self.n_facts, _ptr(sv), _ptr(ov), _ptr(nc))
             keep += [f_obj, sv, ov, nc]
         self.opt_flags = int(flags)      # HRAG_OPT_* bits as set_flags leaves them
@@ -351,16 +373,28 @@ class HippoRAGEngine:
         fresh = None
         if new_rows is not None and len(new_rows):
             obj, rows, dim, dt = _as_16bit(new_rows)
-            if dim != self.dim or (torch.float16 if dt == 1 else torch.bfloat16) != self.emb_dtype:
+            if dim != self.dim or getattr(torch, _TORCH_DTYPE_OF[dt]) != self.emb_dtype or dt == 3:
                 raise ValueError("new rows must match the engine's embedding dim / dtype")
-            fresh = (torch.from_numpy(obj.view(np.int16)) if isinstance(obj, np.ndarray) else obj.view(torch.int16)).to(self.device).contiguous()
+            if self.f32_split:     # fp32 rows -> the engine's [hi | lo | hi] layout, on the device
+                x = (torch.from_numpy(obj) if isinstance(obj, np.ndarray) else obj).to(self.device).contiguous()
+                fresh = torch.empty((rows, 3 * self.dim), dtype=torch.int16, device=self.device)
+                check(self._lib.hrag_split_f32(x.data_ptr(), rows, self.dim, 0, fresh.data_ptr(), _stream()))
+            else:
+                fresh = (torch.from_numpy(obj.view(np.int16)) if isinstance(obj, np.ndarray) else obj.view(torch.int16)).to(self.device).contiguous()
         if n and int(src.min().item()) < 0 and (fresh is None or int((-src.min()).item()) > fresh.shape[0]):
             raise ValueError("src_rows refers to a new row that was not given")
-        out = torch.empty((n, self.dim), dtype=self.emb_dtype, device=self.device)
+        # (a split engine's rows are 3 * dim fp16 elements; the result is only ever handed to the next engine)
+        out = (torch.empty((n, 3 * self.dim), dtype=torch.float16, device=self.device) if self.f32_split
+               else torch.empty((n, self.dim), dtype=self.emb_dtype, device=self.device))
+        if which not in ("facts", "passages"):
+            raise ValueError("which must be 'facts' or 'passages'")
+        held = self.fact_rows if which == "facts" else self.passage_rows
+        if n and int(src.max().item()) >= held:
+            raise ValueError(f"src_rows refers to row {int(src.max().item())} of {held} held {which} rows")
         check(self._lib.hrag_engine_gather_embeddings(self._handle, 0 if which == "facts" else 1, src.data_ptr(), n,
                                                       fresh.data_ptr() if fresh is not None else None,
                                                       out.data_ptr(), _stream()))
-        return out
+        return SplitRows(out, self.dim) if self.f32_split else out
 
     # ------------------------------------------------------------------ row shard (include/hrag.h hrag_shard_*)
     def shard_layout(self, batch: int, groups: int = 0) -> ShardLayout:

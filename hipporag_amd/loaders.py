@@ -161,8 +161,9 @@ def load_reference_workdir(save_dir: str, llm_name: str, embedding_model_name: s
     obj = np.array([ent(f[2]) for f in rag.facts], np.int32)
     pv = np.array([vid[k] for k in p_keys], np.int32)
     rag.entity_embeddings = e_emb if len(e_keys) else None
-    rag._arrays = dict(csr=csr, passage_vertex=pv, passage_emb=float_to_bf16_bits(p_emb),
-                       fact_emb=float_to_bf16_bits(f_emb) if len(f_keys) else None, subj=subj, obj=obj,
+    # the stores' fp32 vectors as the engine takes them (RetrievalConfig.embedding_precision: fp32-faithful by default)
+    rag._arrays = dict(csr=csr, passage_vertex=pv, passage_emb=rag._emb_for_engine(p_emb),
+                       fact_emb=rag._emb_for_engine(f_emb) if len(f_keys) else None, subj=subj, obj=obj,
                        num_chunks=num_chunks)
     rag.ready_to_retrieve = False
     logger.info("loaded %d passages, %d entities, %d facts, %d directed entries from %s", len(p_keys), len(e_keys),

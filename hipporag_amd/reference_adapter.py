@@ -84,8 +84,10 @@ def index_arrays_from_reference(rag) -> dict:
             "subj_vertex": subj, "obj_vertex": obj, "num_chunks": nchunks, "facts": facts}
 
 
-def build_engine_from_reference(rag, *, max_batch: int = 256):
-    """Device index from the reference object's host state (prepare_retrieval_objects must have run)."""
+def build_engine_from_reference(rag, *, max_batch: int = 256, embedding_precision: str = "f32"):
+    """Device index from the reference object's host state (prepare_retrieval_objects must have run).
+    embedding_precision "f32" (default): the reference's fp32 matrices as they are (HippoRAG.py:1342-1345) on the
+    fp32-faithful engine (HRAG_F32_SPLIT); "bf16": rounded to bf16, a third of the embedding stream."""
     from .engine import HippoRAGEngine
     a = index_arrays_from_reference(rag)
     facts = a["facts"]
@@ -93,8 +95,11 @@ def build_engine_from_reference(rag, *, max_batch: int = 256):
     pv = a["passage_vertex"]
     has_facts = len(facts) > 0
     cfg = rag.global_config
-    eng = HippoRAGEngine(csr, pv, float_to_bf16_bits(a["passage_emb"]),
-                         float_to_bf16_bits(a["fact_emb"]) if has_facts else None,
+    if embedding_precision not in ("f32", "bf16"):
+        raise ValueError("embedding_precision must be 'f32' or 'bf16'")
+    conv = (lambda e: np.ascontiguousarray(e, np.float32)) if embedding_precision == "f32" else float_to_bf16_bits
+    eng = HippoRAGEngine(csr, pv, conv(a["passage_emb"]),
+                         conv(a["fact_emb"]) if has_facts else None,
                          a["subj_vertex"] if has_facts else None, a["obj_vertex"] if has_facts else None,
                          a["num_chunks"] if has_facts else None, max_batch=max_batch,
                          max_topk=int(min(2048, max(1, min(cfg.retrieval_top_k, len(pv))))))
@@ -102,7 +107,7 @@ def build_engine_from_reference(rag, *, max_batch: int = 256):
 
 
 def attach(rag, *, max_batch: int = 256, ppr_iters: Optional[int] = None, batched_retrieve: bool = True,
-           ppr_tol: float = 3e-6, ppr_max_iters: int = 400):
+           ppr_tol: float = 3e-6, ppr_max_iters: int = 400, embedding_precision: str = "f32"):
     """Patch ``rag`` in place; returns it.  Call again after ``index()`` / ``delete()`` (they change
     the graph and the stores; the reference only resets ``ready_to_retrieve`` on delete, :411)."""
     import torch
@@ -110,7 +115,7 @@ def attach(rag, *, max_batch: int = 256, ppr_iters: Optional[int] = None, batche
         detach(rag)
     if not getattr(rag, "ready_to_retrieve", False):
         rag.prepare_retrieval_objects()
-    eng, facts = build_engine_from_reference(rag, max_batch=max_batch)
+    eng, facts = build_engine_from_reference(rag, max_batch=max_batch, embedding_precision=embedding_precision)
     cfg = rag.global_config
     from .retriever import sweeps_for_damping
     # fixed sweep count of the power iteration: given, or derived from the damping factor (20 at 0.5)
@@ -121,7 +126,7 @@ def attach(rag, *, max_batch: int = 256, ppr_iters: Optional[int] = None, batche
 
     def q_tensor(queries: List[str], kind: str):
         m = np.stack([np.asarray(rag.query_to_embedding[kind][q], np.float32).reshape(-1) for q in queries])
-        return torch.from_numpy(m).to(dev).to(torch.bfloat16)
+        return torch.from_numpy(m).to(dev).to(getattr(eng, "emb_dtype", torch.bfloat16))
 
     def get_fact_scores(query: str) -> np.ndarray:                        # :1427-1465
         if len(facts) == 0:

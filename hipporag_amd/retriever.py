@@ -131,6 +131,10 @@ class RetrievalConfig:
     embedding_return_as_normalized: bool = True   # :144
     is_directed_graph: bool = False      # :176
     # engine-only knobs (no reference analogue)
+    embedding_precision: str = "f32"     # "f32": scores like the reference's fp32 np.dot (HippoRAG.py:1459,1496) -- the
+                                         # stores' fp32 vectors as hi + lo bf16, three MFMA products per element
+                                         # (HRAG_F32_SPLIT, 3x the embedding stream); "bf16": vectors rounded to bf16 (1x
+                                         # stream; near-tied facts / passages may swap against the reference)
     ppr_iters: Optional[int] = None      # None: derived from damping (sweeps_for_damping: 20 at 0.5)
     # convergence contract (include/hrag.h, hrag_retrieve; the reference's PRPACK iterates to 1e-10,
     # HippoRAG.py:1736-1743): the engine measures the relative update of the passage scores and keeps sweeping
@@ -369,10 +373,18 @@ class HippoRAG:
         obj = np.array([vid(f[2]) for f in self.facts], np.int32)
         pv = np.array([g.index[k] for k in self.passage_node_keys], np.int32)
         has_facts = len(self.facts) > 0
-        self._arrays = dict(csr=csr, passage_vertex=pv, passage_emb=float_to_bf16_bits(self._pass_emb),
-                            fact_emb=float_to_bf16_bits(self._fact_emb) if has_facts else None, subj=subj, obj=obj,
+        self._arrays = dict(csr=csr, passage_vertex=pv, passage_emb=self._emb_for_engine(self._pass_emb),
+                            fact_emb=self._emb_for_engine(self._fact_emb) if has_facts else None, subj=subj, obj=obj,
                             num_chunks=num_chunks)
         self.ready_to_retrieve = False                      # explicit invalidate hook
+
+    def _emb_for_engine(self, emb):
+        """The stores' fp32 rows as the engine takes them: fp32 (HRAG_F32_SPLIT) or bf16 bit patterns."""
+        prec = self.global_config.embedding_precision
+        if prec not in ("f32", "bf16"):
+            raise ValueError(f"embedding_precision must be 'f32' or 'bf16', not {prec!r}")
+        e = np.ascontiguousarray(emb, dtype=np.float32)
+        return e if prec == "f32" else float_to_bf16_bits(e)
 
     # ------------------------------------------------------------------ delete :337-411
     def delete(self, docs_to_delete: Sequence[str]):
@@ -457,7 +469,8 @@ class HippoRAG:
         has_facts = a["fact_emb"] is not None and a["fact_emb"].shape[0] > 0
         pe, fe = a["passage_emb"], (a["fact_emb"] if has_facts else None)
         old, held = self.engine, getattr(self, "_engine_rows", None)
-        if old is not None and held is not None and old.dim == a["passage_emb"].shape[1]:
+        same_kind = old is not None and old.f32_split == (a["passage_emb"].dtype == np.float32)
+        if old is not None and held is not None and same_kind and old.dim == a["passage_emb"].shape[1]:
             def compose(which, keys, bits, held_keys):
                 pos = {k: i for i, k in enumerate(held_keys)}
                 src, fresh = [], []
@@ -471,6 +484,13 @@ class HippoRAG:
             pe = compose("passages", self.passage_node_keys, a["passage_emb"], held["passages"])
             if has_facts and held["facts"]:
                 fe = compose("facts", self.fact_node_keys, a["fact_emb"], held["facts"])
+        if old is not None:
+            # the gathered matrices no longer depend on the old engine: free its index before the new one is built
+            # (peak device memory = one index + the embedding matrices, not two indexes)
+            import torch
+            torch.cuda.synchronize(old.device)
+            old.close()
+            self.engine = None
         engine = HippoRAGEngine(a["csr"], a["passage_vertex"], pe, fe,
                                 a["subj"] if has_facts else None, a["obj"] if has_facts else None,
                                 a["num_chunks"] if has_facts else None,
@@ -478,8 +498,6 @@ class HippoRAG:
                                 max_topk=min(2048, max(self.global_config.retrieval_top_k, 1)),
                                 slab_width=self.global_config.slab_width,
                                 flags=0)
-        if old is not None:
-            old.close()
         self.engine = engine
         self._engine_rows = {"passages": list(self.passage_node_keys), "facts": list(self.fact_node_keys) if has_facts else []}
         self.passage_node_idxs = a["passage_vertex"].tolist()
@@ -504,7 +522,7 @@ class HippoRAG:
     def _q_tensor(self, queries: List[str], kind: str):
         import torch
         m = np.stack([np.asarray(self.query_to_embedding[kind][q], np.float32).reshape(-1) for q in queries])
-        return torch.from_numpy(m).to(self.engine.device).to(torch.bfloat16)
+        return torch.from_numpy(m).to(self.engine.device).to(self.engine.emb_dtype)
 
     # ------------------------------------------------------------------ per-method seams (B = 1)
     def get_fact_scores(self, query: str) -> np.ndarray:                  # :1427-1465

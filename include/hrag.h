@@ -72,11 +72,26 @@ typedef struct hrag_graph_desc {
                                    /* iterates in the degree-scaled variable x / col_sum.             */
 } hrag_graph_desc;
 
-typedef enum hrag_dtype { HRAG_BF16 = 0, HRAG_FP16 = 1 } hrag_dtype; /* IEEE binary16 = BASELINE configs[4] */
+typedef enum hrag_dtype {
+    HRAG_BF16 = 0,
+    HRAG_FP16 = 1,     /* IEEE binary16 = BASELINE configs[4] */
+    HRAG_F32_SPLIT = 2,/* fp32 in, fp32-faithful scores: what the reference computes (np.dot of fp32 matrices,           */
+                       /* HippoRAG.py:1342-1345,1459,1496; embedding_store.py:216-221).  `data` is fp32 [rows, dim]; the  */
+                       /* engine stores every vector as hi + lo (two fp16: 22 significant bits) in the layout            */
+                       /* [hi | lo | hi] and a query as [qhi | qhi | qlo], so that one fp16 MFMA dot product of          */
+                       /* 3 * dim elements IS hi.qhi + lo.qhi + hi.qlo = the fp32 product up to 2^-21 |x||q| -- through  */
+                       /* kernel unchanged, at 3x the embedding stream.  Every q_*_dev pointer of such an engine is      */
+                       /* fp32 [B, dim].  Ranking with bf16-rounded embeddings instead flips near-tied facts / passages  */
+                       /* (tests/test_gpu_f32_split.py counts them on a reference-run fixture)                          */
+    HRAG_F32_SPLIT_ROWS = 3 /* the same engine from rows that are ALREADY in the split layout: `data` is fp16             */
+                       /* [rows, 3 * dim] as hrag_split_f32 / hrag_engine_gather_embeddings produce it (`dim` stays the  */
+                       /* logical dimension): the index-update path, where the held rows never leave the device          */
+} hrag_dtype;
 
 /* Row-major, L2-normalised embedding matrix (self.fact_embeddings /
- * self.passage_embeddings, HippoRAG.py:1343-1345), rounded to bf16 or fp16 (facts and
- * passages use the same dtype; every q_*_dev query pointer then carries that dtype too).
+ * self.passage_embeddings, HippoRAG.py:1343-1345), rounded to bf16 or fp16, or fp32 (HRAG_F32_SPLIT); facts and
+ * passages use the same dtype; every q_*_dev query pointer then carries that dtype too (declared uint16_t for the
+ * 16-bit types; fp32 [B, dim] behind the same pointer on an HRAG_F32_SPLIT engine).
  * Row sharding: this engine holds rows [row_offset, row_offset + rows). */
 typedef struct hrag_embed_desc {
     int64_t rows;
@@ -261,6 +276,10 @@ hrag_status hrag_normalize_split_bf16(const float *x_dev, int64_t rows, int32_t 
                                       uint16_t *hi_dev, uint16_t *lo_dev, hrag_stream stream);
 hrag_status hrag_sim_gemm(const uint16_t *emb_dev, int64_t rows, int32_t dim, const uint16_t *q_dev,
                           int32_t batch, float *out_dev, int64_t ld, int32_t accumulate, hrag_stream stream);
+/* fp32 [rows, dim] -> the fp16 [rows, 3 * dim] layout of an HRAG_F32_SPLIT engine: [hi | lo | hi] for embedding rows,
+ * [hi | hi | lo] with as_query != 0 (new rows for hrag_engine_gather_embeddings; the engine converts its own inputs). */
+hrag_status hrag_split_f32(const float *x_dev, int64_t rows, int32_t dim, int32_t as_query, uint16_t *out_dev,
+                           hrag_stream stream);
 
 /* Measurement hook: run `n` PPR SpMM sweeps over the engine's current state buffers for
  * `batch` right-hand sides (state is whatever the last hrag_retrieve / hrag_ppr left).
@@ -422,7 +441,8 @@ hrag_status hrag_shard_finish(hrag_engine *e, const float *min_dev, const float 
  * the reference re-reads everything from its stores in prepare_retrieval_objects): compose the embedding
  * matrix of the NEXT engine from the rows this engine already holds and the rows that are new,
  *   out[i] = src_rows_dev[i] >= 0 ? held row src_rows_dev[i] : new_rows_dev[-src_rows_dev[i] - 1],
- * which: 0 = facts, 1 = passages; rows are dim 16-bit elements; out_dev [n, dim] is caller-owned and can be
+ * which: 0 = facts, 1 = passages; rows are dim 16-bit elements (3 * dim on an HRAG_F32_SPLIT engine: new rows in the
+ * layout of hrag_split_f32); out_dev [n, dim] is caller-owned and can be
  * handed to hrag_engine_create as hrag_embed_desc.data (device pointers are accepted there). */
 hrag_status hrag_engine_gather_embeddings(hrag_engine *e, int32_t which, const int32_t *src_rows_dev, int64_t n,
                                           const void *new_rows_dev, void *out_dev, hrag_stream stream);

@@ -25,7 +25,7 @@ import networkx as nx  # noqa: E402
 
 import oracle  # noqa: E402
 from hipporag_amd.graph import bf16_bits_to_float, float_to_bf16_bits  # noqa: E402
-from hipporag_amd.retriever import HippoRAG  # noqa: E402
+from hipporag_amd.retriever import HippoRAG, RetrievalConfig  # noqa: E402
 
 DOCS = [  # sample_data.py:1-11
     "Oliver Badman is a politician.",
@@ -76,7 +76,7 @@ class MockEmbeddingModel:
 
 def toy_fixture():
     model = MockEmbeddingModel()
-    rag = HippoRAG(embedding_model=model)
+    rag = HippoRAG(RetrievalConfig(embedding_precision="bf16"), embedding_model=model)
     rag.index_from_openie(DOCS, TRIPLES)
     a = rag._arrays
     csr = a["csr"]

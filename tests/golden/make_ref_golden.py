@@ -11,7 +11,8 @@ dense_passage_retrieval / run_ppr / retrieve returned.
 The reference's vertex numbering and fact order come from Python sets (extract_entity_nodes,
 flatten_facts), i.e. from string hashes: PYTHONHASHSEED=0 makes the run reproducible.  The mock
 embedding model emits bf16-representable fp32 vectors so that the reference (fp32 numpy) and the
-device path (bf16 MFMA, fp32 accumulate) see identical inputs.
+device path (bf16 MFMA, fp32 accumulate) see identical inputs -- except in ref_synth_f32.npz, whose vectors are
+the mock model's fp32 output as it is (the case a real embedding store presents; the engine's HRAG_F32_SPLIT mode).
 """
 
 from __future__ import annotations
@@ -109,10 +110,10 @@ def make_filter(queries, mode):
     return filt, calls
 
 
-def run_case(name, docs, triples, queries, filter_mode, **cfg):
+def run_case(name, docs, triples, queries, filter_mode, model=None, **cfg):
     tmp = tempfile.mkdtemp(prefix="refgold_")
     try:
-        rag = rh.build_reference_rag(tmp, docs, triples, Bf16Mock(), **cfg)
+        rag = rh.build_reference_rag(tmp, docs, triples, model or Bf16Mock(), **cfg)
         filt, calls = make_filter(queries, filter_mode)
         rag.rerank_filter = filt
         sols, log = rh.capture(rag, queries)
@@ -178,6 +179,9 @@ def main():
     run_case("toy", mg.DOCS, mg.TRIPLES, mg.QUERIES, "identity")
     docs, triples, queries = synth_corpus()
     run_case("synth", docs, triples, queries, "mixed")
+    # the same corpus with the mock model's fp32 vectors AS THEY ARE (not bf16-representable): what a real embedding
+    # store holds.  Pins the fp32-faithful similarity mode (HRAG_F32_SPLIT) -- and shows what bf16 rounding flips
+    run_case("synth_f32", docs, triples, queries, "mixed", model=mg.MockEmbeddingModel())
 
 
 if __name__ == "__main__":

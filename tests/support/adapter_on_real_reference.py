@@ -37,7 +37,8 @@ class OracleEngine:
                  num_chunks=None, *, max_batch=256, max_topk=200, **_):
         import scipy.sparse as sp
         p = sp.csr_matrix((csr.val.astype(np.float64), csr.col_idx, csr.row_ptr), shape=(csr.num_vertices,) * 2)
-        self.index = oracle.RefIndex(bf16_bits_to_float(fact_emb), bf16_bits_to_float(passage_emb), subj_vertex,
+        as_f32 = lambda e: np.asarray(e, np.float32) if e.dtype == np.float32 else bf16_bits_to_float(e)   # fp32-faithful / bf16 bits
+        self.index = oracle.RefIndex(as_f32(fact_emb), as_f32(passage_emb), subj_vertex,
                                      obj_vertex, num_chunks, np.asarray(passage_vertex), p)
         self.device, self.max_batch, self.max_topk = torch.device("cpu"), max_batch, max_topk
         self.closed = False

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+from hipporag_amd import RetrievalConfig
 from hipporag_amd.loaders import (filter_invalid_triples, load_embedding_store, load_openie_results,
                                   load_reference_workdir, write_reference_workdir)
 from tests.golden.make_golden import DOCS, QUERIES, TRIPLES, MockEmbeddingModel
@@ -36,7 +37,8 @@ def test_store_and_openie_files_round_trip(workdir):
 def test_workdir_loader_reproduces_toy_index(workdir):
     t = np.load(os.path.join(GOLD, "toy_corpus.npz"))
     rag = load_reference_workdir(workdir, "meta/llama-3", "nvidia/NV-Embed-v2", synonymy="none",
-                                 embedding_model=MockEmbeddingModel())
+                                 embedding_model=MockEmbeddingModel(),
+                                 global_config=RetrievalConfig(embedding_precision="bf16"))
     a = rag._arrays
     for key, arr in (("row_ptr", a["csr"].row_ptr), ("col_idx", a["csr"].col_idx), ("val", a["csr"].val),
                      ("subj", a["subj"]), ("obj", a["obj"]), ("num_chunks", a["num_chunks"]),
@@ -67,7 +69,8 @@ def test_workdir_loader_accepts_exported_igraph_edges(workdir, tmp_path):
 def test_gpu_retrieve_from_workdir(workdir, gpu_device):
     t = np.load(os.path.join(GOLD, "toy_corpus.npz"))
     rag = load_reference_workdir(workdir, "meta/llama-3", "nvidia/NV-Embed-v2", synonymy="none",
-                                 embedding_model=MockEmbeddingModel())
+                                 embedding_model=MockEmbeddingModel(),
+                                 global_config=RetrievalConfig(embedding_precision="bf16"))   # the fixture's vectors are bf16-rounded
     rag.global_config.max_batch, rag.global_config.ppr_iters = 4, 40
     sols = rag.retrieve(QUERIES, num_to_retrieve=5)
     for q, sol in enumerate(sols):

@@ -57,7 +57,7 @@ def test_gpu_index_without_facts_returns_dpr_results(gpu_device):
     import torch
     from tests.golden.make_golden import DOCS, QUERIES, MockEmbeddingModel
     from hipporag_amd.engine import HippoRAGEngine
-    rag = HippoRAG(RetrievalConfig(max_batch=4), embedding_model=MockEmbeddingModel())
+    rag = HippoRAG(RetrievalConfig(embedding_precision="bf16", max_batch=4), embedding_model=MockEmbeddingModel())
     rag.index_from_openie(DOCS, [[] for _ in DOCS])
     sols = rag.retrieve(QUERIES, num_to_retrieve=4)
     dpr = rag.retrieve_dpr(QUERIES, num_to_retrieve=4)
@@ -85,7 +85,7 @@ def test_gpu_retrieve_ircot_matches_the_per_query_loop(gpu_device):
     merged rankings must equal the reference's per-query loop (retrieve([query]) / retrieve([thought]) one
     at a time, max-merge of the scores), including the early stop on 'So the answer is:'."""
     from tests.golden.make_golden import DOCS, QUERIES, TRIPLES, MockEmbeddingModel
-    rag = HippoRAG(RetrievalConfig(max_batch=4, ppr_iters=40), embedding_model=MockEmbeddingModel())
+    rag = HippoRAG(RetrievalConfig(embedding_precision="bf16", max_batch=4, ppr_iters=40), embedding_model=MockEmbeddingModel())
     rag.index_from_openie(DOCS, TRIPLES)
     seen = []
 
@@ -125,7 +125,7 @@ def test_gpu_retrieve_ircot_matches_the_per_query_loop(gpu_device):
 def test_gpu_num_to_retrieve_beyond_max_topk_warns(gpu_device, caplog):
     import logging
     from tests.golden.make_golden import DOCS, QUERIES, TRIPLES, MockEmbeddingModel
-    rag = HippoRAG(RetrievalConfig(max_batch=4, retrieval_top_k=3), embedding_model=MockEmbeddingModel())
+    rag = HippoRAG(RetrievalConfig(embedding_precision="bf16", max_batch=4, retrieval_top_k=3), embedding_model=MockEmbeddingModel())
     rag.index_from_openie(DOCS, TRIPLES)
     with caplog.at_level(logging.WARNING, logger="hipporag_amd"):
         sols = rag.retrieve(QUERIES[:1], num_to_retrieve=6)

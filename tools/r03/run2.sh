@@ -3,5 +3,5 @@
 set -x
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r03b_tests.log 2>&1; echo "tests rc=$?"
-tail -30 gpurun_out/r03b_tests.log
+timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/r03j_tests.log 2>&1; echo "tests rc=$?"
+tail -30 gpurun_out/r03j_tests.log

@@ -447,11 +447,12 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--slab-width", type=int, default=0)
-    ap.add_argument("--mode", default="replica", choices=["rowshard", "replica"],
+    ap.add_argument("--mode", default="replica", choices=["rowshard", "replica", "hybrid"],
                     help="multi-GPU mode whose rate is `value` (N > 1).  replica (default): queries sharded, no "
-                         "data-path collective.  The row-sharded leg (BASELINE.json's layout) is always measured and "
-                         "reported beside it; it only becomes `value` with --mode rowshard: its RCCL exchange has never "
-                         "met a second GPU (no multi-GPU box was available to any round)")
+                         "data-path collective.  The hybrid leg (embeddings row-sharded, one all-to-all, PPR "
+                         "query-parallel) and the row-sharded leg (BASELINE.json's layout: PPR rows sharded, one all-gather per "
+                         "sweep) are always measured and reported beside it; they only become `value` with --mode hybrid / "
+                         "rowshard: their RCCL paths have never met a second GPU (no multi-GPU box was available to any round)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-queries", type=int, default=12)
     ap.add_argument("--cpu-vec-queries", type=int, default=32, help="batch of the vectorised CPU baseline leg")

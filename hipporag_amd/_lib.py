@@ -73,6 +73,8 @@ SIGNATURES = {
     "hrag_score_facts": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),
     "hrag_retrieve": (C.c_int, [_P, _P, _I32, _P, _P, _P, _I32, _I32, _F32, _F32, _I32, _I32, _F32, _I32, _P, _P, _P,
                                 _P, _P, _P]),
+    "hrag_retrieve_scored": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _F32, _F32, _I32, _I32, _F32, _I32, _P, _P,
+                                       _P, _P, _P, _P]),
     "hrag_dense_retrieve": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),
     "hrag_sim_scores": (C.c_int, [_P, _I32, _P, _I32, _P, _P]),
     "hrag_ppr": (C.c_int, [_P, _P, _I32, _F32, _I32, _P, _P, _P]),

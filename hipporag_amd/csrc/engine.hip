@@ -640,7 +640,9 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         if (st == HRAG_OK && err != hipSuccess) { set_error("split of the fp32 embeddings failed: %s", hipGetErrorString(err)); st = HRAG_EHIP; }
         return st;
     };
-    E_TRY(upload_emb(&e->d_pemb, passages->data, e->p_rows, passages->dtype));
+    // passages->data == NULL: an engine WITHOUT passage embeddings -- the raw passage scores come from the caller
+    // (hrag_retrieve_scored: the PPR side of the hybrid multi-GPU mode, whose embeddings live row-sharded elsewhere)
+    if (passages->data) E_TRY(upload_emb(&e->d_pemb, passages->data, e->p_rows, passages->dtype));
     if (e->split) E_TRY(dev_alloc(&e->d_qsplit, (int64_t)opts->max_batch * e->kdim));
     if (facts) {
         e->f_rows = facts->rows; e->f_offset = facts->row_offset; e->n_facts = fd->n_facts;
@@ -935,18 +937,23 @@ hrag_status hrag_stage_doc_scores(hrag_engine *e, const float *x, const double *
     return HRAG_OK;
 }
 
-hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
-                          const int32_t *kept_idx, const float *kept_score, const int32_t *kept_count,
-                          int32_t kf, int32_t link_top_k, float damping, float passage_node_weight,
-                          int32_t ppr_iters, int32_t ppr_max_iters, float ppr_tol, int32_t k, int32_t *doc_idx_out,
-                          float *doc_score_out, int32_t *flags_out, float *residual_out, int32_t *iters_out,
-                          hrag_stream stream) {
+// hrag_retrieve / hrag_retrieve_scored: the passage scores come from this engine's embeddings (q_pass) or from the
+// caller (pass_scores fp32 [batch, pass_ld] raw cosine scores in passage order)
+static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const float *pass_scores, int64_t pass_ld,
+                                 int32_t batch, const int32_t *kept_idx, const float *kept_score,
+                                 const int32_t *kept_count, int32_t kf, int32_t link_top_k, float damping,
+                                 float passage_node_weight, int32_t ppr_iters, int32_t ppr_max_iters, float ppr_tol,
+                                 int32_t k, int32_t *doc_idx_out, float *doc_score_out, int32_t *flags_out,
+                                 float *residual_out, int32_t *iters_out, hrag_stream stream) {
     HRAG_TRY(check_batch(e, batch));
     HRAG_REQUIRE(ppr_tol >= 0.f && ppr_tol == ppr_tol, "ppr_tol must be >= 0");
     HRAG_REQUIRE(ppr_tol == 0.f || ppr_max_iters >= ppr_iters, "ppr_max_iters=%d < ppr_iters=%d", ppr_max_iters, ppr_iters);
-    HRAG_REQUIRE(q_pass && kept_idx && kept_score && kept_count && doc_idx_out && doc_score_out, "NULL argument");
+    HRAG_REQUIRE((q_pass || pass_scores) && kept_idx && kept_score && kept_count && doc_idx_out && doc_score_out,
+                 "NULL argument");
     HRAG_REQUIRE(e->n_rows == e->V && e->p_rows == e->n_passages,
                  "hrag_retrieve needs an unsharded engine; sharded engines use the hrag_stage_* operators");
+    HRAG_REQUIRE(pass_scores || e->d_pemb, "the engine was created without passage embeddings: use hrag_retrieve_scored");
+    HRAG_REQUIRE(!pass_scores || pass_ld >= e->n_passages, "pass_ld=%lld < n_passages", (long long)pass_ld);
     HRAG_REQUIRE(k >= 1 && k <= e->max_topk, "k=%d outside [1, max_topk=%d]", k, e->max_topk);
     HRAG_REQUIRE(ppr_iters >= 0, "ppr_iters must be >= 0");
     HRAG_REQUIRE(damping >= 0.f && damping < 1.f, "damping %g outside [0, 1)", (double)damping);
@@ -970,8 +977,14 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     if (est) HRAG_HIP_TRY(hipMemsetAsync(est, 0, (size_t)batch * sizeof(int32_t), s));
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_START], s));
     // dense_passage_retrieval: raw scores + min / max (HippoRAG.py:1496-1498)
-    HRAG_TRY(prep_query(e, q_pass, batch, s, &q_pass));
-    HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->kdim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
+    if (pass_scores) {
+        HRAG_HIP_TRY(hipMemcpy2DAsync(e->d_spass, (size_t)e->ld_p * sizeof(float), pass_scores,
+                                      (size_t)pass_ld * sizeof(float), (size_t)e->n_passages * sizeof(float),
+                                      (size_t)batch, hipMemcpyDeviceToDevice, s));
+    } else {
+        HRAG_TRY(prep_query(e, q_pass, batch, s, &q_pass));
+        HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->kdim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
+    }
     const bool sv_half = sv && use_sv_half(e, ppr_iters);
     HRAG_TRY(launch_row_minmax(e->d_spass, batch, e->n_passages, e->ld_p, e->d_mn_p, e->d_mx_p, s,
                                (f16 || sv_half) ? e->d_ssum : nullptr));
@@ -1118,11 +1131,35 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
     return HRAG_OK;
 }
 
+hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch,
+                          const int32_t *kept_idx, const float *kept_score, const int32_t *kept_count,
+                          int32_t kf, int32_t link_top_k, float damping, float passage_node_weight,
+                          int32_t ppr_iters, int32_t ppr_max_iters, float ppr_tol, int32_t k, int32_t *doc_idx_out,
+                          float *doc_score_out, int32_t *flags_out, float *residual_out, int32_t *iters_out,
+                          hrag_stream stream) {
+    HRAG_REQUIRE(q_pass != nullptr, "NULL argument");
+    return retrieve_impl(e, q_pass, nullptr, 0, batch, kept_idx, kept_score, kept_count, kf, link_top_k, damping,
+                         passage_node_weight, ppr_iters, ppr_max_iters, ppr_tol, k, doc_idx_out, doc_score_out,
+                         flags_out, residual_out, iters_out, stream);
+}
+
+hrag_status hrag_retrieve_scored(hrag_engine *e, const float *pass_scores, int64_t pass_ld, int32_t batch,
+                                 const int32_t *kept_idx, const float *kept_score, const int32_t *kept_count,
+                                 int32_t kf, int32_t link_top_k, float damping, float passage_node_weight,
+                                 int32_t ppr_iters, int32_t ppr_max_iters, float ppr_tol, int32_t k,
+                                 int32_t *doc_idx_out, float *doc_score_out, int32_t *flags_out, float *residual_out,
+                                 int32_t *iters_out, hrag_stream stream) {
+    HRAG_REQUIRE(pass_scores != nullptr, "NULL argument");
+    return retrieve_impl(e, nullptr, pass_scores, pass_ld, batch, kept_idx, kept_score, kept_count, kf, link_top_k,
+                         damping, passage_node_weight, ppr_iters, ppr_max_iters, ppr_tol, k, doc_idx_out, doc_score_out,
+                         flags_out, residual_out, iters_out, stream);
+}
+
 hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch, int32_t k,
                                 int32_t *doc_idx_out, float *doc_score_out, hrag_stream stream) {
     HRAG_TRY(check_batch(e, batch));
     HRAG_REQUIRE(q_pass && doc_idx_out && doc_score_out, "NULL argument");
-    HRAG_REQUIRE(e->p_rows == e->n_passages, "hrag_dense_retrieve needs the whole passage matrix");
+    HRAG_REQUIRE(e->p_rows == e->n_passages && e->d_pemb, "hrag_dense_retrieve needs the whole passage matrix");
     HRAG_REQUIRE(k >= 1 && k <= e->max_topk, "k=%d outside [1, max_topk=%d]", k, e->max_topk);
     hipStream_t s = (hipStream_t)stream;
     HRAG_TRY(prep_query(e, q_pass, batch, s, &q_pass));

@@ -327,6 +327,31 @@ class TorchComm:
         dist.all_gather(out, t, group=self.group)
         return out
 
+    def all_to_all(self, parts, shapes):
+        """parts[d] goes to rank d; returns the list of what every rank sent here (shapes[s] = shape of rank s's
+        part).  RCCL: one all_to_all; gloo (CPU tests) has none: paired isend / irecv."""
+        torch, dist = _td()
+        if self.world == 1:
+            return [parts[0]]
+        out = [torch.empty(tuple(shapes[s]), dtype=parts[0].dtype, device=parts[0].device) for s in range(self.world)]
+        parts = [p.contiguous() for p in parts]
+        if dist.get_backend(self.group) == "gloo":
+            out[self.rank].copy_(parts[self.rank])
+            reqs = []
+            for d in range(self.world):
+                if d != self.rank:
+                    reqs.append(dist.isend(parts[d], self._global(d), group=self.group))
+                    reqs.append(dist.irecv(out[d], self._global(d), group=self.group))
+            for r in reqs:
+                r.wait()
+        else:
+            dist.all_to_all(out, parts, group=self.group)
+        return out
+
+    def _global(self, g: int) -> int:
+        torch, dist = _td()
+        return g if self.group is None else dist.get_global_rank(self.group, g)
+
     def exchange(self, buf, lay, g: int):
         """Start the all-gather of exchange group g of state buffer `buf` (uint8 [state_bytes]); returns a
         handle for wait().  The collective is ordered after everything enqueued on the current stream."""
@@ -384,6 +409,10 @@ class LocalComm:
 
     def all_gather(self, t):
         return self._collect(t)
+
+    def all_to_all(self, parts, shapes):
+        sent = self._collect(list(parts))            # sent[s][d] = what rank s sends to rank d
+        return [sent[s][self.rank] for s in range(self.world)]
 
     def shared_buffers(self, key, make):
         if self.rank == 0:
@@ -476,6 +505,58 @@ class ShardedRetriever:
         return top_idx, top_val, flags | sat
 
 
+class HybridRetriever:
+    """The hybrid multi-GPU mode SURVEY.md 8(e) ends on: the EMBEDDINGS are row-sharded over the GPUs (the part of
+    the index that grows with the corpus: configs[4] holds 20 GB of them), the PPR runs QUERY-PARALLEL on a replicated
+    graph (164 MB of CSR at configs[3]) with no exchange at all.
+
+      phase A   every rank scores ALL queries of the global batch against ITS fact rows (local top-k) -> all-gather of
+                the candidates + MIN / MAX all-reduce -> the same merge as the row-sharded mode (replicated result);
+      phase B   every rank scores ALL queries against ITS passage rows [B, Np / N] -> ONE all-to-all hands rank r the
+                score rows of ITS B / N queries over all passages [B / N, Np] -> hrag_retrieve_scored on those queries.
+
+    Wire per global batch: B * Np * 4 bytes in total for the all-to-all ((N - 1) / N of it crosses links) plus the
+    candidate lists -- 0.45 GB at configs[3] (B = 1024) against 20 sweeps x 0.91 GB RECEIVED PER GPU of the
+    row-sharded PPR (146 GB in total): a factor 300.  Every passage score is the same MFMA chain whatever matrix slice
+    it is computed from, so the result is bit-identical to the single-GPU engine on the same queries.
+    sim = ShardStages of this rank's shard engine (dist.build_shard_engine: its embedding shards are what is used),
+    ppr = a HippoRAGEngine WITHOUT embeddings over the whole graph, pshards = the passage ranges of the ranks."""
+
+    def __init__(self, sim, ppr, comm, pshards):
+        self.sim, self.ppr, self.comm, self.pshards = sim, ppr, comm, list(pshards)
+
+    def score_facts(self, q_fact, k: int = 5):
+        torch = _td()[0]
+        c = self.comm
+        idx, val, mn, mx = self.sim.shard_score_facts(q_fact, k)
+        idx_all, val_all = c.all_gather(idx), c.all_gather(val)
+        c.all_reduce(mn, "min")
+        c.all_reduce(mx, "max")
+        top_idx, top_val = merge_ranked(idx_all, val_all, k, self.sim.topk)
+        rng = (mx - mn).unsqueeze(1)
+        norm = torch.where(rng == 0, torch.ones_like(top_val), (top_val - mn.unsqueeze(1)) / rng)   # misc_utils.py:130-139
+        return top_idx, torch.where(top_idx < 0, torch.zeros_like(norm), norm)
+
+    def my_rows(self, batch: int):
+        w, r = self.comm.world, self.comm.rank
+        if batch % w:
+            raise ValueError(f"the global batch ({batch}) must be a multiple of the world size ({w})")
+        return slice(r * (batch // w), (r + 1) * (batch // w))
+
+    def retrieve(self, q_pass, kept_idx, kept_score, kept_count, **kw):
+        """q_pass / kept_*: the GLOBAL batch (replicated); returns this rank's RetrieveOutput for its B / N queries."""
+        torch = _td()[0]
+        c, w = self.comm, self.comm.world
+        b = q_pass.shape[0]
+        mine = self.my_rows(b)
+        bn = b // w
+        s_local = self.sim.e.sim_scores("passages", q_pass)                     # [B, Np_local]
+        parts = [s_local[d * bn:(d + 1) * bn] for d in range(w)]
+        got = c.all_to_all(parts, [(bn, hi - lo) for lo, hi in self.pshards])
+        scores = torch.cat(got, dim=1).contiguous()                            # [B / N, Np] in passage order
+        return self.ppr.retrieve_scored(scores, kept_idx[mine], kept_score[mine], kept_count[mine], **kw)
+
+
 def run_local_shards(world: int, sidx: "ShardedIndex", pass_emb, fact_emb, q_fact, q_pass, retrieve_kw: dict,
                      groups: int, device, max_topk: int, filter_fn=None, timings: Optional[dict] = None,
                      sell_seg_len: int = 0):
@@ -528,6 +609,68 @@ def run_local_shards(world: int, sidx: "ShardedIndex", pass_emb, fact_emb, q_fac
         for a, w in zip(results[r], results[0]):
             np.testing.assert_array_equal(a, w)
     return results[0]
+
+
+def build_ppr_engine(graph, passage_vertex, subj_vertex, obj_vertex, num_chunks, dim: int, max_batch: int,
+                     max_topk: int, flags: int = 0):
+    """The PPR side of the hybrid mode: the whole graph + the fact lookup arrays, NO embeddings."""
+    from .engine import HippoRAGEngine
+    return HippoRAGEngine(graph, passage_vertex, None, None, subj_vertex, obj_vertex, num_chunks, dim=dim,
+                          max_batch=max_batch, max_topk=max_topk, flags=flags)
+
+
+def run_local_hybrid(world: int, kg_arrays: dict, sidx: "ShardedIndex", pass_emb, fact_emb, q_fact, q_pass,
+                     retrieve_kw: dict, device, max_topk: int, timings: Optional[dict] = None):
+    """The hybrid mode with all `world` ranks as threads of this process on ONE device (LocalComm).  kg_arrays: the
+    ORIGINAL index (csr, passage_vertex, subj_vertex, obj_vertex, num_chunks) for the PPR engines.  Returns, in
+    query order, (fact idx, fact score) of the global batch and the concatenated per-rank (doc idx, doc score, flags)."""
+    import threading
+    torch = _td()[0]
+    from .engine import ShardStages
+    shared, results, errors = {}, [None] * world, []
+    b = q_fact.shape[0]
+    bn = b // world
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(device)
+            sim = build_shard_engine(sidx, pass_emb, fact_emb, rank, max_batch=b, max_topk=max_topk)
+            ppr = build_ppr_engine(kg_arrays["csr"], kg_arrays["passage_vertex"], kg_arrays["subj_vertex"],
+                                   kg_arrays["obj_vertex"], kg_arrays["num_chunks"], sim.dim, max_batch=bn,
+                                   max_topk=max_topk)
+            hy = HybridRetriever(ShardStages(sim), ppr, LocalComm(rank, world, shared), sidx.passages)
+            torch.cuda.synchronize()
+            shared["_barrier"].wait()
+            t0 = time.perf_counter()
+            idx, sc = hy.score_facts(q_fact, k=5)
+            cnt = torch.full((b,), 5, dtype=torch.int32, device=device)
+            out = hy.retrieve(q_pass, idx, sc, cnt, **retrieve_kw)
+            torch.cuda.synchronize()
+            if timings is not None and rank == 0:
+                timings["wall_s_all_ranks_on_one_device"] = time.perf_counter() - t0
+            results[rank] = tuple(t.cpu().numpy() for t in (idx, sc, out.doc_idx, out.doc_score, out.flags))
+            shared["_barrier"].wait()
+            sim.close()
+            ppr.close()
+        except Exception as exc:
+            errors.append((rank, exc))
+            try:
+                shared["_barrier"].abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=1200)
+    if errors:
+        raise RuntimeError(f"hybrid threads failed: {errors}")
+    for r in range(1, world):
+        np.testing.assert_array_equal(results[r][0], results[0][0])     # the merged fact candidates are replicated
+        np.testing.assert_array_equal(results[r][1], results[0][1])
+    return (results[0][0], results[0][1], np.concatenate([r[2] for r in results]),
+            np.concatenate([r[3] for r in results]), np.concatenate([r[4] for r in results]))
 
 
 # --------------------------------------------------------------------------------------------
@@ -613,7 +756,9 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
                       if phases else None),
         "replica": {"value": replica_qps, "unit": "queries/s", "ms_per_step": replica_s * 1e3 / max(args.steps, 1),
                     "parallelism": f"replica x{world}: every GPU holds the whole index and serves its own {B} queries"},
-        "rowshard": None,
+        "rowshard": None, "hybrid": None,
+        "multi_gpu_note": "no multi-GPU box was available to any round: every N > 1 figure of this repository is the "
+                          "driver's to take; the legs below are printed by rank 0 whenever N > 1",
     }
 
     # The row-sharded leg (the layout BASELINE.json's north star names) must never cost the line: a
@@ -625,6 +770,11 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
         if rank == 0 and not printed.is_set():
             printed.set()
             result["rowshard"] = rowshard
+            result["hybrid"] = hybrid_box.get("res")
+            hyb = hybrid_box.get("res")
+            if args.mode == "hybrid" and isinstance(hyb, dict) and "value" in hyb and hyb.get("parity", {}).get("ok"):
+                result["value"], result["ms_per_step"] = hyb["value"], hyb["ms_per_step"]
+                result["config"]["parallelism"] = hyb["parallelism"]
             ok = isinstance(rowshard, dict) and "value" in rowshard and rowshard.get("parity", {}).get("ok")
             if ok and args.mode == "rowshard":
                 # primary number = the mandated layout; the replica figure stays beside it
@@ -650,15 +800,30 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
 
     limit = float(getattr(args, "rowshard_timeout_s", 240.0))
     rowshard = None
+    hybrid_box = {}
     if getattr(args, "no_rowshard", False) or limit <= 0:
         rowshard = {"skipped": True}
     else:
-        leg_done = watchdog(limit, "row-sharded leg")
+        leg_done = watchdog(limit, "hybrid + row-sharded legs")
+        sidx = seng = None
         try:
-            rowshard = _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW,
-                                     seed, V, dev, barrier_sync, max_over_ranks, eng)
-        except Exception as exc:  # the replica measurement above stays valid; report instead of dying
-            rowshard = {"error": f"{type(exc).__name__}: {exc}"}
+            gb = world * B
+            sidx = shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+            seng = build_shard_engine(sidx, pass_emb, fact_emb, rank, gb, K_P)
+        except Exception as exc:
+            rowshard = {"error": f"shard engine: {type(exc).__name__}: {exc}"}
+        if seng is not None:
+            try:    # embeddings row-sharded, PPR query-parallel (no exchange in the PPR)
+                hybrid_box["res"] = _hybrid_leg(args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS,
+                                                DAMP, PW, seed, dev, barrier_sync, max_over_ranks, eng)
+            except Exception as exc:
+                hybrid_box["res"] = {"error": f"{type(exc).__name__}: {exc}"}
+            try:
+                rowshard = _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW,
+                                         seed, V, dev, barrier_sync, max_over_ranks, eng, sidx=sidx, seng=seng)
+            except Exception as exc:  # the replica measurement above stays valid; report instead of dying
+                rowshard = {"error": f"{type(exc).__name__}: {exc}"}
+            seng.close()
         leg_done.set()
     eng.close()
     emit(rowshard)
@@ -669,8 +834,56 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
     return 0
 
 
+def _hybrid_leg(args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW, seed, dev,
+                barrier_sync, max_over_ranks, replica_eng):
+    """The global batch (world * B) in the hybrid mode: every rank scores all queries against ITS embedding rows, one
+    all-to-all hands it the passage-score rows of its B queries, the PPR runs on the rank's own (replicated-graph)
+    engine without any exchange.  Checked bit for bit against the single-GPU engine on the rank's queries."""
+    torch, dist = _td()
+    from . import synth
+    from .engine import ShardStages
+    gb = world * B
+    hy = HybridRetriever(ShardStages(seng), replica_eng, TorchComm(rank, world), sidx.passages)
+    steps, warm = max(1, args.steps), max(1, min(args.warmup, 2))
+    n = steps + warm
+    gqf = [synth.make_queries_torch(fact_emb, gb, seed + 7000 + i)[0] for i in range(n)]
+    gqp = [synth.make_queries_torch(pass_emb, gb, seed + 7500 + i)[0] for i in range(n)]
+    gcnt = torch.full((gb,), K_F, dtype=torch.int32, device=dev)
+    kw = dict(link_top_k=K_F, damping=DAMP, passage_node_weight=PW, ppr_iters=ITERS, k=K_P)
+
+    def step(i):
+        idx, sc = hy.score_facts(gqf[i], k=K_F)
+        return idx, sc, hy.retrieve(gqp[i], idx, sc, gcnt, **kw)
+
+    for i in range(warm):
+        step(i)
+    barrier_sync()
+    t0 = time.perf_counter()
+    for i in range(warm, n):
+        idx, sc, out = step(i)
+    barrier_sync()
+    sec = max_over_ranks(time.perf_counter() - t0)
+    mine = hy.my_rows(gb)
+    i1, s1 = replica_eng.score_facts(gqf[n - 1][mine], k=K_F)
+    one = replica_eng.retrieve(gqp[n - 1][mine], i1, s1, gcnt[mine], **kw)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(out.doc_idx, one.doc_idx) and torch.equal(out.doc_score, one.doc_score) and
+                torch.equal(idx[mine], i1) and torch.equal(sc[mine], s1))
+    ok = torch.tensor([1 if same else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    np_total = len(sidx.passage_vertex)
+    return {"value": gb * steps / sec, "unit": "queries/s", "global_batch": gb, "steps": steps,
+            "ms_per_step": sec * 1e3 / steps,
+            "parallelism": f"hybrid x{world}: fact / passage embeddings row-sharded, one all-to-all of passage-score rows, "
+                           f"PPR query-parallel on a replicated graph (no exchange)",
+            "wire_bytes_per_global_batch_total": int((world - 1) / world * gb * np_total * 4 + world * (world - 1) * gb * K_F * 8),
+            "wire_bytes_received_per_gpu_per_global_batch": int((world - 1) / world * B * np_total * 4 + (world - 1) * gb * K_F * 8),
+            "parity": {"against": "single-GPU engine on this rank's queries, every rank", "bit_identical_on_every_rank": bool(ok.item() == 1),
+                       "ok": bool(ok.item() == 1)}}
+
+
 def _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW, seed, V, dev,
-                  barrier_sync, max_over_ranks, replica_eng):
+                  barrier_sync, max_over_ranks, replica_eng, sidx=None, seng=None):
     """The global batch (world * B) over the row-sharded corpus: fp8-state shards, one all-gather per
     exchange group and sweep; checked against the single-GPU engine on the same queries."""
     torch, dist = _td()
@@ -678,8 +891,11 @@ def _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS,
     from .engine import ShardStages
     gb = world * B
     groups = int(getattr(args, "exchange_groups", 2))
-    sidx = shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
-    seng = build_shard_engine(sidx, pass_emb, fact_emb, rank, gb, K_P)
+    own_engine = seng is None
+    if sidx is None:
+        sidx = shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+    if seng is None:
+        seng = build_shard_engine(sidx, pass_emb, fact_emb, rank, gb, K_P)
     rs = ShardedRetriever(ShardStages(seng), TorchComm(rank, world), groups=groups)
     rs_steps, rs_warm = max(1, args.steps), max(1, min(args.warmup, 2))
     n = rs_steps + rs_warm
@@ -725,6 +941,8 @@ def _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS,
                        f"{lay.n_groups} exchange group(s) pipelined against the sweeps of the other group(s)",
            "wire_bytes_received_per_gpu_per_sweep": wire, "state_bytes_per_buffer": int(lay.state_bytes),
            "n_slabs": int(lay.n_slabs), "exchange_groups": int(lay.n_groups),
+           "wire_bytes_received_per_gpu_per_global_batch": wire * ITERS,
            "rows_per_shard": int(sidx.rows_per_shard), "nnz_this_shard": nnz_own, "parity": parity}
-    seng.close()
+    if own_engine:
+        seng.close()
     return res

@@ -108,7 +108,11 @@ class HippoRAGEngine:
                  max_topk: int = 200, slab_width: int = 0, long_row_nnz: int = 0,
                  row_offset: int = 0, passage_offset: int = 0, fact_offset: int = 0,
                  n_passages: Optional[int] = None, n_facts: Optional[int] = None,
-                 device: Optional[int] = None, flags: int = 0, segment_nnz: int = 0, sell_seg_len: int = 0):
+                 device: Optional[int] = None, flags: int = 0, segment_nnz: int = 0, sell_seg_len: int = 0,
+                 dim: Optional[int] = None):
+        """passage_emb=None (with dim=...): an engine WITHOUT embeddings -- the PPR side of the hybrid multi-GPU mode
+        (dist.HybridRetriever): passage scores arrive through retrieve_scored(), seeds still come from subj_vertex /
+        obj_vertex / num_chunks."""
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("HippoRAGEngine needs an MI355X-class GPU: no HIP device is visible "
@@ -119,7 +123,12 @@ class HippoRAGEngine:
 
         pv = np.ascontiguousarray(passage_vertex, dtype=np.int32)
         self.n_passages = int(pv.shape[0]) if n_passages is None else int(n_passages)
-        p_obj, p_rows, dim, dt = _as_16bit(passage_emb)
+        if passage_emb is None:
+            if not dim or fact_emb is not None:
+                raise ValueError("an engine without passage embeddings needs dim= and takes no fact embeddings")
+            p_obj, p_rows, dt = None, self.n_passages, 0
+        else:
+            p_obj, p_rows, dim, dt = _as_16bit(passage_emb)
         self.emb_dtype = getattr(torch, _TORCH_DTYPE_OF[dt])    # the dtype queries travel in (fp32 on a split engine)
         self.f32_split = dt in (2, 3)
         row_ptr = np.ascontiguousarray(graph.row_ptr, dtype=np.int32)
@@ -135,10 +144,19 @@ class HippoRAGEngine:
         gd = GraphDesc(graph.num_vertices, row_offset, n_rows, col_idx.shape[0], _ptr(row_ptr),
                        _ptr(col_idx), _ptr(val), self.n_passages, _ptr(pv),
                        _ptr(col_sum) if col_sum is not None else None)
-        pd = EmbedDesc(p_rows, passage_offset, dim, dt, _ptr(p_obj))
+        pd = EmbedDesc(p_rows, passage_offset, dim, dt, _ptr(p_obj) if p_obj is not None else None)
         fdesc = fd = None
         keep = [pv, p_obj, row_ptr, col_idx, val, col_sum]
         self.n_facts = 0
+        if fact_emb is None and passage_emb is None and subj_vertex is not None:
+            # scores-only engine: the fact lookup arrays (seeds) without fact embeddings
+            sv = np.ascontiguousarray(subj_vertex, dtype=np.int32)
+            ov = np.ascontiguousarray(obj_vertex, dtype=np.int32)
+            nc = np.ascontiguousarray(num_chunks, dtype=np.int32)
+            self.n_facts = int(sv.shape[0])
+            fdesc = EmbedDesc(0, 0, dim, dt, None)
+            fd = FactDesc(self.n_facts, _ptr(sv), _ptr(ov), _ptr(nc))
+            keep += [sv, ov, nc]
         if fact_emb is not None:
             f_obj, f_rows, f_dim, f_dt = _as_16bit(fact_emb)
             if f_dim != dim or (f_dt != dt and not (f_dt in (2, 3) and dt in (2, 3))):
@@ -252,6 +270,28 @@ class HippoRAGEngine:
                                       ppr_tol, k, idx.data_ptr(), sc.data_ptr(), flags.data_ptr(),
                                       resid.data_ptr() if resid is not None else None,
                                       used.data_ptr() if used is not None else None, _stream()))
+        return RetrieveOutput(idx, sc, flags, resid, used)
+
+    def retrieve_scored(self, pass_scores, kept_idx, kept_score, kept_count, *, link_top_k: int = 5,
+                        damping: float = 0.5, passage_node_weight: float = 0.05, ppr_iters: int = 20, k: int = 200,
+                        ppr_tol: float = 0.0, ppr_max_iters: int = 0) -> RetrieveOutput:
+        """retrieve() with the raw passage scores fp32 [B, >= Np] supplied by the caller (hrag_retrieve_scored)."""
+        torch = _torch()
+        sc_in = pass_scores.to(self.device, torch.float32)
+        if sc_in.stride(-1) != 1:
+            sc_in = sc_in.contiguous()
+        b = sc_in.shape[0]
+        kept_idx = kept_idx.to(self.device, torch.int32).contiguous()
+        kept_score = kept_score.to(self.device, torch.float32).contiguous()
+        kept_count = kept_count.to(self.device, torch.int32).contiguous()
+        kf = kept_idx.shape[1]
+        idx, sc = self._empty((b, k), torch.int32), self._empty((b, k), torch.float32)
+        flags, resid, used = self._empty((b,), torch.int32), self._empty((b,), torch.float32), self._empty((b,), torch.int32)
+        check(self._lib.hrag_retrieve_scored(self._handle, sc_in.data_ptr(), sc_in.stride(0), b, kept_idx.data_ptr(),
+                                             kept_score.data_ptr(), kept_count.data_ptr(), kf, link_top_k, damping,
+                                             passage_node_weight, ppr_iters, max(ppr_max_iters, ppr_iters), ppr_tol, k,
+                                             idx.data_ptr(), sc.data_ptr(), flags.data_ptr(), resid.data_ptr(),
+                                             used.data_ptr(), _stream()))
         return RetrieveOutput(idx, sc, flags, resid, used)
 
     def retrieve_converged(self, q_pass, kept_idx, kept_score, kept_count, *, damping: float = 0.5,

@@ -237,6 +237,20 @@ hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass_dev, int32_t ba
                           int32_t *flags_out_dev, float *residual_out_dev, int32_t *iters_out_dev,
                           hrag_stream stream);
 
+/* hrag_retrieve with the RAW passage scores supplied by the caller instead of computed from this engine's passage
+ * embeddings: pass_scores_dev fp32 [B, pass_ld], np.dot(passage_embeddings, q) in passage order (HippoRAG.py:1496).
+ * Everything else -- min-max, prior, seeds, PPR, ranking, the DPR fallback -- is hrag_retrieve's.  The PPR side of
+ * the hybrid multi-GPU mode (hipporag_amd/dist.py HybridRetriever: embeddings row-sharded, the scores of a GPU's
+ * queries arrive by an all-to-all, the PPR runs query-parallel on a replicated graph without any exchange).  Such an
+ * engine can be created WITHOUT passage embeddings: hrag_embed_desc.data == NULL with rows = n_passages (and a fact
+ * descriptor with rows == 0 next to a full hrag_fact_desc). */
+hrag_status hrag_retrieve_scored(hrag_engine *e, const float *pass_scores_dev, int64_t pass_ld, int32_t batch,
+                                 const int32_t *kept_idx_dev, const float *kept_score_dev,
+                                 const int32_t *kept_count_dev, int32_t kf, int32_t link_top_k, float damping,
+                                 float passage_node_weight, int32_t ppr_iters, int32_t ppr_max_iters, float ppr_tol,
+                                 int32_t k, int32_t *doc_idx_out_dev, float *doc_score_out_dev, int32_t *flags_out_dev,
+                                 float *residual_out_dev, int32_t *iters_out_dev, hrag_stream stream);
+
 /* == dense_passage_retrieval (HippoRAG.py:1467-1502, StandardRAG.py:393-429), top-k only. */
 hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass_dev, int32_t batch,
                                 int32_t k, int32_t *doc_idx_out_dev, float *doc_score_out_dev,

@@ -307,3 +307,75 @@ def test_shard_index_is_an_isomorphic_balanced_relabelling():
         assert max(nnz) <= 1.02 * (sum(nnz) / world) + 64, nnz
         np.testing.assert_array_equal(s.num_chunks[s.perm], kg.num_chunks)
         np.testing.assert_array_equal(s.subj_vertex, s.perm[kg.subj_vertex])
+
+
+# ------------------------------------------------------------------------------------------ hybrid mode
+class _FakePprEngine:
+    """hipporag_amd.engine.HippoRAGEngine.retrieve_scored on the CPU: the oracle from given raw passage scores."""
+
+    def __init__(self, index):
+        self.ix = index
+
+    def retrieve_scored(self, scores, kept_idx, kept_score, kept_count, *, link_top_k, damping, passage_node_weight,
+                        ppr_iters, k, **_):
+        import dataclasses
+        ix = dataclasses.replace(self.ix, linking_top_k=link_top_k, damping=damping, passage_node_weight=passage_node_weight)
+        b = scores.shape[0]
+        d_idx, d_sc = np.full((b, k), -1, np.int32), np.zeros((b, k), np.float32)
+        for i in range(b):
+            n = int(kept_count[i])
+            s = scores[i].numpy()
+            by_p = oracle.min_max_normalize(s)
+            if n == 0:
+                order = oracle.topk_desc(by_p, k)
+                d_idx[i, :len(order)], d_sc[i, :len(order)] = order, by_p[order]
+                continue
+            fs = np.zeros(len(ix.subj_vertex), np.float32)
+            kept = kept_idx[i, :n].numpy()
+            fs[kept] = kept_score[i, :n].numpy()
+            sid, sw = oracle.seed_weights(ix, fs, kept.tolist(), link_top_k)
+            ids, sc, _ = oracle.run_ppr(ix, oracle.reset_vector(ix, sid, sw, by_p), damping, "power", ppr_iters)
+            d_idx[i, :min(k, len(ids))], d_sc[i, :min(k, len(ids))] = ids[:k], sc[:k]
+        return SimpleNamespace(doc_idx=torch.from_numpy(d_idx), doc_score=torch.from_numpy(d_sc))
+
+
+def _hybrid_rank(comm, sidx, index, rank, qf, qp, b):
+    sim = FakeShardStages(sidx, index, rank)
+    sim.e = SimpleNamespace(sim_scores=lambda which, q: torch.from_numpy((q.double().numpy() @ sim.pe.T).astype(np.float32)))
+    hy = hd.HybridRetriever(sim, _FakePprEngine(index), comm, sidx.passages)
+    idx, sc = hy.score_facts(qf, k=5)
+    cnt = torch.full((b,), 5, dtype=torch.int32)
+    cnt[1] = 0                                                        # a DPR-fallback query
+    out = hy.retrieve(qp, idx, sc, cnt, link_top_k=5, damping=0.5, passage_node_weight=0.05, ppr_iters=40, k=40)
+    return hy.my_rows(b), idx, cnt, out
+
+
+def _check_hybrid(index, qf, qp, rows, cnt, out):
+    for i, q in enumerate(range(rows.start, rows.stop)):
+        flt = (lambda cand, n=int(cnt[q]): cand[:n])
+        ref = oracle.retrieve_one(index, qf[q].float().numpy(), qp[q].float().numpy(), filter_fn=flt,
+                                  ppr_mode="power", ppr_iters=40)
+        np.testing.assert_array_equal(out.doc_idx[i].numpy(), ref.sorted_doc_ids[:40])
+        np.testing.assert_allclose(out.doc_score[i].numpy(), ref.sorted_doc_scores[:40], rtol=3e-6, atol=1e-7)
+
+
+def _gloo_hybrid_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        kg, index, sidx, qf, qp, b = _problem(world)
+        rows, idx, cnt, out = _hybrid_rank(hd.TorchComm(rank, world), sidx, index, rank, qf, qp, b)
+        _check_hybrid(index, qf, qp, rows, cnt, out)
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hybrid_retriever_world2_gloo_matches_oracle():
+    """dist.HybridRetriever over gloo (world 2): embeddings sharded, one all-to-all of passage-score rows (paired
+    isend / irecv on gloo), PPR query-parallel -- every rank's queries against the single-process oracle."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_gloo_hybrid_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: 1, 1: 1}

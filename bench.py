@@ -37,6 +37,10 @@ CONFIGS = {
                  label="configs[1]: synthetic 100k-node/1M-edge KG, 100k x 768 bf16, batch 64"),
     "cfg3": dict(V=1_000_000, E=10_000_000, D=768, B=256, seed=1237,
                  label="configs[2]: synthetic 1M-node/10M-edge KG, 1M x 768 bf16, batch 256"),
+    # NOT a BASELINE configuration: configs[2]'s sizes on a graph WITH locality (synth.make_kg(community=512): what
+    # indexing a corpus document by document produces) -- shows what the sweep does when the gathers can hit the L2
+    "cfg3loc": dict(V=1_000_000, E=10_000_000, D=768, B=256, seed=1237, community=512,
+                    label="NON-BASELINE variant of configs[2]: 1M-node/10M-edge KG with community structure (512-entity communities, 90 % local edges), 1M x 768 bf16, batch 256"),
     # one GPU's share of configs[4] (10M-node power-law KG, 10M x 1024 fp16 embeddings, 4096 / 8 queries)
     "cfg5gpu": dict(V=10_000_000, E=100_000_000, D=1024, B=512, seed=1239, power_law=True, fp16=True,
                     label="configs[4] per-GPU share: synthetic 10M-node/100M-edge power-law KG, 10M x 1024 fp16, batch 512"),
@@ -463,6 +467,8 @@ def main():
     ap.add_argument("--no-rowshard", action="store_true", help="N > 1: skip the secondary row-sharded leg")
     ap.add_argument("--rowshard-timeout-s", type=float, default=240.0,
                     help="N > 1: abandon the row-sharded leg after this long (the primary line still prints)")
+    ap.add_argument("--sell-sigma", type=int, default=0, help="hrag_opts.sell_sigma (SELL-C-sigma sorting window; 0 = global)")
+    ap.add_argument("--engine-flags", type=int, default=0, help="hrag_opts.flags (HRAG_OPT_*), e.g. 2048 = XCD_BLOCKED")
     ap.add_argument("--ppr-tol", type=float, default=3e-6,
                     help="tolerance of the secondary leg that runs under the convergence contract (the headline runs "
                          "BASELINE.json's fixed 20 sweeps and reports the residual they leave)")
@@ -492,12 +498,13 @@ def main():
         return bench_shard_share(args, cfg, dev)
 
     t_setup = time.perf_counter()
-    kg = synth.make_kg(V, E, seed, power_law=bool(cfg.get("power_law")))
+    kg = synth.make_kg(V, E, seed, power_law=bool(cfg.get("power_law")), community=int(cfg.get("community", 0)))
     emb_dtype = torch.float16 if cfg.get("fp16") else torch.bfloat16
     pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev, dtype=emb_dtype)
     fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev, dtype=emb_dtype)
     eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pass_emb, fact_emb, kg.subj_vertex, kg.obj_vertex,
-                         kg.num_chunks, max_batch=B, max_topk=K_P, slab_width=args.slab_width)
+                         kg.num_chunks, max_batch=B, max_topk=K_P, slab_width=args.slab_width, flags=args.engine_flags,
+                         sell_sigma=args.sell_sigma)
     n_batches = args.steps + args.warmup
     qf = [synth.make_queries_torch(fact_emb, B, seed + 100 + i)[0] for i in range(n_batches)]
     qp = [synth.make_queries_torch(pass_emb, B, seed + 500 + i)[0] for i in range(n_batches)]
@@ -556,6 +563,7 @@ def main():
                    "embedding_dtype": "fp16" if cfg.get("fp16") else "bf16",
                    "ppr_state_dtype": ("e4m3 staged corrections + fp32 true residual (fp32 arithmetic)" if f8 else
                                        "f16 hi + f16 correction (fp32 arithmetic)" if f16 else "f32"),
+                   "sell_sigma": args.sell_sigma, "engine_flags": args.engine_flags,
                    "parallelism": "1gpu"},
         "roofline": roofline,
         "ppr_contract": contract, "with_convergence_contract": contract_c,

@@ -9,13 +9,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhrag.so")
 
-HRAG_OK, HRAG_EINVAL, HRAG_ENOMEM, HRAG_EHIP, HRAG_EZERO_RESET, HRAG_ECAPACITY = range(6)
+HRAG_OK, HRAG_EINVAL, HRAG_ENOMEM, HRAG_EHIP, HRAG_EBUSY, HRAG_ECAPACITY = range(6)
 SEED_STRIDE = 32
 HRAG_VERSION = 4      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
 FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, FLAG_FP8_SATURATED, FLAG_NOT_CONVERGED = 1, 2, 4, 8, 16
 # hrag_opts.flags (include/hrag.h HRAG_OPT_*)
 OPT_NATURAL_ROW_ORDER, OPT_NT_CSR, OPT_NT_STORE, OPT_F32_STATE, OPT_TEMPORAL16, OPT_NO_FP8 = 1, 2, 4, 8, 16, 32
-OPT_ROWS_BY_MINCOL, OPT_ROWS_BFS, OPT_SLABS_PER_WG_1, OPT_NO_F16 = 64, 128, 256, 1024
+OPT_ROWS_BY_MINCOL, OPT_ROWS_BFS, OPT_SLABS_PER_WG_1, OPT_NO_F16, OPT_XCD_BLOCKED = 64, 128, 256, 1024, 2048
 
 
 class HragError(RuntimeError):
@@ -44,7 +44,7 @@ class FactDesc(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("max_batch", C.c_int32), ("max_topk", C.c_int32), ("slab_width", C.c_int32),
                 ("long_row_nnz", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32),
-                ("segment_nnz", C.c_int32), ("sell_seg_len", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("segment_nnz", C.c_int32), ("sell_seg_len", C.c_int32), ("sell_sigma", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 class Timings(C.Structure):
@@ -75,6 +75,7 @@ SIGNATURES = {
                                 _P, _P, _P]),
     "hrag_retrieve_scored": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _F32, _F32, _I32, _I32, _F32, _I32, _P, _P,
                                        _P, _P, _P, _P]),
+    "hrag_last_doc_scores": (C.c_int, [_P, _I32, _P, _I64, _P]),
     "hrag_dense_retrieve": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),
     "hrag_sim_scores": (C.c_int, [_P, _I32, _P, _I32, _P, _P]),
     "hrag_ppr": (C.c_int, [_P, _P, _I32, _F32, _I32, _P, _P, _P]),

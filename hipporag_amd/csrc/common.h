@@ -232,6 +232,7 @@ struct Ppr8Args {
     int32_t batch;
     int32_t slab0, n_slabs;    // 128-query slabs covered by this launch
     int32_t wps;               // slabs handled inside one workgroup (1, 2 or 4 wavefronts per chunk); 0 / 1 = one
+    int32_t cg_per_xcd;        // > 0 (HRAG_OPT_XCD_BLOCKED): XCD x walks chunk groups [x * cg_per_xcd, (x + 1) * cg_per_xcd)
     // convergence contract (csrc/shard.hip, ppr8_begin): a launch whose gate word differs from gate_want returns at
     // once -- the extension stages and the alternative final sweeps are enqueued unconditionally and the DEVICE
     // decides which of them run (no host synchronisation, graph-capture safe)

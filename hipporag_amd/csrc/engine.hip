@@ -46,6 +46,7 @@ void free_engine(hrag_engine *e) {
     free_store(e->fsell);
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_last) (void)hipEventDestroy(e->ev_last);
     delete e;
 }
 
@@ -138,8 +139,17 @@ hrag_status build_sell8(const hrag_engine *e, const std::vector<int32_t> &row_pt
             vr.push_back({std::min(seg_len, len - i * seg_len), b0 + i * seg_len, -(n_partial++ + 1), (int32_t)r});
         }
     }
-    // longest first (stable => deterministic); a chunk = 8 consecutive virtual rows
-    std::stable_sort(vr.begin(), vr.end(), [](const VRow &a, const VRow &b) { return a.len > b.len; });
+    // longest first (stable => deterministic); a chunk = 8 consecutive virtual rows.  hrag_opts.sell_sigma: the sort
+    // stays inside windows of that many consecutive rows (SELL-C-sigma), so the processing order follows the vertex
+    // numbering at window granularity -- what a numbering with locality needs for its gathers to hit the L2
+    if (e->sell_sigma >= 8) {
+        const size_t win = (size_t)round_up(e->sell_sigma, 8);
+        for (size_t lo = 0; lo < vr.size(); lo += win)
+            std::stable_sort(vr.begin() + (ptrdiff_t)lo, vr.begin() + (ptrdiff_t)std::min(vr.size(), lo + win),
+                             [](const VRow &a, const VRow &b) { return a.len > b.len; });
+    } else {
+        std::stable_sort(vr.begin(), vr.end(), [](const VRow &a, const VRow &b) { return a.len > b.len; });
+    }
     if (e->opt_flags & (HRAG_OPT_ROWS_BY_MINCOL | HRAG_OPT_ROWS_BFS)) {
         // EXPERIMENT ("row order and L2 reuse"): rows of equal length may be processed in any
         // order, so put rows that share in-neighbours next to each other -- they run on the same XCD at about the
@@ -443,6 +453,7 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     e->short_thresh = opts->long_row_nnz > 0 ? opts->long_row_nnz : 8 * (e->slab_cap / 4);
     e->seg_len = opts->segment_nnz > 0 ? (int)round_up(opts->segment_nnz, 64) : 512;
     e->sell_seg_len = opts->sell_seg_len;
+    e->sell_sigma = opts->sell_sigma;
     e->opt_flags = opts->flags;
 
     // ---- CSR to the device; row lists on the host (copy row_ptr back if it came from the device)
@@ -767,6 +778,7 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     }
     E_HIP(hipMemset(e->d_seed_cnt, 0, (size_t)B * sizeof(int32_t)));
     for (auto &ev : e->ev) E_HIP(hipEventCreate(&ev));
+    E_HIP(hipEventCreateWithFlags(&e->ev_last, hipEventDisableTiming));
     E_HIP(hipDeviceSynchronize());
 #undef E_TRY
 #undef E_HIP
@@ -822,6 +834,7 @@ hrag_status hrag_sim_scores(hrag_engine *e, int32_t which, const uint16_t *q, in
     HRAG_REQUIRE(e && q && out, "NULL argument");
     HRAG_REQUIRE(batch >= 1, "batch must be >= 1");
     HRAG_REQUIRE(which == 0 || which == 1, "which must be 0 (facts) or 1 (passages)");
+    HRAG_ENGINE_CALL(e, stream);
     HRAG_TRY(prep_query(e, q, batch, (hipStream_t)stream, &q));
     if (which == 0) {
         HRAG_REQUIRE(e->d_femb != nullptr || e->f_rows == 0, "engine has no fact embeddings");
@@ -852,6 +865,7 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q, int32_t batch, i
     HRAG_REQUIRE(e->f_rows == e->n_facts, "hrag_score_facts needs the whole fact matrix; a sharded "
                  "engine goes through hrag_sim_scores + hrag_topk_rows + an all-gather");
     hipStream_t s = (hipStream_t)stream;
+    HRAG_ENGINE_CALL(e, stream);
     if (e->profiling) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_FACT0], s));
     HRAG_TRY(prep_query(e, q, batch, s, &q));
     if (batch > 16 && k <= 16 && e->f_rows > 0 && e->d_fused_ws) {
@@ -959,6 +973,7 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
     HRAG_REQUIRE(damping >= 0.f && damping < 1.f, "damping %g outside [0, 1)", (double)damping);
     HRAG_REQUIRE(e->n_passages >= 1, "engine has no passages");
     hipStream_t s = (hipStream_t)stream;
+    HRAG_ENGINE_CALL(e, stream);
     const bool sv = use_sv(e, batch);
     const bool f8 = !sv && batch > 64 && e->d_pool8[0] && ppr8_usable(e, batch, ppr_iters, damping);
     const int f8_iters = ppr_iters;
@@ -1155,6 +1170,17 @@ hrag_status hrag_retrieve_scored(hrag_engine *e, const float *pass_scores, int64
                          flags_out, residual_out, iters_out, stream);
 }
 
+hrag_status hrag_last_doc_scores(hrag_engine *e, int32_t batch, float *out, int64_t ld, hrag_stream stream) {
+    HRAG_TRY(check_batch(e, batch));
+    HRAG_REQUIRE(out && ld >= e->p_rows, "bad argument");
+    HRAG_REQUIRE(e->d_doc != nullptr, "engine has no score rows");
+    HRAG_ENGINE_CALL(e, stream);
+    HRAG_HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * sizeof(float), e->d_doc, (size_t)e->ld_p * sizeof(float),
+                                  (size_t)e->p_rows * sizeof(float), (size_t)batch, hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    return HRAG_OK;
+}
+
 hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t batch, int32_t k,
                                 int32_t *doc_idx_out, float *doc_score_out, hrag_stream stream) {
     HRAG_TRY(check_batch(e, batch));
@@ -1162,6 +1188,7 @@ hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t 
     HRAG_REQUIRE(e->p_rows == e->n_passages && e->d_pemb, "hrag_dense_retrieve needs the whole passage matrix");
     HRAG_REQUIRE(k >= 1 && k <= e->max_topk, "k=%d outside [1, max_topk=%d]", k, e->max_topk);
     hipStream_t s = (hipStream_t)stream;
+    HRAG_ENGINE_CALL(e, stream);
     HRAG_TRY(prep_query(e, q_pass, batch, s, &q_pass));
     HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->kdim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
     return launch_row_topk(e->d_spass, batch, e->n_passages, e->ld_p, k, 0, kNormMinMax, doc_idx_out,
@@ -1175,6 +1202,7 @@ hrag_status hrag_ppr(hrag_engine *e, const float *reset, int32_t batch, float da
     HRAG_REQUIRE(damping >= 0.f && damping < 1.f, "damping %g outside [0, 1)", (double)damping);
     HRAG_REQUIRE(e->n_rows == e->V, "hrag_ppr needs an unsharded engine");
     hipStream_t s = (hipStream_t)stream;
+    HRAG_ENGINE_CALL(e, stream);
     if (!e->d_tele_dense) HRAG_TRY(dev_alloc(&e->d_tele_dense, e->state_elems));  // first use only
     if (use_sv(e, batch)) {   // run_ppr seam at B = 1 (ppr_sv.hip), v dense over all vertices
         const int bp = sv_width(batch);

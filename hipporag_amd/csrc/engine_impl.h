@@ -3,6 +3,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -127,7 +128,7 @@ struct hrag_engine {
     uint16_t *d_pemb = nullptr, *d_femb = nullptr;
     int32_t *d_subj = nullptr, *d_obj = nullptr, *d_num_chunks = nullptr;
     // options
-    int32_t max_batch = 0, max_topk = 0, slab_cap = 32, short_thresh = 0, seg_len = 0, opt_flags = 0, sell_seg_len = 0;
+    int32_t max_batch = 0, max_topk = 0, slab_cap = 32, short_thresh = 0, seg_len = 0, opt_flags = 0, sell_seg_len = 0, sell_sigma = 0;
     // workspace
     int64_t state_elems = 0;  // floats in each of d_x / d_y
     float *d_x = nullptr, *d_y = nullptr, *d_tele = nullptr, *d_tele_dense = nullptr;
@@ -182,6 +183,11 @@ struct hrag_engine {
     float *d_resid = nullptr, *d_est_prev = nullptr;
     float *d_est_ws = nullptr;      // per-wavefront maxima of a sweep that measures est: [slabs][chunks][queries per slab row]
     double *d_mass_tab = nullptr;   // [kP8MaxExt + 1][max_batch]: mass of the (iters + 3 j)-sweep iterate
+    // one call in flight per engine (include/hrag.h): host-side entry flag + the end of the last call on its stream
+    std::atomic<int> in_call{0};
+    hipEvent_t ev_last = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
     // timing
     hipEvent_t ev[EV_COUNT] = {};
     bool profiling = false, have_retrieve_ev = false, have_fact_ev = false;
@@ -209,6 +215,46 @@ struct hrag_engine {
 };
 
 namespace hrag {
+// Guard of the single-call entry points that use the engine's workspace: rejects a second thread inside a call and
+// a call on another stream while the previous one has not finished on the device (HRAG_EBUSY); records the end of
+// this call on its stream when it leaves.  During stream capture the event logic is skipped (a captured event
+// cannot be queried; a captured call replays on the capture's stream).
+struct EngineCall {
+    hrag_engine *e;
+    hipStream_t s;
+    hrag_status st = HRAG_OK;
+    bool entered = false, capturing = false;
+    EngineCall(hrag_engine *eng, hipStream_t stream) : e(eng), s(stream) {
+        if (!e) return;
+        int expected = 0;
+        if (!e->in_call.compare_exchange_strong(expected, 1)) {
+            set_error("engine busy: another thread is inside a call on this engine (one call in flight per engine)");
+            st = HRAG_EBUSY;
+            return;
+        }
+        entered = true;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) capturing = true;
+        if (!capturing && e->have_last && e->last_stream != s && e->ev_last &&
+            hipEventQuery(e->ev_last) == hipErrorNotReady) {
+            set_error("engine busy: the previous call, enqueued on another stream, has not finished (the workspace "
+                      "belongs to the engine: one call in flight, or one engine per stream)");
+            st = HRAG_EBUSY;
+        }
+        (void)hipGetLastError();   // hipEventQuery's hipErrorNotReady is not an error of this call
+    }
+    ~EngineCall() {
+        if (!entered) return;
+        if (st == HRAG_OK && !capturing && e->ev_last) {
+            if (hipEventRecord(e->ev_last, s) == hipSuccess) { e->last_stream = s; e->have_last = true; }
+        }
+        e->in_call.store(0);
+    }
+};
+#define HRAG_ENGINE_CALL(e, stream)                 \
+    EngineCall _engine_call((e), (hipStream_t)(stream)); \
+    if (_engine_call.st != HRAG_OK) return _engine_call.st
+
 // the query matrix as the similarity kernels take it: the caller's pointer, or (HRAG_F32_SPLIT) its fp32 rows split
 // into [hi | hi | lo] in the engine's buffer (one call in flight per engine: include/hrag.h)
 inline hrag_status prep_query(hrag_engine *e, const uint16_t *q, int32_t batch, hipStream_t s, const uint16_t **out) {

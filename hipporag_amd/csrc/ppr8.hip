@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     // different slabs read the same (col, val) blocks at about the same time from the same CU
     const int id = blockIdx.x, wps = a.wps, nsg = a.n_slabs / wps, wave = threadIdx.x >> 6;
     const int slab = a.slab0 + ((id >> 3) % nsg) * wps + (wave & (wps - 1));
-    const int cg = (id / (8 * nsg)) * 8 + (id & 7);
+    const int cg = a.cg_per_xcd > 0 ? (id & 7) * a.cg_per_xcd + id / (8 * nsg) : (id / (8 * nsg)) * 8 + (id & 7);
     const int chunk = __builtin_amdgcn_readfirstlane(cg * (4 / wps) + wave / wps);
     if (chunk >= a.m.n_chunks) return;
     const int2 meta = a.m.chunk_meta[chunk];  // (first step, number of steps)
@@ -612,7 +612,7 @@ __device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
     // a workgroup = 4 wavefronts = (4 / wps) chunks x wps slab PAIRS
     const int id = blockIdx.x, wps = a.wps, nsg = (a.n_slabs >> 1) / wps, wave = threadIdx.x >> 6;
     const int slab = a.slab0 + 2 * (((id >> 3) % nsg) * wps + (wave & (wps - 1)));
-    const int cg = (id / (8 * nsg)) * 8 + (id & 7);
+    const int cg = a.cg_per_xcd > 0 ? (id & 7) * a.cg_per_xcd + id / (8 * nsg) : (id / (8 * nsg)) * 8 + (id & 7);
     const int chunk = __builtin_amdgcn_readfirstlane(cg * (4 / wps) + wave / wps);
     if (chunk >= a.m.n_chunks) return;
     const int2 meta = a.m.chunk_meta[chunk];  // (first step, number of steps)
@@ -976,6 +976,7 @@ hrag_status sweep_mode(const Ppr8Args &a_in, bool main_only, hipStream_t s) {
         const int np = b.n_slabs / 2;
         b.wps = (a.wps == 4 && np % 4 == 0) ? 4 : (a.wps >= 2 && np % 2 == 0) ? 2 : 1;
         const unsigned ncg = (unsigned)ceil_div(a.m.n_chunks, 4 / b.wps);
+        if (a.cg_per_xcd) b.cg_per_xcd = (int32_t)(round_up(ncg, 8) / 8);
         hipLaunchKernelGGL((ppr8_pair_kernel<MODE, RIO, EST>), dim3((unsigned)round_up(ncg, 8) * (unsigned)(np / b.wps)),
                            dim3(256), 0, s, b);
         HRAG_LAUNCH_CHECK();
@@ -988,6 +989,7 @@ hrag_status sweep_mode(const Ppr8Args &a_in, bool main_only, hipStream_t s) {
         Ppr8Args b = a;
         b.wps = (a.wps == 4 && a.n_slabs % 4 == 0) ? 4 : (a.wps >= 2 && a.n_slabs % 2 == 0) ? 2 : 1;
         const unsigned ncg = (unsigned)ceil_div(a.m.n_chunks, 4 / b.wps);
+        if (a.cg_per_xcd) b.cg_per_xcd = (int32_t)(round_up(ncg, 8) / 8);
         hipLaunchKernelGGL((ppr8_kernel<MODE, RIO, EST>), dim3((unsigned)round_up(ncg, 8) * (unsigned)(a.n_slabs / b.wps)),
                            dim3(256), 0, s, b);
         HRAG_LAUNCH_CHECK();

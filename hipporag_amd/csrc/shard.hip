@@ -76,6 +76,7 @@ Ppr8Args base_args(const hrag_engine *e) {
     a.flags = const_cast<int32_t *>(p.flags); a.batch = p.batch;
     a.slab0 = 0; a.n_slabs = p.n_slabs;
     a.wps = (e->opt_flags & HRAG_OPT_SLABS_PER_WG_1) ? 1 : 4;
+    a.cg_per_xcd = (e->opt_flags & HRAG_OPT_XCD_BLOCKED) ? 1 : 0;   // the launcher fills in the count
     return a;
 }
 
@@ -445,7 +446,7 @@ hrag_status hrag_engine_gather_embeddings(hrag_engine *e, int32_t which, const i
 hrag_status hrag_engine_set_flags(hrag_engine *e, int32_t flags, int32_t on) {
     HRAG_REQUIRE(e != nullptr, "engine is NULL");
     const int32_t runtime = HRAG_OPT_NO_FP8 | HRAG_OPT_NT_CSR | HRAG_OPT_NT_STORE | HRAG_OPT_TEMPORAL16 | HRAG_OPT_SLABS_PER_WG_1 |
-                            HRAG_OPT_NO_F16;
+                            HRAG_OPT_NO_F16 | HRAG_OPT_XCD_BLOCKED;
     HRAG_REQUIRE((flags & ~runtime) == 0, "only HRAG_OPT_NO_FP8 / NO_F16 / NT_CSR / NT_STORE / TEMPORAL16 / SLABS_PER_WG_1 can change after creation");
     if (on) e->opt_flags |= flags; else e->opt_flags &= ~flags;
     return HRAG_OK;

@@ -90,6 +90,7 @@ class RetrieveOutput:
     residual: "object" = None    # torch fp32 [B]: damping / (1 - damping) * the relative size of the last sweep's update
                                  # of the passage scores (include/hrag.h, hrag_retrieve); -1 where not measured
     iters_used: "object" = None  # torch int32 [B]: PPR sweeps that ran
+    all_scores: "object" = None  # torch fp32 [B, Np] (retrieve_converged(want_all_scores=True)): every passage's score
 
 
 logger = logging.getLogger(__name__)
@@ -109,7 +110,7 @@ class HippoRAGEngine:
                  row_offset: int = 0, passage_offset: int = 0, fact_offset: int = 0,
                  n_passages: Optional[int] = None, n_facts: Optional[int] = None,
                  device: Optional[int] = None, flags: int = 0, segment_nnz: int = 0, sell_seg_len: int = 0,
-                 dim: Optional[int] = None):
+                 dim: Optional[int] = None, sell_sigma: int = 0):
         """passage_emb=None (with dim=...): an engine WITHOUT embeddings -- the PPR side of the hybrid multi-GPU mode
         (dist.HybridRetriever): passage scores arrive through retrieve_scored(), seeds still come from subj_vertex /
         obj_vertex / num_chunks."""
@@ -173,7 +174,7 @@ class HippoRAGEngine:
             fd = FactDesc(self.n_facts, _ptr(sv), _ptr(ov), _ptr(nc))
             keep += [f_obj, sv, ov, nc]
         self.opt_flags = int(flags)      # HRAG_OPT_* bits as set_flags leaves them
-        opts = Opts(max_batch, max_topk, slab_width, long_row_nnz, self.device.index, flags, segment_nnz, sell_seg_len)
+        opts = Opts(max_batch, max_topk, slab_width, long_row_nnz, self.device.index, flags, segment_nnz, sell_seg_len, sell_sigma)
         with torch.cuda.device(self.device):
             check(self._lib.hrag_engine_create(C.byref(gd), C.byref(fdesc) if fdesc else None,
                                                C.byref(pd), C.byref(fd) if fd else None,
@@ -295,7 +296,8 @@ class HippoRAGEngine:
         return RetrieveOutput(idx, sc, flags, resid, used)
 
     def retrieve_converged(self, q_pass, kept_idx, kept_score, kept_count, *, damping: float = 0.5,
-                           ppr_iters: int = 20, ppr_tol: float = 3e-6, ppr_max_iters: int = 400, **kw) -> RetrieveOutput:
+                           ppr_iters: int = 20, ppr_tol: float = 3e-6, ppr_max_iters: int = 400,
+                           want_all_scores: bool = False, **kw) -> RetrieveOutput:
         """retrieve() + what the host owes the convergence contract (include/hrag.h): a batch whose fp8 state
         saturated is repeated on the wider state (never clipped scores); queries the engine flags
         HRAG_FLAG_NOT_CONVERGED -- its sweep budget did not reach ppr_tol: a slowly mixing graph -- are repeated,
@@ -309,8 +311,11 @@ class HippoRAGEngine:
 
         def run(rows=None, iters=ppr_iters, max_iters=ppr_max_iters):
             sel = slice(None) if rows is None else rows
-            return self.retrieve(q[sel], kept_idx[sel], kept_score[sel], kept_count[sel], damping=damping,
-                                 ppr_iters=iters, ppr_tol=ppr_tol, ppr_max_iters=max(max_iters, iters), **kw)
+            o = self.retrieve(q[sel], kept_idx[sel], kept_score[sel], kept_count[sel], damping=damping,
+                              ppr_iters=iters, ppr_tol=ppr_tol, ppr_max_iters=max(max_iters, iters), **kw)
+            if want_all_scores:     # every passage's score (callers that want more than max_topk documents)
+                o.all_scores = self.last_doc_scores(o.doc_idx.shape[0])
+            return o
 
         def on_wider_state(fn, bits=OPT_NO_FP8):
             had = self.opt_flags & bits               # restore what the engine was created with
@@ -347,12 +352,21 @@ class HippoRAGEngine:
             o2 = on_wider_state(lambda: run(rt, need, need), OPT_NO_FP8 | OPT_NO_F16)
             out.doc_idx[rt], out.doc_score[rt] = o2.doc_idx, o2.doc_score
             out.flags[rt], out.residual[rt], out.iters_used[rt] = o2.flags, o2.residual, o2.iters_used
+            if want_all_scores:
+                out.all_scores[rt] = o2.all_scores
             flags[rows], resid[rows], used[rows] = (o2.flags.cpu().numpy(), o2.residual.cpu().numpy(),
                                                     o2.iters_used.cpu().numpy())
         left = (flags & FLAG_NOT_CONVERGED) != 0
         if left.any():
             logger.warning("PPR residual above ppr_tol=%.2g for %d queries after ppr_max_iters=%d sweeps (max %.2g)",
                            ppr_tol, int(left.sum()), ppr_max_iters, float(resid[left].max()))
+        return out
+
+    def last_doc_scores(self, batch: int):
+        """fp32 [batch, Np]: the scores of ALL passages behind the last retrieve() / retrieve_scored() (hrag_last_doc_scores)."""
+        torch = _torch()
+        out = self._empty((batch, self.passage_rows), torch.float32)
+        check(self._lib.hrag_last_doc_scores(self._handle, batch, out.data_ptr(), self.passage_rows, _stream()))
         return out
 
     def dense_retrieve(self, q_pass, k: int = 200):

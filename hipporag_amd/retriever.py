@@ -170,7 +170,10 @@ def batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Sequenc
     k_f = int(linking_top_k)
     want = max(1, min(int(num_to_retrieve), n_passages))
     k_docs = min(want, eng.max_topk)
-    if k_docs < want:
+    # more documents than the device top-k holds (HippoRAG.py:501-507 slices any prefix of the full ranking): the
+    # scores of all passages come back and are ranked here with the library's rule (score desc, larger index first)
+    beyond = k_docs < want and hasattr(eng, "last_doc_scores")
+    if k_docs < want and not beyond:
         logger.warning("num_to_retrieve=%d exceeds the engine's max_topk=%d: %d documents per query are returned "
                        "(create the engine with a larger retrieval_top_k, <= 2048)", num_to_retrieve, eng.max_topk, k_docs)
     out_rows = []
@@ -205,9 +208,14 @@ def batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Sequenc
         out = eng.retrieve_converged(q_tensor(qs, "passage"), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc),
                                      torch.from_numpy(kept_cnt), link_top_k=k_f, damping=damping,
                                      passage_node_weight=passage_node_weight, ppr_iters=ppr_iters, k=k_docs,
-                                     ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters)
+                                     ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters,
+                                     **({"want_all_scores": True} if beyond else {}))
         flags = out.flags.cpu().numpy()
         d_idx, d_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+        if beyond:
+            full = out.all_scores.cpu().numpy()
+            d_idx = np.stack([np.argsort(r, kind="stable")[::-1][:want] for r in full]).astype(np.int32)
+            d_sc = np.take_along_axis(full, d_idx.astype(np.int64), axis=1)
         if timers is not None:
             timers.ppr_time = getattr(timers, "ppr_time", 0.0) + time.time() - t_p
         for i in range(b):

@@ -52,7 +52,14 @@ def _zipf_ranks(rng: np.random.Generator, n_items: int, size: int, s: float) -> 
 
 
 def make_kg(num_vertices: int, num_edges: int, seed: int, passage_frac: float = 0.125,
-            power_law: bool = False, zipf_s: float = 0.6) -> SyntheticKG:
+            power_law: bool = False, zipf_s: float = 0.6, community: int = 0, local_frac: float = 0.9) -> SyntheticKG:
+    """community > 0: a NON-BASELINE variant with locality (what indexing a corpus document by document produces,
+    HippoRAG.py:867-957: a document's passages talk about the same entities, facts link entities of the same
+    documents): entities come in communities of `community` consecutive ids, passage p belongs to community
+    p * n_comm / N_p, `local_frac` of a passage's entities and of the entity-entity edges stay inside the community
+    (Zipf popularity inside it), the rest is drawn globally as in the baseline generator."""
+    if community > 0:
+        return _make_kg_local(num_vertices, num_edges, seed, passage_frac, zipf_s, community, local_frac)
     rng = np.random.Generator(np.random.PCG64(seed))
     n_p = max(1, int(round(num_vertices * passage_frac)))
     n_e = num_vertices - n_p
@@ -115,6 +122,67 @@ def make_kg(num_vertices: int, num_edges: int, seed: int, passage_frac: float = 
     num_chunks[:n_e] = np.bincount(e_of, minlength=n_e)
     return SyntheticKG(num_vertices, n_e, n_p, src, dst, weight, csr,
                        (n_e + np.arange(n_p)).astype(np.int32),
+                       subj.astype(np.int32), obj.astype(np.int32), num_chunks)
+
+
+def _make_kg_local(num_vertices, num_edges, seed, passage_frac, zipf_s, community, local_frac) -> SyntheticKG:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n_p = max(1, int(round(num_vertices * passage_frac)))
+    n_e = num_vertices - n_p
+    n_comm = max(1, n_e // community)
+    comm_lo = (np.arange(n_comm, dtype=np.int64) * n_e) // n_comm          # first entity of a community
+    comm_sz = np.diff(np.append(comm_lo, n_e))
+
+    def draw(comm, size_like):      # entities: local_frac inside `comm` (Zipf rank inside it), the rest global
+        local = rng.random(size_like.shape[0]) < local_frac
+        r = _zipf_ranks(rng, 1 << 20, size_like.shape[0], zipf_s) / float(1 << 20)
+        inside = comm_lo[comm] + np.minimum((r * comm_sz[comm]).astype(np.int64), comm_sz[comm] - 1)
+        return np.where(local, inside, rng.integers(0, n_e, size_like.shape[0]))
+
+    # (1) passage - entity edges
+    deg = np.minimum(rng.poisson(8.0, n_p) + 1, n_e)
+    p_rep = np.repeat(np.arange(n_p, dtype=np.int64), deg)
+    p_comm = (p_rep * n_comm) // n_p
+    ent = draw(p_comm, p_rep)
+    pe = np.unique(p_rep * n_e + ent)
+    p_of, e_of = pe // n_e, pe % n_e
+    covered = np.zeros(n_e, dtype=bool)
+    covered[e_of] = True
+    lonely = np.flatnonzero(~covered)
+    if lonely.size:         # an entity nobody drew gets a passage of its own community
+        c = np.searchsorted(comm_lo, lonely, side="right") - 1
+        p_lo, p_hi = (c * n_p) // n_comm, np.maximum(((c + 1) * n_p) // n_comm, (c * n_p) // n_comm + 1)
+        p_of = np.concatenate([p_of, np.minimum(p_lo + (rng.random(lonely.size) * (p_hi - p_lo)).astype(np.int64), n_p - 1)])
+        e_of = np.concatenate([e_of, lonely])
+    n_pe = p_of.size
+    # (2)+(3) entity - entity edges on distinct pairs
+    n_ee = min(max(0, num_edges - n_pe), n_e * (n_e - 1) // 2)
+    keys = np.zeros(0, dtype=np.int64)
+    while keys.size < n_ee:
+        need = int((n_ee - keys.size) * 1.3) + 16
+        a = rng.integers(0, n_e, need)
+        b = draw(np.searchsorted(comm_lo, a, side="right") - 1, a)
+        ok = a != b
+        a, b = a[ok], b[ok]
+        keys = np.unique(np.concatenate([keys, np.minimum(a, b) * n_e + np.maximum(a, b)]))
+    if keys.size > n_ee:
+        keys = rng.permutation(keys)[:n_ee]
+    lo, hi = keys // n_e, keys % n_e
+    w_ee = 2.0 * rng.choice(np.array([1.0, 2.0, 3.0]), size=n_ee, p=[0.8, 0.15, 0.05])
+    syn = rng.random(n_ee) < 0.05
+    w_ee[syn] = rng.uniform(0.8, 1.0, int(syn.sum()))
+    src = np.concatenate([n_e + p_of, lo])
+    dst = np.concatenate([e_of, hi])
+    weight = np.concatenate([np.ones(n_pe), w_ee])
+    csr = build_csr(num_vertices, src, dst, weight)
+    n_f = n_e
+    pick = rng.integers(0, max(n_ee, 1), n_f)
+    flip = rng.random(n_f) < 0.5
+    subj = np.where(flip, lo[pick], hi[pick]) if n_ee else rng.integers(0, n_e, n_f)
+    obj = np.where(flip, hi[pick], lo[pick]) if n_ee else rng.integers(0, n_e, n_f)
+    num_chunks = np.zeros(num_vertices, dtype=np.int32)
+    num_chunks[:n_e] = np.bincount(e_of, minlength=n_e)
+    return SyntheticKG(num_vertices, n_e, n_p, src, dst, weight, csr, (n_e + np.arange(n_p)).astype(np.int32),
                        subj.astype(np.int32), obj.astype(np.int32), num_chunks)
 
 

@@ -16,6 +16,10 @@
  *   - every compute entry point takes the HIP stream to enqueue on (pass
  *     torch.cuda.current_stream().cuda_stream) and returns after enqueueing: no
  *     device synchronisation, no allocation in the call path (graph-capture safe);
+ *   - ONE call in flight per engine: the workspace (scores, PPR state, seeds) belongs to the engine, so calls on
+ *     one stream simply queue up, while a call from a second thread or on a second stream before the previous one
+ *     finished is REJECTED with HRAG_EBUSY (never a silent race); concurrency = one engine per stream (the index
+ *     arrays are small next to 288 GB) -- SURVEY.md 8(b)'s separate workspace objects were not built;
  *   - bf16 = the upper 16 bits of an IEEE-754 binary32, passed as uint16_t (fp16 engines:
  *     IEEE binary16 bit patterns in the same uint16_t slots);
  *   - all index outputs are int32, all score outputs fp32;
@@ -40,8 +44,9 @@ typedef enum hrag_status {
     HRAG_EINVAL = 1,      /* bad shape / null pointer / unsupported option                    */
     HRAG_ENOMEM = 2,      /* hipMalloc failed                                                  */
     HRAG_EHIP = 3,        /* a HIP runtime call failed; text in hrag_last_error()              */
-    HRAG_EZERO_RESET = 4, /* reserved: a reset vector without positive mass (HippoRAG.py:1644 assert) is       */
-                          /* reported per query through flags bit 1, never as a status                         */
+    HRAG_EBUSY = 4,       /* the engine's workspace is in use: another thread is inside a call on this engine, or a   */
+                          /* call enqueued on ANOTHER stream has not finished (the workspace lives in the engine: one */
+                          /* call in flight per engine; calls on one stream queue up behind each other as usual)      */
     HRAG_ECAPACITY = 5    /* batch / k larger than the engine was created for                  */
 } hrag_status;
 
@@ -140,6 +145,10 @@ typedef struct hrag_fact_desc {
                                       /* largest one need (a query on a slowly mixing graph that is being repeated for      */
                                       /* HRAG_FLAG_NOT_CONVERGED); runtime-switchable like HRAG_OPT_NO_FP8                    */
 
+#define HRAG_OPT_XCD_BLOCKED 2048     /* fp8 sweep: every XCD walks a CONTIGUOUS eighth of the row order (instead of every    */
+                                      /* eighth chunk group): with hrag_opts.sell_sigma on a graph with locality the rows     */
+                                      /* that share in-neighbours then meet in ONE L2                                          */
+
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */
     int32_t max_topk;     /* largest k_p (retrieval_top_k); <= 2048                              */
@@ -154,7 +163,13 @@ typedef struct hrag_opts {
                           /* sweep of THIS engine (64 .. 2048).  The cut decides the summation order of long rows, so */
                           /* engines whose results must agree bit for bit (the row shards of a graph and the unsharded */
                           /* engine on it) have to be created with the same explicit value                            */
-    int32_t reserved[8];
+    int32_t sell_sigma;   /* SELL-8 matrices: sort rows by length inside windows of this many consecutive rows         */
+                          /* (SELL-C-sigma) instead of globally.  0 = global sort (least padding; right for graphs       */
+                          /* without locality such as the BASELINE generator).  With a vertex numbering that has         */
+                          /* locality -- rows near each other share in-neighbours -- a window keeps the processing order */
+                          /* close to the vertex order, so the gathered state rows are re-used from the XCD's L2; pair   */
+                          /* it with HRAG_OPT_XCD_BLOCKED                                                                 */
+    int32_t reserved[7];
 } hrag_opts;
 
 /* Phase timings of the last hrag_retrieve / hrag_score_facts on an engine, measured
@@ -250,6 +265,12 @@ hrag_status hrag_retrieve_scored(hrag_engine *e, const float *pass_scores_dev, i
                                  float passage_node_weight, int32_t ppr_iters, int32_t ppr_max_iters, float ppr_tol,
                                  int32_t k, int32_t *doc_idx_out_dev, float *doc_score_out_dev, int32_t *flags_out_dev,
                                  float *residual_out_dev, int32_t *iters_out_dev, hrag_stream stream);
+
+/* The scores of ALL passages of the engine's last hrag_retrieve / hrag_retrieve_scored (the array its top-k was taken
+ * from: PPR probability, or the normalised DPR score on the fallback), fp32 [B, ld] in passage order.  For callers that
+ * want more than max_topk = 2048 documents (HippoRAG.py:501-507 slices any prefix of the full ranking): sort these rows
+ * with the library's ranking rule, np.argsort(x, kind="stable")[::-1].  Same stream discipline as every call. */
+hrag_status hrag_last_doc_scores(hrag_engine *e, int32_t batch, float *out_dev, int64_t ld, hrag_stream stream);
 
 /* == dense_passage_retrieval (HippoRAG.py:1467-1502, StandardRAG.py:393-429), top-k only. */
 hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass_dev, int32_t batch,

@@ -122,11 +122,45 @@ def test_gpu_retrieve_ircot_matches_the_per_query_loop(gpu_device):
 
 
 @pytest.mark.gpu
-def test_gpu_num_to_retrieve_beyond_max_topk_warns(gpu_device, caplog):
-    import logging
+def test_gpu_num_to_retrieve_beyond_max_topk_returns_the_full_ranking(gpu_device):
+    """HippoRAG.py:501-507 slices any prefix of the full ranking: asking for more documents than the engine's device
+    top-k holds (max_topk <= 2048) returns them anyway -- the scores of all passages come back (hrag_last_doc_scores)
+    and are ranked with the library's rule; the first max_topk entries are the device's own."""
     from tests.golden.make_golden import DOCS, QUERIES, TRIPLES, MockEmbeddingModel
     rag = HippoRAG(RetrievalConfig(embedding_precision="bf16", max_batch=4, retrieval_top_k=3), embedding_model=MockEmbeddingModel())
     rag.index_from_openie(DOCS, TRIPLES)
-    with caplog.at_level(logging.WARNING, logger="hipporag_amd"):
-        sols = rag.retrieve(QUERIES[:1], num_to_retrieve=6)
-    assert len(sols[0].docs) == 3 and any("max_topk" in r.message for r in caplog.records)
+    few = rag.retrieve(QUERIES, num_to_retrieve=3)
+    many = rag.retrieve(QUERIES, num_to_retrieve=7)
+    for a, b in zip(few, many):
+        assert len(b.docs) == 7 and b.docs[:3] == a.docs
+        np.testing.assert_array_equal(np.asarray(b.doc_scores[:3]), np.asarray(a.doc_scores))
+        assert np.all(np.diff(np.asarray(b.doc_scores)) <= 0)
+
+
+@pytest.mark.gpu
+def test_gpu_a_call_on_another_stream_while_one_is_in_flight_is_rejected(gpu_device):
+    """One call in flight per engine (the workspace belongs to the engine, include/hrag.h): a call on a second stream
+    before the previous one has finished on the device returns HRAG_EBUSY instead of racing; after a synchronise it
+    goes through, and calls on ONE stream simply queue up."""
+    import torch
+    from hipporag_amd import _lib, synth
+    from hipporag_amd.engine import HippoRAGEngine
+    kg = synth.make_kg(3000, 30000, 5)
+    pb, fb = synth.make_embeddings_np(kg.n_passages, 64, 1), synth.make_embeddings_np(kg.n_facts, 64, 2)
+    q = torch.from_numpy(synth.make_queries_np(fb, 8, seed=1)[0].view(np.int16)).to(gpu_device).view(torch.bfloat16)
+    with HippoRAGEngine(kg.csr, kg.passage_vertex, pb, fb, kg.subj_vertex, kg.obj_vertex, kg.num_chunks,
+                        max_batch=8, max_topk=10) as eng:
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(s1):
+            torch.cuda._sleep(400_000_000)              # keeps stream 1 busy for a good while
+            eng.score_facts(q, k=5)
+            eng.score_facts(q, k=5)                     # same stream: queues up
+        with torch.cuda.stream(s2):
+            with pytest.raises(_lib.HragError) as err:
+                eng.score_facts(q, k=5)
+            assert err.value.status == _lib.HRAG_EBUSY
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s2):
+            idx, _ = eng.score_facts(q, k=5)
+        torch.cuda.synchronize()
+        assert int(idx.min()) >= 0

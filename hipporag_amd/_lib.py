@@ -97,9 +97,12 @@ SIGNATURES = {
     "hrag_shard_score_facts": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
     "hrag_shard_passage_scores": (C.c_int, [_P, _P, _I32, _P, _P, _P]),
     "hrag_shard_prior_stats": (C.c_int, [_P, _P, _P, _F32, _P, _I32, _P, _P, _P]),
-    "hrag_shard_ppr_begin": (C.c_int, [_P, _P, _P, _P, _P, _F32, _P, _P, _P, _P, _I32, _F32, _I32, _I32, _P, _P, _P, _P]),
-    "hrag_shard_ppr_sweep": (C.c_int, [_P, _I32, _I32, C.POINTER(_I32), _P]),
-    "hrag_shard_finish": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P]),
+    "hrag_shard_ppr_begin": (C.c_int, [_P, _P, _P, _P, _P, _F32, _P, _P, _P, _P, _I32, _F32, _I32, _I32, _F32, _I32, _P, _P,
+                                       _P, C.POINTER(_I32), _P]),
+    "hrag_shard_ppr_sweep": (C.c_int, [_P, _I32, _I32, C.POINTER(_I32), C.POINTER(_I32), _P]),
+    "hrag_shard_ppr_est": (C.c_int, [_P, _I32, _P, _I32, _P]),
+    "hrag_shard_ppr_decide": (C.c_int, [_P, _I32, _P]),
+    "hrag_shard_finish": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
     "hrag_engine_set_flags": (C.c_int, [_P, _I32, _I32]),
     "hrag_engine_gather_embeddings": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P]),
     "hrag_get_timings": (C.c_int, [_P, C.POINTER(Timings)]),

@@ -394,8 +394,9 @@ hrag_status hrag_shard_prior_stats(hrag_engine *e, const float *mn, const float 
 hrag_status hrag_shard_ppr_begin(hrag_engine *e, const float *mn, const float *mx, const float *zmax,
                                  const double *mass, float passage_node_weight, const int32_t *seed_vtx,
                                  const float *seed_w, const int32_t *seed_cnt, int32_t *flags, int32_t batch,
-                                 float damping, int32_t ppr_iters, int32_t n_groups, void *state0, void *state1,
-                                 void *state2, hrag_stream stream) {
+                                 float damping, int32_t ppr_iters, int32_t ppr_max_iters, float ppr_tol,
+                                 int32_t n_groups, void *state0, void *state1, void *state2, int32_t *n_steps_out,
+                                 hrag_stream stream) {
     HRAG_TRY(shard_batch(e, batch));
     HRAG_REQUIRE(mn && mx && zmax && mass && seed_vtx && seed_w && seed_cnt && flags, "NULL argument");
     HRAG_REQUIRE(damping >= 0.f && damping < 1.f, "damping %g outside [0, 1)", (double)damping);
@@ -405,19 +406,41 @@ hrag_status hrag_shard_ppr_begin(hrag_engine *e, const float *mn, const float *m
                  "the engine lays %d queries out in %d exchange groups, not %d: size the state buffers with "
                  "hrag_shard_layout_query and pass its n_groups", batch, lay.n_groups, n_groups);
     uint8_t *bufs[3] = {static_cast<uint8_t *>(state0), static_cast<uint8_t *>(state1), static_cast<uint8_t *>(state2)};
-    return ppr8_begin(e, mn, mx, zmax, mass, passage_node_weight, seed_vtx, seed_w, seed_cnt, flags, batch, damping,
-                      ppr_iters, lay, bufs, (hipStream_t)stream);
+    HRAG_REQUIRE(ppr_tol >= 0.f && (ppr_tol == 0.f || ppr_max_iters >= ppr_iters), "bad ppr_tol / ppr_max_iters");
+    HRAG_TRY(ppr8_begin(e, mn, mx, zmax, mass, passage_node_weight, seed_vtx, seed_w, seed_cnt, flags, batch, damping,
+                        ppr_iters, lay, bufs, (hipStream_t)stream, ppr_max_iters, ppr_tol, true));
+    if (n_steps_out) *n_steps_out = e->p8.n_steps;
+    return HRAG_OK;
 }
 
 hrag_status hrag_shard_ppr_sweep(hrag_engine *e, int32_t sweep, int32_t group, int32_t *exchange_out,
-                                 hrag_stream stream) {
+                                 int32_t *checkpoint_out, hrag_stream stream) {
     HRAG_REQUIRE(e != nullptr, "engine is NULL");
     HRAG_REQUIRE(group >= 0, "group must be >= 0");
-    return ppr8_sweep(e, sweep, group, exchange_out, (hipStream_t)stream);
+    HRAG_TRY(ppr8_sweep(e, sweep, group, exchange_out, (hipStream_t)stream));
+    if (checkpoint_out) *checkpoint_out = e->p8.steps[sweep].decide != -1 ? 1 : 0;
+    return HRAG_OK;
+}
+
+// est of the last checkpoint boundary (final == 0) or of the final sweep (final != 0) over the OWNED passages: read it
+// (set == 0: float bits -> est_dev fp32 [B]), all-reduce MAX over the shards, write it back (set != 0)
+hrag_status hrag_shard_ppr_est(hrag_engine *e, int32_t final, float *est_dev, int32_t set, hrag_stream stream) {
+    HRAG_REQUIRE(e && est_dev && e->p8.active, "bad argument / no fp8 PPR session");
+    int32_t *mine = final ? e->d_est_f : e->d_est_ck;
+    const size_t bytes = (size_t)e->p8.batch * sizeof(float);   // non-negative floats: the bit patterns ARE the floats
+    HRAG_HIP_TRY(hipMemcpyAsync(set ? (void *)mine : (void *)est_dev, set ? (const void *)est_dev : (const void *)mine, bytes,
+                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return HRAG_OK;
+}
+
+hrag_status hrag_shard_ppr_decide(hrag_engine *e, int32_t sweep, hrag_stream stream) {
+    HRAG_REQUIRE(e != nullptr, "engine is NULL");
+    return ppr8_decide(e, sweep, (hipStream_t)stream);
 }
 
 hrag_status hrag_shard_finish(hrag_engine *e, const float *mn, const float *mx, int32_t *flags, int32_t batch,
-                              int32_t k, int32_t *idx_out, float *score_out, hrag_stream stream) {
+                              int32_t k, int32_t *idx_out, float *score_out, float *residual_out, int32_t *iters_out,
+                              hrag_stream stream) {
     HRAG_TRY(shard_batch(e, batch));
     HRAG_REQUIRE(mn && mx && flags && idx_out && score_out, "NULL argument");
     HRAG_REQUIRE(k >= 1 && k <= e->max_topk, "k=%d outside [1, max_topk=%d]", k, e->max_topk);
@@ -427,11 +450,20 @@ hrag_status hrag_shard_finish(hrag_engine *e, const float *mn, const float *mx, 
         HRAG_TRY(launch_fill_i32(idx_out, -1, (int64_t)batch * k, s));
         HRAG_HIP_TRY(hipMemsetAsync(score_out, 0, (size_t)batch * k * sizeof(float), s));
         HRAG_TRY(ppr8_finalize(e, flags, s));
+        if (residual_out)
+            HRAG_HIP_TRY(hipMemcpyAsync(residual_out, e->d_resid, (size_t)batch * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (iters_out)
+            HRAG_HIP_TRY(hipMemcpyAsync(iters_out, e->d_iters_used, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         return launch_flag_zero_mass(e->d_sums, batch, flags, 2, s);
     }
     HRAG_TRY(ppr8_doc_scores(e, mn, mx, flags, batch, s, true));
-    return launch_row_topk(e->d_doc, batch, e->p_rows, e->ld_p, k, (int32_t)e->p_offset, kNormNone, idx_out,
-                           score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes);
+    HRAG_TRY(launch_row_topk(e->d_doc, batch, e->p_rows, e->ld_p, k, (int32_t)e->p_offset, kNormNone, idx_out,
+                             score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
+    if (residual_out)
+        HRAG_HIP_TRY(hipMemcpyAsync(residual_out, e->d_resid, (size_t)batch * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (iters_out)
+        HRAG_HIP_TRY(hipMemcpyAsync(iters_out, e->d_iters_used, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    return HRAG_OK;
 }
 
 hrag_status hrag_engine_gather_embeddings(hrag_engine *e, int32_t which, const int32_t *src_rows, int64_t n,

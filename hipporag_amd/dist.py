@@ -477,7 +477,10 @@ class ShardedRetriever:
         return top_idx, torch.where(top_idx < 0, torch.zeros_like(norm), norm)
 
     def retrieve(self, q_pass, kept_idx, kept_score, kept_count, *, link_top_k=5, damping=0.5,
-                 passage_node_weight=0.05, ppr_iters=20, k=200):
+                 passage_node_weight=0.05, ppr_iters=20, k=200, ppr_tol=0.0, ppr_max_iters=0):
+        """Returns (doc ids, doc scores, flags) -- and with ppr_tol > 0 additionally (residual, sweeps used): the
+        convergence contract of hrag_retrieve on the shards.  Every shard measures the relative update of ITS
+        passages; the measures are all-reduced (MAX) before every decision, so all shards run the same steps."""
         st, c = self.st, self.comm
         b = q_pass.shape[0]
         lay, bufs = self._state(b)
@@ -488,20 +491,40 @@ class ShardedRetriever:
         zmax, mass = st.shard_prior_stats(mn, mx, passage_node_weight, flags)
         c.all_reduce(zmax, "max")
         c.all_reduce(mass, "sum")
-        st.shard_ppr_begin(mn, mx, zmax, mass, passage_node_weight, (sv, sw, sc), flags, damping, ppr_iters,
-                           lay.n_groups, bufs)
+        contract = ppr_tol > 0
+        if contract:
+            n_steps = st.shard_ppr_begin(mn, mx, zmax, mass, passage_node_weight, (sv, sw, sc), flags, damping, ppr_iters,
+                                         lay.n_groups, bufs, ppr_tol, ppr_max_iters)
+        else:
+            st.shard_ppr_begin(mn, mx, zmax, mass, passage_node_weight, (sv, sw, sc), flags, damping, ppr_iters,
+                               lay.n_groups, bufs)
+            n_steps = ppr_iters
         # group g's exchange overlaps with the sweep of the other groups: a sweep of group g only waits for
         # group g's previous exchange
         pend = [c.exchange(bufs[0], lay, g) for g in range(lay.n_groups)]
-        for i in range(ppr_iters):
+        for i in range(n_steps):
+            ck = False
             for g in range(lay.n_groups):
                 c.wait(pend[g])
-                xb = st.shard_ppr_sweep(i, g)
+                if contract:
+                    xb, ck = st.shard_ppr_step(i, g)
+                else:
+                    xb = st.shard_ppr_sweep(i, g)
                 pend[g] = c.exchange(bufs[xb], lay, g) if xb >= 0 else None
-        idx, val = st.shard_finish(mn, mx, flags, k)
+            if ck:      # a checkpoint boundary: the batch's measure over ALL passages, then the decision
+                est = c.all_reduce(st.shard_ppr_est(False), "max")
+                st.shard_ppr_est(False, est)
+                st.shard_ppr_decide(i)
+        if contract:
+            st.shard_ppr_est(True, c.all_reduce(st.shard_ppr_est(True), "max"))
+            idx, val, resid, used = st.shard_finish(mn, mx, flags, k, True)
+        else:
+            idx, val = st.shard_finish(mn, mx, flags, k)
         top_idx, top_val = merge_ranked(c.all_gather(idx), c.all_gather(val), k, st.topk)
         sat = (flags & 8).contiguous()               # raised on the shard that owns the row that saturated
         c.all_reduce(sat, "max")
+        if contract:
+            return top_idx, top_val, flags | sat, resid, used
         return top_idx, top_val, flags | sat
 
 

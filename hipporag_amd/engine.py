@@ -489,28 +489,56 @@ class HippoRAGEngine:
         return zmax, mass
 
     def shard_ppr_begin(self, mn, mx, zmax, mass, passage_node_weight, seeds, flags, damping, ppr_iters,
-                        n_groups, bufs):
+                        n_groups, bufs, ppr_tol: float = 0.0, ppr_max_iters: int = 0) -> int:
+        """Returns the number of steps of the session (ppr_iters, plus the conditional steps of the convergence
+        contract when ppr_tol > 0: run them all, the device decides which ones do anything)."""
         sv, sw, sc = seeds
         b = mn.shape[0]
+        self._p8_batch = b
+        n_steps = C.c_int32(0)
         check(self._lib.hrag_shard_ppr_begin(self._handle, mn.data_ptr(), mx.data_ptr(), zmax.data_ptr(),
                                              mass.data_ptr(), passage_node_weight, sv.data_ptr(), sw.data_ptr(),
-                                             sc.data_ptr(), flags.data_ptr(), b, damping, ppr_iters, n_groups,
+                                             sc.data_ptr(), flags.data_ptr(), b, damping, ppr_iters,
+                                             max(ppr_max_iters, ppr_iters), ppr_tol, n_groups,
                                              bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(),
-                                             _stream()))
+                                             C.byref(n_steps), _stream()))
+        return n_steps.value
+
+    def shard_ppr_step(self, step: int, group: int):
+        """(state buffer to exchange or -1, True when the step is a checkpoint of the convergence contract)."""
+        x, ck = C.c_int32(-1), C.c_int32(0)
+        check(self._lib.hrag_shard_ppr_sweep(self._handle, step, group, C.byref(x), C.byref(ck), _stream()))
+        return x.value, bool(ck.value)
 
     def shard_ppr_sweep(self, sweep: int, group: int) -> int:
-        x = C.c_int32(-1)
-        check(self._lib.hrag_shard_ppr_sweep(self._handle, sweep, group, C.byref(x), _stream()))
-        return x.value
+        return self.shard_ppr_step(sweep, group)[0]
 
-    def shard_finish(self, mn, mx, flags, k: int):
+    def shard_ppr_est(self, final: bool, est=None):
+        """est=None: this shard's measure (fp32 [B]); est given: write the all-reduced values back."""
+        torch = _torch()
+        b = self._p8_batch
+        if est is None:
+            out = self._empty((b,), torch.float32)
+            check(self._lib.hrag_shard_ppr_est(self._handle, 1 if final else 0, out.data_ptr(), 0, _stream()))
+            return out
+        check(self._lib.hrag_shard_ppr_est(self._handle, 1 if final else 0, est.data_ptr(), 1, _stream()))
+        return est
+
+    def shard_ppr_decide(self, step: int):
+        check(self._lib.hrag_shard_ppr_decide(self._handle, step, _stream()))
+
+    def shard_finish(self, mn, mx, flags, k: int, want_residual: bool = False):
         torch = _torch()
         b = mn.shape[0]
         idx = self._empty((b, k), torch.int32)
         val = self._empty((b, k), torch.float32)
+        resid = self._empty((b,), torch.float32) if want_residual else None
+        used = self._empty((b,), torch.int32) if want_residual else None
         check(self._lib.hrag_shard_finish(self._handle, mn.data_ptr(), mx.data_ptr(), flags.data_ptr(), b, k,
-                                          idx.data_ptr(), val.data_ptr(), _stream()))
-        return idx, val
+                                          idx.data_ptr(), val.data_ptr(),
+                                          resid.data_ptr() if want_residual else None,
+                                          used.data_ptr() if want_residual else None, _stream()))
+        return (idx, val, resid, used) if want_residual else (idx, val)
 
 
 class CapturedPipeline:
@@ -692,5 +720,14 @@ class ShardStages(EngineStages):
     def shard_ppr_sweep(self, sweep, group):
         return self.e.shard_ppr_sweep(sweep, group)
 
-    def shard_finish(self, mn, mx, flags, k):
-        return self.e.shard_finish(mn, mx, flags, k)
+    def shard_ppr_step(self, step, group):
+        return self.e.shard_ppr_step(step, group)
+
+    def shard_ppr_est(self, final, est=None):
+        return self.e.shard_ppr_est(final, est)
+
+    def shard_ppr_decide(self, step):
+        return self.e.shard_ppr_decide(step)
+
+    def shard_finish(self, mn, mx, flags, k, want_residual=False):
+        return self.e.shard_finish(mn, mx, flags, k, want_residual)

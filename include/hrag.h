@@ -412,7 +412,8 @@ hrag_status hrag_stage_doc_scores(hrag_engine *e, const float *x_dev, const doub
  *             hrag_stage_seeds (replicated)
  *             hrag_shard_prior_stats -> all-reduce MAX of zmax, SUM of mass
  *             hrag_shard_ppr_begin -> exchange every group of state[0]
- *             ppr_iters x n_groups x hrag_shard_ppr_sweep -> exchange group g of state[*exchange_out]
+ *             n_steps x n_groups x hrag_shard_ppr_sweep -> exchange group g of state[*exchange_out]
+ *                 (n_steps = ppr_iters without a tolerance; checkpoint steps: est all-reduce + hrag_shard_ppr_decide)
  *             hrag_shard_finish -> gather + merge the local top-k lists
  * ------------------------------------------------------------------------------------------ */
 #define HRAG_FLAG_FP8_SATURATED 8
@@ -456,21 +457,33 @@ hrag_status hrag_shard_ppr_begin(hrag_engine *e, const float *min_dev, const flo
                                  const float *zmax_dev, const double *mass_dev, float passage_node_weight,
                                  const int32_t *seed_vtx_dev, const float *seed_w_dev,
                                  const int32_t *seed_cnt_dev, int32_t *flags_dev, int32_t batch,
-                                 float damping, int32_t ppr_iters, int32_t n_groups, void *state0_dev,
-                                 void *state1_dev, void *state2_dev, hrag_stream stream);
+                                 float damping, int32_t ppr_iters, int32_t ppr_max_iters, float ppr_tol,
+                                 int32_t n_groups, void *state0_dev, void *state1_dev, void *state2_dev,
+                                 int32_t *n_steps_out, hrag_stream stream);
 
 /* sweep `sweep` (0 .. ppr_iters - 1, in order per group) on the owned rows of exchange group `group`;
  * *exchange_out = index of the state buffer whose owned block of that group was written and must be
  * exchanged before the group's next sweep (-1 after the last sweep: nothing to exchange). */
 hrag_status hrag_shard_ppr_sweep(hrag_engine *e, int32_t sweep, int32_t group, int32_t *exchange_out,
-                                 hrag_stream stream);
+                                 int32_t *checkpoint_out, hrag_stream stream);
+
+/* The convergence contract of hrag_retrieve on row shards (ppr_tol > 0 in hrag_shard_ppr_begin; *n_steps_out then
+ * counts the conditional steps too: run ALL of them, the gate words decide on the device which ones do anything --
+ * and every shard decides alike because the measure is all-reduced):
+ *   after a step whose *checkpoint_out was set (all groups swept):
+ *        hrag_shard_ppr_est(e, 0, est, 0) -> all-reduce MAX of est fp32 [B] over the shards ->
+ *        hrag_shard_ppr_est(e, 0, est, 1) -> hrag_shard_ppr_decide(e, step)
+ *   before hrag_shard_finish: the same get / all-reduce MAX / set with final = 1 (the final sweep's measure), so that
+ *   residual_out, iters_out and flags bit 4 come out identical on every shard. */
+hrag_status hrag_shard_ppr_est(hrag_engine *e, int32_t final, float *est_dev, int32_t set, hrag_stream stream);
+hrag_status hrag_shard_ppr_decide(hrag_engine *e, int32_t sweep, hrag_stream stream);
 
 /* doc scores of the owned passages (PPR probability, or the normalised DPR score on the fallback)
  * and their local top-k: idx_out_dev int32 [B, k] GLOBAL passage positions, score_out_dev fp32 [B, k].
  * flags_dev is read-modify-written (bit 1). */
 hrag_status hrag_shard_finish(hrag_engine *e, const float *min_dev, const float *max_dev, int32_t *flags_dev,
                               int32_t batch, int32_t k, int32_t *idx_out_dev, float *score_out_dev,
-                              hrag_stream stream);
+                              float *residual_out_dev, int32_t *iters_out_dev, hrag_stream stream);
 
 /* Index update with the embeddings staying on the device (incremental index() / delete(), HippoRAG.py:262-411:
  * the reference re-reads everything from its stores in prepare_retrieval_objects): compose the embedding

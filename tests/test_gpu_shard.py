@@ -121,3 +121,62 @@ def test_shards_with_filter_subsets_dpr_fallback_isolated_passages_and_empty_fac
             assert tie_aware_equal(got[2][q], want_ids, want_sc, rel_gap=2e-5), q
             want = ref.x[pv][got[2][q]]
             assert (np.abs(got[3][q] - want) / want).max() < 1e-5, q
+
+
+def test_convergence_contract_on_shards_matches_the_single_gpu_engine(gpu_device):
+    """ppr_tol on row shards (hrag_shard_ppr_begin / _est / _decide): every shard measures the relative update of ITS
+    passages, the measures are all-reduced before each device-side decision, so all shards run the same extension
+    stages -- and the result, the residual and the sweep count are those of the single-GPU engine, bit for bit.
+    The tolerance is set low enough that extension stages do run."""
+    import threading
+    import torch
+    from hipporag_amd import dist as hd
+    from hipporag_amd.engine import HippoRAGEngine, ShardStages
+    world, b, tol = 4, 130, 1e-7
+    kg, pass_bits, fact_bits, index = make_case(12000, 120000, 128, seed=611)
+    sidx = hd.shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+    qf_t = _bf16(synth.make_queries_np(fact_bits, b, seed=3)[0], gpu_device)
+    qp_t = _bf16(synth.make_queries_np(pass_bits, b, seed=4)[0], gpu_device)
+    kw = dict(link_top_k=5, damping=0.5, passage_node_weight=0.05, ppr_iters=20, k=100, ppr_tol=tol, ppr_max_iters=29)
+    shared, results, errors = {}, [None] * world, []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(gpu_device)
+            eng = hd.build_shard_engine(sidx, pass_bits, fact_bits, rank, max_batch=b, max_topk=100, sell_seg_len=64)
+            rs = hd.ShardedRetriever(ShardStages(eng), hd.LocalComm(rank, world, shared), groups=2)
+            idx, sc = rs.score_facts(qf_t, k=5)
+            cnt = torch.full((b,), 5, dtype=torch.int32, device=gpu_device)
+            out = rs.retrieve(qp_t, idx, sc, cnt, **kw)
+            torch.cuda.synchronize()
+            results[rank] = tuple(t.cpu().numpy() for t in out)
+            shared["_barrier"].wait()
+            eng.close()
+        except Exception as exc:
+            errors.append((rank, exc))
+            try:
+                shared["_barrier"].abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    for r in range(1, world):
+        for a, w in zip(results[r], results[0]):
+            np.testing.assert_array_equal(a, w)
+    d_idx, d_sc, flags, resid, used = results[0]
+    with HippoRAGEngine(sidx.csr, sidx.passage_vertex, pass_bits, fact_bits, sidx.subj_vertex, sidx.obj_vertex,
+                        sidx.num_chunks, max_batch=b, max_topk=100, sell_seg_len=64) as eng:
+        idx, sc = eng.score_facts(qf_t, k=5)
+        one = eng.retrieve(qp_t, idx, sc, torch.full((b,), 5, dtype=torch.int32, device=gpu_device), **kw)
+        torch.cuda.synchronize()
+    assert int(used.max()) > 20                                           # extension stages did run
+    np.testing.assert_array_equal(used, one.iters_used.cpu().numpy())
+    np.testing.assert_array_equal(resid, one.residual.cpu().numpy())
+    np.testing.assert_array_equal(flags, one.flags.cpu().numpy())
+    np.testing.assert_array_equal(d_idx, one.doc_idx.cpu().numpy())
+    np.testing.assert_array_equal(d_sc, one.doc_score.cpu().numpy())

@@ -73,8 +73,11 @@ def main():
             if base == "ppr8_pair_kernel":      # two slabs per wavefront: the same sweep, the usual kernel at B >= 256
                 base = "ppr8_kernel"
             if base == "ppr8_kernel" and "bytes_per_launch" in d and "<" in k:
-                inst8[k[k.index("<"):].replace(" ", "")] = {"bytes_per_launch": d["bytes_per_launch"],
-                                                            "l2_hit_rate": d.get("l2_hit_rate")}
+                # <mode, residual form, est>: the third argument marks the instantiation that also measures the
+                # convergence contract's est (checkpoint boundary / final sweep) -> "<m,r>" or "<m,r,est>"
+                targs = k[k.index("<") + 1:k.rindex(">")].replace(" ", "").split(",")
+                key = "<" + ",".join(targs[:2]) + (",est" if len(targs) > 2 and targs[2] == "true" else "") + ">"
+                inst8[key] = {"bytes_per_launch": d["bytes_per_launch"], "l2_hit_rate": d.get("l2_hit_rate")}
             n = d["launches"].get("FETCH_SIZE", 0)
             if "bytes_per_launch" in d and base in ("ppr8_kernel", "ppr16_kernel", "ppr_spmm_kernel") and n > seen.get(base, 0):
                 seen[base] = n      # the variant with the most launches (mode H for ppr16_kernel, C for ppr8_kernel)

@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 3 measurement pass: whole GPU suite, the bench line of every configuration (CPU baselines included), small-batch
+# latencies, rocprofv3 kernel stats + PMC passes of the cfg 3 command
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r03z}
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$REPO"
+timeout 1500 python -m pytest tests -q -m gpu --maxfail=12 --tb=short > "$OUT/gpu_tests.log" 2>&1
+tail -3 "$OUT/gpu_tests.log"
+timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_cfg3.json" 2> "$OUT/bench_cfg3.err"
+tail -c 300 "$OUT/bench_cfg3.json"; echo
+for CFG in cfg1s cfg2; do
+  timeout 600 python bench.py --config $CFG --steps 50 --warmup 5 --cpu-queries 16 > "$OUT/bench_$CFG.json" 2> "$OUT/bench_$CFG.err"
+  tail -c 200 "$OUT/bench_$CFG.json"; echo
+done
+timeout 600 python tools/sweep_smallb.py --batches 1,2,4,8,16,32 --out "$OUT/sweep_smallb.json" > "$OUT/sweep_smallb.log" 2> "$OUT/sweep_smallb.err"
+cut -c1-80 "$OUT/sweep_smallb.log"
+bash tools/gpu_profile.sh "$TAG/prof" --steps 5 --warmup 1 > "$OUT/profile.log" 2>&1
+tail -3 "$OUT/profile.log"
+find "$OUT" -name '*kernel_trace.csv' -size +3M -delete
+find "$OUT" -name '*counter_collection.csv' -size +8M -delete
+du -sh "$OUT"

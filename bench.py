@@ -41,6 +41,10 @@ CONFIGS = {
     # indexing a corpus document by document produces) -- shows what the sweep does when the gathers can hit the L2
     "cfg3loc": dict(V=1_000_000, E=10_000_000, D=768, B=256, seed=1237, community=512,
                     label="NON-BASELINE variant of configs[2]: 1M-node/10M-edge KG with community structure (512-entity communities, 90 % local edges), 1M x 768 bf16, batch 256"),
+    # ... and the same graph under the REFERENCE's vertex numbering (entity ids in hash order): what the engine's
+    # locality numbering (--locality auto: graph.locality_order) has to recover
+    "cfg3hash": dict(V=1_000_000, E=10_000_000, D=768, B=256, seed=1237, community=512, hash_order=True,
+                     label="NON-BASELINE variant of configs[2]: the community-structured 1M-node/10M-edge KG with its entity ids shuffled (the reference's hash-order numbering), 1M x 768 bf16, batch 256"),
     # one GPU's share of configs[4] (10M-node power-law KG, 10M x 1024 fp16 embeddings, 4096 / 8 queries)
     "cfg5gpu": dict(V=10_000_000, E=100_000_000, D=1024, B=512, seed=1239, power_law=True, fp16=True,
                     label="configs[4] per-GPU share: synthetic 10M-node/100M-edge power-law KG, 10M x 1024 fp16, batch 512"),
@@ -471,6 +475,8 @@ def main():
                     help="N > 1: abandon the row-sharded leg after this long (the primary line still prints)")
     ap.add_argument("--sell-sigma", type=int, default=0, help="hrag_opts.sell_sigma (SELL-C-sigma sorting window; 0 = global)")
     ap.add_argument("--engine-flags", type=int, default=0, help="hrag_opts.flags (HRAG_OPT_*), e.g. 2048 = XCD_BLOCKED")
+    ap.add_argument("--locality", default=None, choices=["auto", "on"],
+                    help="HippoRAGEngine(locality=...): renumber the vertices by the first passage that links them")
     ap.add_argument("--ppr-tol", type=float, default=3e-6,
                     help="tolerance of the secondary leg that runs under the convergence contract (the headline runs "
                          "BASELINE.json's fixed 20 sweeps and reports the residual they leave)")
@@ -501,12 +507,14 @@ def main():
 
     t_setup = time.perf_counter()
     kg = synth.make_kg(V, E, seed, power_law=bool(cfg.get("power_law")), community=int(cfg.get("community", 0)))
+    if cfg.get("hash_order"):
+        kg = synth.hash_order(kg, seed + 77)
     emb_dtype = torch.float16 if cfg.get("fp16") else torch.bfloat16
     pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev, dtype=emb_dtype)
     fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev, dtype=emb_dtype)
     eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pass_emb, fact_emb, kg.subj_vertex, kg.obj_vertex,
                          kg.num_chunks, max_batch=B, max_topk=K_P, slab_width=args.slab_width, flags=args.engine_flags,
-                         sell_sigma=args.sell_sigma)
+                         sell_sigma=args.sell_sigma, locality=args.locality)
     n_batches = args.steps + args.warmup
     qf = [synth.make_queries_torch(fact_emb, B, seed + 100 + i)[0] for i in range(n_batches)]
     qp = [synth.make_queries_torch(pass_emb, B, seed + 500 + i)[0] for i in range(n_batches)]
@@ -542,8 +550,11 @@ def main():
     out, elapsed, contract = timed()                                    # BASELINE.json: exactly 20 PPR iterations
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     qps = B * args.steps / elapsed
-    _, el_c, contract_c = timed(args.ppr_tol, args.ppr_max_iters)       # the mirror's default: the convergence contract
-    contract_c.update({"value": B * args.steps / el_c, "unit": "queries/s", "ms_per_step": el_c * 1e3 / max(args.steps, 1)})
+    if args.ppr_tol > 0:
+        _, el_c, contract_c = timed(args.ppr_tol, args.ppr_max_iters)   # the mirror's default: the convergence contract
+        contract_c.update({"value": B * args.steps / el_c, "unit": "queries/s", "ms_per_step": el_c * 1e3 / max(args.steps, 1)})
+    else:
+        contract_c = {"skipped": "--ppr-tol 0"}
 
     # phase breakdown of one more step (HIP events inside the library, same stream)
     eng.set_profiling(True)
@@ -565,7 +576,8 @@ def main():
                    "embedding_dtype": "fp16" if cfg.get("fp16") else "bf16",
                    "ppr_state_dtype": ("e4m3 staged corrections + fp32 true residual (fp32 arithmetic)" if f8 else
                                        "f16 hi + f16 correction (fp32 arithmetic)" if f16 else "f32"),
-                   "sell_sigma": args.sell_sigma, "engine_flags": args.engine_flags,
+                   "sell_sigma": args.sell_sigma, "engine_flags": args.engine_flags, "locality": args.locality,
+                   "locality_score_after_renumbering": eng.locality_score, "engine_opt_flags": eng.opt_flags,
                    "parallelism": "1gpu"},
         "roofline": roofline,
         "ppr_contract": contract, "with_convergence_contract": contract_c,

@@ -110,8 +110,14 @@ class HippoRAGEngine:
                  row_offset: int = 0, passage_offset: int = 0, fact_offset: int = 0,
                  n_passages: Optional[int] = None, n_facts: Optional[int] = None,
                  device: Optional[int] = None, flags: int = 0, segment_nnz: int = 0, sell_seg_len: int = 0,
-                 dim: Optional[int] = None, sell_sigma: int = 0):
-        """passage_emb=None (with dim=...): an engine WITHOUT embeddings -- the PPR side of the hybrid multi-GPU mode
+                 dim: Optional[int] = None, sell_sigma: int = 0, locality: Optional[str] = None):
+        """locality ("auto" / "on" / None): the graph compiler's locality numbering (graph.locality_order: vertices
+        renumbered by the first passage that links them; everything the caller sees -- passage positions, fact ids,
+        hrag_ppr's vertex order -- keeps the caller's numbering).  "on" also switches the sweep to SELL-C-sigma windows
+        and the XCD-blocked launch; "auto" does so when the renumbered matrix actually has locality
+        (graph.locality_score >= 0.3).  Unsharded engines only.
+
+        passage_emb=None (with dim=...): an engine WITHOUT embeddings -- the PPR side of the hybrid multi-GPU mode
         (dist.HybridRetriever): passage scores arrive through retrieve_scored(), seeds still come from subj_vertex /
         obj_vertex / num_chunks."""
         torch = _torch()
@@ -123,6 +129,33 @@ class HippoRAGEngine:
         self._handle = C.c_void_p(0)
 
         pv = np.ascontiguousarray(passage_vertex, dtype=np.int32)
+        self._perm = self._inv_perm = None
+        self.locality_score = None
+        if locality:
+            if locality not in ("auto", "on"):
+                raise ValueError("locality must be None, 'auto' or 'on'")
+            if row_offset != 0 or graph.row_ptr.shape[0] - 1 != graph.num_vertices:
+                raise ValueError("the locality numbering is for unsharded engines (dist.shard_index relabels shards)")
+            from .graph import locality_order, locality_score, relabel_csr
+            perm = locality_order(graph, pv)
+            graph = relabel_csr(graph, perm)
+            pv = np.ascontiguousarray(perm[pv], dtype=np.int32)
+            if subj_vertex is not None:
+                sv_ = np.asarray(subj_vertex, dtype=np.int64)
+                ov_ = np.asarray(obj_vertex, dtype=np.int64)
+                subj_vertex = np.where(sv_ >= 0, perm[np.clip(sv_, 0, None)], -1).astype(np.int32)
+                obj_vertex = np.where(ov_ >= 0, perm[np.clip(ov_, 0, None)], -1).astype(np.int32)
+                nc_ = np.zeros(graph.num_vertices, dtype=np.int32)
+                nc_[perm] = np.asarray(num_chunks, dtype=np.int32)
+                num_chunks = nc_
+            self.locality_score = locality_score(graph)
+            if locality == "on" or self.locality_score >= 0.3:
+                sell_sigma = sell_sigma or 16384
+                flags |= _lib.OPT_XCD_BLOCKED
+            self._perm = torch.from_numpy(perm).to(self.device)              # caller's vertex id -> engine's
+            inv = np.empty_like(perm)
+            inv[perm] = np.arange(perm.shape[0])
+            self._inv_perm = torch.from_numpy(inv).to(self.device)
         self.n_passages = int(pv.shape[0]) if n_passages is None else int(n_passages)
         if passage_emb is None:
             if not dim or fact_emb is not None:
@@ -397,10 +430,14 @@ class HippoRAGEngine:
         if r.dim() != 2 or r.shape[1] != self.num_vertices:
             raise ValueError(f"reset must be [B, {self.num_vertices}]")
         b = r.shape[0]
+        if self._perm is not None:      # the engine's vertex numbering: reset_engine[:, new] = reset[:, old]
+            r = r.index_select(1, self._inv_perm).contiguous()
         x = self._empty((b, self.num_vertices), torch.float32)
         flags = self._empty((b,), torch.int32)
         check(self._lib.hrag_ppr(self._handle, r.data_ptr(), b, damping, iters, x.data_ptr(),
                                  flags.data_ptr(), _stream()))
+        if self._perm is not None:
+            x = x.index_select(1, self._perm).contiguous()
         return x, flags
 
     def ppr_sweeps(self, batch: int, n: int, damping: float = 0.5, main_only: bool = False,

@@ -79,6 +79,62 @@ def build_csr(num_vertices: int, src, dst, weight) -> CSRGraph:
                     colsum.astype(np.float64))
 
 
+def locality_order(csr: CSRGraph, passage_vertex) -> np.ndarray:
+    """perm[old vertex] = new vertex: the graph compiler's locality numbering.
+
+    The reference numbers its entity vertices in the order a Python set yields them (extract_entity_nodes,
+    HippoRAG.py:1159-1187: hash order), so neighbouring ids have nothing to do with each other -- while the corpus
+    has locality: a document's passages mention the same entities.  The rule here: non-passage vertices are ordered
+    by the FIRST passage (in passage order) that links them (stable; vertices no passage links keep their relative
+    order at the end), passage vertices follow in passage order.  Rows that are close in the new numbering then share
+    in-neighbours, which is what hrag_opts.sell_sigma + HRAG_OPT_XCD_BLOCKED turn into L2 hits."""
+    v = csr.num_vertices
+    pv = np.asarray(passage_vertex, dtype=np.int64)
+    is_p = np.zeros(v, dtype=bool)
+    is_p[pv] = True
+    first = np.full(v, np.iinfo(np.int64).max, dtype=np.int64)
+    rp = np.asarray(csr.row_ptr, dtype=np.int64)
+    lens = rp[pv + 1] - rp[pv]
+    if lens.sum():
+        # the entries of the passage rows, passage by passage
+        starts = np.repeat(rp[pv], lens)
+        offs = np.arange(lens.sum(), dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
+        cols = np.asarray(csr.col_idx, dtype=np.int64)[starts + offs]
+        np.minimum.at(first, cols, np.repeat(np.arange(pv.shape[0], dtype=np.int64), lens))
+    ents = np.flatnonzero(~is_p)
+    order = ents[np.argsort(first[ents], kind="stable")]
+    perm = np.empty(v, dtype=np.int64)
+    perm[order] = np.arange(order.shape[0])
+    perm[pv] = order.shape[0] + np.arange(pv.shape[0])
+    return perm
+
+
+def relabel_csr(csr: CSRGraph, perm: np.ndarray) -> CSRGraph:
+    """The same matrix with vertex i renamed perm[i] (rows and columns; columns stay sorted inside a row)."""
+    v = csr.num_vertices
+    perm = np.asarray(perm, dtype=np.int64)
+    rows = np.repeat(np.arange(v, dtype=np.int64), np.diff(csr.row_ptr))
+    new_r, new_c = perm[rows], perm[np.asarray(csr.col_idx, dtype=np.int64)]
+    order = np.argsort(new_r * np.int64(v) + new_c, kind="stable")
+    row_ptr = np.zeros(v + 1, dtype=np.int64)
+    np.cumsum(np.bincount(new_r, minlength=v), out=row_ptr[1:])
+    col_sum = None
+    if csr.col_sum is not None:
+        col_sum = np.empty(v, dtype=np.float64)
+        col_sum[perm] = csr.col_sum
+    return CSRGraph(v, row_ptr.astype(np.int32), new_c[order].astype(np.int32), np.asarray(csr.val)[order],
+                    np.asarray(csr.raw)[order], col_sum)
+
+
+def locality_score(csr: CSRGraph, window: int = 4096) -> float:
+    """Fraction of the matrix entries whose column lies within `window` ids of their row: how much a numbering gives
+    the sweep to re-use (the benchmark generator: ~1 %; a corpus numbered by locality_order: most of them)."""
+    rows = np.repeat(np.arange(csr.num_vertices, dtype=np.int64), np.diff(csr.row_ptr))
+    if rows.size == 0:
+        return 0.0
+    return float(np.mean(np.abs(rows - np.asarray(csr.col_idx, dtype=np.int64)) < window))
+
+
 def float_to_bf16_bits(x: np.ndarray) -> np.ndarray:
     """Round-to-nearest-even fp32 -> bf16, returned as uint16 (the wire format of hrag_embed_desc)."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)

@@ -101,7 +101,7 @@ def build_engine_from_reference(rag, *, max_batch: int = 256, embedding_precisio
     eng = HippoRAGEngine(csr, pv, conv(a["passage_emb"]),
                          conv(a["fact_emb"]) if has_facts else None,
                          a["subj_vertex"] if has_facts else None, a["obj_vertex"] if has_facts else None,
-                         a["num_chunks"] if has_facts else None, max_batch=max_batch,
+                         a["num_chunks"] if has_facts else None, max_batch=max_batch, locality="auto",
                          max_topk=int(min(2048, max(1, min(cfg.retrieval_top_k, len(pv))))))
     return eng, facts
 

@@ -136,6 +136,10 @@ class RetrievalConfig:
                                          # (HRAG_F32_SPLIT, 3x the embedding stream); "bf16": vectors rounded to bf16 (1x
                                          # stream; near-tied facts / passages may swap against the reference)
     ppr_iters: Optional[int] = None      # None: derived from damping (sweeps_for_damping: 20 at 0.5)
+    locality: Optional[str] = "auto"     # the engine renumbers the vertices by the first passage that links them (the
+                                         # reference's entity ids are in hash order) and, when that numbering has
+                                         # locality, sweeps in SELL-C-sigma windows with an XCD-blocked launch
+                                         # (DESIGN.md 4.1); None: the caller's numbering as it is
     # convergence contract (include/hrag.h, hrag_retrieve; the reference's PRPACK iterates to 1e-10,
     # HippoRAG.py:1736-1743): the engine measures the relative update of the passage scores and keeps sweeping
     # while it predicts an error above ppr_tol.  3e-6 keeps every passage score within the 1e-5 relative parity
@@ -505,7 +509,7 @@ class HippoRAG:
                                 max_batch=self.global_config.max_batch,
                                 max_topk=min(2048, max(self.global_config.retrieval_top_k, 1)),
                                 slab_width=self.global_config.slab_width,
-                                flags=0)
+                                flags=0, locality=self.global_config.locality)
         self.engine = engine
         self._engine_rows = {"passages": list(self.passage_node_keys), "facts": list(self.fact_node_keys) if has_facts else []}
         self.passage_node_idxs = a["passage_vertex"].tolist()

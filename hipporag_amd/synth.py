@@ -186,6 +186,21 @@ def _make_kg_local(num_vertices, num_edges, seed, passage_frac, zipf_s, communit
                        subj.astype(np.int32), obj.astype(np.int32), num_chunks)
 
 
+def hash_order(kg: SyntheticKG, seed: int) -> SyntheticKG:
+    """The same graph with its ENTITY vertex ids shuffled: the numbering the reference produces (entity vertices are
+    added in the order a Python set yields them, HippoRAG.py:1159-1187), under which no locality of the corpus shows
+    in the ids.  What graph.locality_order is there to undo."""
+    from .graph import relabel_csr
+    rng = np.random.Generator(np.random.PCG64(seed))
+    h = np.arange(kg.num_vertices, dtype=np.int64)
+    h[:kg.n_entities] = rng.permutation(kg.n_entities)
+    nc = np.zeros_like(kg.num_chunks)
+    nc[h] = kg.num_chunks
+    return SyntheticKG(kg.num_vertices, kg.n_entities, kg.n_passages, h[kg.src], h[kg.dst], kg.weight,
+                       relabel_csr(kg.csr, h), kg.passage_vertex, h[kg.subj_vertex].astype(np.int32),
+                       h[kg.obj_vertex].astype(np.int32), nc)
+
+
 def make_embeddings_np(rows: int, dim: int, seed: int) -> np.ndarray:
     """Unit-norm Gaussian rows rounded to bf16; returns the uint16 bit patterns [rows, dim]."""
     rng = np.random.Generator(np.random.PCG64(seed))

@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 if [ -z "${HRAG_PMC_ONLY:-}" ]; then
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- \
-    python "$REPO/bench.py" --no-cpu-baseline "$@" > "$OUT/bench_under_rocprof.log" 2>&1
+    python "$REPO/bench.py" --no-cpu-baseline --ppr-tol 0 "$@" > "$OUT/bench_under_rocprof.log" 2>&1
 fi
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
     N=$(echo $C | tr ' ' '_')

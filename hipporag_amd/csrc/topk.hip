@@ -156,7 +156,24 @@ __global__ __launch_bounds__(TK_THREADS) void row_topk_kernel(
         __syncthreads();
         return r;
     };
-    unsigned int cnt = count_ge(thresh);
+    // collect straight away (the usual case: k .. ~1.3 k candidates); only when they do NOT fit is the exact kk-th
+    // key found by bisection (counting passes) and the collection repeated -- one streaming pass less than counting first
+    auto collect = [&](uint64_t t) -> unsigned int {
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        for_each_in_row(s, n, tid, [&](float v, uint32_t i) {
+            const uint64_t key = rank_key(v, i);
+            if (key >= t) {
+                const unsigned int slot = atomicAdd(&s_count, 1u);
+                if (slot < TK_CAP) buf[slot] = key;
+            }
+        });
+        __syncthreads();
+        const unsigned int r = s_count;
+        __syncthreads();
+        return r;
+    };
+    unsigned int cnt = collect(thresh);
     if (cnt > TK_CAP) {
         // exact kk-th largest key by bisection: count(>= lo) >= kk always holds
         uint64_t lo = thresh, hi = ~0ull;
@@ -168,18 +185,9 @@ __global__ __launch_bounds__(TK_THREADS) void row_topk_kernel(
                 hi = mid - 1;
         }
         thresh = lo;
+        cnt = collect(thresh);
     }
-    if (tid == 0) s_count = 0;
-    __syncthreads();
-    for_each_in_row(s, n, tid, [&](float v, uint32_t i) {
-        const uint64_t key = rank_key(v, i);
-        if (key >= thresh) {
-            const unsigned int slot = atomicAdd(&s_count, 1u);
-            if (slot < TK_CAP) buf[slot] = key;
-        }
-    });
-    __syncthreads();
-    cnt = s_count < (unsigned int)TK_CAP ? s_count : (unsigned int)TK_CAP;
+    cnt = cnt < (unsigned int)TK_CAP ? cnt : (unsigned int)TK_CAP;
     int p2 = 2;
     while (p2 < (int)cnt) p2 <<= 1;
     for (int j = (int)cnt + tid; j < p2; j += TK_THREADS) buf[j] = 0;

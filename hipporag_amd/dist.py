@@ -477,10 +477,15 @@ class ShardedRetriever:
         return top_idx, torch.where(top_idx < 0, torch.zeros_like(norm), norm)
 
     def retrieve(self, q_pass, kept_idx, kept_score, kept_count, *, link_top_k=5, damping=0.5,
-                 passage_node_weight=0.05, ppr_iters=20, k=200, ppr_tol=0.0, ppr_max_iters=0):
+                 passage_node_weight=0.05, ppr_iters=20, k=200, ppr_tol=0.0, ppr_max_iters=0,
+                 check_saturation=True):
         """Returns (doc ids, doc scores, flags) -- and with ppr_tol > 0 additionally (residual, sweeps used): the
         convergence contract of hrag_retrieve on the shards.  Every shard measures the relative update of ITS
-        passages; the measures are all-reduced (MAX) before every decision, so all shards run the same steps."""
+        passages; the measures are all-reduced (MAX) before every decision, so all shards run the same steps.
+        check_saturation: the row shards have no wider state to repeat a batch on, so a batch that raised
+        HRAG_FLAG_FP8_SATURATED (a violated scale bound: never on valid inputs) raises here instead of handing
+        clipped scores on (include/hrag.h: "never return clipped scores"); it costs one host read per batch --
+        a timing loop passes False and checks the flags afterwards."""
         st, c = self.st, self.comm
         b = q_pass.shape[0]
         lay, bufs = self._state(b)
@@ -523,6 +528,10 @@ class ShardedRetriever:
         top_idx, top_val = merge_ranked(c.all_gather(idx), c.all_gather(val), k, st.topk)
         sat = (flags & 8).contiguous()               # raised on the shard that owns the row that saturated
         c.all_reduce(sat, "max")
+        if check_saturation and bool(sat.any()):
+            raise RuntimeError("fp8 PPR state saturated on a row shard (HRAG_FLAG_FP8_SATURATED): a static scale bound "
+                               "was violated; the scores of the flagged queries are not trustworthy and the row-sharded "
+                               "path has no wider state to repeat them on -- use the replica / hybrid mode for this batch")
         if contract:
             return top_idx, top_val, flags | sat, resid, used
         return top_idx, top_val, flags | sat
@@ -929,7 +938,7 @@ def _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS,
     def rs_step(i):
         idx, sc = rs.score_facts(gqf[i], k=K_F)
         return rs.retrieve(gqp[i], idx, sc, gcnt, link_top_k=K_F, damping=DAMP, passage_node_weight=PW,
-                           ppr_iters=ITERS, k=K_P)
+                           ppr_iters=ITERS, k=K_P, check_saturation=False)      # flags are checked after the timed loop
 
     for i in range(rs_warm):
         rs_step(i)

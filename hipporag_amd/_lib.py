@@ -91,8 +91,10 @@ SIGNATURES = {
     "hrag_colsum_workspace_bytes": (C.c_int64, [_P, _I32]),
     "hrag_stage_doc_scores": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _P, _P, _P, _P, _I64, _P]),
     "hrag_normalize_split_bf16": (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _P]),
-    "hrag_sim_gemm": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P]),
-    "hrag_split_f32": (C.c_int, [_P, _I64, _I32, _I32, _P, _P]),
+    "hrag_sim_gemm": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _I32, _P]),
+    "hrag_sim_topk_workspace_bytes": (C.c_int64, [_I64, _I32]),
+    "hrag_sim_topk": (C.c_int, [_P, _I64, _I32, _P, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
+    "hrag_split_f32": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "hrag_shard_layout_query": (C.c_int, [_P, _I32, _I32, C.POINTER(ShardLayout)]),
     "hrag_shard_score_facts": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
     "hrag_shard_passage_scores": (C.c_int, [_P, _P, _I32, _P, _P, _P]),

@@ -400,7 +400,8 @@ hrag_status launch_row_minmax(const float *scores, int32_t batch, int64_t n, int
                               float *mn_out, float *mx_out, hipStream_t s, float *sum_out = nullptr);
 
 // knn.hip : fp32 rows -> the 3 * dim bf16 layout of HRAG_F32_SPLIT engines ([hi | lo | hi]; queries [hi | hi | lo])
-hrag_status launch_split3(const float *x, int64_t rows, int32_t dim, int32_t as_query, uint16_t *out, hipStream_t s);
+hrag_status launch_split3(const float *x, int64_t rows, int32_t dim, int32_t as_query, uint16_t *out, hipStream_t s,
+                          int32_t normalize = 0);
 
 // seeds.hip
 hrag_status launch_build_seeds(const int32_t *kept_idx, const float *kept_score,

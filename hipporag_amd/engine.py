@@ -469,7 +469,7 @@ class HippoRAGEngine:
             if self.f32_split:     # fp32 rows -> the engine's [hi | lo | hi] layout, on the device
                 x = (torch.from_numpy(obj) if isinstance(obj, np.ndarray) else obj).to(self.device).contiguous()
                 fresh = torch.empty((rows, 3 * self.dim), dtype=torch.int16, device=self.device)
-                check(self._lib.hrag_split_f32(x.data_ptr(), rows, self.dim, 0, fresh.data_ptr(), _stream()))
+                check(self._lib.hrag_split_f32(x.data_ptr(), rows, self.dim, 0, 0, fresh.data_ptr(), _stream()))
             else:
                 fresh = (torch.from_numpy(obj.view(np.int16)) if isinstance(obj, np.ndarray) else obj.view(torch.int16)).to(self.device).contiguous()
         if n and int(src.min().item()) < 0 and (fresh is None or int((-src.min()).item()) > fresh.shape[0]):

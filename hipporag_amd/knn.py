@@ -2,9 +2,11 @@
 
 Mirrors reference src/hipporag/utils/embed_utils.py:6-94 (the only GPU compute the reference itself
 issues: blocked ``torch.mm`` + ``torch.topk``), called by ``add_synonymy_edges``
-(HippoRAG.py:959-1020) with k = synonymy_edge_topk = 2047.  Here: L2-normalise + hi/lo bf16 split
-(csrc/knn.hip), three MFMA passes into an fp32 score block (csrc/sim_gemm.hip, ~fp32-accurate), exact
-row top-k (csrc/topk.hip).  No key blocking is needed -- a [query_batch x n_keys] fp32 block fits
+(HippoRAG.py:959-1020) with k = synonymy_edge_topk = 2047.  Here: L2-normalise + split into two fp16 halves
+in the layout [hi | lo | hi] (keys) / [hi | hi | lo] (queries) (csrc/knn.hip ``split3_kernel``), ONE pass of the
+wide-batch 256-row MFMA GEMM over 3 * dim elements into an fp32 score block (every product exact, the sum is the
+fp32 product to 2^-21: ``precision="f32"``, the default), exact row top-k (csrc/topk.hip).  Round 1 ran three
+accumulating passes of bf16 halves on the 128-row kernel (61 TFLOP/s effective).  No key blocking is needed -- a [query_batch x n_keys] fp32 block fits
 HBM comfortably -- so ``key_batch_size`` is accepted and ignored (the reference's per-block top-k
 followed by a merge is exact, hence equivalent).
 
@@ -22,21 +24,26 @@ from ._lib import check
 
 
 def retrieve_knn(query_ids: List[str], key_ids: List[str], query_vecs, key_vecs, k: int = 2047,
-                 query_batch_size: int = 1000, key_batch_size: int = 10000, *, precision: str = "bf16x3",
-                 return_arrays: bool = False):
+                 query_batch_size: int = 1000, key_batch_size: int = 10000, *, precision: str = "f32",
+                 return_arrays: bool = False, min_score: float = None):
     """Top-k keys per query by cosine similarity.
 
     Returns ``{query_id: (list of key ids, list of scores)}`` like the reference; with
     ``return_arrays=True`` returns ``(idx int32 [nq, k'], score fp32 [nq, k'])`` instead (k' =
     min(k, n_keys)), which is what a graph builder wants at scale.
-    precision: "bf16x3" (three passes, |error| ~1e-6, default) or "bf16" (one pass, ~2e-3).
+    min_score: the caller only reads neighbours down to this score (add_synonymy_edges stops at the first score
+    below synonymy_edge_sim_threshold, HippoRAG.py:1004-1007): the device result is cut to the longest row prefix that
+    reaches it before it crosses PCIe (entries below it come back as idx -1 / score 0) -- at k = 2047 the full arrays
+    are 16 KB per query and dominate the call.
+    precision: "f32" (fp16 hi + lo halves, one pass over 3 * dim: |error| ~1e-7, default; "bf16x3" is accepted as an
+    alias) or "bf16" (rounded vectors, one pass over dim, ~2e-3).
     """
     import torch
     if len(key_vecs) == 0:
         return {}                                                        # embed_utils.py:22
     if not torch.cuda.is_available():
         raise RuntimeError("retrieve_knn needs an MI355X-class GPU (no CPU fallback on this path)")
-    if precision not in ("bf16x3", "bf16"):
+    if precision not in ("f32", "bf16x3", "bf16"):
         raise ValueError(precision)
     lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -48,39 +55,76 @@ def retrieve_knn(query_ids: List[str], key_ids: List[str], query_vecs, key_vecs,
     kk = int(min(k, n_keys))
     if kk > 2048:
         raise ValueError("k > 2048 is not supported by the selection kernel")
-    split = precision == "bf16x3"
+    split = precision != "bf16"
+    kdim, dtype = (3 * dim, 1) if split else (dim, 0)        # hrag_dtype: fp16 halves / bf16
 
-    def norm_split(x):
+    def prepare(x, as_query):
+        """F.normalize + the kernel's input layout"""
+        if split:
+            out = torch.empty((x.shape[0], 3 * dim), dtype=torch.int16, device=dev)
+            check(lib.hrag_split_f32(x.data_ptr(), x.shape[0], dim, 1 if as_query else 0, 1, out.data_ptr(), stream))
+            return out
         hi = torch.empty(x.shape, dtype=torch.int16, device=dev)
-        lo = torch.empty(x.shape, dtype=torch.int16, device=dev) if split else None
-        check(lib.hrag_normalize_split_bf16(x.data_ptr(), x.shape[0], x.shape[1], 1, hi.data_ptr(),
-                                            lo.data_ptr() if split else None, stream))
-        return hi, lo
+        check(lib.hrag_normalize_split_bf16(x.data_ptr(), x.shape[0], dim, 1, hi.data_ptr(), None, stream))
+        return hi
 
-    k_hi, k_lo = norm_split(kv)
+    keys = prepare(kv, False)
     del kv
     qv_all = np.asarray(query_vecs, dtype=np.float32)
     nq = qv_all.shape[0]
     ld = (n_keys + 3) // 4 * 4
-    out_idx = np.empty((nq, kk), np.int32)
-    out_sc = np.empty((nq, kk), np.float32)
+    out_idx = np.full((nq, kk), -1, np.int32) if min_score is not None else np.empty((nq, kk), np.int32)
+    out_sc = np.zeros((nq, kk), np.float32) if min_score is not None else np.empty((nq, kk), np.float32)
     qb = max(1, int(query_batch_size))
-    scores = torch.empty((min(qb, nq), ld), dtype=torch.float32, device=dev)
+    if min_score is not None:
+        qb = max(qb, 4096)     # no [qb, n_keys] block in this mode: wider query tiles keep the key stream on the MFMAs
+    scores = None
+    fused_k = min(16, n_keys)
+    if min_score is not None:
+        # the thresholded call never writes a [qb, n_keys] block unless a query has 16 or more neighbours above the
+        # threshold: the fused top-16 (tile maxima + rescore, exact) answers the others
+        ws_bytes = int(lib.hrag_sim_topk_workspace_bytes(n_keys, min(qb, nq)))
+        ws = torch.zeros((ws_bytes,), dtype=torch.uint8, device=dev)
     for lo_q in range(0, nq, qb):
         q = torch.from_numpy(qv_all[lo_q: lo_q + qb]).to(dev).contiguous()
         b = q.shape[0]
-        q_hi, q_lo = norm_split(q)
-        s = scores[:b]
-        if split:   # small terms first
-            check(lib.hrag_sim_gemm(k_hi.data_ptr(), n_keys, dim, q_lo.data_ptr(), b, s.data_ptr(), ld, 0, stream))
-            check(lib.hrag_sim_gemm(k_lo.data_ptr(), n_keys, dim, q_hi.data_ptr(), b, s.data_ptr(), ld, 1, stream))
-            check(lib.hrag_sim_gemm(k_hi.data_ptr(), n_keys, dim, q_hi.data_ptr(), b, s.data_ptr(), ld, 1, stream))
+        qq = prepare(q, True)
+        if min_score is not None:
+            i16 = torch.empty((b, fused_k), dtype=torch.int32, device=dev)
+            v16 = torch.empty((b, fused_k), dtype=torch.float32, device=dev)
+            check(lib.hrag_sim_topk(keys.data_ptr(), n_keys, kdim, qq.data_ptr(), b, fused_k, dtype, ws.data_ptr(),
+                                    ws_bytes, i16.data_ptr(), v16.data_ptr(), stream))
+            keep = v16 >= float(min_score)
+            w = min(int(keep.sum(1).max().item()), kk)
+            if w:
+                out_idx[lo_q: lo_q + b, :w] = torch.where(keep[:, :w], i16[:, :w], torch.full_like(i16[:, :w], -1)).cpu().numpy()
+                out_sc[lo_q: lo_q + b, :w] = torch.where(keep[:, :w], v16[:, :w], torch.zeros_like(v16[:, :w])).cpu().numpy()
+            more = torch.nonzero(keep[:, fused_k - 1]).flatten() if (kk > fused_k and n_keys > fused_k) else None
+            if more is None or more.numel() == 0:
+                continue
+            # the rare queries whose 16th neighbour is still above the threshold: the dense path, for them only
+            qq = qq[more].contiguous()
+            b = qq.shape[0]
+            rows_out = (lo_q + more).cpu().numpy()
         else:
-            check(lib.hrag_sim_gemm(k_hi.data_ptr(), n_keys, dim, q_hi.data_ptr(), b, s.data_ptr(), ld, 0, stream))
+            rows_out = None
+        if scores is None:
+            scores = torch.empty((min(qb, nq), ld), dtype=torch.float32, device=dev)
+        s = scores[:b]
+        check(lib.hrag_sim_gemm(keys.data_ptr(), n_keys, kdim, qq.data_ptr(), b, s.data_ptr(), ld, 0, dtype, stream))
         idx = torch.empty((b, kk), dtype=torch.int32, device=dev)
         val = torch.empty((b, kk), dtype=torch.float32, device=dev)
         check(lib.hrag_topk_rows(s.data_ptr(), b, n_keys, ld, kk, 0, 0, idx.data_ptr(), val.data_ptr(),
                                  None, None, stream))
+        if min_score is not None:      # rows are sorted: keep the longest prefix any of these rows needs
+            keep = val >= float(min_score)
+            w = int(keep.sum(1).max().item())
+            out_idx[rows_out, :] = -1
+            out_sc[rows_out, :] = 0
+            if w:
+                out_idx[rows_out, :w] = torch.where(keep[:, :w], idx[:, :w], torch.full_like(idx[:, :w], -1)).cpu().numpy()
+                out_sc[rows_out, :w] = torch.where(keep[:, :w], val[:, :w], torch.zeros_like(val[:, :w])).cpu().numpy()
+            continue
         out_idx[lo_q: lo_q + b] = idx.cpu().numpy()
         out_sc[lo_q: lo_q + b] = val.cpu().numpy()
     if return_arrays:
@@ -101,15 +145,18 @@ def synonymy_candidates(entity_keys: Sequence[str], entity_texts: Sequence[str],
     Returns [(key_a, key_b, score)] ready for ``HippoRAG.index_from_openie(synonym_edges=...)``-style
     consumers working on keys."""
     import re
-    idx, sc = retrieve_knn(list(entity_keys), list(entity_keys), entity_embs, entity_embs, k=topk,
-                           query_batch_size=query_batch_size, return_arrays=True)
+    # the loop below reads at most max_per_node + 1 neighbours (+ the self match) and stops at the threshold: the
+    # same edges as from the full top-`topk` lists, without selecting / shipping 2047 entries per entity
+    idx, sc = retrieve_knn(list(entity_keys), list(entity_keys), entity_embs, entity_embs,
+                           k=min(topk, max_per_node + 3), query_batch_size=query_batch_size, return_arrays=True,
+                           min_score=sim_threshold)
     edges = []
     for i, key in enumerate(entity_keys):
         if len(re.sub("[^A-Za-z0-9]", "", entity_texts[i])) <= 2:
             continue
         n = 0
         for j, s in zip(idx[i], sc[i]):
-            if s < sim_threshold or n > max_per_node:
+            if j < 0 or s < sim_threshold or n > max_per_node:
                 break
             if j != i and entity_texts[j] != "":
                 edges.append((key, entity_keys[j], float(s)))

@@ -304,17 +304,32 @@ hrag_status hrag_topk_rows(const float *scores_dev, int32_t batch, int64_t n, in
 /* ---- index-time entity KNN (retrieve_knn, utils/embed_utils.py:6-94; engine-less) ----
  * hrag_normalize_split_bf16: F.normalize (embed_utils.py:25,28) when normalize != 0, then the split
  *   x = hi + lo into two bf16 matrices (lo_dev may be NULL: plain bf16 rounding).
- * hrag_sim_gemm: out[b][m] (+)= sum_k q[b][k] * emb[m][k]  (torch.mm, :53); bf16 in, fp32 out,
- *   row stride ld; accumulate != 0 adds to out (three passes lo.hi + hi.lo + hi.hi ~ an fp32 product).
+ * hrag_sim_gemm: out[b][m] (+)= sum_k q[b][k] * emb[m][k]  (torch.mm, :53); bf16 / fp16 in (dtype), fp32 out,
+ *   row stride ld; accumulate != 0 adds to out.  retrieve_knn (hipporag_amd/knn.py) runs it ONCE per query block on
+ *   the split layout of hrag_split_f32 (normalize != 0: F.normalize first): [hi | lo | hi] x [qhi | qhi | qlo],
+ *   fp16 halves = the fp32 product to 2^-21, on the wide-batch 256-row kernel.
  * The top-k of each score row is hrag_topk_rows (k <= 2048 covers synonymy_edge_topk = 2047). */
 hrag_status hrag_normalize_split_bf16(const float *x_dev, int64_t rows, int32_t dim, int32_t normalize,
                                       uint16_t *hi_dev, uint16_t *lo_dev, hrag_stream stream);
 hrag_status hrag_sim_gemm(const uint16_t *emb_dev, int64_t rows, int32_t dim, const uint16_t *q_dev,
-                          int32_t batch, float *out_dev, int64_t ld, int32_t accumulate, hrag_stream stream);
+                          int32_t batch, float *out_dev, int64_t ld, int32_t accumulate, int32_t dtype,
+                          hrag_stream stream);
+/* The k <= 16 best rows per query WITHOUT the score matrix (the engine-less form of hrag_score_facts' fused path: the
+ * GEMM epilogue keeps every 128-row tile's maximum, the k tiles with the largest maxima are rescored with the same MFMA
+ * chain -- exact, bit-identical to hrag_sim_gemm + hrag_topk_rows): idx int32 [B, k], raw scores fp32 [B, k].
+ * retrieve_knn(min_score=...) uses it: when a query's 16th best score is below the synonymy threshold, its neighbours
+ * above the threshold are all among these 16 and no [B, rows] block is ever written (embed_utils.py:53-73 materialises
+ * it block by block).  workspace_dev: hrag_sim_topk_workspace_bytes(rows, batch) bytes, ZEROED ONCE by the caller
+ * before the first call (the call leaves it reusable). */
+int64_t hrag_sim_topk_workspace_bytes(int64_t rows, int32_t batch);
+hrag_status hrag_sim_topk(const uint16_t *emb_dev, int64_t rows, int32_t dim, const uint16_t *q_dev, int32_t batch,
+                          int32_t k, int32_t dtype, void *workspace_dev, int64_t workspace_bytes,
+                          int32_t *idx_out_dev, float *val_out_dev, hrag_stream stream);
 /* fp32 [rows, dim] -> the fp16 [rows, 3 * dim] layout of an HRAG_F32_SPLIT engine: [hi | lo | hi] for embedding rows,
- * [hi | hi | lo] with as_query != 0 (new rows for hrag_engine_gather_embeddings; the engine converts its own inputs). */
-hrag_status hrag_split_f32(const float *x_dev, int64_t rows, int32_t dim, int32_t as_query, uint16_t *out_dev,
-                           hrag_stream stream);
+ * [hi | hi | lo] with as_query != 0 (new rows for hrag_engine_gather_embeddings; the engine converts its own inputs);
+ * normalize != 0: rows are L2-normalised first (x / max(||x||, 1e-12), the KNN's F.normalize). */
+hrag_status hrag_split_f32(const float *x_dev, int64_t rows, int32_t dim, int32_t as_query, int32_t normalize,
+                           uint16_t *out_dev, hrag_stream stream);
 
 /* Measurement hook: run `n` PPR SpMM sweeps over the engine's current state buffers for
  * `batch` right-hand sides (state is whatever the last hrag_retrieve / hrag_ppr left).

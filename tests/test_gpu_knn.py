@@ -67,3 +67,24 @@ def test_synonymy_candidates_rules(gpu_device):
     assert not any(a == "entity-2" for a, _, _ in edges)          # "ab": <= 2 alphanumerics -> skipped as a query
     assert ("entity-8", "entity-2") in pairs                       # ... but still a valid neighbour
     assert all(a != b and s >= 0.8 for a, b, s in edges)
+
+
+@pytest.mark.parametrize("n_dup", [3, 40])
+def test_thresholded_knn_matches_the_full_lists(gpu_device, n_dup):
+    """retrieve_knn(min_score=t): exactly the prefix of every full top-k list that lies above t -- through the fused
+    top-16 (no score block) when a query has fewer than 16 such neighbours (n_dup = 3), through the dense path for the
+    queries that have more (n_dup = 40: clusters of 40 near-duplicates)."""
+    from hipporag_amd.knn import retrieve_knn
+    rng = np.random.default_rng(7)
+    base = rng.standard_normal((60, 96)).astype(np.float32)
+    keys = np.concatenate([base] + [base[:20] + 0.02 * rng.standard_normal((20, 96)).astype(np.float32) for _ in range(n_dup)])
+    keys = np.concatenate([keys, rng.standard_normal((3000, 96)).astype(np.float32)])
+    q = keys[:120]
+    full_i, full_s = retrieve_knn(None, None, q, keys, k=64, query_batch_size=50, return_arrays=True)
+    thr_i, thr_s = retrieve_knn(None, None, q, keys, k=64, query_batch_size=50, return_arrays=True, min_score=0.8)
+    assert (full_s[:20] >= 0.8).sum(1).min() >= min(n_dup, 64) - 1         # the duplicated rows really have that many
+    for r in range(len(q)):
+        n = int((full_s[r] >= 0.8).sum())
+        np.testing.assert_array_equal(thr_i[r, :n], full_i[r, :n])
+        np.testing.assert_array_equal(thr_s[r, :n], full_s[r, :n])
+        assert np.all(thr_i[r, n:] == -1) and np.all(thr_s[r, n:] == 0)

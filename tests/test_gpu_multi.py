@@ -1,0 +1,86 @@
+"""The N > 1 paths over REAL RCCL (backend "nccl"), two processes on two GPUs: the row-sharded retriever with two
+exchange groups (in-place all_gather_into_tensor of the owners' blocks, pipelined against the other group's sweep) and
+the hybrid retriever (all_to_all of passage-score rows), each bit-identical to the single-GPU engine.
+
+Skipped unless the box has at least two GPUs -- no such box was available to the rounds that wrote this code (every
+`gpurun` box has one): the emulated-rank tests (tests/test_gpu_shard.py, tests/test_gpu_hybrid.py) and the gloo tests
+(tests/test_shard_orchestration.py) are what has actually run.  On a multi-GPU box this is the first thing to run."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    from hipporag_amd import dist as hd, synth
+    from hipporag_amd.engine import HippoRAGEngine, ShardStages
+    from tests.helpers import make_case
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        b = 512                                             # four 128-query slabs: two exchange groups of two
+        kg, pass_bits, fact_bits, _ = make_case(12000, 120000, 128, seed=901)
+        sidx = hd.shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+
+        def bf16(bits):
+            return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).to(dev).view(torch.bfloat16)
+
+        qf, qp = bf16(synth.make_queries_np(fact_bits, b, seed=3)[0]), bf16(synth.make_queries_np(pass_bits, b, seed=4)[0])
+        cnt = torch.full((b,), 5, dtype=torch.int32, device=dev)
+        kw = dict(link_top_k=5, damping=0.5, passage_node_weight=0.05, ppr_iters=20, k=100)
+        comm = hd.TorchComm(rank, world)
+        seng = hd.build_shard_engine(sidx, pass_bits, fact_bits, rank, max_batch=b, max_topk=100, sell_seg_len=64)
+        rs = hd.ShardedRetriever(ShardStages(seng), comm, groups=2)
+        assert seng.shard_layout(b, 2).n_groups == 2
+        idx, sc = rs.score_facts(qf, k=5)
+        d_idx, d_sc, flags = rs.retrieve(qp, idx, sc, cnt, **kw)
+        # the single-GPU engine on the relabelled index, same long-row cut
+        with HippoRAGEngine(sidx.csr, sidx.passage_vertex, pass_bits, fact_bits, sidx.subj_vertex, sidx.obj_vertex,
+                            sidx.num_chunks, max_batch=b, max_topk=100, sell_seg_len=64) as one:
+            i1, s1 = one.score_facts(qf, k=5)
+            o1 = one.retrieve(qp, i1, s1, cnt, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(idx, i1) and torch.equal(sc, s1)
+            assert torch.equal(d_idx, o1.doc_idx) and torch.equal(d_sc, o1.doc_score) and int(flags.max()) == 0
+        # hybrid: embeddings sharded, one all_to_all, PPR on this rank's half of the batch (original index)
+        ppr = hd.build_ppr_engine(kg.csr, kg.passage_vertex, kg.subj_vertex, kg.obj_vertex, kg.num_chunks, 128, b // world, 100)
+        hy = hd.HybridRetriever(ShardStages(seng), ppr, comm, sidx.passages)
+        hidx, hsc = hy.score_facts(qf, k=5)
+        out = hy.retrieve(qp, hidx, hsc, cnt, **kw)
+        mine = hy.my_rows(b)
+        with HippoRAGEngine(kg.csr, kg.passage_vertex, pass_bits, fact_bits, kg.subj_vertex, kg.obj_vertex,
+                            kg.num_chunks, max_batch=b, max_topk=100) as one:
+            i1, s1 = one.score_facts(qf, k=5)
+            o1 = one.retrieve(qp[mine], i1[mine], s1[mine], cnt[mine], **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(hidx, i1) and torch.equal(hsc, s1)
+            assert torch.equal(out.doc_idx, o1.doc_idx) and torch.equal(out.doc_score, o1.doc_score)
+        seng.close()
+        ppr.close()
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_rowshard_and_hybrid_on_two_gpus_match_the_single_gpu_engine():
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (every gpurun box has one)")
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: 1, 1: 1}

@@ -771,8 +771,8 @@ def test_sim_gemm256_is_bit_identical_to_the_small_tile_kernel(gpu_device, rows,
     new = torch.full((batch, ld), float("nan"), device=gpu_device)
     old = torch.zeros((batch, ld), device=gpu_device)
     stream = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.hrag_sim_gemm(emb.data_ptr(), rows, dim, q.data_ptr(), batch, new.data_ptr(), ld, 0, stream))
-    _lib.check(lib.hrag_sim_gemm(emb.data_ptr(), rows, dim, q.data_ptr(), batch, old.data_ptr(), ld, 1, stream))
+    _lib.check(lib.hrag_sim_gemm(emb.data_ptr(), rows, dim, q.data_ptr(), batch, new.data_ptr(), ld, 0, 0, stream))
+    _lib.check(lib.hrag_sim_gemm(emb.data_ptr(), rows, dim, q.data_ptr(), batch, old.data_ptr(), ld, 1, 0, stream))
     torch.cuda.synchronize()
     assert torch.equal(new[:, :rows], old[:, :rows])
     want = q.double() @ emb.double().T

@@ -110,7 +110,43 @@ def make_filter(queries, mode):
     return filt, calls
 
 
-def run_case(name, docs, triples, queries, filter_mode, model=None, **cfg):
+def dump_object_state(rag, queries, filter_mode, sols, path):
+    """The indexed reference OBJECT as reference_adapter.attach() reads it (the attributes the reference's own index()
+    / prepare_retrieval_objects left on it, HippoRAG.py:1287-1389), in builtin + numpy types only, and what the
+    reference's own retrieve() answered: tests/restored_reference.py rebuilds the object on the GPU box, where the
+    package cannot be imported, and attach() meets the real engine there."""
+    import pickle
+    g = rag.graph
+    fact_keys = list(rag.fact_node_keys)
+    state = {
+        "vcount": int(g.vcount()),
+        "edgelist": [(int(a), int(b)) for a, b in g.get_edgelist()],
+        "edge_weight": [float(w) for w in g.es["weight"]],
+        "vertex_names": [str(n) for n in g.vs["name"]],
+        "node_name_to_vertex_idx": {str(k): int(v) for k, v in rag.node_name_to_vertex_idx.items()},
+        "passage_node_idxs": [int(i) for i in rag.passage_node_idxs],
+        "passage_node_keys": [str(k) for k in rag.passage_node_keys],
+        "entity_node_keys": [str(k) for k in rag.entity_node_keys],
+        "fact_node_keys": fact_keys,
+        "passage_embeddings": np.asarray(rag.passage_embeddings, np.float32),
+        "fact_embeddings": np.asarray(rag.fact_embeddings, np.float32),
+        "ent_node_to_chunk_ids": {str(k): sorted(str(c) for c in v) for k, v in rag.ent_node_to_chunk_ids.items()},
+        "fact_rows": {k: {"hash_id": r["hash_id"], "content": r["content"]}
+                      for k, r in rag.fact_embedding_store.get_rows(fact_keys).items()},
+        "chunk_rows": {k: {"hash_id": rag.chunk_embedding_store.get_row(k)["hash_id"],
+                           "content": rag.chunk_embedding_store.get_row(k)["content"]} for k in rag.passage_node_keys},
+        "config": {f: getattr(rag.global_config, f) for f in
+                   ("retrieval_top_k", "linking_top_k", "damping", "passage_node_weight")},
+        "query_to_embedding": {kind: {q: np.asarray(rag.query_to_embedding[kind][q], np.float32) for q in queries}
+                               for kind in ("triple", "passage")},
+        "queries": list(queries), "filter_mode": filter_mode,
+        "reference_retrieve": [{"docs": list(s.docs), "doc_scores": np.asarray(s.doc_scores, np.float64)} for s in sols],
+    }
+    with open(path, "wb") as f:
+        pickle.dump(state, f, protocol=4)
+
+
+def run_case(name, docs, triples, queries, filter_mode, model=None, dump_state=False, **cfg):
     tmp = tempfile.mkdtemp(prefix="refgold_")
     try:
         rag = rh.build_reference_rag(tmp, docs, triples, model or Bf16Mock(), **cfg)
@@ -165,6 +201,8 @@ def run_case(name, docs, triples, queries, filter_mode, model=None, **cfg):
         out["passage_texts"] = np.array([rag.chunk_embedding_store.get_row(k)["content"] for k in rag.passage_node_keys])
         out["queries"] = np.array(list(queries))
         np.savez_compressed(os.path.join(HERE, f"ref_{name}.npz"), **out)
+        if dump_state:
+            dump_object_state(rag, queries, filter_mode, sols, os.path.join(HERE, f"ref_state_{name}.pkl"))
         n_syn = sum(1 for w in a["edge_w"] if 0.8 <= w < 1.0)
         print(f"ref_{name}.npz: V={v} igraph edges={len(a['edge_w'])} (synonymy-like weights: {n_syn}) Np={np_} "
               f"F={len(a['subj_vertex'])} queries={q} dpr_fallbacks={int(used_dpr.sum())} "
@@ -181,7 +219,7 @@ def main():
     run_case("synth", docs, triples, queries, "mixed")
     # the same corpus with the mock model's fp32 vectors AS THEY ARE (not bf16-representable): what a real embedding
     # store holds.  Pins the fp32-faithful similarity mode (HRAG_F32_SPLIT) -- and shows what bf16 rounding flips
-    run_case("synth_f32", docs, triples, queries, "mixed", model=mg.MockEmbeddingModel())
+    run_case("synth_f32", docs, triples, queries, "mixed", model=mg.MockEmbeddingModel(), dump_state=True)
 
 
 if __name__ == "__main__":

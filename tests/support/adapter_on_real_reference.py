@@ -42,6 +42,8 @@ class OracleEngine:
                                      obj_vertex, num_chunks, np.asarray(passage_vertex), p)
         self.device, self.max_batch, self.max_topk = torch.device("cpu"), max_batch, max_topk
         self.closed = False
+        # like HippoRAGEngine: fp32 matrices -> the queries stay fp32 (HRAG_F32_SPLIT), bf16 bits -> bf16 queries
+        self.emb_dtype = torch.float32 if np.asarray(passage_emb).dtype == np.float32 else torch.bfloat16
 
     def score_facts(self, q, k=5):
         q = q.float().numpy()
@@ -77,7 +79,9 @@ class OracleEngine:
                 sid, sw = oracle.seed_weights(ix, scores, kept.tolist(), link_top_k)
                 by_p = np.empty_like(dpr_sc)
                 by_p[dpr_ids] = dpr_sc
-                ids, sc, _ = oracle.run_ppr(ix, oracle.reset_vector(ix, sid, sw, by_p), damping, "power", ppr_iters)
+                # with a tolerance the device iterates until the passage scores stand still: the exact solve stands in
+                ids, sc, _ = oracle.run_ppr(ix, oracle.reset_vector(ix, sid, sw, by_p), damping,
+                                            "exact" if ppr_tol > 0 else "power", ppr_iters)
             d_idx[i, :min(k, len(ids))], d_sc[i, :min(k, len(ids))] = ids[:k], sc[:k]
         return engine_mod.RetrieveOutput(torch.from_numpy(d_idx), torch.from_numpy(d_sc), torch.from_numpy(flags))
 

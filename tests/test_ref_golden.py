@@ -193,6 +193,26 @@ def test_fixtures_are_reproducible(tmp_path):
                 np.testing.assert_allclose(new[key], old[key], rtol=1e-12, atol=0, err_msg=key)
             else:
                 np.testing.assert_array_equal(new[key], old[key], err_msg=key)
+    # the recorded object state (tests/restored_reference.py) is part of the same run
+    import pickle
+
+    def same(a, b, at):
+        if isinstance(a, dict):
+            assert a.keys() == b.keys(), at
+            for k in a:
+                same(a[k], b[k], f"{at}/{k}")
+        elif isinstance(a, np.ndarray):
+            np.testing.assert_allclose(a, b, rtol=1e-12, atol=0, err_msg=at)
+        elif isinstance(a, (list, tuple)) and a and isinstance(a[0], (dict, np.ndarray)):
+            assert len(a) == len(b), at
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, f"{at}[{i}]")
+        else:
+            assert a == b, at
+
+    with open(os.path.join(str(tmp_path), "ref_state_synth_f32.pkl"), "rb") as f_new, \
+            open(os.path.join(GOLD, "ref_state_synth_f32.pkl"), "rb") as f_old:
+        same(pickle.load(f_new), pickle.load(f_old), "state")
 
 
 # ------------------------------------------------------------------------------------------ GPU

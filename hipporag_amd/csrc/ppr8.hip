@@ -319,12 +319,14 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow
         __builtin_nontemporal_store(encode16(out), reinterpret_cast<v4i_t *>(a.y + off));
     } else {
         f32x2_t c[8], rin[8];
-        const v4i_t cv = __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(a.x + off));
+        const int slot = a.row_slot[lrow];
+        const bool is_passage = slot >= 0 && slot < a.p_rows;
+        v4i_t cv = {0, 0, 0, 0};
+        // B0: c_0 = Q(v/d) exists only on the rows with a teleport row (ppr8_init_kernel writes no others)
+        if (MODE != kP8ModeB0 || slot >= 0) cv = __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(a.x + off));
         decode16(cv, c);
         float *rrow = a.R + ((size_t)slab * a.n_rows + (size_t)lrow) * 128;
         uint16_t *hrow = a.rho + ((size_t)slab * a.n_rows + (size_t)lrow) * 128;
-        const int slot = a.row_slot[lrow];
-        const bool is_passage = slot >= 0 && slot < a.p_rows;
         if constexpr (MODE == kP8ModeB0) {
             load_zv(a.tele, a.tele_rows, a.row_slot, a.deg, a.n_slabs64, slab, lrow, grow, gl, rin);   // R_in = b v/d
 #pragma unroll
@@ -733,14 +735,15 @@ __device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
 template <int MODE, int RIO, bool EST>
 __global__ __launch_bounds__(256, 2) void ppr8_pair_kernel(const Ppr8Args a) { ppr8_pair_body<MODE, RIO, EST>(a); }
 
-// c_0 = Q(v/d * c0_scale) for every OWNED row of the launch's slabs (R_0 = b v/d is formed on the fly by
-// the first boundary sweep, mode B0).
+// c_0 = Q(v/d * c0_scale) on the OWNED rows of the launch's slabs that carry a teleport row (passages, seeds): it is
+// zero elsewhere, and its only reader, the first boundary sweep (mode B0: R_0 = b v/d is formed on the fly), neither
+// gathers a column outside the bitmap of those rows nor reads its own c there -- 7/8 of the state is not written.
 __global__ __launch_bounds__(256) void ppr8_init_kernel(const Ppr8Args a, float c0_scale) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t lrow = t >> 3;
     const int gl = (int)(t & 7);
     const int slab = a.slab0 + blockIdx.y;
-    if (lrow >= a.n_rows) return;
+    if (lrow >= a.n_rows || a.row_slot[lrow] < 0) return;
     const int64_t grow = a.row_offset + lrow;
     f32x2_t z[8], q[8];
     load_zv(a.tele, a.tele_rows, a.row_slot, a.deg, a.n_slabs64, slab, lrow, grow, gl, z);

@@ -531,20 +531,28 @@ def main():
     def timed(tol=0.0, max_iters=0):
         for i in range(args.warmup):
             o = step(i, tol, max_iters)
+        # one event per step boundary on the stream the library launches on (torch's current stream): the median step
+        # time of SURVEY 8(d) beside the wall clock that `value` is computed from
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         res, used, flg = [], [], []
+        marks[0].record()
         for i in range(args.warmup, n_batches):
             o = step(i, tol, max_iters)
+            marks[i - args.warmup + 1].record()
             res.append(o.residual); used.append(o.iters_used); flg.append(o.flags)     # device tensors: no sync
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
         contract = {"ppr_tol": tol, "ppr_max_iters": max(max_iters, PPR_ITERS) if tol > 0 else PPR_ITERS,
                     "ppr_residual_max": float(torch.stack(res).max()),
                     "ppr_residual_definition": "damping / (1 - damping) * max over passages of the relative update of "
                                                "the passage score in the last sweep (include/hrag.h, hrag_retrieve)",
                     "sweeps_used_min": int(torch.stack(used).min()), "sweeps_used_max": int(torch.stack(used).max()),
-                    "queries_flagged_not_converged": int((torch.stack(flg) & 16).ne(0).sum())}
+                    "queries_flagged_not_converged": int((torch.stack(flg) & 16).ne(0).sum()),
+                    "step_ms_median_hip_events": per_step[len(per_step) // 2] if per_step else None,
+                    "step_ms_min_max_hip_events": [per_step[0], per_step[-1]] if per_step else None}
         return o, el, contract
 
     out, elapsed, contract = timed()                                    # BASELINE.json: exactly 20 PPR iterations
@@ -580,6 +588,8 @@ def main():
                    "locality_score_after_renumbering": eng.locality_score, "engine_opt_flags": eng.opt_flags,
                    "parallelism": "1gpu"},
         "roofline": roofline,
+        "step_ms_median_hip_events": contract.pop("step_ms_median_hip_events"),
+        "step_ms_min_max_hip_events": contract.pop("step_ms_min_max_hip_events"),
         "ppr_contract": contract, "with_convergence_contract": contract_c,
         "phases_ms": {k: phases[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")},
         "sim_algorithmic_bytes": sim_algorithmic_bytes(kg.n_facts, kg.n_passages, D, B),

@@ -531,19 +531,23 @@ def main():
     def timed(tol=0.0, max_iters=0):
         for i in range(args.warmup):
             o = step(i, tol, max_iters)
-        # one event per step boundary on the stream the library launches on (torch's current stream): the median step
-        # time of SURVEY 8(d) beside the wall clock that `value` is computed from
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         res, used, flg = [], [], []
-        marks[0].record()
         for i in range(args.warmup, n_batches):
             o = step(i, tol, max_iters)
-            marks[i - args.warmup + 1].record()
             res.append(o.residual); used.append(o.iters_used); flg.append(o.flags)     # device tensors: no sync
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        # SURVEY 8(d)'s median of per-step HIP-event times, in a loop of its own AFTER the wall-clock region (an event
+        # per step inside it cost sporadic 7-26 ms stalls on the small configurations); events on torch's current
+        # stream = the stream the library launches on
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        marks[0].record()
+        for i in range(args.warmup, n_batches):
+            step(i, tol, max_iters)
+            marks[i - args.warmup + 1].record()
+        torch.cuda.synchronize()
         per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
         contract = {"ppr_tol": tol, "ppr_max_iters": max(max_iters, PPR_ITERS) if tol > 0 else PPR_ITERS,
                     "ppr_residual_max": float(torch.stack(res).max()),

@@ -269,9 +269,8 @@ hrag_status launch_ppr8_scale(const float *zmax, const double *mass, float passa
 // est[slab * w + col] = max(itself, column maxima of ws[slab][chunk][w]) for slabs [slab0, slab0 + n_slabs)
 hrag_status launch_est_reduce(const float *ws, int32_t n_chunks, int32_t w, int32_t slab0, int32_t n_slabs, int32_t batch,
                               int32_t *est, const int32_t *gate, int32_t gate_want, hipStream_t s);
-hrag_status launch_ppr8_decide(int32_t *est_ck, float *est_prev, const int32_t *flags, int32_t batch, float kappa,
-                               float expo, float g, float tol, int32_t j, int32_t e_max, int32_t *ctl, int32_t n_ctl,
-                               hipStream_t s);
+hrag_status launch_ppr8_decide(int32_t *est_f, const int32_t *flags, int32_t batch, float g, float tol, int32_t j,
+                               int32_t e_max, int32_t *ctl, hipStream_t s);
 hrag_status launch_ppr8_finalize(const int32_t *est_f, int32_t *flags, int32_t batch, float g, float tol,
                                  int32_t iters, const int32_t *ctl, int32_t e_max, const double *mass_tab,
                                  int64_t tab_stride, double *sums, float *resid, int32_t *iters_used, hipStream_t s);

@@ -38,8 +38,8 @@ void free_engine(hrag_engine *e) {
                     e->d_xp8, e->d_row_ptele, e->d_iso, e->d_piso, e->d_colmask_static, e->d_colmask,
                     e->d_stagep, e->d_pool8[0], e->d_pool8[1], e->d_pool8[2], e->d_sv16[0], e->d_sv16[1],
                     e->d_sv16[2], e->d_sv16[3], e->d_zmax_bits, e->d_zmax,
-                    e->d_mass, e->d_prior_part, e->d_est_ck, e->d_est_f, e->d_ctl, e->d_iters_used, e->d_resid,
-                    e->d_mass_tab, e->d_est_prev, e->d_est_ws, e->d_qsplit};
+                    e->d_mass, e->d_prior_part, e->d_est_f, e->d_ctl, e->d_iters_used, e->d_resid,
+                    e->d_mass_tab, e->d_est_ws, e->d_qsplit};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_store(e->sell);
@@ -751,16 +751,14 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     // colsum partials: worst case is the narrowest slab (most slabs * bc stays ~B, padded)
     E_TRY(dev_alloc(&e->d_colsum_partial, (int64_t)kColsumBlocks * (round_up(B, 4) + 64)));
     E_TRY(dev_alloc(&e->d_sums, B));
-    E_TRY(dev_alloc(&e->d_est_ck, B));
     E_TRY(dev_alloc(&e->d_est_f, B));
-    E_TRY(dev_alloc(&e->d_ctl, 2 * (kP8MaxExt + 1)));
+    E_TRY(dev_alloc(&e->d_ctl, kP8MaxExt + 1));
     E_TRY(dev_alloc(&e->d_iters_used, B));
     E_TRY(dev_alloc(&e->d_resid, B));
-    E_TRY(dev_alloc(&e->d_est_prev, B));
     {
         // every wavefront of a sweep that measures est writes one row of (queries per slab row) floats; the widest
-        // user is the checkpoint boundary of the fp8 state (all chunks of the main matrix, 128 queries per row)
-        const int64_t c_p = std::max<int64_t>(e->sell.n_pchunks, e->fsell.n_pchunks), c_f = e->fsell.n_chunks;
+        // user is the final sweep of the fp8 state (the chunks that hold passage rows, 128 queries per row)
+        const int64_t c_p = e->fsell.n_pchunks, c_f = e->fsell.n_chunks;
         int64_t n = c_f * 8;                                                   // small batches (last sweep: passage rows)
         if (e->f8_ready) n = std::max(n, (int64_t)n_slabs128(B) * c_p * 128);   // the chunks that hold passage rows
         if (e->f16_ready) n = std::max(n, (int64_t)n_slabs64(e->f16_max_batch) * c_f * 64);
@@ -1120,7 +1118,7 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
                              doc_score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
     if (!f8) {
         if (est) {
-            HRAG_HIP_TRY(hipMemsetAsync(e->d_ctl, 0, (size_t)2 * (kP8MaxExt + 1) * sizeof(int32_t), s));
+            HRAG_HIP_TRY(hipMemsetAsync(e->d_ctl, 0, (size_t)(kP8MaxExt + 1) * sizeof(int32_t), s));
             HRAG_TRY(launch_ppr8_finalize(est, e->d_flags, batch, damping / (1.0f - damping), ppr_tol, ppr_iters, e->d_ctl,
                                           0, nullptr, 0, e->d_sums, e->d_resid, e->d_iters_used, s));
         } else {

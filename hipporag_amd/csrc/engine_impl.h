@@ -78,12 +78,11 @@ struct Ppr8Step {
     int32_t x, y, rt;    // state buffer indices (y: written = to be exchanged, -1 for mode F; rt: the stage's rhs)
     float inv_cs, cs_next;
     int32_t rio;         // residual form of a boundary / final step (Ppr8Args.rio)
-    // convergence contract: gate = index of the control word the launch is conditional on (-1: always runs),
-    // ckpt = this boundary measures est (the relative update of the passage scores) and is followed by decision
-    // number `decide` (-1: none), kappa = the contraction predicted for the stage that follows
+    // convergence contract: gate = index of the control word the launch is conditional on (-1: always runs);
+    // decide = j >= 0: this final sweep (variant j) is followed by decision number j (ppr8_decide_kernel: its measured
+    // update against the tolerance), -1: none
     int32_t gate = -1, gate_want = 1;
-    int32_t ckpt = 0, decide = -1;   // decide: -1 none, -2 probe (remember the values for the next decision), >= 0
-    float kappa = 0.f, expo = 1.f;   // expo = sweeps of the next stage / sweeps since the previous checkpoint
+    int32_t decide = -1;
 };
 struct Ppr8Session {
     bool active = false;
@@ -176,11 +175,11 @@ struct hrag_engine {
     float *d_zmax = nullptr;
     double *d_mass = nullptr, *d_prior_part = nullptr;
     Ppr8Session p8;
-    // convergence contract of the PPR solve (every state type): est = max over the passages of the relative size of the
-    // last update, as float bits (atomicMax) -- at the last checkpoint boundary / at the final sweep; control words
-    // [0 .. kP8MaxExt]: extension stage j + 1 runs, [kP8MaxExt + 1 ..]: final sweep variant j runs; the results
-    int32_t *d_est_ck = nullptr, *d_est_f = nullptr, *d_ctl = nullptr, *d_iters_used = nullptr;
-    float *d_resid = nullptr, *d_est_prev = nullptr;
+    // convergence contract of the PPR solve (every state type): est_f = max over the passages of the relative size of
+    // the update the (latest) final sweep applied, as float bits; control words ctl[j] = 1: extension stage j + 1 runs
+    // (the launches of that stage are gated on it); the results
+    int32_t *d_est_f = nullptr, *d_ctl = nullptr, *d_iters_used = nullptr;
+    float *d_resid = nullptr;
     float *d_est_ws = nullptr;      // per-wavefront maxima of a sweep that measures est: [slabs][chunks][queries per slab row]
     double *d_mass_tab = nullptr;   // [kP8MaxExt + 1][max_batch]: mass of the (iters + 3 j)-sweep iterate
     // one call in flight per engine (include/hrag.h): host-side entry flag + the end of the last call on its stream

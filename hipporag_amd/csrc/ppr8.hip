@@ -302,8 +302,8 @@ __device__ __forceinline__ size_t state_off(const Ppr8Args &a, int slab, int64_t
 // The host switches a boundary to this form once damping^k <= 2^-6 (k = sweeps done), where 2^-15 |R| is
 // below 5e-7 of the solution (csrc/shard.hip; emulation: 2.5e-7 -> 3.9e-7 on the benchmark graph against 2^-9,
 // 4e-6 at 2^-3); the early boundaries keep the fp32 R.
-// er (modes B / F with a.est): on return |R_p| / z_p of this lane's 16 queries when the row is an owned passage
-// (the relative size of the update the boundary applies to the passage score), untouched otherwise.
+// er (mode F with a.est): on return |R_p| / z_p of this lane's 16 queries when the row is an owned passage (the
+// relative size of the update the final sweep applies to the passage score), untouched otherwise.
 template <int MODE, int RIO, bool EST>
 __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow, int gl,
                                            const f32x2_t (&acc)[8], f32x2_t (&er)[8]) {
@@ -366,26 +366,6 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow
             if (is_passage) {
                 const size_t poff = ((size_t)slab * a.p_rows + (size_t)slot) * 128 + (size_t)gl * 16;
                 *reinterpret_cast<v4i_t *>(a.stage_out + poff) = cv;
-                if constexpr (MODE == kP8ModeB && EST) {
-                    {   // checkpoint boundary: z_p = X_p + R_p, X_p = the stages' c / cs summed (as mode F does)
-                        f32x2_t z[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) z[j] = f32x2_t{0.f, 0.f};
-                        for (int s = 0; s + 1 < a.n_stage; ++s) {
-                            f32x2_t cs[8];
-                            decode16(*reinterpret_cast<const v4i_t *>(a.stage[s] + poff), cs);
-                            const f32x2_t si = {a.stage_inv[s], a.stage_inv[s]};
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) z[j] = __builtin_elementwise_fma(cs[j], si, z[j]);
-                        }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const f32x2_t zz = __builtin_elementwise_fma(c[j], inv, z[j]) + out[j];
-                            er[j].x = zz.x > 0.f ? fabsf(out[j].x) / zz.x : 0.f;
-                            er[j].y = zz.y > 0.f ? fabsf(out[j].y) / zz.y : 0.f;
-                        }
-                    }
-                }
             }
         } else {   // kP8ModeF: z = R' + sum_s c_s / cs_s (earliest stage first), x = d z
             if (!is_passage) return;
@@ -514,7 +494,7 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     // partial sums travel write-through / L1-bypassing (sc1): writer and reader may sit on different XCDs
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
         a.partial + (size_t)slab * a.m.n_partial * 128, 0, a.m.n_partial * 512, 0x00020000);
-    constexpr bool kEst = EST && (MODE == kP8ModeB || MODE == kP8ModeF);
+    constexpr bool kEst = EST && MODE == kP8ModeF;
     f32x2_t er[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) er[j] = f32x2_t{0.f, 0.f};
@@ -674,7 +654,7 @@ __device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
         a.partial + (size_t)slab * a.m.n_partial * 128, 0, a.m.n_partial * 512, 0x00020000);
     const __amdgpu_buffer_rsrc_t q1 = __builtin_amdgcn_make_buffer_rsrc(
         a.partial + (size_t)(slab + 1) * a.m.n_partial * 128, 0, a.m.n_partial * 512, 0x00020000);
-    constexpr bool kEst = EST && (MODE == kP8ModeB || MODE == kP8ModeF);
+    constexpr bool kEst = EST && MODE == kP8ModeF;
     f32x2_t er[8];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -893,46 +873,33 @@ __global__ __launch_bounds__(256) void est_reduce_kernel(const float *__restrict
     }
 }
 
-// Convergence contract, decision number j (after a checkpoint boundary): est_ck[q] holds the relative size of the
-// update that boundary applied to the passage scores (max over the passages, float bits).  The update the NEXT stage's
-// closing sweep will apply is predicted per query as est * kappa_q, kappa_q = min(kappa, 1.5 * rho_q^expo): kappa is
-// the model bound (damping^m + the e4m3 rounding of the stage's right-hand side), rho_q the contraction MEASURED
-// between the previous checkpoint (est_prev) and this one, expo = sweeps of the next stage / sweeps since the previous
-// checkpoint -- a graph that mixes well contracts much faster than damping per sweep, and the model bound alone would
-// buy it a stage it does not need.  g = damping / (1 - damping) turns an update into the error left after it.
-// ctl[j] = 1: the next stage is closed by another checkpoint boundary and extension stage j + 1 follows;
-// ctl[n_ctl + j] = 1: the next stage is the last, final sweep variant j runs.  A decision whose predecessor stopped
-// leaves both at 0.  j < 0: probe only (remember this checkpoint's values for the next decision).
-// A prediction that turns out optimistic is caught by the final sweep's own measurement (flags bit 4).
-__global__ __launch_bounds__(256) void ppr8_decide_kernel(int32_t *est_ck, float *est_prev,
-                                                          const int32_t *__restrict__ flags, int32_t batch, float kappa,
-                                                          float expo, float g, float tol, int32_t j, int32_t e_max,
-                                                          int32_t *ctl, int32_t n_ctl) {
+// Convergence contract, decision number j (after final sweep variant j ran: the stage it closes may be the last).
+// est_f[q] holds the relative size of the update that final sweep applied to the passage scores (max over the
+// passages, float bits) -- MEASURED, not predicted: g = damping / (1 - damping) turns it into the error left.  While
+// it exceeds tol for some query (and an extension stage is left) ctl[j] = 1: the boundary that closes the stage for
+// real, extension stage j + 1 and final sweep variant j + 1 run (their launches are gated on ctl[j]), and est_f starts
+// from zero for that sweep; otherwise ctl[j] stays 0, every later launch skips itself, est_f is what
+// ppr8_finalize_kernel reports.  A decision whose predecessor stopped does nothing.
+__global__ __launch_bounds__(256) void ppr8_decide_kernel(int32_t *est_f, const int32_t *__restrict__ flags,
+                                                          int32_t batch, float g, float tol, int32_t j, int32_t e_max,
+                                                          int32_t *ctl) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
-    const bool alive = j <= 0 || ctl[j - 1] == 1;
+    const bool alive = j == 0 || ctl[j - 1] == 1;
     float m = 0.f;
-    if (alive) {
-        for (int q = tid; q < batch; q += 256) {
-            const float cur = __int_as_float(est_ck[q]), prev = est_prev[q];
-            float kq = kappa;
-            if (prev > 0.f && cur < prev) kq = fminf(kappa, fmaxf(1.5f * powf(cur / prev, expo), 0.02f));
-            if (!(flags[q] & 1)) m = fmaxf(m, cur * kq);
-            est_prev[q] = cur;
-            est_ck[q] = 0;   // the next checkpoint starts from zero
-        }
-    }
+    if (alive)
+        for (int q = tid; q < batch; q += 256)
+            if (!(flags[q] & 1)) m = fmaxf(m, __int_as_float(est_f[q]));
     red[tid] = m;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
         __syncthreads();
     }
-    if (tid == 0 && alive && j >= 0) {
-        const bool go = tol > 0.f && j < e_max && g * red[0] > tol;
-        ctl[j] = go ? 1 : 0;
-        ctl[n_ctl + j] = go ? 0 : 1;
-    }
+    const bool go = alive && tol > 0.f && j < e_max && g * red[0] > tol;
+    if (go)
+        for (int q = tid; q < batch; q += 256) est_f[q] = 0;
+    if (tid == 0 && alive) ctl[j] = go ? 1 : 0;
 }
 
 // Results of the contract per query: resid = g * (relative size of the final sweep's update of the passage scores),
@@ -1008,7 +975,7 @@ static hrag_status sweep_dispatch(const Ppr8Args &a, int mode, bool main_only, h
 hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, bool main_only, hipStream_t s) {
     if (a.n_slabs <= 0) return HRAG_OK;
     HRAG_TRY(sweep_dispatch(a, mode, main_only, s));
-    if (a.est && (mode == kP8ModeB || mode == kP8ModeF))   // column maxima of the per-wavefront scratch
+    if (a.est && mode == kP8ModeF)   // column maxima of the per-wavefront scratch
         return launch_est_reduce(a.est_ws, a.m.n_pchunks, 128, a.slab0, a.n_slabs, a.batch, a.est, a.gate, a.gate_want, s);
     return HRAG_OK;
 }
@@ -1019,12 +986,6 @@ static hrag_status sweep_dispatch(const Ppr8Args &a, int mode, bool main_only, h
         case kP8ModeC: return sweep_mode<kP8ModeC, 0>(a, main_only, s);
         case kP8ModeB0: return sweep_mode<kP8ModeB0, 0>(a, main_only, s);
         case kP8ModeB:
-            if (a.est) {   // checkpoint boundary of the convergence contract
-                if (rio == 0) return sweep_mode<kP8ModeB, 0, true>(a, main_only, s);
-                if (rio == 2) return sweep_mode<kP8ModeB, 2, true>(a, main_only, s);
-                if (rio == 3) return sweep_mode<kP8ModeB, 3, true>(a, main_only, s);
-                break;
-            }
             if (rio == 0) return sweep_mode<kP8ModeB, 0>(a, main_only, s);
             if (rio == 2) return sweep_mode<kP8ModeB, 2>(a, main_only, s);
             if (rio == 3) return sweep_mode<kP8ModeB, 3>(a, main_only, s);
@@ -1092,11 +1053,9 @@ hrag_status launch_est_reduce(const float *ws, int32_t n_chunks, int32_t w, int3
     return HRAG_OK;
 }
 
-hrag_status launch_ppr8_decide(int32_t *est_ck, float *est_prev, const int32_t *flags, int32_t batch, float kappa,
-                               float expo, float g, float tol, int32_t j, int32_t e_max, int32_t *ctl, int32_t n_ctl,
-                               hipStream_t s) {
-    hipLaunchKernelGGL(ppr8_decide_kernel, dim3(1), dim3(256), 0, s, est_ck, est_prev, flags, batch, kappa, expo, g,
-                       tol, j, e_max, ctl, n_ctl);
+hrag_status launch_ppr8_decide(int32_t *est_f, const int32_t *flags, int32_t batch, float g, float tol, int32_t j,
+                               int32_t e_max, int32_t *ctl, hipStream_t s) {
+    hipLaunchKernelGGL(ppr8_decide_kernel, dim3(1), dim3(256), 0, s, est_f, flags, batch, g, tol, j, e_max, ctl);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -137,7 +137,6 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
         ex = std::min(std::max(ex, -60), 60);
         return std::ldexp(1.0f, ex);
     };
-    auto kappa_for = [&](int m) { return (float)(std::pow(al, m) + 1.0 / 16.0); };
     int n = 0, c = 0, rt = -1;   // c_0 lives in buffer 0
     int k_done = 0;              // sweeps completed
     bool r16 = false;            // the stored residual is in the 3-byte form (rt + fp16 remainder)
@@ -164,10 +163,13 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
         p.stage_inv[si] = 1.0f / cs;
         ++k_done;
         if (si >= n_stage - 1) {
-            // the stage may be the last one: final sweep variant j (passage rows only), gated on ctl[n_ctl + j]
+            // the stage may be the last one: final sweep variant j (passage rows only) measures the update it applies;
+            // decision j follows it (ppr8_decide_kernel): while that update is above the tolerance, the boundary below
+            // closes the stage for real and extension stage j + 1 runs
+            const int j = si - (n_stage - 1);
             Ppr8Step st{kP8ModeF, si, c, -1, rt, 1.0f / cs, 1.0f, r16 ? 1 : 0};
-            st.gate = est ? (kP8MaxExt + 1) + (si - (n_stage - 1)) : -1;
-            if (e_max == 0) st.gate = -1;
+            st.gate = stage_gate;
+            st.decide = (e_max > 0 && j < e_max) ? j : -1;
             p.steps[n++] = st;
         }
         if (si + 1 < n_total) {
@@ -180,14 +182,6 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
             const int rio = (r16 ? 1 : 0) | (out16 ? 2 : 0);
             Ppr8Step st{si == 0 ? kP8ModeB0 : kP8ModeB, si, c, y, rt, 1.0f / cs, cs_next, rio};
             if (si >= n_stage - 1) st.gate = si - (n_stage - 1);   // closes a stage that could have been the last
-            if (e_max > 0 && si >= n_stage - 3 && si > 0) {
-                // checkpoints: the two last regular boundaries (the first one only probes: the decisions work with
-                // the contraction measured between two checkpoints) and the extensions' boundaries
-                st.ckpt = 1;
-                st.decide = si == n_stage - 3 ? -2 : si - (n_stage - 2);
-                st.kappa = kappa_for(plan[si + 1]);
-                st.expo = (float)plan[si + 1] / (float)plan[si];
-            }
             p.steps[n++] = st;
             r16 = out16;
             rt = y;
@@ -196,12 +190,8 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     HRAG_REQUIRE(n <= (int)(sizeof(p.steps) / sizeof(p.steps[0])), "internal: %d steps", n);
     p.n_steps = n;
     p.n_stage = n_stage;
-    if (est) {
-        HRAG_HIP_TRY(hipMemsetAsync(e->d_est_prev, 0, (size_t)batch * sizeof(float), s));
-        HRAG_HIP_TRY(hipMemsetAsync(e->d_est_ck, 0, (size_t)batch * sizeof(int32_t), s));
-        HRAG_HIP_TRY(hipMemsetAsync(e->d_est_f, 0, (size_t)batch * sizeof(int32_t), s));
-    }
-    HRAG_HIP_TRY(hipMemsetAsync(e->d_ctl, 0, (size_t)2 * (kP8MaxExt + 1) * sizeof(int32_t), s));
+    if (est) HRAG_HIP_TRY(hipMemsetAsync(e->d_est_f, 0, (size_t)batch * sizeof(int32_t), s));
+    HRAG_HIP_TRY(hipMemsetAsync(e->d_ctl, 0, (size_t)(kP8MaxExt + 1) * sizeof(int32_t), s));
 
     // ---- reset vector on the owned rows: per-query scale, passage prior rows, seed rows, column bitmap
     HRAG_TRY(launch_ppr8_scale(zmax, mass, passage_weight, seed_vtx, seed_w, seed_cnt, e->d_deg, e->d_iso, e->V,
@@ -251,12 +241,6 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
         a.rt = st.rt >= 0 ? p.buf[st.rt] : nullptr;
         a.rio = st.rio;
         a.stage_out = stage_copy(e, st.stage);
-        if (st.ckpt) {   // z at the passage rows = the stages' c / cs summed + R, like mode F
-            for (int k = 0; k < st.stage; ++k) a.stage[k] = stage_copy(e, k);
-            for (int k = 0; k <= st.stage; ++k) a.stage_inv[k] = p.stage_inv[k];
-            a.n_stage = st.stage + 1;
-            a.est = e->d_est_ck; a.est_ws = e->d_est_ws;
-        }
     } else {   // kP8ModeF: the passage rows only; stage st.stage is the last one
         a.rt = st.rt >= 0 ? p.buf[st.rt] : nullptr;
         a.rio = st.rio;
@@ -275,10 +259,9 @@ hrag_status ppr8_decide(hrag_engine *e, int32_t i, hipStream_t s) {
     const Ppr8Session &p = e->p8;
     HRAG_REQUIRE(p.active && i >= 0 && i < p.n_steps, "no such step");
     const Ppr8Step &st = p.steps[i];
-    if (st.decide == -1) return HRAG_OK;
+    if (st.decide < 0) return HRAG_OK;
     const float g = p.damping / (1.0f - p.damping);
-    return launch_ppr8_decide(e->d_est_ck, e->d_est_prev, p.flags, p.batch, st.kappa, st.expo, g, p.tol, st.decide,
-                              p.e_max, e->d_ctl, kP8MaxExt + 1, s);
+    return launch_ppr8_decide(e->d_est_f, p.flags, p.batch, g, p.tol, st.decide, p.e_max, e->d_ctl, s);
 }
 
 hrag_status ppr8_finalize(hrag_engine *e, int32_t *flags, hipStream_t s) {
@@ -422,11 +405,11 @@ hrag_status hrag_shard_ppr_sweep(hrag_engine *e, int32_t sweep, int32_t group, i
     return HRAG_OK;
 }
 
-// est of the last checkpoint boundary (final == 0) or of the final sweep (final != 0) over the OWNED passages: read it
-// (set == 0: float bits -> est_dev fp32 [B]), all-reduce MAX over the shards, write it back (set != 0)
-hrag_status hrag_shard_ppr_est(hrag_engine *e, int32_t final, float *est_dev, int32_t set, hrag_stream stream) {
+// est of the latest final sweep over the OWNED passages: read it (set == 0: float bits -> est_dev fp32 [B]), all-reduce
+// MAX over the shards, write it back (set != 0)
+hrag_status hrag_shard_ppr_est(hrag_engine *e, float *est_dev, int32_t set, hrag_stream stream) {
     HRAG_REQUIRE(e && est_dev && e->p8.active, "bad argument / no fp8 PPR session");
-    int32_t *mine = final ? e->d_est_f : e->d_est_ck;
+    int32_t *mine = e->d_est_f;
     const size_t bytes = (size_t)e->p8.batch * sizeof(float);   // non-negative floats: the bit patterns ARE the floats
     HRAG_HIP_TRY(hipMemcpyAsync(set ? (void *)mine : (void *)est_dev, set ? (const void *)est_dev : (const void *)mine, bytes,
                                 hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -516,12 +516,11 @@ class ShardedRetriever:
                 else:
                     xb = st.shard_ppr_sweep(i, g)
                 pend[g] = c.exchange(bufs[xb], lay, g) if xb >= 0 else None
-            if ck:      # a checkpoint boundary: the batch's measure over ALL passages, then the decision
-                est = c.all_reduce(st.shard_ppr_est(False), "max")
-                st.shard_ppr_est(False, est)
+            if ck:      # a final sweep that measured: the batch's residual over ALL passages, then the decision
+                st.shard_ppr_est(c.all_reduce(st.shard_ppr_est(), "max"))
                 st.shard_ppr_decide(i)
         if contract:
-            st.shard_ppr_est(True, c.all_reduce(st.shard_ppr_est(True), "max"))
+            st.shard_ppr_est(c.all_reduce(st.shard_ppr_est(), "max"))
             idx, val, resid, used = st.shard_finish(mn, mx, flags, k, True)
         else:
             idx, val = st.shard_finish(mn, mx, flags, k)

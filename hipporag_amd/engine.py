@@ -542,7 +542,8 @@ class HippoRAGEngine:
         return n_steps.value
 
     def shard_ppr_step(self, step: int, group: int):
-        """(state buffer to exchange or -1, True when the step is a checkpoint of the convergence contract)."""
+        """(state buffer to exchange or -1, True when the step is a final sweep that measures the residual: the convergence
+        contract's all-reduce + decision follow it)."""
         x, ck = C.c_int32(-1), C.c_int32(0)
         check(self._lib.hrag_shard_ppr_sweep(self._handle, step, group, C.byref(x), C.byref(ck), _stream()))
         return x.value, bool(ck.value)
@@ -550,15 +551,16 @@ class HippoRAGEngine:
     def shard_ppr_sweep(self, sweep: int, group: int) -> int:
         return self.shard_ppr_step(sweep, group)[0]
 
-    def shard_ppr_est(self, final: bool, est=None):
-        """est=None: this shard's measure (fp32 [B]); est given: write the all-reduced values back."""
+    def shard_ppr_est(self, est=None):
+        """est=None: this shard's measure of the latest final sweep (fp32 [B]); est given: write the all-reduced values
+        back."""
         torch = _torch()
         b = self._p8_batch
         if est is None:
             out = self._empty((b,), torch.float32)
-            check(self._lib.hrag_shard_ppr_est(self._handle, 1 if final else 0, out.data_ptr(), 0, _stream()))
+            check(self._lib.hrag_shard_ppr_est(self._handle, out.data_ptr(), 0, _stream()))
             return out
-        check(self._lib.hrag_shard_ppr_est(self._handle, 1 if final else 0, est.data_ptr(), 1, _stream()))
+        check(self._lib.hrag_shard_ppr_est(self._handle, est.data_ptr(), 1, _stream()))
         return est
 
     def shard_ppr_decide(self, step: int):
@@ -760,8 +762,8 @@ class ShardStages(EngineStages):
     def shard_ppr_step(self, step, group):
         return self.e.shard_ppr_step(step, group)
 
-    def shard_ppr_est(self, final, est=None):
-        return self.e.shard_ppr_est(final, est)
+    def shard_ppr_est(self, est=None):
+        return self.e.shard_ppr_est(est)
 
     def shard_ppr_decide(self, step):
         return self.e.shard_ppr_decide(step)

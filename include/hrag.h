@@ -232,10 +232,12 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q_fact_dev, int32_t
  *                   update its last sweep applied to the passage scores,
  *                       residual = damping / (1 - damping) * max over passages p of |x_p(K) - x_p(K-1)| / x_p(K)
  *                   (the error a contraction with factor `damping` has left after an update of that size), and
- *                   keeps sweeping -- decided ON THE DEVICE from the same measure at a checkpoint sweep, no host
- *                   synchronisation -- while the prediction for the batch is above ppr_tol and fewer than
- *                   ppr_max_iters sweeps ran.  The fp8-state path (batch > 64) extends in stages of 1, 2, 3, 3 sweeps up
- *                   to 30; the other state types run the fixed count and report.
+ *                   keeps sweeping -- decided ON THE DEVICE, no host synchronisation -- while that MEASURED residual
+ *                   is above ppr_tol for some query of the batch and fewer than ppr_max_iters sweeps ran.  The
+ *                   fp8-state path (batch > 64) extends in stages of 1, 2, 3, 3 sweeps up to 30 (the final sweep of a
+ *                   stage runs over the passage rows only and measures; the launches of the next stage are enqueued
+ *                   and skip themselves when a control word says so); the other state types run the fixed count
+ *                   and report.
  *   ppr_max_iters   upper bound on the sweeps (>= ppr_iters; ignored when ppr_tol == 0)
  *   residual_out_dev fp32 [B] (may be NULL): the residual above for the sweeps that ran (0 on the DPR fallback)
  *   iters_out_dev   int32 [B] (may be NULL): sweeps that ran for the query's batch
@@ -428,7 +430,7 @@ hrag_status hrag_stage_doc_scores(hrag_engine *e, const float *x_dev, const doub
  *             hrag_shard_prior_stats -> all-reduce MAX of zmax, SUM of mass
  *             hrag_shard_ppr_begin -> exchange every group of state[0]
  *             n_steps x n_groups x hrag_shard_ppr_sweep -> exchange group g of state[*exchange_out]
- *                 (n_steps = ppr_iters without a tolerance; checkpoint steps: est all-reduce + hrag_shard_ppr_decide)
+ *                 (n_steps = ppr_iters without a tolerance; measuring steps: est all-reduce + hrag_shard_ppr_decide)
  *             hrag_shard_finish -> gather + merge the local top-k lists
  * ------------------------------------------------------------------------------------------ */
 #define HRAG_FLAG_FP8_SATURATED 8
@@ -485,12 +487,12 @@ hrag_status hrag_shard_ppr_sweep(hrag_engine *e, int32_t sweep, int32_t group, i
 /* The convergence contract of hrag_retrieve on row shards (ppr_tol > 0 in hrag_shard_ppr_begin; *n_steps_out then
  * counts the conditional steps too: run ALL of them, the gate words decide on the device which ones do anything --
  * and every shard decides alike because the measure is all-reduced):
- *   after a step whose *checkpoint_out was set (all groups swept):
- *        hrag_shard_ppr_est(e, 0, est, 0) -> all-reduce MAX of est fp32 [B] over the shards ->
- *        hrag_shard_ppr_est(e, 0, est, 1) -> hrag_shard_ppr_decide(e, step)
- *   before hrag_shard_finish: the same get / all-reduce MAX / set with final = 1 (the final sweep's measure), so that
- *   residual_out, iters_out and flags bit 4 come out identical on every shard. */
-hrag_status hrag_shard_ppr_est(hrag_engine *e, int32_t final, float *est_dev, int32_t set, hrag_stream stream);
+ *   after a step whose *checkpoint_out was set (a final sweep that measures; all groups swept):
+ *        hrag_shard_ppr_est(e, est, 0) -> all-reduce MAX of est fp32 [B] over the shards ->
+ *        hrag_shard_ppr_est(e, est, 1) -> hrag_shard_ppr_decide(e, step)
+ *   before hrag_shard_finish: the same get / all-reduce MAX / set once more (a session without extension stages has no
+ *   measuring step), so that residual_out, iters_out and flags bit 4 come out identical on every shard. */
+hrag_status hrag_shard_ppr_est(hrag_engine *e, float *est_dev, int32_t set, hrag_stream stream);
 hrag_status hrag_shard_ppr_decide(hrag_engine *e, int32_t sweep, hrag_stream stream);
 
 /* doc scores of the owned passages (PPR probability, or the normalised DPR score on the fallback)

@@ -263,3 +263,31 @@ def test_a_violated_scale_bound_raises_the_saturation_flag(gpu_device):
     eng.close()
     assert np.all(got["correct"] == 0)
     assert np.all(got["violated"] & FLAG_FP8_SATURATED), got["violated"]
+
+
+def test_the_device_extends_exactly_when_the_measured_residual_is_above_the_tolerance(gpu_device):
+    """The decision is taken from the residual the stage's final sweep MEASURED (csrc/ppr8.hip ppr8_decide_kernel), not
+    from a prediction: a tolerance just above what 20 sweeps leave costs no extra sweep, one just below it buys
+    extension stages until the measured residual is under it."""
+    import torch
+    from hipporag_amd.engine import HippoRAGEngine
+    b = 130
+    kg, pb, fb, qf, qp = _small_engine_inputs(b, gpu_device)
+    with HippoRAGEngine(kg.csr, kg.passage_vertex, pb, fb, kg.subj_vertex, kg.obj_vertex, kg.num_chunks,
+                        max_batch=b, max_topk=50) as eng:
+        idx, sc = eng.score_facts(qf, k=5)
+        cnt = _t(np.full(b, 5, np.int32), gpu_device)
+        fixed = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50)
+        torch.cuda.synchronize()
+        assert eng.timings()["slab_width"] == 128
+        r20 = float(fixed.residual.max())
+        assert r20 > 0 and int(fixed.iters_used.max()) == 20
+        above = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50, ppr_tol=1.05 * r20, ppr_max_iters=30)
+        below = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50, ppr_tol=0.95 * r20, ppr_max_iters=30)
+        torch.cuda.synchronize()
+        assert int(above.iters_used.max()) == 20 and np.all(above.flags.cpu().numpy() == 0)
+        assert torch.equal(above.doc_score, fixed.doc_score) and torch.equal(above.doc_idx, fixed.doc_idx)
+        assert torch.equal(above.residual, fixed.residual)
+        used = int(below.iters_used.min())
+        assert used == int(below.iters_used.max()) and used in (21, 23, 26, 29)       # whole stages of 1, 2, 3, 3 sweeps
+        assert float(below.residual.max()) <= 0.95 * r20 and np.all(below.flags.cpu().numpy() == 0)

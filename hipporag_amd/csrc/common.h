@@ -351,6 +351,26 @@ hrag_status launch_slab_to_rows(const float *slab, int64_t slab_rows, const int3
 hrag_status launch_gather_rows(const void *emb, const void *fresh, const int32_t *src, int64_t n, int32_t row_bytes,
                                void *out, hipStream_t s);
 hrag_status launch_fill_i32(int32_t *dst, int32_t value, int64_t n, hipStream_t s);
+// Several small fills / device-to-device copies of a call in ONE launch (a hipMemsetAsync / hipMemcpyAsync each is its
+// own ~7 us blit kernel; a retrieve had 9 .. 13 of them).  src == nullptr: zero fill of `reps` regions of `bytes` bytes,
+// `stride` bytes apart; otherwise one copy (reps = 1).  Sizes and addresses are multiples of 4 bytes.
+struct BlitOp {
+    void *dst;
+    const void *src;
+    int64_t bytes, stride;
+    int32_t reps;
+};
+struct BlitList {
+    BlitOp op[8];
+    int32_t n = 0;
+    void zero(void *dst, int64_t bytes, int32_t reps = 1, int64_t stride = 0) {
+        if (dst && bytes > 0 && reps > 0 && n < 8) op[n++] = BlitOp{dst, nullptr, bytes, stride, reps};
+    }
+    void copy(void *dst, const void *src, int64_t bytes) {
+        if (dst && src && bytes > 0 && n < 8) op[n++] = BlitOp{dst, src, bytes, 0, 1};
+    }
+};
+hrag_status launch_blits(const BlitList &l, hipStream_t s);
 hrag_status launch_flag_zero_mass(const double *sums, int32_t batch, int32_t *flags, int32_t bit,
                                   hipStream_t s);
 // convergence contract, fp32 slab state: est[q] = max over the passages of |x - x_prev| / x (float bits, atomicMax)

@@ -982,12 +982,17 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
     if (sv) { lay.bc = bp; lay.n_slabs = 1; }
     const bool prof = e->profiling;
 
-    HRAG_HIP_TRY(hipMemsetAsync(e->d_flags, 0, (size_t)batch * sizeof(int32_t), s));
     // convergence contract on the fp16 / small-batch / fp32 states: the fixed count runs, the last sweep measures the
     // relative update of the passage scores (residual_out, flags bit 4); only the fp8 state extends on the device
     const bool want_est = residual_out != nullptr || ppr_tol > 0.f;
     int32_t *est = (want_est && !f8 && ppr_iters >= 1) ? e->d_est_f : nullptr;
-    if (est) HRAG_HIP_TRY(hipMemsetAsync(est, 0, (size_t)batch * sizeof(int32_t), s));
+    {
+        BlitList z;   // the call's small fills in one launch (common.h)
+        z.zero(e->d_flags, (int64_t)batch * sizeof(int32_t));
+        z.zero(est, (int64_t)batch * sizeof(int32_t));
+        if (!f8) z.zero(e->d_ctl, (int64_t)(kP8MaxExt + 1) * sizeof(int32_t));   // read by the finalize step below
+        HRAG_TRY(launch_blits(z, s));
+    }
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_START], s));
     // dense_passage_retrieval: raw scores + min / max (HippoRAG.py:1496-1498)
     if (pass_scores) {
@@ -1028,16 +1033,18 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
         HRAG_TRY(launch_rows_to_slab(e->d_spass, e->ld_p, e->n_passages, batch, kMinMaxScale, e->d_mn_p,
                                      e->d_mx_p, passage_node_weight, e->d_flags, e->d_tele16, lay, s,
                                      e->tele16_rows, e->d_qscale));
-        for (int sl = 0; sl < lay.n_slabs; ++sl)
-            HRAG_HIP_TRY(hipMemsetAsync(e->d_tele16 + ((size_t)sl * e->tele16_rows + (size_t)e->n_passages) * 64,
-                                        0, (size_t)batch * kMaxSeeds * 64 * sizeof(float), s));
-        HRAG_HIP_TRY(hipMemcpyAsync(e->d_row_slot, e->d_row_to_tele, (size_t)e->V * sizeof(int32_t),
-                                    hipMemcpyDeviceToDevice, s));
+        {
+            // seed rows of the teleport matrix start from zero, row -> teleport-row map and the column bitmap (the
+            // columns where h_0 = f16(v) can be non-zero: passage vertices + this batch's seeds) from their static parts
+            BlitList z;
+            z.zero(e->d_tele16 + (size_t)e->n_passages * 64, (int64_t)batch * kMaxSeeds * 64 * sizeof(float), lay.n_slabs,
+                   (int64_t)e->tele16_rows * 64 * sizeof(float));
+            z.copy(e->d_row_slot, e->d_row_to_tele, (int64_t)e->V * sizeof(int32_t));
+            z.copy(e->d_colmask, e->d_colmask_static, (int64_t)e->colmask_words * sizeof(uint32_t));
+            HRAG_TRY(launch_blits(z, s));
+        }
         HRAG_TRY(launch_ppr16_seed_rows(e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt, e->d_qscale, batch,
                                         e->n_passages, e->V, e->d_row_slot, e->d_tele16, e->tele16_rows, 64, s));
-        // columns where h_0 = f16(v) can be non-zero: the passage vertices + this batch's seeds (first sweep)
-        HRAG_HIP_TRY(hipMemcpyAsync(e->d_colmask, e->d_colmask_static, (size_t)e->colmask_words * sizeof(uint32_t),
-                                    hipMemcpyDeviceToDevice, s));
         HRAG_TRY(launch_ppr8_mask_seeds(e->d_seed_vtx, e->d_seed_cnt, batch, e->V, e->d_colmask, s));
     } else if (sv) {
         // small batch (ppr_sv.hip): v = [Np + seed rows][bp] fp32, same "seeds are teleport rows" form; with the
@@ -1050,15 +1057,15 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
         }
         HRAG_TRY(launch_ppr_sv_tele(e->d_spass, e->ld_p, e->n_passages, batch, e->d_mn_p, e->d_mx_p,
                                     passage_node_weight, e->d_flags, e->d_tele_sv, bp, s, qs));
-        HRAG_HIP_TRY(hipMemsetAsync(e->d_tele_sv + (size_t)e->n_passages * bp, 0,
-                                    (size_t)batch * kMaxSeeds * bp * sizeof(float), s));
-        HRAG_HIP_TRY(hipMemcpyAsync(e->d_row_slot, e->d_row_to_tele, (size_t)e->V * sizeof(int32_t),
-                                    hipMemcpyDeviceToDevice, s));
+        {
+            BlitList z;   // as on the fp16 path: zeroed seed rows, row map and column bitmap from their static parts
+            z.zero(e->d_tele_sv + (size_t)e->n_passages * bp, (int64_t)batch * kMaxSeeds * bp * sizeof(float));
+            z.copy(e->d_row_slot, e->d_row_to_tele, (int64_t)e->V * sizeof(int32_t));
+            z.copy(e->d_colmask, e->d_colmask_static, (int64_t)e->colmask_words * sizeof(uint32_t));
+            HRAG_TRY(launch_blits(z, s));
+        }
         HRAG_TRY(launch_ppr16_seed_rows(e->d_seed_vtx, e->d_seed_w, e->d_seed_cnt, qs, batch,
                                         e->n_passages, e->V, e->d_row_slot, e->d_tele_sv, 0, bp, s));
-        // columns where x_0 = v can be non-zero: the passage vertices + this batch's seeds (first sweep)
-        HRAG_HIP_TRY(hipMemcpyAsync(e->d_colmask, e->d_colmask_static, (size_t)e->colmask_words * sizeof(uint32_t),
-                                    hipMemcpyDeviceToDevice, s));
         HRAG_TRY(launch_ppr8_mask_seeds(e->d_seed_vtx, e->d_seed_cnt, batch, e->V, e->d_colmask, s));
     } else {
         HRAG_TRY(hrag_stage_teleport(e, e->d_spass, e->ld_p, e->d_mn_p, e->d_mx_p, passage_node_weight,
@@ -1116,24 +1123,23 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
     HRAG_TRY(launch_flag_zero_mass(e->d_sums, batch, e->d_flags, 2, s));
     HRAG_TRY(launch_row_topk(e->d_doc, batch, e->n_passages, e->ld_p, k, 0, kNormNone, doc_idx_out,
                              doc_score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
-    if (!f8) {
-        if (est) {
-            HRAG_HIP_TRY(hipMemsetAsync(e->d_ctl, 0, (size_t)(kP8MaxExt + 1) * sizeof(int32_t), s));
-            HRAG_TRY(launch_ppr8_finalize(est, e->d_flags, batch, damping / (1.0f - damping), ppr_tol, ppr_iters, e->d_ctl,
-                                          0, nullptr, 0, e->d_sums, e->d_resid, e->d_iters_used, s));
-        } else {
-            HRAG_TRY(launch_fill_i32(reinterpret_cast<int32_t *>(e->d_resid), (int32_t)0xbf800000u, batch, s));   // -1: not measured
-            HRAG_TRY(launch_fill_i32(e->d_iters_used, ppr_iters, batch, s));
+    const bool measured = f8 || est != nullptr;
+    if (!f8 && est)
+        HRAG_TRY(launch_ppr8_finalize(est, e->d_flags, batch, damping / (1.0f - damping), ppr_tol, ppr_iters, e->d_ctl,
+                                      0, nullptr, 0, e->d_sums, e->d_resid, e->d_iters_used, s));
+    {
+        BlitList out;   // the per-query results in one launch
+        out.copy(flags_out, e->d_flags, (int64_t)batch * sizeof(int32_t));
+        if (measured) {
+            out.copy(residual_out, e->d_resid, (int64_t)batch * sizeof(float));
+            out.copy(iters_out, e->d_iters_used, (int64_t)batch * sizeof(int32_t));
         }
+        HRAG_TRY(launch_blits(out, s));
     }
-    if (flags_out)
-        HRAG_HIP_TRY(hipMemcpyAsync(flags_out, e->d_flags, (size_t)batch * sizeof(int32_t),
-                                    hipMemcpyDeviceToDevice, s));
-    if (residual_out)
-        HRAG_HIP_TRY(hipMemcpyAsync(residual_out, e->d_resid, (size_t)batch * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (iters_out)
-        HRAG_HIP_TRY(hipMemcpyAsync(iters_out, e->d_iters_used, (size_t)batch * sizeof(int32_t),
-                                    hipMemcpyDeviceToDevice, s));
+    if (!measured) {   // no sweep measured anything (ppr_iters == 0, or nothing asked for): -1 / the count as given
+        if (residual_out) HRAG_TRY(launch_fill_i32(reinterpret_cast<int32_t *>(residual_out), (int32_t)0xbf800000u, batch, s));
+        if (iters_out) HRAG_TRY(launch_fill_i32(iters_out, ppr_iters, batch, s));
+    }
     if (prof) {
         HRAG_HIP_TRY(hipEventRecord(e->ev[EV_RANK], s));
         e->have_retrieve_ev = true;

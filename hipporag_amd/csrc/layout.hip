@@ -8,6 +8,8 @@
 //                               normalisation sum(x) = 1 (HippoRAG.py:1745), or the normalised
 //                               DPR scores for queries on the DPR fallback (:467-469).
 // Tiles go through LDS so that both the global reads and the global writes are coalesced.
+#include <algorithm>
+
 #include "common.h"
 
 namespace hrag {
@@ -126,6 +128,30 @@ __global__ void fill_i32_kernel(int32_t *dst, int32_t value, int64_t n) {
     if (i < n) dst[i] = value;
 }
 
+// BlitList (common.h): operation blockIdx.y, grid-stride over its 16-byte (or, unaligned, 4-byte) units
+__global__ __launch_bounds__(256) void blit_kernel(const BlitList l) {
+    const BlitOp op = l.op[blockIdx.y];
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+    const bool v16 = (((uintptr_t)op.dst | (uintptr_t)op.src | (uintptr_t)op.bytes | (uintptr_t)op.stride) & 15) == 0;
+    if (v16) {
+        const int64_t per = op.bytes >> 4, total = per * op.reps;
+        for (int64_t u = t0; u < total; u += step) {
+            const int64_t rep = u / per, off = u - rep * per;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (op.src) v = reinterpret_cast<const uint4 *>(op.src)[off];
+            reinterpret_cast<uint4 *>(static_cast<char *>(op.dst) + rep * op.stride)[off] = v;
+        }
+    } else {
+        const int64_t per = op.bytes >> 2, total = per * op.reps;
+        for (int64_t u = t0; u < total; u += step) {
+            const int64_t rep = u / per, off = u - rep * per;
+            uint32_t v = 0u;
+            if (op.src) v = reinterpret_cast<const uint32_t *>(op.src)[off];
+            reinterpret_cast<uint32_t *>(static_cast<char *>(op.dst) + rep * op.stride)[off] = v;
+        }
+    }
+}
+
 __global__ void flag_zero_mass_kernel(const double *sums, int32_t batch, int32_t *flags, int32_t bit) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= batch) return;
@@ -194,6 +220,19 @@ hrag_status launch_gather_rows(const void *emb, const void *fresh, const int32_t
 hrag_status launch_fill_i32(int32_t *dst, int32_t value, int64_t n, hipStream_t s) {
     if (n <= 0) return HRAG_OK;
     hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, dst, value, n);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_blits(const BlitList &l, hipStream_t s) {
+    if (l.n <= 0) return HRAG_OK;
+    int64_t most = 1;
+    for (int i = 0; i < l.n; ++i) {
+        HRAG_REQUIRE((l.op[i].bytes & 3) == 0 && (l.op[i].stride & 3) == 0, "blit sizes must be multiples of 4 bytes");
+        most = std::max<int64_t>(most, l.op[i].bytes * l.op[i].reps / 16);
+    }
+    const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(most, 256 * 4), 2048);
+    hipLaunchKernelGGL(blit_kernel, dim3(std::max(gx, 1u), (unsigned)l.n), dim3(256), 0, s, l);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -190,8 +190,6 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     HRAG_REQUIRE(n <= (int)(sizeof(p.steps) / sizeof(p.steps[0])), "internal: %d steps", n);
     p.n_steps = n;
     p.n_stage = n_stage;
-    if (est) HRAG_HIP_TRY(hipMemsetAsync(e->d_est_f, 0, (size_t)batch * sizeof(int32_t), s));
-    HRAG_HIP_TRY(hipMemsetAsync(e->d_ctl, 0, (size_t)(kP8MaxExt + 1) * sizeof(int32_t), s));
 
     // ---- reset vector on the owned rows: per-query scale, passage prior rows, seed rows, column bitmap
     HRAG_TRY(launch_ppr8_scale(zmax, mass, passage_weight, seed_vtx, seed_w, seed_cnt, e->d_deg, e->d_iso, e->V,
@@ -200,16 +198,20 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     l64.bc = 64; l64.n_slabs = n_slabs64(batch);
     HRAG_TRY(launch_rows_to_slab(e->d_spass, e->ld_p, e->p_rows, batch, kMinMaxScale, mn, mx, passage_weight,
                                  flags, e->d_tele16, l64, s, e->tele16_rows, e->d_qscale));
-    for (int sl = 0; sl < l64.n_slabs; ++sl)
-        HRAG_HIP_TRY(hipMemsetAsync(e->d_tele16 + ((size_t)sl * e->tele16_rows + (size_t)e->p_rows) * 64, 0,
-                                    (size_t)batch * kMaxSeeds * 64 * sizeof(float), s));
-    if (e->n_rows > 0)
-        HRAG_HIP_TRY(hipMemcpyAsync(e->d_row_slot, e->d_row_ptele, (size_t)e->n_rows * sizeof(int32_t),
-                                    hipMemcpyDeviceToDevice, s));
+    {
+        // one launch for the session's small fills and copies: the contract's words, the seed rows of the teleport
+        // matrix, the row -> teleport-row map and the column bitmap from their static parts
+        BlitList z;
+        if (est) z.zero(e->d_est_f, (int64_t)batch * sizeof(int32_t));
+        z.zero(e->d_ctl, (int64_t)(kP8MaxExt + 1) * sizeof(int32_t));
+        z.zero(e->d_tele16 + (size_t)e->p_rows * 64, (int64_t)batch * kMaxSeeds * 64 * sizeof(float), l64.n_slabs,
+               (int64_t)e->tele16_rows * 64 * sizeof(float));
+        z.copy(e->d_row_slot, e->d_row_ptele, (int64_t)e->n_rows * sizeof(int32_t));
+        z.copy(e->d_colmask, e->d_colmask_static, (int64_t)e->colmask_words * sizeof(uint32_t));
+        HRAG_TRY(launch_blits(z, s));
+    }
     HRAG_TRY(launch_ppr16_seed_rows(seed_vtx, seed_w, seed_cnt, e->d_qscale, batch, e->p_rows, e->V, e->d_row_slot,
                                     e->d_tele16, e->tele16_rows, 64, s, e->row_offset, e->n_rows));
-    HRAG_HIP_TRY(hipMemcpyAsync(e->d_colmask, e->d_colmask_static, (size_t)e->colmask_words * sizeof(uint32_t),
-                                hipMemcpyDeviceToDevice, s));
     HRAG_TRY(launch_ppr8_mask_seeds(seed_vtx, seed_cnt, batch, e->V, e->d_colmask, s));
     // ---- c_0 = Q(v/d * 2^7) on the owned rows of every group
     Ppr8Args a = base_args(e);
@@ -442,11 +444,10 @@ hrag_status hrag_shard_finish(hrag_engine *e, const float *mn, const float *mx, 
     HRAG_TRY(ppr8_doc_scores(e, mn, mx, flags, batch, s, true));
     HRAG_TRY(launch_row_topk(e->d_doc, batch, e->p_rows, e->ld_p, k, (int32_t)e->p_offset, kNormNone, idx_out,
                              score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
-    if (residual_out)
-        HRAG_HIP_TRY(hipMemcpyAsync(residual_out, e->d_resid, (size_t)batch * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (iters_out)
-        HRAG_HIP_TRY(hipMemcpyAsync(iters_out, e->d_iters_used, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    return HRAG_OK;
+    BlitList out;
+    out.copy(residual_out, e->d_resid, (int64_t)batch * sizeof(float));
+    out.copy(iters_out, e->d_iters_used, (int64_t)batch * sizeof(int32_t));
+    return launch_blits(out, s);
 }
 
 hrag_status hrag_engine_gather_embeddings(hrag_engine *e, int32_t which, const int32_t *src_rows, int64_t n,

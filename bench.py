@@ -7,10 +7,11 @@ One "step" = one batch of B queries through the whole hot path with inputs resid
 Workload (BASELINE.json: the metric is quoted on the 1M-node KG): configs[2] =
   synthetic 1M-node / 10M-edge KG, 1M x 768 bf16 embeddings, batch 256, 20 PPR iterations.
 
-    python bench.py [--gpus N --steps K --warmup W] [--config cfg2|cfg3]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py [--gpus N --steps K --warmup W] [--config cfg2|cfg3|cfg4]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1, external launcher)
 
-Prints ONE JSON line (rank 0).
+N > 1 without a launcher (no WORLD_SIZE in the environment): bench.py spawns its own N ranks, one per GPU
+(hipporag_amd/launch.py), and prints rank 0's line.  Prints ONE JSON line (rank 0), last.
 """
 
 from __future__ import annotations
@@ -48,6 +49,11 @@ CONFIGS = {
     # one GPU's share of configs[4] (10M-node power-law KG, 10M x 1024 fp16 embeddings, 4096 / 8 queries)
     "cfg5gpu": dict(V=10_000_000, E=100_000_000, D=1024, B=512, seed=1239, power_law=True, fp16=True,
                     label="configs[4] per-GPU share: synthetic 10M-node/100M-edge power-law KG, 10M x 1024 fp16, batch 512"),
+    # configs[3] itself: the 1M-node KG sharded across the GPUs of ONE node, GLOBAL batch 1024 whatever N is (strong
+    # scaling: 128 queries per GPU at N = 8).  N = 1: the whole batch on one GPU.  N > 1 (`--gpus N`): `value` = the best
+    # parity-green corpus-sharded leg (hybrid, else rowshard), the replica leg beside it
+    "cfg4": dict(V=1_000_000, E=10_000_000, D=768, B=1024, seed=1237, global_batch=1024,
+                 label="configs[3]: synthetic 1M-node/10M-edge KG sharded across the GPUs of one node, global batch 1024"),
     # one GPU's share of configs[3]: shard 0 of the 8-way row shard of the 1M-node KG with the GLOBAL batch of
     # 1024 queries (compute of one GPU; the exchanges need the other 7 GPUs and are not performed)
     "cfg4gpu": dict(V=1_000_000, E=10_000_000, D=768, B=1024, seed=1237, shard_of=8,
@@ -457,12 +463,13 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--slab-width", type=int, default=0)
-    ap.add_argument("--mode", default="replica", choices=["rowshard", "replica", "hybrid"],
-                    help="multi-GPU mode whose rate is `value` (N > 1).  replica (default): queries sharded, no "
-                         "data-path collective.  The hybrid leg (embeddings row-sharded, one all-to-all, PPR "
-                         "query-parallel) and the row-sharded leg (BASELINE.json's layout: PPR rows sharded, one all-gather per "
-                         "sweep) are always measured and reported beside it; they only become `value` with --mode hybrid / "
-                         "rowshard: their RCCL paths have never met a second GPU (no multi-GPU box was available to any round)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "rowshard", "replica", "hybrid"],
+                    help="multi-GPU leg whose rate is `value` (N > 1).  All three legs are always measured and printed: "
+                         "replica (queries sharded, every GPU holds the whole index, no data-path collective), hybrid "
+                         "(embeddings row-sharded, one all-to-all of passage-score rows, PPR query-parallel on a replicated "
+                         "graph) and rowshard (BASELINE.json's layout: CSR rows + embeddings sharded, one all-gather of the "
+                         "e4m3 iterate per sweep).  auto (default): the best PARITY-GREEN corpus-sharded leg -- hybrid, else "
+                         "rowshard -- and the replica leg only when neither is green (said in `value_leg`)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-queries", type=int, default=12)
     ap.add_argument("--cpu-vec-queries", type=int, default=32, help="batch of the vectorised CPU baseline leg")
@@ -482,6 +489,12 @@ def main():
                          "BASELINE.json's fixed 20 sweeps and reports the residual they leave)")
     ap.add_argument("--ppr-max-iters", type=int, default=29)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("HRAG_FORCE_DIST"):
+        # the driver's command is plain `python bench.py --gpus N ...`: be our own launcher -- N ranks of this very
+        # command, one per GPU, rendezvous on 127.0.0.1; rank 0's JSON line is the last line of our stdout
+        from hipporag_amd.launch import self_spawn
+        return self_spawn(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
     import torch
     from hipporag_amd import synth

@@ -104,6 +104,7 @@ SIGNATURES = {
     "hrag_shard_ppr_sweep": (C.c_int, [_P, _I32, _I32, C.POINTER(_I32), C.POINTER(_I32), _P]),
     "hrag_shard_ppr_est": (C.c_int, [_P, _P, _I32, _P]),
     "hrag_shard_ppr_decide": (C.c_int, [_P, _I32, _P]),
+    "hrag_shard_ppr_gate": (C.c_int, [_P, _I32, C.POINTER(_I32), _P]),
     "hrag_shard_finish": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
     "hrag_engine_set_flags": (C.c_int, [_P, _I32, _I32]),
     "hrag_engine_gather_embeddings": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P]),

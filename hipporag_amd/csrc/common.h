@@ -363,11 +363,14 @@ struct BlitOp {
 struct BlitList {
     BlitOp op[8];
     int32_t n = 0;
+    bool overflow = false;   // a ninth operation was queued: launch_blits fails (HRAG_EINVAL) instead of dropping it
     void zero(void *dst, int64_t bytes, int32_t reps = 1, int64_t stride = 0) {
-        if (dst && bytes > 0 && reps > 0 && n < 8) op[n++] = BlitOp{dst, nullptr, bytes, stride, reps};
+        if (!(dst && bytes > 0 && reps > 0)) return;
+        if (n < 8) op[n++] = BlitOp{dst, nullptr, bytes, stride, reps}; else overflow = true;
     }
     void copy(void *dst, const void *src, int64_t bytes) {
-        if (dst && src && bytes > 0 && n < 8) op[n++] = BlitOp{dst, src, bytes, 0, 1};
+        if (!(dst && src && bytes > 0)) return;
+        if (n < 8) op[n++] = BlitOp{dst, src, bytes, 0, 1}; else overflow = true;
     }
 };
 hrag_status launch_blits(const BlitList &l, hipStream_t s);

@@ -838,6 +838,7 @@ hrag_status hrag_sim_scores(hrag_engine *e, int32_t which, const uint16_t *q, in
         HRAG_REQUIRE(e->d_femb != nullptr || e->f_rows == 0, "engine has no fact embeddings");
         return launch_sim_gemm(e->d_femb, e->f_rows, e->kdim, q, batch, out, e->f_rows, (hipStream_t)stream, 0, e->emb_dtype);
     }
+    HRAG_REQUIRE(e->d_pemb != nullptr || e->p_rows == 0, "engine has no passage embeddings (created for hrag_retrieve_scored)");
     return launch_sim_gemm(e->d_pemb, e->p_rows, e->kdim, q, batch, out, e->p_rows, (hipStream_t)stream, 0, e->emb_dtype);
 }
 

@@ -214,10 +214,14 @@ struct hrag_engine {
 };
 
 namespace hrag {
-// Guard of the single-call entry points that use the engine's workspace: rejects a second thread inside a call and
-// a call on another stream while the previous one has not finished on the device (HRAG_EBUSY); records the end of
-// this call on its stream when it leaves.  During stream capture the event logic is skipped (a captured event
-// cannot be queried; a captured call replays on the capture's stream).
+// Guard of the single-call entry points that use the engine's workspace.  A second THREAD inside a call is rejected
+// (HRAG_EBUSY: the host-side entry flag).  A call on ANOTHER STREAM than the previous one is ordered behind it on the
+// device -- hipStreamWaitEvent on the event that marks the end of the previous call -- so the workspace is never used
+// by two calls at once and a caller who already ordered the two streams (or did not) gets correct results without a
+// host synchronisation.  The end of this call is recorded on its stream when it leaves.  During stream capture the
+// event logic is skipped (a captured event cannot be waited on from outside the capture); KNOWN HOLE: replays of a
+// captured graph do not pass through here, so a direct call on another stream racing a replay is not ordered -- replay
+// on the stream the direct calls use, or synchronise between them (engine.CapturedPipeline documents the same).
 struct EngineCall {
     hrag_engine *e;
     hipStream_t s;
@@ -234,13 +238,13 @@ struct EngineCall {
         entered = true;
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) capturing = true;
-        if (!capturing && e->have_last && e->last_stream != s && e->ev_last &&
-            hipEventQuery(e->ev_last) == hipErrorNotReady) {
-            set_error("engine busy: the previous call, enqueued on another stream, has not finished (the workspace "
-                      "belongs to the engine: one call in flight, or one engine per stream)");
-            st = HRAG_EBUSY;
+        if (!capturing && e->have_last && e->last_stream != s && e->ev_last) {
+            const hipError_t err = hipStreamWaitEvent(s, e->ev_last, 0);
+            if (err != hipSuccess) {
+                set_error("hipStreamWaitEvent on the previous call's end event -> %s", hipGetErrorString(err));
+                st = HRAG_EHIP;
+            }
         }
-        (void)hipGetLastError();   // hipEventQuery's hipErrorNotReady is not an error of this call
     }
     ~EngineCall() {
         if (!entered) return;

@@ -225,6 +225,7 @@ hrag_status launch_fill_i32(int32_t *dst, int32_t value, int64_t n, hipStream_t 
 }
 
 hrag_status launch_blits(const BlitList &l, hipStream_t s) {
+    HRAG_REQUIRE(!l.overflow, "internal: more than 8 operations in one BlitList (a fill or copy would be dropped)");
     if (l.n <= 0) return HRAG_OK;
     int64_t most = 1;
     for (int i = 0; i < l.n; ++i) {

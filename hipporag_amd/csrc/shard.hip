@@ -363,6 +363,7 @@ hrag_status hrag_shard_passage_scores(hrag_engine *e, const uint16_t *q, int32_t
     HRAG_REQUIRE(e->shard_aligned, "the passage embedding shard must hold exactly the passages of the owned rows");
     hipStream_t s = (hipStream_t)stream;
     if (e->p_rows == 0) return fill_minmax_neutral(mn_out, mx_out, batch, s);
+    HRAG_REQUIRE(e->d_pemb != nullptr, "engine has no passage embeddings (created for hrag_retrieve_scored)");
     HRAG_TRY(prep_query(e, q, batch, s, &q));
     HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->kdim, q, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
     return launch_row_minmax(e->d_spass, batch, e->p_rows, e->ld_p, mn_out, mx_out, s);
@@ -421,6 +422,22 @@ hrag_status hrag_shard_ppr_est(hrag_engine *e, float *est_dev, int32_t set, hrag
 hrag_status hrag_shard_ppr_decide(hrag_engine *e, int32_t sweep, hrag_stream stream) {
     HRAG_REQUIRE(e != nullptr, "engine is NULL");
     return ppr8_decide(e, sweep, (hipStream_t)stream);
+}
+
+// Host-side view of a device decision: does step `step` of the session do anything?  (A step without a gate always
+// runs.)  Synchronises `stream` -- the one place of the shard interface that does: the row-sharded host loop pays a
+// collective per step, so once a decision has closed a gate it wants to stop issuing the steps behind it.
+hrag_status hrag_shard_ppr_gate(hrag_engine *e, int32_t step, int32_t *open_out, hrag_stream stream) {
+    HRAG_REQUIRE(e && open_out && e->p8.active, "bad argument / no fp8 PPR session");
+    const Ppr8Session &p = e->p8;
+    if (step < 0 || step >= p.n_steps) { *open_out = 0; return HRAG_OK; }   // past the last step: nothing left to run
+    const Ppr8Step &st = p.steps[step];
+    if (st.gate < 0) { *open_out = 1; return HRAG_OK; }
+    int32_t word = 0;
+    HRAG_HIP_TRY(hipMemcpyAsync(&word, e->d_ctl + st.gate, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HRAG_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *open_out = word == st.gate_want ? 1 : 0;
+    return HRAG_OK;
 }
 
 hrag_status hrag_shard_finish(hrag_engine *e, const float *mn, const float *mx, int32_t *flags, int32_t batch,

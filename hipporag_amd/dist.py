@@ -507,6 +507,7 @@ class ShardedRetriever:
         # group g's exchange overlaps with the sweep of the other groups: a sweep of group g only waits for
         # group g's previous exchange
         pend = [c.exchange(bufs[0], lay, g) for g in range(lay.n_groups)]
+        est_global = False      # the engine's est already holds the all-reduced measure of the last final sweep
         for i in range(n_steps):
             ck = False
             for g in range(lay.n_groups):
@@ -516,11 +517,21 @@ class ShardedRetriever:
                 else:
                     xb = st.shard_ppr_sweep(i, g)
                 pend[g] = c.exchange(bufs[xb], lay, g) if xb >= 0 else None
+            est_global = False
             if ck:      # a final sweep that measured: the batch's residual over ALL passages, then the decision
                 st.shard_ppr_est(c.all_reduce(st.shard_ppr_est(), "max"))
                 st.shard_ppr_decide(i)
+                est_global = True
+                # the decision is the same on every shard (the measure was all-reduced).  Once it closes the gate of
+                # the next step every later step is closed as well: stop issuing them -- each one would still cost a
+                # full-state exchange per group for buffers nobody wrote (one host read per decision, <= 4 per batch)
+                if not st.shard_ppr_gate_open(i + 1):
+                    break
+        for h in pend:          # an exchange started by the last step that ran
+            c.wait(h)
         if contract:
-            st.shard_ppr_est(c.all_reduce(st.shard_ppr_est(), "max"))
+            if not est_global:
+                st.shard_ppr_est(c.all_reduce(st.shard_ppr_est(), "max"))
             idx, val, resid, used = st.shard_finish(mn, mx, flags, k, True)
         else:
             idx, val = st.shard_finish(mn, mx, flags, k)
@@ -615,7 +626,7 @@ def run_local_shards(world: int, sidx: "ShardedIndex", pass_emb, fact_emb, q_fac
             cnt = torch.full((b,), 5, dtype=torch.int32, device=device)
             if filter_fn is not None:
                 idx, sc, cnt = filter_fn(idx, sc)
-            d_idx, d_sc, flags = rs.retrieve(q_pass, idx, sc, cnt, **retrieve_kw)
+            d_idx, d_sc, flags = rs.retrieve(q_pass, idx, sc, cnt, **retrieve_kw)[:3]   # ppr_tol > 0: + (residual, sweeps)
             torch.cuda.synchronize()
             if timings is not None and rank == 0:
                 timings["wall_s_all_shards_on_one_device"] = time.perf_counter() - t0
@@ -707,21 +718,45 @@ def run_local_hybrid(world: int, kg_arrays: dict, sidx: "ShardedIndex", pass_emb
 # --------------------------------------------------------------------------------------------
 # bench.py --gpus N (N > 1)
 # --------------------------------------------------------------------------------------------
+def pick_value_leg(mode: str, hybrid, rowshard) -> str:
+    """Which leg of an N > 1 run becomes `value`: a leg counts only when it produced a rate AND its parity check
+    against the single-GPU engine is green.  auto: the corpus-sharded legs first (hybrid, then rowshard) -- the
+    replica leg shards nothing and is the fallback, never the preference."""
+    def green(leg):
+        return isinstance(leg, dict) and "value" in leg and bool(leg.get("parity", {}).get("ok"))
+    if mode == "replica":
+        return "replica"
+    if mode in ("hybrid", "auto") and green(hybrid):
+        return "hybrid"
+    if mode in ("rowshard", "auto") and green(rowshard):
+        return "rowshard"
+    return "replica"
+
+
 def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_fn=None) -> int:
     torch, dist = _td()
     from . import synth
     from .engine import HippoRAGEngine
 
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
-                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks "
+                         f"(plain `python bench.py --gpus {args.gpus}` spawns them itself; or "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < world:
+        raise SystemExit(f"bench.py --gpus {world} needs {world} GPUs on this node (one rank per device); "
+                         f"{n_dev} visible to rank {rank}")
+    cfg = configs[args.config]
+    strong = "global_batch" in cfg                  # configs[3]: the global batch is fixed, the per-GPU batch shrinks
+    if strong and not args.batch and cfg["global_batch"] % world:
+        raise SystemExit(f"--config {args.config}: the global batch {cfg['global_batch']} is not a multiple of --gpus {world}")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    cfg = configs[args.config]
     V, E, D, seed = cfg["V"], cfg["E"], cfg["D"], cfg["seed"]
-    B = args.batch or cfg["B"]                      # per-GPU batch: weak scaling
+    # per-GPU batch: fixed (weak scaling), or the fixed global batch dealt to the GPUs (strong scaling, configs[3])
+    B = args.batch or (cfg["global_batch"] // world if strong else cfg["B"])
     K_F, K_P, ITERS, DAMP, PW = 5, 200, 20, 0.5, 0.05
 
     kg = synth.make_kg(V, E, seed, power_law=bool(cfg.get("power_law")))   # same seed on every rank => identical index
@@ -776,7 +811,8 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
         "metric": "retrieval_queries_per_sec", "value": replica_qps, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": replica_s * 1e3 / max(args.steps, 1), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong" if strong and not args.batch else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "value_leg": "replica",
         "config": {"workload": cfg["label"], "V": V, "E": E, "nnz": kg.csr.nnz,
                    "n_passages": kg.n_passages, "n_facts": kg.n_facts, "dim": D,
                    "global_batch": world * B, "per_gpu_batch": B, "ppr_iters": ITERS,
@@ -788,8 +824,9 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
         "replica": {"value": replica_qps, "unit": "queries/s", "ms_per_step": replica_s * 1e3 / max(args.steps, 1),
                     "parallelism": f"replica x{world}: every GPU holds the whole index and serves its own {B} queries"},
         "rowshard": None, "hybrid": None,
-        "multi_gpu_note": "no multi-GPU box was available to any round: every N > 1 figure of this repository is the "
-                          "driver's to take; the legs below are printed by rank 0 whenever N > 1",
+        "multi_gpu_note": "`value` = the best parity-green corpus-sharded leg (hybrid, else rowshard; `value_leg` names "
+                          "it); all three legs are printed whenever N > 1.  No multi-GPU box was available to the "
+                          "rounds that wrote this code: every N > 1 figure is the driver's to take",
     }
 
     # The row-sharded leg (the layout BASELINE.json's north star names) must never cost the line: a
@@ -802,16 +839,13 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
             printed.set()
             result["rowshard"] = rowshard
             result["hybrid"] = hybrid_box.get("res")
-            hyb = hybrid_box.get("res")
-            if args.mode == "hybrid" and isinstance(hyb, dict) and "value" in hyb and hyb.get("parity", {}).get("ok"):
-                result["value"], result["ms_per_step"] = hyb["value"], hyb["ms_per_step"]
-                result["config"]["parallelism"] = hyb["parallelism"]
-            ok = isinstance(rowshard, dict) and "value" in rowshard and rowshard.get("parity", {}).get("ok")
-            if ok and args.mode == "rowshard":
-                # primary number = the mandated layout; the replica figure stays beside it
-                result["value"] = rowshard["value"]
-                result["ms_per_step"] = rowshard["ms_per_step"]
-                result["config"]["parallelism"] = rowshard["parallelism"]
+            pick = pick_value_leg(getattr(args, "mode", "auto"), hybrid_box.get("res"), rowshard)
+            if pick != "replica":
+                # primary number = a leg that shards the CORPUS; the replica figure stays beside it
+                leg = result[pick]
+                result["value"], result["ms_per_step"] = leg["value"], leg["ms_per_step"]
+                result["config"]["parallelism"] = leg["parallelism"]
+            result["value_leg"] = pick
             try:   # RCCL's version banner sits in the C stdio buffer: emit it first so that the JSON is the last line
                 import ctypes
                 ctypes.CDLL(None).fflush(None)

@@ -566,6 +566,12 @@ class HippoRAGEngine:
     def shard_ppr_decide(self, step: int):
         check(self._lib.hrag_shard_ppr_decide(self._handle, step, _stream()))
 
+    def shard_ppr_gate_open(self, step: int) -> bool:
+        """Will step `step` do anything (hrag_shard_ppr_gate; synchronises the stream)?"""
+        o = C.c_int32(0)
+        check(self._lib.hrag_shard_ppr_gate(self._handle, step, C.byref(o), _stream()))
+        return bool(o.value)
+
     def shard_finish(self, mn, mx, flags, k: int, want_residual: bool = False):
         torch = _torch()
         b = mn.shape[0]
@@ -767,6 +773,9 @@ class ShardStages(EngineStages):
 
     def shard_ppr_decide(self, step):
         return self.e.shard_ppr_decide(step)
+
+    def shard_ppr_gate_open(self, step):
+        return self.e.shard_ppr_gate_open(step)
 
     def shard_finish(self, mn, mx, flags, k, want_residual=False):
         return self.e.shard_finish(mn, mx, flags, k, want_residual)

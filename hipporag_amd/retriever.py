@@ -503,13 +503,25 @@ class HippoRAG:
             torch.cuda.synchronize(old.device)
             old.close()
             self.engine = None
-        engine = HippoRAGEngine(a["csr"], a["passage_vertex"], pe, fe,
-                                a["subj"] if has_facts else None, a["obj"] if has_facts else None,
-                                a["num_chunks"] if has_facts else None,
-                                max_batch=self.global_config.max_batch,
-                                max_topk=min(2048, max(self.global_config.retrieval_top_k, 1)),
-                                slab_width=self.global_config.slab_width,
-                                flags=0, locality=self.global_config.locality)
+        def build(pe_, fe_):
+            return HippoRAGEngine(a["csr"], a["passage_vertex"], pe_, fe_,
+                                  a["subj"] if has_facts else None, a["obj"] if has_facts else None,
+                                  a["num_chunks"] if has_facts else None,
+                                  max_batch=self.global_config.max_batch,
+                                  max_topk=min(2048, max(self.global_config.retrieval_top_k, 1)),
+                                  slab_width=self.global_config.slab_width,
+                                  flags=0, locality=self.global_config.locality)
+        try:
+            engine = build(pe, fe)
+        except Exception as exc:
+            # the old engine is gone (closed above to keep the peak at ONE index): leave a consistent "not ready"
+            # state -- the host arrays still hold the whole index, so the next prepare_retrieval_objects() rebuilds
+            # from them -- and say what happened instead of serving from a half-built object
+            self.engine, self._engine_rows, self.ready_to_retrieve = None, None, False
+            raise RuntimeError("building the device index failed; the previous engine was already released (peak "
+                               "memory = one index).  The retriever is NOT ready: free device memory (or lower "
+                               "max_batch / use embedding_precision='bf16') and call prepare_retrieval_objects() "
+                               f"again -- {type(exc).__name__}: {exc}") from exc
         self.engine = engine
         self._engine_rows = {"passages": list(self.passage_node_keys), "facts": list(self.fact_node_keys) if has_facts else []}
         self.passage_node_idxs = a["passage_vertex"].tolist()

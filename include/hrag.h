@@ -16,10 +16,14 @@
  *   - every compute entry point takes the HIP stream to enqueue on (pass
  *     torch.cuda.current_stream().cuda_stream) and returns after enqueueing: no
  *     device synchronisation, no allocation in the call path (graph-capture safe);
- *   - ONE call in flight per engine: the workspace (scores, PPR state, seeds) belongs to the engine, so calls on
- *     one stream simply queue up, while a call from a second thread or on a second stream before the previous one
- *     finished is REJECTED with HRAG_EBUSY (never a silent race); concurrency = one engine per stream (the index
- *     arrays are small next to 288 GB) -- SURVEY.md 8(b)'s separate workspace objects were not built;
+ *   - ONE call in flight per engine: the workspace (scores, PPR state, seeds) belongs to the engine.  Calls on one
+ *     stream queue up as usual; a call on ANOTHER stream is ordered behind the previous call ON THE DEVICE (the
+ *     library makes the new stream wait for the event that ends the previous call: no host synchronisation, no
+ *     error -- a multi-stream pipeline just serialises on this engine's workspace); a call from a second THREAD
+ *     while one is still inside the library is REJECTED with HRAG_EBUSY (never a silent race).  Real concurrency =
+ *     one engine per stream (the index arrays are small next to 288 GB) -- SURVEY.md 8(b)'s separate workspace
+ *     objects were not built.  Replays of a captured HIP graph bypass the library and are NOT ordered against
+ *     direct calls on other streams: keep them on one stream;
  *   - bf16 = the upper 16 bits of an IEEE-754 binary32, passed as uint16_t (fp16 engines:
  *     IEEE binary16 bit patterns in the same uint16_t slots);
  *   - all index outputs are int32, all score outputs fp32;
@@ -44,9 +48,8 @@ typedef enum hrag_status {
     HRAG_EINVAL = 1,      /* bad shape / null pointer / unsupported option                    */
     HRAG_ENOMEM = 2,      /* hipMalloc failed                                                  */
     HRAG_EHIP = 3,        /* a HIP runtime call failed; text in hrag_last_error()              */
-    HRAG_EBUSY = 4,       /* the engine's workspace is in use: another thread is inside a call on this engine, or a   */
-                          /* call enqueued on ANOTHER stream has not finished (the workspace lives in the engine: one */
-                          /* call in flight per engine; calls on one stream queue up behind each other as usual)      */
+    HRAG_EBUSY = 4,       /* another THREAD is inside a call on this engine (the workspace lives in the engine: one   */
+                          /* call in flight; calls on other streams are ordered behind it on the device, see above)   */
     HRAG_ECAPACITY = 5    /* batch / k larger than the engine was created for                  */
 } hrag_status;
 
@@ -87,7 +90,7 @@ typedef enum hrag_dtype {
                        /* 3 * dim elements IS hi.qhi + lo.qhi + hi.qlo = the fp32 product up to 2^-21 |x||q| -- through  */
                        /* kernel unchanged, at 3x the embedding stream.  Every q_*_dev pointer of such an engine is      */
                        /* fp32 [B, dim].  Ranking with bf16-rounded embeddings instead flips near-tied facts / passages  */
-                       /* (tests/test_gpu_f32_split.py counts them on a reference-run fixture)                          */
+                       /* (tests/test_ref_golden.py counts them on the reference-run fixture ref_synth_f32.npz)             */
     HRAG_F32_SPLIT_ROWS = 3 /* the same engine from rows that are ALREADY in the split layout: `data` is fp16             */
                        /* [rows, 3 * dim] as hrag_split_f32 / hrag_engine_gather_embeddings produce it (`dim` stays the  */
                        /* logical dimension): the index-update path, where the held rows never leave the device          */
@@ -494,6 +497,11 @@ hrag_status hrag_shard_ppr_sweep(hrag_engine *e, int32_t sweep, int32_t group, i
  *   measuring step), so that residual_out, iters_out and flags bit 4 come out identical on every shard. */
 hrag_status hrag_shard_ppr_est(hrag_engine *e, float *est_dev, int32_t set, hrag_stream stream);
 hrag_status hrag_shard_ppr_decide(hrag_engine *e, int32_t sweep, hrag_stream stream);
+/* *open_out = 1 when step `step` of the session will do something (no gate, or its gate word says go), 0 when a
+ * decision has closed its gate (every later step is then closed too) or `step` is past the last one.  The ONLY shard
+ * entry point that synchronises the stream: a host loop that pays a collective per step calls it once after each
+ * hrag_shard_ppr_decide and stops issuing steps -- and their exchanges -- when it returns 0. */
+hrag_status hrag_shard_ppr_gate(hrag_engine *e, int32_t step, int32_t *open_out, hrag_stream stream);
 
 /* doc scores of the owned passages (PPR probability, or the normalised DPR score on the fallback)
  * and their local top-k: idx_out_dev int32 [B, k] GLOBAL passage positions, score_out_dev fp32 [B, k].

@@ -1,0 +1,90 @@
+"""`python bench.py --gpus N` is its own launcher (hipporag_amd/launch.py): the driver runs exactly that command, with
+no torchrun in front.  CPU tests: the launcher with a stub worker (environment, rank 0's JSON line last, a dying rank
+ends the job), bench.py itself on this GPU-less box (must fail AFTER spawning, with the device-count message), and the
+choice of the leg that becomes `value` at N > 1."""
+
+import io
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from hipporag_amd import launch
+from hipporag_amd.dist import pick_value_leg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stub(tmp_path, body):
+    p = tmp_path / "worker.py"
+    p.write_text(textwrap.dedent(body))
+    return [sys.executable, str(p)]
+
+
+def test_spawn_ranks_gives_every_rank_the_torchrun_environment_and_prints_rank0s_line_last(tmp_path):
+    cmd = _stub(tmp_path, """
+        import json, os, sys
+        r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+        assert int(os.environ["MASTER_PORT"]) > 0 and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        print(f"chatter from rank {r}")                      # must never end up after the JSON line
+        if r == 0:
+            print(json.dumps({"metric": "stub", "world": w, "port": os.environ["MASTER_PORT"]}))
+    """)
+    out, err = io.StringIO(), io.StringIO()
+    rc = launch.spawn_ranks(3, cmd, out=out, err=err, timeout_s=60)
+    assert rc == 0
+    lines = out.getvalue().strip().splitlines()
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["metric"] == "stub" and rec["world"] == 3
+    for r in range(3):
+        assert f"chatter from rank {r}" in err.getvalue()
+
+
+def test_spawn_ranks_a_dying_rank_ends_the_job_with_its_exit_code(tmp_path):
+    cmd = _stub(tmp_path, """
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.exit("rank 1: needs 2 devices, 0 visible")   # SystemExit(str) -> exit code 1, message on stderr
+        time.sleep(600)                                       # the survivors would hang in a collective
+    """)
+    out, err = io.StringIO(), io.StringIO()
+    rc = launch.spawn_ranks(2, cmd, out=out, err=err, timeout_s=120)
+    assert rc == 1
+    assert "rank 1 exited with code 1" in err.getvalue()
+    assert out.getvalue() == ""
+
+
+def test_spawn_ranks_times_out(tmp_path):
+    cmd = _stub(tmp_path, "import time; time.sleep(600)")
+    out, err = io.StringIO(), io.StringIO()
+    assert launch.spawn_ranks(2, cmd, out=out, err=err, timeout_s=1.0) == 124
+
+
+def test_bench_gpus_2_spawns_its_ranks_and_fails_on_the_device_count_here():
+    """On this GPU-less container the N > 1 bench must get as far as its ranks (no 'launch with torchrun' hint) and
+    fail there with the device-count message; nothing is printed on stdout."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HRAG_FORCE_DIST")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--config", "tiny"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "needs 2 GPUs on this node" in p.stderr, p.stderr[-2000:]
+    assert "torch.distributed.run" not in p.stderr.split("needs 2 GPUs")[0][-400:]
+    assert p.stdout.strip() == ""
+
+
+def test_value_leg_prefers_a_parity_green_corpus_sharded_leg():
+    green = {"value": 1.0, "ms_per_step": 1.0, "parity": {"ok": True}}
+    red = {"value": 9.0, "ms_per_step": 1.0, "parity": {"ok": False}}
+    failed = {"error": "boom"}
+    assert pick_value_leg("auto", green, green) == "hybrid"
+    assert pick_value_leg("auto", red, green) == "rowshard"
+    assert pick_value_leg("auto", failed, red) == "replica"
+    assert pick_value_leg("auto", None, {"skipped": True}) == "replica"
+    assert pick_value_leg("rowshard", green, green) == "rowshard"
+    assert pick_value_leg("hybrid", red, green) == "replica"
+    assert pick_value_leg("replica", green, green) == "replica"

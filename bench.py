@@ -222,19 +222,20 @@ def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, bu
     n_done, t0 = 0, time.perf_counter()
     ids_equal, max_rel = True, 0.0
     exact_pos = n_pos = exact_rows = 0
-    from tests.helpers import tie_aware_report
+    from tests.helpers import ranked_parity
+    tie_window = 0.0
     while n_done < min(max_queries, qf.shape[0]):
         ids, scores = ref.retrieve_one(qf[n_done], qp[n_done])
-        k = gpu_idx.shape[1]
         g_ids = gpu_idx[n_done]
-        # permutations are tolerated inside near-tie classes only (reference scores closer than twice the score
-        # bar); how many ranks needed that is reported beside the verdict
-        rep = tie_aware_report(g_ids, ids[:k], scores[:k], rel_gap=2e-5)
+        full = np.empty(len(ids)); full[ids] = scores
+        # permutations are tolerated only inside a tie window that follows the MEASURED score error (2.2 x the worst
+        # relative deviation of this query's scores, at least 2e-6, at most 2e-5: tests/helpers.ranked_parity); how
+        # many ranks needed that is reported beside the verdict
+        rep = ranked_parity(g_ids, gpu_scores[n_done], ids, scores, full)
         ids_equal = ids_equal and rep["equal"]
         exact_pos += rep["exact_positions"]; n_pos += rep["n"]; exact_rows += int(rep["exact_positions"] == rep["n"])
-        full = np.empty(len(ids)); full[ids] = scores
-        rel = np.abs(gpu_scores[n_done] - full[g_ids]) / np.maximum(full[g_ids], 1e-300)
-        max_rel = max(max_rel, float(rel.max()))
+        max_rel = max(max_rel, rep["worst_rel_err"])
+        tie_window = max(tie_window, rep["rel_gap"])
         n_done += 1
         if time.perf_counter() - t0 > budget_s:
             break
@@ -249,7 +250,9 @@ def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, bu
     }
     parity = {"queries_checked": n_done, "topk_ids_equal": bool(ids_equal),
               "topk_ids_equal_definition": "identical ranked ids; a permutation is accepted only inside a run of "
-                                           "oracle scores closer than 2e-5 relative (tie class)",
+                                           "oracle scores closer than tie_window_rel = max(2e-6, 2.2 x the measured "
+                                           "max relative score error) (tie class)",
+              "tie_window_rel": tie_window,
               "exact_id_fraction": exact_pos / max(n_pos, 1), "queries_with_identical_id_lists": exact_rows,
               "max_rel_score_err": max_rel}
     # ---- "vectorised" leg: batched sgemm + argpartition + OpenMP SpMM over all host cores, the
@@ -484,7 +487,7 @@ def main():
     ap.add_argument("--engine-flags", type=int, default=0, help="hrag_opts.flags (HRAG_OPT_*), e.g. 2048 = XCD_BLOCKED")
     ap.add_argument("--locality", default=None, choices=["auto", "on"],
                     help="HippoRAGEngine(locality=...): renumber the vertices by the first passage that links them")
-    ap.add_argument("--ppr-tol", type=float, default=3e-6,
+    ap.add_argument("--ppr-tol", type=float, default=1.5e-6,
                     help="tolerance of the secondary leg that runs under the convergence contract (the headline runs "
                          "BASELINE.json's fixed 20 sweeps and reports the residual they leave)")
     ap.add_argument("--ppr-max-iters", type=int, default=29)

@@ -329,7 +329,7 @@ class HippoRAGEngine:
         return RetrieveOutput(idx, sc, flags, resid, used)
 
     def retrieve_converged(self, q_pass, kept_idx, kept_score, kept_count, *, damping: float = 0.5,
-                           ppr_iters: int = 20, ppr_tol: float = 3e-6, ppr_max_iters: int = 400,
+                           ppr_iters: int = 20, ppr_tol: float = 1.5e-6, ppr_max_iters: int = 400,
                            want_all_scores: bool = False, **kw) -> RetrieveOutput:
         """retrieve() + what the host owes the convergence contract (include/hrag.h): a batch whose fp8 state
         saturated is repeated on the wider state (never clipped scores); queries the engine flags

@@ -107,7 +107,7 @@ def build_engine_from_reference(rag, *, max_batch: int = 256, embedding_precisio
 
 
 def attach(rag, *, max_batch: int = 256, ppr_iters: Optional[int] = None, batched_retrieve: bool = True,
-           ppr_tol: float = 3e-6, ppr_max_iters: int = 400, embedding_precision: str = "f32"):
+           ppr_tol: float = 1.5e-6, ppr_max_iters: int = 400, embedding_precision: str = "f32"):
     """Patch ``rag`` in place; returns it.  Call again after ``index()`` / ``delete()`` (they change
     the graph and the stores; the reference only resets ``ready_to_retrieve`` on delete, :411)."""
     import torch

@@ -142,10 +142,11 @@ class RetrievalConfig:
                                          # (DESIGN.md 4.1); None: the caller's numbering as it is
     # convergence contract (include/hrag.h, hrag_retrieve; the reference's PRPACK iterates to 1e-10,
     # HippoRAG.py:1736-1743): the engine measures the relative update of the passage scores and keeps sweeping
-    # while it predicts an error above ppr_tol.  3e-6 keeps every passage score within the 1e-5 relative parity
-    # bar on the graphs this repository tests (the measure is within 3.5x of the true error wherever that is above
-    # the fp32 noise floor); 0 = exactly ppr_iters sweeps
-    ppr_tol: float = 3e-6
+    # while that measure is above ppr_tol.  The measure can UNDER-read the true error: the worst ratio measured
+    # (tools/probe_convergence.py, ring graph) is residual / error = 0.29, so a query that passes at ppr_tol may carry
+    # ppr_tol / 0.29.  1.5e-6 puts that worst case at 5.2e-6 = the 1e-5 relative parity bar with a factor 1.9 to
+    # spare (round 3 shipped 3e-6: 1.03e-5 in that worst case, no margin); 0 = exactly ppr_iters sweeps
+    ppr_tol: float = 1.5e-6
     ppr_max_iters: int = 400             # bound on the sweeps a slowly mixing graph may cost (fp8 state: 30, then
                                          # the flagged queries are repeated on the wider state)
     max_batch: int = 256

@@ -244,9 +244,13 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q_fact_dev, int32_t
  *   ppr_max_iters   upper bound on the sweeps (>= ppr_iters; ignored when ppr_tol == 0)
  *   residual_out_dev fp32 [B] (may be NULL): the residual above for the sweeps that ran (0 on the DPR fallback)
  *   iters_out_dev   int32 [B] (may be NULL): sweeps that ran for the query's batch
- * The measure sees the passage rows only: on a bipartite graph whose reset vector lives on one side the passage
- * rows change on alternate sweeps only and a single sweep's update can read 0 (HippoRAG graphs hold a triangle
- * passage - subject - object for every fact, so they are not bipartite where it matters). */
+ * The measure sees the passage rows only and is a heuristic, not a bound: where the error of a passage score is
+ * fed from residual that sits on NON-passage rows (a slowly mixing graph with the seeds far from the passages: the
+ * ring of tests/test_gpu_fp8_adversarial.py) it under-reads, down to 0.29 of the true error measured -- the mirror's
+ * default ppr_tol = 1.5e-6 is the 1e-5 bar divided by that and by a margin of 1.9; where convergence oscillates
+ * (bipartite-like graphs, the BASELINE generator) it over-reads by up to (1 + damping) / (1 - damping).  It does NOT
+ * go blind on a bipartite graph: the iteration starts at x_0 = v, whose trailing term (damping P)^k v moves the
+ * passage rows on every sweep, odd or even (tests/test_gpu_fp8_adversarial.py pins 20 and 21 sweeps). */
 #define HRAG_FLAG_NOT_CONVERGED 16
 hrag_status hrag_retrieve(hrag_engine *e, const uint16_t *q_pass_dev, int32_t batch,
                           const int32_t *kept_idx_dev, const float *kept_score_dev,

@@ -5,7 +5,7 @@ larger damping factor.  Every case compares ALL passage scores (k = Np) with the
 that no value had to be clamped to the e4m3 range (flags bit 3, HRAG_FLAG_FP8_SATURATED).
 
 Bars.  The parity bar is 1e-5 relative against the exact solution (PRPACK solves to 1e-10,
-HippoRAG.py:1736-1743) and EVERY case asserts it.  A fixed number of sweeps cannot meet it on a slowly mixing
+HippoRAG.py:1736-1743) and EVERY case asserts it with a margin of 1.5 (worst < 6.7e-6) under the default tolerance.  A fixed number of sweeps cannot meet it on a slowly mixing
 graph whatever the state type (the fp64 20-sweep iterate itself is 7e-4 off on the ring, 1.9e-6 on the star
 forest): what meets it is the convergence contract of hrag_retrieve (include/hrag.h) -- ppr_tol on the measured
 relative update of the passage scores, device-side extension stages on the fp8 state (star forest: 26 sweeps),
@@ -18,6 +18,7 @@ import pytest
 import oracle
 from hipporag_amd import synth
 from hipporag_amd.graph import bf16_bits_to_float, build_csr
+from tests.helpers import write_test_report
 
 pytestmark = pytest.mark.gpu
 
@@ -120,7 +121,8 @@ def test_fp8_state_on_adversarial_graphs_all_passages(gpu_device, name, b):
         qf_bits[i] = fact_bits[i]                        # these queries' best fact is a pinned one
     qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=6)
     from hipporag_amd._lib import FLAG_NOT_CONVERGED
-    tol = 3e-6                                            # RetrievalConfig.ppr_tol
+    tol = 1.5e-6                                          # RetrievalConfig.ppr_tol: worst-case under-reading of the measure
+                                                          # (0.29) still lands at 5.2e-6, the bar with a factor 1.9 to spare
     with HippoRAGEngine(csr, index.passage_vertex, pass_bits, fact_bits, index.subj_vertex, index.obj_vertex,
                         index.num_chunks, max_batch=b, max_topk=n_p) as eng:
         idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
@@ -148,8 +150,8 @@ def test_fp8_state_on_adversarial_graphs_all_passages(gpu_device, name, b):
         assert (raw_flags & FLAG_NOT_CONVERGED).any() and used.max() > 30
     elif name == "stars":                                 # the device added stages, nothing needed repeating
         assert raw_used.max() > iters and not (raw_flags & FLAG_NOT_CONVERGED).any()
-    elif "barbell" in name or "tiny" in name:             # well-mixing graphs: exactly the sweeps asked for
-        assert np.all(raw_used == iters) and np.all(raw_flags == 0)
+    elif "barbell" in name or "tiny" in name:             # well-mixing graphs: at most one short extension stage, no flag
+        assert raw_used.max() <= iters + 3 and np.all(raw_flags == 0)
     qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
     check = list(range(len(pinned))) + list(range(len(pinned), b, max(1, b // 12)))
     worst = 0.0
@@ -162,7 +164,7 @@ def test_fp8_state_on_adversarial_graphs_all_passages(gpu_device, name, b):
         nz = want > 0
         worst = max(worst, float(np.abs(full[nz] / want[nz] - 1).max()))
         assert np.all(full[~nz] == 0), q
-    assert worst < 1e-5, (name, b, worst)                 # the parity bar itself, every case
+    assert worst < 1e-5 / 1.5, (name, b, worst)           # the parity bar WITH a margin of 1.5, every case
 
 
 def test_fixed_sweep_count_reports_the_residual_it_leaves(gpu_device):
@@ -291,3 +293,89 @@ def test_the_device_extends_exactly_when_the_measured_residual_is_above_the_tole
         used = int(below.iters_used.min())
         assert used == int(below.iters_used.max()) and used in (21, 23, 26, 29)       # whole stages of 1, 2, 3, 3 sweeps
         assert float(below.residual.max()) <= 0.95 * r20 and np.all(below.flags.cpu().numpy() == 0)
+
+
+@pytest.mark.parametrize("b", [1, 8, 40])
+def test_the_other_state_types_run_the_fixed_count_flag_and_leave_the_repeat_to_the_caller(gpu_device, b):
+    """hrag_retrieve extends in-kernel on the fp8 state only (batch > 64).  The small-batch (B <= 8), fp16 (B <= 64)
+    and fp32 states run exactly ppr_iters sweeps, MEASURE the same residual in their last sweep and, when ppr_tol > 0
+    and it is above the tolerance, set HRAG_FLAG_NOT_CONVERGED: a raw caller of the C ABI gets a flag, never silently
+    unconverged scores; HippoRAGEngine.retrieve_converged (what the mirror and the adapter call) repeats the flagged
+    queries with the sweeps their residual asks for.  Ring graph: 20 sweeps leave ~1e-3."""
+    import dataclasses
+    import torch
+    from hipporag_amd._lib import FLAG_NOT_CONVERGED
+    from hipporag_amd.engine import HippoRAGEngine
+    n, src, dst, w, pv, pinned = _ring()
+    csr, pass_bits, fact_bits, index = _index(n, src, dst, w, pv, 64, seed=11)
+    n_p, tol = len(pv), 1.5e-6
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=5)
+    qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=6)
+    qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+    with HippoRAGEngine(csr, index.passage_vertex, pass_bits, fact_bits, index.subj_vertex, index.obj_vertex,
+                        index.num_chunks, max_batch=b, max_topk=n_p) as eng:
+        idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
+        cnt = _t(np.full(b, 5, np.int32), gpu_device)
+        raw = eng.retrieve(_bf16(qp_bits, gpu_device), idx, sc, cnt, ppr_iters=20, k=n_p, ppr_tol=tol, ppr_max_iters=400)
+        torch.cuda.synchronize()
+        assert eng.timings()["slab_width"] != 128         # NOT the fp8 state
+        assert np.all(raw.iters_used.cpu().numpy() == 20)                      # no in-kernel extension on these states
+        assert np.all(raw.flags.cpu().numpy() & FLAG_NOT_CONVERGED)            # ... but every query says so
+        assert float(raw.residual.min()) > tol
+        out = eng.retrieve_converged(_bf16(qp_bits, gpu_device), idx, sc, cnt, ppr_iters=20, k=n_p, ppr_tol=tol,
+                                     ppr_max_iters=400)
+        torch.cuda.synchronize()
+    assert np.all(out.flags.cpu().numpy() == 0) and float(out.residual.max()) <= tol
+    got_idx, got_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+    worst = 0.0
+    for q in range(0, b, max(1, b // 6)):
+        want = oracle.retrieve_one(index, qf[q], qp[q]).x[index.passage_vertex]
+        worst = max(worst, float(np.abs(got_sc[q] / want[got_idx[q]] - 1).max()))
+    assert worst < 1e-5 / 1.5, (b, worst)
+
+
+def test_on_a_bipartite_graph_the_passage_only_measure_still_reads_every_sweep(gpu_device):
+    """The convergence measure sees the PASSAGE rows only (include/hrag.h, hrag_retrieve).  Round 3 documented a blind
+    spot for bipartite graphs -- passages on one side, entities on the other, NO entity-entity edge: mass moves between
+    the sides, so "the passage rows change on alternate sweeps only and a single sweep's update can read 0".  That is
+    true of the SERIES terms but not of the iteration the engine runs: it starts at x_0 = v, so x_k carries the
+    trailing term (aP)^k v, and the passage rows move on EVERY sweep -- by (aP)^k v after an even sweep and by
+    -a (aP)^(k-1) v after an odd one (CPU emulation: the measure reads 2.9 .. 3.2x the true error at sweeps 19, 20, 21,
+    22 alike: the (1 + a) / (1 - a) = 3 of a purely oscillating mode, i.e. pessimistic = safe).  This test pins it on
+    the device for an even and an odd count: the residual is never BELOW the true error, and it contracts by ~a from
+    20 to 21 instead of collapsing."""
+    import dataclasses
+    import torch
+    from hipporag_amd.engine import HippoRAGEngine
+    rng = np.random.default_rng(5)
+    n_p, n_e = 256, 768
+    n = n_p + n_e
+    pv = np.arange(n_e, n)                                   # passages last, like the reference's vertex order
+    src = np.repeat(pv, 6)
+    dst = rng.integers(0, n_e, len(src))                     # passage -- entity edges only
+    csr, pass_bits, fact_bits, index = _index(n, src, dst, np.ones(len(src)), pv, 64, seed=3)
+    b = 70
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=5)
+    qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=6)
+    qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+    res, err = {}, {}
+    with HippoRAGEngine(csr, index.passage_vertex, pass_bits, fact_bits, index.subj_vertex, index.obj_vertex,
+                        index.num_chunks, max_batch=b, max_topk=n_p) as eng:
+        idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
+        cnt = _t(np.full(b, 5, np.int32), gpu_device)
+        for iters in (20, 21):
+            out = eng.retrieve(_bf16(qp_bits, gpu_device), idx, sc, cnt, ppr_iters=iters, k=n_p)
+            torch.cuda.synchronize()
+            assert eng.timings()["slab_width"] == 128 and np.all(out.flags.cpu().numpy() == 0)
+            got_idx, got_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+            resid = out.residual.cpu().numpy()
+            worst = ratio = 0.0
+            for q in range(0, b, 10):
+                want = oracle.retrieve_one(index, qf[q], qp[q]).x[index.passage_vertex]
+                e = float(np.abs(got_sc[q] / want[got_idx[q]] - 1).max())
+                worst = max(worst, e)
+                assert resid[q] >= e, (iters, q, resid[q], e)          # never an under-reading here
+            res[iters], err[iters] = float(resid.max()), worst
+    write_test_report("bipartite_measure", {"residual_by_sweeps": res, "true_rel_err_by_sweeps": err})
+    assert 0.3 * res[20] < res[21] < 0.8 * res[20], (res, err)        # contracts by ~damping; no collapse on the odd count
+    assert res[20] < 12 * err[20] and res[21] < 12 * err[21], (res, err)

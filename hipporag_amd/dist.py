@@ -753,6 +753,10 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1:      # HRAG_FORCE_DIST=1 on one GPU without a launcher: a rendezvous with ourselves
+        from .launch import free_port
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     V, E, D, seed = cfg["V"], cfg["E"], cfg["D"], cfg["seed"]
     # per-GPU batch: fixed (weak scaling), or the fixed global batch dealt to the GPUs (strong scaling, configs[3])

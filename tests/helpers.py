@@ -95,3 +95,20 @@ def write_test_report(name: str, record: dict) -> None:
             json.dump(record, f)
     except OSError:
         pass
+
+
+def prior_noise_allowance(index, q_pass) -> np.ndarray:
+    """Per-passage relative allowance for what the REFERENCE leaves undefined: its passage prior is
+    min_max_normalize(np.dot(passage_embeddings, q)) in fp32 (HippoRAG.py:1496-1498, misc_utils.py:130-139), and the
+    fp32 dot product carries ~1e-7 of summation-order noise (two BLAS builds differ by it).  A passage whose
+    normalised score is s takes that noise into its prior -- and, on graphs where a passage's PPR score is dominated
+    by its own prior (the ring: passages 8 hops apart), into its final score -- at ~1e-7 / (range * s) relative: the
+    oracle's own two dot variants (exact fp64 vs fp32 BLAS) differ by 1.5e-5 at a passage with s = 0.0016.  Returned:
+    a model floor (6e-8 / range) / s for every passage, in passage order; callers add it to the score bar."""
+    from oracle.hipporag_ref import _dot
+    raw = _dot(index.passage_emb, np.asarray(q_pass, dtype=np.float32), True).astype(np.float64)
+    rng = float(raw.max() - raw.min())
+    if rng <= 0:
+        return np.zeros(len(raw))
+    nrm = (raw - raw.min()) / rng
+    return (6e-8 / rng) / np.maximum(nrm, 1e-9)

@@ -200,8 +200,9 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
 
 
 def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, budget_s, max_queries,
-                 vec_queries=32, nx_budget_s=6.0):
-    """Reference-style CPU loop on a bounded sample (rank 0 only) + parity spot check."""
+                 vec_queries=32, nx_budget_s=6.0, also=None):
+    """Reference-style CPU loop on a bounded sample (rank 0 only) + parity spot check.
+    also: {name: (ids, scores)} -- further device results for the same queries, checked against the same oracle rows."""
     import oracle
     from oracle.cpu_baseline import ReferenceStyleRetriever
     try:
@@ -224,6 +225,7 @@ def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, bu
     exact_pos = n_pos = exact_rows = 0
     from tests.helpers import ranked_parity
     tie_window = 0.0
+    also_stats = {}
     while n_done < min(max_queries, qf.shape[0]):
         ids, scores = ref.retrieve_one(qf[n_done], qp[n_done])
         g_ids = gpu_idx[n_done]
@@ -236,6 +238,13 @@ def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, bu
         exact_pos += rep["exact_positions"]; n_pos += rep["n"]; exact_rows += int(rep["exact_positions"] == rep["n"])
         max_rel = max(max_rel, rep["worst_rel_err"])
         tie_window = max(tie_window, rep["rel_gap"])
+        for name, (a_idx, a_sc) in (also or {}).items():
+            r2 = ranked_parity(a_idx[n_done], a_sc[n_done], ids, scores, full)
+            st = also_stats.setdefault(name, {"topk_ids_equal": True, "exact": 0, "n": 0, "max_rel_score_err": 0.0, "tie_window_rel": 0.0})
+            st["topk_ids_equal"] = st["topk_ids_equal"] and bool(r2["equal"])
+            st["exact"] += r2["exact_positions"]; st["n"] += r2["n"]
+            st["max_rel_score_err"] = max(st["max_rel_score_err"], r2["worst_rel_err"])
+            st["tie_window_rel"] = max(st["tie_window_rel"], r2["rel_gap"])
         n_done += 1
         if time.perf_counter() - t0 > budget_s:
             break
@@ -255,6 +264,9 @@ def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, bu
               "tie_window_rel": tie_window,
               "exact_id_fraction": exact_pos / max(n_pos, 1), "queries_with_identical_id_lists": exact_rows,
               "max_rel_score_err": max_rel}
+    for name, st in also_stats.items():
+        parity[name] = {"topk_ids_equal": st["topk_ids_equal"], "exact_id_fraction": st["exact"] / max(st["n"], 1),
+                        "max_rel_score_err": st["max_rel_score_err"], "tie_window_rel": st["tie_window_rel"]}
     # ---- "vectorised" leg: batched sgemm + argpartition + OpenMP SpMM over all host cores, the
     # same algorithm and sweep count as the GPU path -- the ratio against THIS number is the one free of the
     # reference's Python overhead
@@ -477,6 +489,7 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=12)
     ap.add_argument("--cpu-vec-queries", type=int, default=32, help="batch of the vectorised CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-accel", action="store_true", help="skip the HRAG_OPT_ACCEL leg (never `value`)")
     ap.add_argument("--exchange-groups", type=int, default=2,
                     help="row-sharded mode: exchange groups pipelined against the sweeps")
     ap.add_argument("--sweep-launches", type=int, default=40)
@@ -571,6 +584,7 @@ def main():
                                                "the passage score in the last sweep (include/hrag.h, hrag_retrieve)",
                     "sweeps_used_min": int(torch.stack(used).min()), "sweeps_used_max": int(torch.stack(used).max()),
                     "queries_flagged_not_converged": int((torch.stack(flg) & 16).ne(0).sum()),
+                    "queries_flagged_fp8_saturated": int((torch.stack(flg) & 8).ne(0).sum()),
                     "step_ms_median_hip_events": per_step[len(per_step) // 2] if per_step else None,
                     "step_ms_min_max_hip_events": [per_step[0], per_step[-1]] if per_step else None}
         return o, el, contract
@@ -583,6 +597,27 @@ def main():
         contract_c.update({"value": B * args.steps / el_c, "unit": "queries/s", "ms_per_step": el_c * 1e3 / max(args.steps, 1)})
     else:
         contract_c = {"skipped": "--ppr-tol 0"}
+
+    # Secondary leg, never `value`: HRAG_OPT_ACCEL -- the stages of the fp8-state PPR as Chebyshev steps (undirected
+    # graph: real spectrum), fewer sweeps for the accuracy PPR_ITERS plain sweeps have; same K steps, same queries.
+    # The headline above is BASELINE.json's literal 20 sweeps.
+    accel, out_a = {"skipped": "not the fp8-state path"}, None
+    if eng.timings()["slab_width"] == 128 and not args.no_accel:
+        from hipporag_amd._lib import OPT_ACCEL
+        eng.set_flags(OPT_ACCEL, True)
+        out_a, el_a, accel = timed()
+        accel.update({"value": B * args.steps / el_a, "unit": "queries/s", "ms_per_step": el_a * 1e3 / max(args.steps, 1),
+                      "what": "HRAG_OPT_ACCEL: ppr_iters = 20 names the accuracy, sweeps_used the sweeps that ran "
+                              "(Chebyshev steps inside the fp8 stages; include/hrag.h)"})
+        same = out_a.doc_idx == out.doc_idx
+        rel = ((out_a.doc_score - out.doc_score).abs() / out.doc_score.clamp_min(1e-30))[same]
+        accel["vs_20_plain_sweeps_same_queries"] = {"top_k_positions_with_the_same_id": float(same.float().mean()),
+                                                     "max_rel_score_diff_at_those": float(rel.max()) if rel.numel() else None}
+        if args.ppr_tol > 0:
+            _, el_ac, ac = timed(args.ppr_tol, args.ppr_max_iters)
+            ac.update({"value": B * args.steps / el_ac, "unit": "queries/s", "ms_per_step": el_ac * 1e3 / max(args.steps, 1)})
+            accel["with_convergence_contract"] = ac
+        eng.set_flags(OPT_ACCEL, False)
 
     # phase breakdown of one more step (HIP events inside the library, same stream)
     eng.set_profiling(True)
@@ -610,16 +645,18 @@ def main():
         "roofline": roofline,
         "step_ms_median_hip_events": contract.pop("step_ms_median_hip_events"),
         "step_ms_min_max_hip_events": contract.pop("step_ms_min_max_hip_events"),
-        "ppr_contract": contract, "with_convergence_contract": contract_c,
+        "ppr_contract": contract, "with_convergence_contract": contract_c, "with_accelerated_stages": accel,
         "phases_ms": {k: phases[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")},
         "sim_algorithmic_bytes": sim_algorithmic_bytes(kg.n_facts, kg.n_passages, D, B),
         "n_long_rows": phases["n_long_rows"], "setup_s": setup_s,
     }
     if not args.no_cpu_baseline:
         last = n_batches - 1
+        also = ({"with_accelerated_stages": (out_a.doc_idx.cpu().numpy(), out_a.doc_score.cpu().numpy())}
+                if out_a is not None else None)
         cb, parity = cpu_baseline(kg, fact_emb, pass_emb, qf[last], qp[last], out.doc_idx.cpu().numpy(),
                                   out.doc_score.cpu().numpy(), args.cpu_budget_s, args.cpu_queries,
-                                  vec_queries=args.cpu_vec_queries)
+                                  vec_queries=args.cpu_vec_queries, also=also)
         result["cpu_baseline"] = cb
         result["parity_spot_check"] = parity
         result["speedup_vs_cpu_port"] = qps / cb["value"]

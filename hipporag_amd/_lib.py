@@ -16,6 +16,7 @@ FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, FLAG_FP8_SATURATED, FLAG_NO
 # hrag_opts.flags (include/hrag.h HRAG_OPT_*)
 OPT_NATURAL_ROW_ORDER, OPT_NT_CSR, OPT_NT_STORE, OPT_F32_STATE, OPT_TEMPORAL16, OPT_NO_FP8 = 1, 2, 4, 8, 16, 32
 OPT_ROWS_BY_MINCOL, OPT_ROWS_BFS, OPT_SLABS_PER_WG_1, OPT_NO_F16, OPT_XCD_BLOCKED = 64, 128, 256, 1024, 2048
+OPT_ACCEL = 4096
 
 
 class HragError(RuntimeError):

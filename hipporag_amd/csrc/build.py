@@ -89,7 +89,9 @@ def _build_locked(hipcc: str, force: bool, verbose: bool) -> str:
     objs = [o for o, _ in results]
     if force or any(changed for _, changed in results) or not os.path.exists(LIB):
         tmp = LIB + f".tmp{os.getpid()}"
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
+        # -z defs: an internal launcher that is declared but not defined (or defined in an anonymous namespace) fails
+        # HERE, on the CPU build box, instead of at the first call on the GPU box (the library is dlopen'ed RTLD_LAZY)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", tmp, *objs]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

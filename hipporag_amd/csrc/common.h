@@ -176,6 +176,7 @@ constexpr int kP8MaxStages = 12;      // stage lengths 1,2,3,..,3,(1|2) => <= 11
 constexpr float kP8C0Scale = 128.f;   // c_0 = Q(v/d * 2^7),  max(v/d) in (1/2, 1]
 constexpr int32_t kFlagFp8Saturated = 8;   // flags bit 3 (HRAG_FLAG_FP8_SATURATED)
 constexpr int32_t kFlagNotConverged = 16;  // flags bit 4 (HRAG_FLAG_NOT_CONVERGED)
+constexpr int kP8DynInv = kP8MaxStages + 4;   // offset of the 1 / cs half of the dynamic scale table
 constexpr int kP8MaxExt = 4;          // extension stages the convergence contract may add: 1, 2, 3, 3 sweeps -- a
                                       // prediction just above the tolerance costs one sweep, a slowly mixing graph gets 9
 __host__ __device__ inline int p8_ext_sweeps(int n_ext) {   // sweeps of the first n_ext extension stages
@@ -212,6 +213,17 @@ struct Ppr8Args {
     uint16_t *rho;             // ... or its fp16 remainder next to the fp8 right-hand side (same shape), see rio
     int32_t rio;               // bit 0: R is read as (rt + rho) / cs; bit 1: R is written as rho (ppr8.hip finish_row)
     float alpha, beta, inv_cs, cs_next;
+    // mode C: y = Q(c_mul * (At x) + r_mul * rt).  Plain stage sweep: (alpha, 1); accelerated stages (HRAG_OPT_ACCEL,
+    // csrc/shard.hip ppr8_plan_accel): second iterate of a stage (w2 alpha, w2), third (w3 alpha, 1)
+    float c_mul, r_mul;
+    // HRAG_OPT_ACCEL: stage scales measured on the device (ppr8.hip scale_inv / scale_cs): dyn[k] = cs of stage k,
+    // dyn[kP8DynInv + k] = 1 / cs; dyn_stage = the stage a boundary / final launch closes; mmax_ws = one slot per
+    // (chunk, slab unit of this launch) for the boundary's max |R cs'|, mmax_atomic = the same for long rows
+    const float *dyn = nullptr;
+    int32_t dyn_stage = 0;
+    float *mmax_ws = nullptr;
+    int32_t *mmax_atomic = nullptr;
+    int32_t mmax_units = 1, mmax_slab0 = 0;
     const float *tele;         // fp32 [n_slabs64][tele_rows][64]: v at the owned passages, then the seed rows
     int64_t tele_rows;
     int32_t n_slabs64;
@@ -274,6 +286,11 @@ hrag_status launch_ppr8_decide(int32_t *est_f, const int32_t *flags, int32_t bat
 hrag_status launch_ppr8_finalize(const int32_t *est_f, int32_t *flags, int32_t batch, float g, float tol,
                                  int32_t iters, const int32_t *ctl, int32_t e_max, const double *mass_tab,
                                  int64_t tab_stride, double *sums, float *resid, int32_t *iters_used, hipStream_t s);
+// HRAG_OPT_ACCEL: the scale of stage `stage + 2` from the maximum the boundary closing `stage` measured (seed != 0:
+// write the first two scales)
+hrag_status launch_ppr8_next_scale(const float *ws, int32_t n_slots, int32_t *word, float *dyn, int32_t stage,
+                                   float kappa_growth, int32_t seed, float cs0, float cs1, const int32_t *gate,
+                                   int32_t gate_want, hipStream_t s);
 // colmask |= bits of the seed vertices
 hrag_status launch_ppr8_mask_seeds(const int32_t *seed_vtx, const int32_t *seed_cnt, int32_t batch,
                                    int64_t num_vertices, uint32_t *colmask, hipStream_t s);

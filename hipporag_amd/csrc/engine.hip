@@ -39,7 +39,7 @@ void free_engine(hrag_engine *e) {
                     e->d_stagep, e->d_pool8[0], e->d_pool8[1], e->d_pool8[2], e->d_sv16[0], e->d_sv16[1],
                     e->d_sv16[2], e->d_sv16[3], e->d_zmax_bits, e->d_zmax,
                     e->d_mass, e->d_prior_part, e->d_est_f, e->d_ctl, e->d_iters_used, e->d_resid,
-                    e->d_mass_tab, e->d_est_ws, e->d_qsplit};
+                    e->d_mass_tab, e->d_est_ws, e->d_qsplit, e->d_dyn, e->d_mmax_ws, e->d_mmax_word};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_store(e->sell);
@@ -765,6 +765,15 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         E_TRY(dev_alloc(&e->d_est_ws, std::max<int64_t>(n, 1)));
     }
     E_TRY(dev_alloc(&e->d_mass_tab, (int64_t)(kP8MaxExt + 1) * B));
+    if (e->f8_ready) {   // HRAG_OPT_ACCEL: measured stage scales
+        e->mmax_slots = (int64_t)(e->sell.n_chunks + 8) * n_slabs128(B);
+        E_TRY(dev_alloc(&e->d_dyn, 2 * kP8DynInv));
+        E_TRY(dev_alloc(&e->d_mmax_ws, e->mmax_slots));
+        E_TRY(dev_alloc(&e->d_mmax_word, 1));
+        E_HIP(hipMemset(e->d_dyn, 0, 2 * kP8DynInv * sizeof(float)));
+        E_HIP(hipMemset(e->d_mmax_ws, 0, (size_t)e->mmax_slots * sizeof(float)));
+        E_HIP(hipMemset(e->d_mmax_word, 0, sizeof(int32_t)));
+    }
     {
         char *ws = nullptr;
         E_TRY(dev_alloc(&ws, (int64_t)kTopkWsBytes));
@@ -1025,7 +1034,7 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
         HRAG_TRY(ppr8_prior(e, e->d_mn_p, e->d_mx_p, passage_node_weight, e->d_flags, batch, e->d_zmax, e->d_mass, s));
         HRAG_TRY(ppr8_begin(e, e->d_mn_p, e->d_mx_p, e->d_zmax, e->d_mass, passage_node_weight, e->d_seed_vtx,
                             e->d_seed_w, e->d_seed_cnt, e->d_flags, batch, damping, f8_iters, sl, e->d_pool8, s,
-                            ppr_max_iters, ppr_tol, residual_out != nullptr));
+                            ppr_max_iters, ppr_tol, residual_out != nullptr, true));
     } else if (f16) {
         // v is scaled per query by a power of two so that every iterate fits fp16 (ppr16.hip); the seeds
         // become extra teleport rows, i.e. v is one array that every sweep reads identically

@@ -78,15 +78,20 @@ struct Ppr8Step {
     int32_t x, y, rt;    // state buffer indices (y: written = to be exchanged, -1 for mode F; rt: the stage's rhs)
     float inv_cs, cs_next;
     int32_t rio;         // residual form of a boundary / final step (Ppr8Args.rio)
+    float c_mul = 0.f, r_mul = 1.f;   // mode C: multipliers of the gathered sum and of the right-hand side
     // convergence contract: gate = index of the control word the launch is conditional on (-1: always runs);
     // decide = j >= 0: this final sweep (variant j) is followed by decision number j (ppr8_decide_kernel: its measured
     // update against the tolerance), -1: none
     int32_t gate = -1, gate_want = 1;
     int32_t decide = -1;
+    // HRAG_OPT_ACCEL, boundary steps: kappa_growth = (max-norm contraction of the NEXT stage) x (growth of the iterate of
+    // the stage after it): what ppr8_next_scale_kernel multiplies the measured maximum with (0: last boundary)
+    float kappa_growth = 0.f;
 };
 struct Ppr8Session {
     bool active = false;
-    int32_t batch = 0, iters = 0, n_steps = 0, n_stage = 0;
+    int32_t batch = 0, iters = 0, n_steps = 0, n_stage = 0;   // iters: the sweeps of the base plan (accelerated: fewer than asked)
+    bool accel = false;
     int32_t n_slabs = 0, n_groups = 0, spg = 0;
     int64_t group_bytes = 0;
     float damping = 0.f;
@@ -182,6 +187,11 @@ struct hrag_engine {
     float *d_resid = nullptr;
     float *d_est_ws = nullptr;      // per-wavefront maxima of a sweep that measures est: [slabs][chunks][queries per slab row]
     double *d_mass_tab = nullptr;   // [kP8MaxExt + 1][max_batch]: mass of the (iters + 3 j)-sweep iterate
+    // HRAG_OPT_ACCEL: stage scales measured on the device (ppr8.hip): table [2 * kP8DynInv], one slot per (chunk, slab)
+    // for a boundary's max |R cs'|, the atomic word of the long rows
+    float *d_dyn = nullptr, *d_mmax_ws = nullptr;
+    int32_t *d_mmax_word = nullptr;
+    int64_t mmax_slots = 0;
     // one call in flight per engine (include/hrag.h): host-side entry flag + the end of the last call on its stream
     std::atomic<int> in_call{0};
     hipEvent_t ev_last = nullptr;
@@ -276,6 +286,10 @@ inline hrag_status prep_query(hrag_engine *e, const uint16_t *q, int32_t batch, 
 // (damping^iters <= 2^-18) and the stage plan fits.
 bool ppr8_usable(const hrag_engine *e, int batch, int iters, float damping);
 int ppr8_plan(int iters, int *plan);
+// HRAG_OPT_ACCEL: stage lengths 1, 3, 3, ... (+ a closing plain stage of 1 sweep when `measured`: the convergence measure
+// then reads a plain sweep's update) standing for the accuracy of `iters` plain sweeps; kind[i] = 1 marks a stage whose
+// sweeps are Chebyshev steps.  Returns the number of stages, 0 when the variant saves no sweep
+int ppr8_plan_accel(int iters, float damping, bool measured, int *plan, int *kind);
 // layout of the state buffers for `batch` queries in `want_groups` exchange groups (0 = the narrowest groups: slab
 // pairs; the group width is kept even, see hrag.h)
 hrag_status ppr8_layout(const hrag_engine *e, int32_t batch, int32_t want_groups, hrag_shard_layout *out);
@@ -289,7 +303,7 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
                        float passage_weight, const int32_t *seed_vtx, const float *seed_w,
                        const int32_t *seed_cnt, int32_t *flags, int32_t batch, float damping, int32_t iters,
                        const hrag_shard_layout &lay, uint8_t *const bufs[3], hipStream_t s,
-                       int32_t max_iters = 0, float tol = 0.f, bool want_est = false);
+                       int32_t max_iters = 0, float tol = 0.f, bool want_est = false, bool allow_accel = false);
 // step `i` (0-based, < p8.n_steps) on exchange group `group` (-1: every group); *exchange = buffer written (-1: none)
 hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchange, hipStream_t s);
 // after the checkpoint step `i` ran on every group: decide whether the next stage is the last (one tiny launch)

@@ -293,6 +293,19 @@ __device__ __forceinline__ size_t state_off(const Ppr8Args &a, int slab, int64_t
     return (size_t)g * (size_t)a.group_bytes + (size_t)grow * a.row_stride + (size_t)k * 128 + (size_t)gl * 16;
 }
 
+// Stage scales.  Plain plan: static powers of two in the kernel arguments.  HRAG_OPT_ACCEL (a.dyn != nullptr): MEASURED
+// per stage on the device -- dyn[k] = cs of stage k, dyn[kP8DynInv + k] = 1 / cs -- because a Chebyshev stage is not a
+// max-norm contraction by its spectral factor and a static chain built on its rigorous max-norm bound (7 / T_3) sinks
+// the values by ~2.5x per stage below where the e4m3 range resolves them (cfg 3: 1.8e-6 instead of 4.4e-7, and the
+// contract then needs 26 sweeps).  Every boundary reports max |R cs'| of the batch (mq, per wavefront -> a.mmax_ws);
+// ppr8_next_scale_kernel turns it into the scale of the stage after next.  Wave-uniform scalar loads.
+__device__ __forceinline__ float scale_inv(const Ppr8Args &a, int stage, float fallback) {
+    return a.dyn ? a.dyn[kP8DynInv + stage] : fallback;
+}
+__device__ __forceinline__ float scale_cs(const Ppr8Args &a, int stage, float fallback) {
+    return a.dyn ? a.dyn[stage] : fallback;
+}
+
 // Finish one output row (lrow: LOCAL row): lane gl of its group owns queries 16*gl .. 16*gl+15 of the slab.
 // RIO (boundary / final modes): how the true residual R travels between two boundaries.
 //   bit 0: R_in  = (rt + rho) / cs  -- the stage's quantised right-hand side rt = Q(R cs) (still in its state
@@ -304,17 +317,20 @@ __device__ __forceinline__ size_t state_off(const Ppr8Args &a, int slab, int64_t
 // 4e-6 at 2^-3); the early boundaries keep the fp32 R.
 // er (mode F with a.est): on return |R_p| / z_p of this lane's 16 queries when the row is an owned passage (the
 // relative size of the update the final sweep applies to the passage score), untouched otherwise.
+// mq (modes B / B0): raised to max |R_new cs'| of this lane's 16 queries (what the dynamic stage scales are measured on).
 template <int MODE, int RIO, bool EST>
 __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow, int gl,
-                                           const f32x2_t (&acc)[8], f32x2_t (&er)[8]) {
+                                           const f32x2_t (&acc)[8], f32x2_t (&er)[8], float &mq) {
     const int64_t grow = a.row_offset + lrow;
+    const float inv_cs = scale_inv(a, a.dyn_stage, a.inv_cs), cs_next = scale_cs(a, a.dyn_stage + 1, a.cs_next);
     const size_t off = state_off(a, slab, grow, gl);
     f32x2_t out[8];
     if constexpr (MODE == kP8ModeC) {
         f32x2_t r[8];
         decode16(__builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(a.rt + off)), r);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) out[j] = __builtin_elementwise_fma(acc[j], f32x2_t{a.alpha, a.alpha}, r[j]);
+        for (int j = 0; j < 8; ++j)   // r_mul = 1 on a plain stage: that product is exact, one rounding as before
+            out[j] = __builtin_elementwise_fma(acc[j], f32x2_t{a.c_mul, a.c_mul}, r[j] * f32x2_t{a.r_mul, a.r_mul});
         if (__builtin_expect(any_sat16(out), 0)) flag_sat16(out, slab, gl, a.batch, a.flags);
         __builtin_nontemporal_store(encode16(out), reinterpret_cast<v4i_t *>(a.y + off));
     } else {
@@ -336,11 +352,11 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow
             decode16(__builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(a.rt + off)), r8);
             ld16h(hrow, gl, rin);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rin[j] = (rin[j] + r8[j]) * a.inv_cs;   // inv_cs is a power of two: exact
+            for (int j = 0; j < 8; ++j) rin[j] = (rin[j] + r8[j]) * inv_cs;   // inv_cs is a power of two: exact
         } else {
             ld16i(rrow, gl, rin);
         }
-        const f32x2_t al = {a.alpha, a.alpha}, inv = {a.inv_cs, a.inv_cs};
+        const f32x2_t al = {a.alpha, a.alpha}, inv = {inv_cs, inv_cs};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const f32x2_t t = __builtin_elementwise_fma(acc[j], al, -c[j]);   // a (At c) - c, one rounding
@@ -349,8 +365,14 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow
         if constexpr (MODE == kP8ModeB || MODE == kP8ModeB0) {
             f32x2_t q[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) q[j] = out[j] * a.cs_next;
-            if (__builtin_expect(any_sat16(q), 0)) flag_sat16(q, slab, gl, a.batch, a.flags);
+            for (int j = 0; j < 8; ++j) q[j] = out[j] * cs_next;
+            {
+                float m = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m = fmaxf(m, fmaxf(fabsf(q[j].x), fabsf(q[j].y)));
+                mq = fmaxf(mq, m);
+                if (__builtin_expect(m > kE4m3Max, 0)) flag_sat16(q, slab, gl, a.batch, a.flags);
+            }
             const v4i_t enc = encode16(q);
             __builtin_nontemporal_store(enc, reinterpret_cast<v4i_t *>(a.y + off));
             if constexpr ((RIO & 2) != 0) {
@@ -376,11 +398,13 @@ __device__ __forceinline__ void finish_row(const Ppr8Args &a, int slab, int lrow
             for (int s = 0; s + 1 < a.n_stage; ++s) {
                 f32x2_t cs[8];
                 decode16(*reinterpret_cast<const v4i_t *>(a.stage[s] + poff), cs);
-                const f32x2_t si = {a.stage_inv[s], a.stage_inv[s]};
+                const float sinv = scale_inv(a, s, a.stage_inv[s]);
+                const f32x2_t si = {sinv, sinv};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) z[j] = __builtin_elementwise_fma(cs[j], si, z[j]);
             }
-            const f32x2_t sl = {a.stage_inv[a.n_stage - 1], a.stage_inv[a.n_stage - 1]};
+            const float linv = scale_inv(a, a.n_stage - 1, a.stage_inv[a.n_stage - 1]);
+            const f32x2_t sl = {linv, linv};
             const float dg = a.deg[grow];
             f32x2_t xs[8];
 #pragma unroll
@@ -428,6 +452,21 @@ __device__ __forceinline__ void est_commit(const Ppr8Args &a, int slab, int chun
             if (q < a.batch && er[j].x > 0.f) atomicMax(&a.est[q], __float_as_int(er[j].x));
             if (q + 1 < a.batch && er[j].y > 0.f) atomicMax(&a.est[q + 1], __float_as_int(er[j].y));
         }
+    }
+}
+
+// Dynamic stage scales (HRAG_OPT_ACCEL): the wavefront's maximum of |R_new cs'| goes to ITS slot of a.mmax_ws (plain
+// store, every slot is rewritten by every boundary launch: nothing to initialise); WAVE = false (a long row finished by
+// the last-arriving wavefront: a handful of rows): integer atomicMax on the bits of the non-negative float.
+template <bool WAVE>
+__device__ __forceinline__ void mmax_commit(const Ppr8Args &a, int slot, float mq) {
+    if (!a.mmax_ws) return;   // wave-uniform
+    if constexpr (WAVE) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) mq = fmaxf(mq, __shfl_xor(mq, o, 64));
+        if ((threadIdx.x & 63) == 0) a.mmax_ws[slot] = mq;
+    } else {
+        if (mq > 0.f) atomicMax(a.mmax_atomic, __float_as_int(mq));
     }
 }
 
@@ -498,12 +537,14 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
     f32x2_t er[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) er[j] = f32x2_t{0.f, 0.f};
+    float mq = 0.f;
     if (tgt >= 0) {
-        finish_row<MODE, RIO, EST>(a, slab, tgt, gl, acc, er);
+        finish_row<MODE, RIO, EST>(a, slab, tgt, gl, acc, er, mq);
     } else if (seg) {
         st16i_sc1(qrs, (unsigned)(-(tgt + 1)) * 512u, gl, acc);
     }
     if constexpr (kEst) est_commit<true>(a, slab, chunk, gl, grp, er);   // every lane takes part in the reduction
+    if constexpr (MODE == kP8ModeB || MODE == kP8ModeB0) mmax_commit<true>(a, chunk * a.mmax_units + (slab - a.mmax_slab0), mq);
     // Long rows arrive as segments in different wavefronts; the segment that arrives LAST (agent-scope
     // counter) lends its whole wavefront to the row: the 8 lane groups stride over the row's partial sums, the 8
     // group totals are added with xor-shuffles -- a fixed summation order, whoever comes last -- and the row is
@@ -542,8 +583,10 @@ __global__ __launch_bounds__(256, 4) void ppr8_kernel(const Ppr8Args a) {
         if (grp == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) er[j] = f32x2_t{0.f, 0.f};
-            finish_row<MODE, RIO, EST>(a, slab, a.m.lrow_row[mm], gl, acc, er);
+            float m2 = 0.f;
+            finish_row<MODE, RIO, EST>(a, slab, a.m.lrow_row[mm], gl, acc, er, m2);
             if constexpr (kEst) est_commit<false>(a, slab, chunk, gl, 0, er);
+            if constexpr (MODE == kP8ModeB || MODE == kP8ModeB0) mmax_commit<false>(a, 0, m2);
         }
         if (lane == 0) __hip_atomic_store(cnts + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -656,17 +699,19 @@ __device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
         a.partial + (size_t)(slab + 1) * a.m.n_partial * 128, 0, a.m.n_partial * 512, 0x00020000);
     constexpr bool kEst = EST && MODE == kP8ModeF;
     f32x2_t er[8];
+    float mq = 0.f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) er[j] = f32x2_t{0.f, 0.f};
         if (tgt >= 0) {
-            finish_row<MODE, RIO, EST>(a, slab + half, tgt, gl, half ? acc1 : acc0, er);
+            finish_row<MODE, RIO, EST>(a, slab + half, tgt, gl, half ? acc1 : acc0, er, mq);
         } else if (seg) {
             st16i_sc1(half ? q1 : q0, (unsigned)(-(tgt + 1)) * 512u, gl, half ? acc1 : acc0);
         }
         if constexpr (kEst) est_commit<true>(a, slab + half, chunk, gl, grp, er);
     }
+    if constexpr (MODE == kP8ModeB || MODE == kP8ModeB0) mmax_commit<true>(a, chunk * a.mmax_units + (slab - a.mmax_slab0), mq);
     // long rows: as in ppr8_kernel; one arrival (the first slab's counter) covers both slabs of the pair
     if (__builtin_amdgcn_ballot_w64(seg) == 0) return;   // wave-uniform
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -704,8 +749,10 @@ __device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
             if (grp == 0) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) er[j] = f32x2_t{0.f, 0.f};
-                finish_row<MODE, RIO, EST>(a, slab + half, a.m.lrow_row[mm], gl, acc0, er);
+                float m2 = 0.f;
+                finish_row<MODE, RIO, EST>(a, slab + half, a.m.lrow_row[mm], gl, acc0, er, m2);
                 if constexpr (kEst) est_commit<false>(a, slab + half, chunk, gl, 0, er);
+                if constexpr (MODE == kP8ModeB || MODE == kP8ModeB0) mmax_commit<false>(a, 0, m2);
             }
         }
         if (lane == 0) __hip_atomic_store(cnts + mm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -920,6 +967,51 @@ __global__ void ppr8_finalize_kernel(const int32_t *__restrict__ est_f, int32_t 
     if (tol > 0.f && r > tol) flags[q] |= kFlagNotConverged;
 }
 
+// Dynamic stage scales (HRAG_OPT_ACCEL), after the boundary that closed stage `stage` with cs' = dyn[stage + 1]:
+//   M = max over the batch of |R_new| = (max of the wavefront slots and of the atomic word) / cs';
+//   the NEXT boundary's residual is bounded by kappa M (kappa: the max-norm contraction of stage `stage + 1`), and the
+//   stage after it grows its iterate by at most `growth`: dyn[stage + 2] = the power of two that maps kappa M growth to
+//   <= 224 (half the e4m3 range, like the static chain).  M = 0 (nothing left) keeps the previous scale.
+// seed = 1: write dyn[0] = cs0, dyn[1] = cs1 (the two scales known before anything was measured) and return.
+__global__ __launch_bounds__(1024) void ppr8_next_scale_kernel(const float *__restrict__ ws, int32_t n_slots, int32_t *word,
+                                                               float *dyn, int32_t stage, float kappa_growth, int32_t seed,
+                                                               float cs0, float cs1, const int32_t *gate, int32_t gate_want) {
+    if (gate && *gate != gate_want) return;
+    if (seed) {
+        if (threadIdx.x == 0) {
+            dyn[0] = cs0; dyn[kP8DynInv + 0] = 1.0f / cs0;
+            dyn[1] = cs1; dyn[kP8DynInv + 1] = 1.0f / cs1;
+            *word = 0;
+        }
+        return;
+    }
+    __shared__ float red[1024];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n_slots; i += 1024) m = fmaxf(m, ws[i]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mq = fmaxf(red[0], __int_as_float(*word));
+        *word = 0;
+        const float cs_used = dyn[stage + 1];
+        float cs = cs_used;                       // nothing measured: keep the scale
+        const float bound = mq / cs_used * kappa_growth;
+        if (bound > 0.f && bound < 3e38f) {
+            int ex = (int)floorf(log2f(224.0f / bound));
+            // floorf(log2f()) can be one off at exact powers of two: never let the bound exceed 224
+            if (ldexpf(1.0f, ex) * bound > 224.0f) --ex;
+            ex = ex < -60 ? -60 : (ex > 60 ? 60 : ex);
+            cs = ldexpf(1.0f, ex);
+        }
+        dyn[stage + 2] = cs;
+        dyn[kP8DynInv + stage + 2] = 1.0f / cs;
+    }
+}
+
 __global__ void ppr8_mask_seeds_kernel(const int32_t *__restrict__ seed_vtx, const int32_t *__restrict__ seed_cnt,
                                        int32_t batch, int64_t num_vertices, uint32_t *colmask) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1074,6 +1166,15 @@ hrag_status launch_ppr8_mask_seeds(const int32_t *seed_vtx, const int32_t *seed_
     const int total = batch * kMaxSeeds;
     hipLaunchKernelGGL(ppr8_mask_seeds_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, seed_vtx,
                        seed_cnt, batch, num_vertices, colmask);
+    HRAG_LAUNCH_CHECK();
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr8_next_scale(const float *ws, int32_t n_slots, int32_t *word, float *dyn, int32_t stage,
+                                   float kappa_growth, int32_t seed, float cs0, float cs1, const int32_t *gate,
+                                   int32_t gate_want, hipStream_t s) {
+    hipLaunchKernelGGL(ppr8_next_scale_kernel, dim3(1), dim3(1024), 0, s, ws, n_slots, word, dyn, stage, kappa_growth, seed,
+                       cs0, cs1, gate, gate_want);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

@@ -28,6 +28,54 @@ int ppr8_plan(int iters, int *plan) {
     return n;
 }
 
+// Accelerated stages (HRAG_OPT_ACCEL).  A stage solves (I - G) c = R', G = a At, from c_0 = 0, c_1 = R'.  On an
+// undirected graph (HippoRAG's: is_directed_graph = False) At = D^-1 A is similar to a symmetric matrix: the spectrum of
+// G is real, inside [-a, a], and the Chebyshev semi-iteration
+//     c_{k+1} = w_{k+1} (G c_k + R' - c_{k-1}) + c_{k-1},   w_1 = 1, w_2 = 1 / (1 - a^2 / 2), w_{k+1} = 1 / (1 - a^2 w_k / 4)
+// leaves 1 / T_m(1 / a) of the residual after m sweeps instead of a^m (a = 0.5: 1/26 instead of 1/8 after three).  With
+// c_0 = 0 and c_1 = R' the first two steps need no history term:
+//     c_2 = w_2 (G c_1 + R'),   c_3 = w_3 G c_2 + R'
+// -- two scalars per stage sweep (Ppr8Args.c_mul / r_mul); every boundary still forms the TRUE residual with plain a, so
+// the refinement stays exact.  The e4m3 rounding of the iterates puts a floor of ~1/14 under the contraction of a stage
+// (measured, tools/exp_fp8_chebyshev.py), so three sweeps are the sweet spot: 1, 3, 3, ... with
+// n3 = ceil((iters - 1) ln(1/a) / ln(1 / max(1/T_3(1/a), 1/14))) stages stands for `iters` plain sweeps (a = 0.5,
+// iters = 20: 16 sweeps, 4 full boundaries instead of 6).
+//   * Mass.  T_3 is odd, so the error polynomial of every stage vanishes at 0 like the plain one: the mass of the
+//     result is M - a S from the first sweep on, whatever the polynomial (ppr8_scale_kernel's closed form holds).
+//   * Scales.  A Chebyshev residual polynomial is NOT a contraction by 1/T_3 in the max norm: p_3(G) = (4 G^3 / a^3 -
+//     3 G / a) / T_3(1/a) has max-norm <= 7 / T_3(1/a) (0.27 at a = 0.5, against the spectral 0.038).  The static
+//     power-of-two stage scales are built on THAT bound (ppr8_begin), so the e4m3 range cannot be left on any graph for the
+//     same reason as on the plain plan; values sit lower in the range than they need to on well-mixing graphs (a factor
+//     ~2.5 per stage: 2 of e4m3's 15 binades after five stages).
+//   * Convergence measure.  The contract's measure is the size of the update a PLAIN sweep applies: after Chebyshev
+//     stages the true residual is spread over the whole spectrum (equi-oscillation) and its mid-spectrum part, which the
+//     next plain sweep annihilates, makes the measure read 60x the true error (cfg 3, round 3).  With `measured` the plan
+//     therefore ends on a plain stage of ONE sweep (its boundary + the passage-row final sweep: the measure then reads
+//     what is left after a plain sweep, the quantity the a-posteriori bound a / (1 - a) |update| is about), and the
+//     extension stages are plain.
+static double cheb_T(int m, double x) {          // Chebyshev polynomial T_m(x), x >= 1
+    double t0 = 1.0, t1 = x;
+    if (m == 0) return 1.0;
+    for (int k = 1; k < m; ++k) { const double t2 = 2.0 * x * t1 - t0; t0 = t1; t1 = t2; }
+    return t1;
+}
+constexpr double kAccelFloor = 1.0 / 14.0;       // contraction floor of an e4m3 stage
+
+int ppr8_plan_accel(int iters, float damping, bool measured, int *plan, int *kind) {
+    const double al = (double)damping;
+    if (!(al >= 0.2) || al >= 1.0 || iters < 8) return 0;   // small damping: the plain stages sit on the floor already
+    const double k3 = std::max(1.0 / cheb_T(3, 1.0 / al), kAccelFloor);
+    int n3 = (int)std::ceil((double)(iters - 1) * std::log(1.0 / al) / std::log(1.0 / k3) - 1e-9);
+    { const char *v = getenv("HRAG_ACCEL_N3"); if (v && atoi(v) > 0) n3 = atoi(v); }   // experiment
+    const int total = 1 + 3 * n3 + (measured ? 1 : 0);
+    if (n3 < 2 || total >= iters || n3 + 1 + (measured ? 1 : 0) > kP8MaxStages) return 0;
+    int n = 0;
+    plan[n] = 1; kind[n++] = 0;
+    for (int i = 0; i < n3; ++i) { plan[n] = 3; kind[n++] = 1; }
+    if (measured) { plan[n] = 1; kind[n++] = 0; }
+    return n;
+}
+
 // The truncation error of K sweeps is ~ damping^K of the mass whatever the state type; the staged scheme
 // multiplies it by up to ~6 on graphs whose spectrum makes the bound tight (bipartite hubs), so it takes a
 // batch when damping^K <= 2^-20 (0.5: K >= 20; 0.3: the minimum of 16; 0.6: K >= 28; 0.7 would need 39 > 30
@@ -70,6 +118,7 @@ Ppr8Args base_args(const hrag_engine *e) {
     a.spg = p.spg; a.row_stride = (uint32_t)p.spg * 128u; a.group_bytes = p.group_bytes;
     a.R = e->d_R8; a.rho = e->d_rho8; a.rio = 0;
     a.alpha = p.damping; a.beta = 1.0f - p.damping;
+    a.c_mul = p.damping; a.r_mul = 1.0f;
     a.tele = e->d_tele16; a.tele_rows = e->tele16_rows; a.n_slabs64 = n_slabs64(p.batch);
     a.row_slot = e->d_row_slot; a.deg = e->d_deg; a.p_rows = e->p_rows;
     a.colmask = e->d_colmask; a.colmask_bytes = (uint32_t)(e->colmask_words * 4); a.zero_row = (uint32_t)e->V;
@@ -97,7 +146,7 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
                        float passage_weight, const int32_t *seed_vtx, const float *seed_w,
                        const int32_t *seed_cnt, int32_t *flags, int32_t batch, float damping, int32_t iters,
                        const hrag_shard_layout &lay, uint8_t *const bufs[3], hipStream_t s, int32_t max_iters,
-                       float tol, bool want_est) {
+                       float tol, bool want_est, bool allow_accel) {
     HRAG_REQUIRE(ppr8_usable(e, batch, iters, damping),
                  "the fp8-state PPR does not serve ppr_iters=%d at damping %g (needs 16..30 sweeps and "
                  "damping^ppr_iters <= 2^-20) or the engine has no fp8 state", iters, (double)damping);
@@ -114,8 +163,21 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     // `damping` per sweep (At is row-stochastic), |R_0| <= max(a, 1 - a) max(v/d) + the rounding of c_0; a stage
     // of m sweeps grows its iterate by at most (1 - a^m) / (1 - a).  cs = the power of two that maps that bound
     // to <= 224 (half the e4m3 range: the bound ignores rounding noise; a clamped value raises flags bit 3).
-    int plan[kP8MaxStages + 4];
-    const int n_stage = ppr8_plan(iters, plan);
+    int plan[kP8MaxStages + 4], kind[kP8MaxStages + 4] = {};
+    const int asked = iters;
+    // accelerated stages need the measured scale chain: the single-GPU engine only (a row shard would have to all-reduce
+    // one float per boundary; the shard entry points run the plain plan)
+    const bool may_accel = allow_accel && (e->opt_flags & HRAG_OPT_ACCEL) && e->d_dyn && e->n_rows == e->V;
+    int n_stage = may_accel ? ppr8_plan_accel(iters, damping, tol > 0.f, plan, kind) : 0;
+    const bool accel = n_stage > 0;
+    if (!accel) n_stage = ppr8_plan(iters, plan);
+    if (accel) {                                   // the base plan's own sweep count is what the session runs and reports
+        iters = 0;
+        for (int i = 0; i < n_stage; ++i) iters += plan[i];
+        p.iters = iters;
+    }
+    p.accel = accel;
+    (void)asked;
     HRAG_REQUIRE(n_stage >= 2 && n_stage <= kP8MaxStages, "ppr_iters=%d needs %d fp8 stages (2..%d)", iters, n_stage,
                  kP8MaxStages);
     // ---- convergence contract (reference: PRPACK iterates until its residual is below 1e-10, HippoRAG.py:1736-1743;
@@ -130,17 +192,36 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     for (int j = 0; j < e_max; ++j) plan[n_stage + j] = p8_ext_sweeps(j + 1) - p8_ext_sweeps(j);   // 1, 2, 3, 3
     p.e_max = e_max; p.want_est = est; p.tol = tol;
     const double al = (double)damping;
+    const double w2 = 1.0 / (1.0 - al * al / 2.0), w3 = 1.0 / (1.0 - al * al * w2 / 4.0);   // Chebyshev weights
     double bound = std::max(al, 1.0 - al) + 0.07;
-    auto scale_for = [&](int m) {
-        const double growth = al < 1.0 ? (1.0 - std::pow(al, m)) / (1.0 - al) : (double)m;
+    // growth of a stage's iterate over its right-hand side; an accelerated 3-sweep stage: |c_2| <= w2 (a + 1),
+    // |c_3| <= w3 a w2 (a + 1) + 1
+    auto growth_of = [&](int si) {
+        const int m = plan[si];
+        double growth = al < 1.0 ? (1.0 - std::pow(al, m)) / (1.0 - al) : (double)m;
+        if (kind[si]) growth = std::max(w2 * (al + 1.0), w3 * al * w2 * (al + 1.0) + 1.0);
+        return std::max(growth, 1.0);
+    };
+    auto scale_for = [&](int si) {
+        const double growth = growth_of(si);
         int ex = (int)std::floor(std::log2(224.0 / std::max(bound * std::max(growth, 1.0), 1e-18)));   // damping ~ 0: bound -> 0
         ex = std::min(std::max(ex, -60), 60);
         return std::ldexp(1.0f, ex);
     };
+    // max-norm contraction of the true residual over stage si (the static scales rest on it) and the modelled one (when
+    // the 3-byte residual form is precise enough): plain a^m for both; accelerated 7 / T_3(1/a) against 1 / T_3(1/a)
+    static const double accel_norm = [] { const char *v = getenv("HRAG_ACCEL_NORM"); return v ? atof(v) : 0.0; }();   // experiment
+    auto norm_contraction = [&](int si) {
+        if (kind[si] && accel_norm > 0.0) return accel_norm;
+        return kind[si] ? std::min(1.0, 7.0 / cheb_T(plan[si], 1.0 / al)) : std::pow(al, plan[si]);
+    };
+    auto model_contraction = [&](int si) {
+        return kind[si] ? std::max(1.0 / cheb_T(plan[si], 1.0 / al), 1.0 / 16.0) : std::pow(al, plan[si]);
+    };
     int n = 0, c = 0, rt = -1;   // c_0 lives in buffer 0
-    int k_done = 0;              // sweeps completed
+    double shrunk = 1.0;         // modelled size of the residual relative to the start (plain plan: damping^sweeps)
     bool r16 = false;            // the stored residual is in the 3-byte form (rt + fp16 remainder)
-    float cs = kP8C0Scale, cs_next = scale_for(plan[1]);
+    float cs = kP8C0Scale, cs_next = scale_for(1);
     const int n_total = n_stage + e_max;
     for (int si = 0; si < n_total; ++si) {
         const int m = plan[si];
@@ -152,16 +233,20 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
             for (int j = 1; j < m; ++j) {
                 const int dst = c == rt ? (c + 1) % 3 : 3 - c - rt;
                 Ppr8Step st{kP8ModeC, si, c, dst, rt, 0.f, 0.f, 0};
+                st.c_mul = damping; st.r_mul = 1.0f;
+                if (kind[si]) {   // iterate j + 1 of an accelerated stage (m = 3: no history term, see ppr8_plan_accel)
+                    st.c_mul = (float)((j == 1 ? w2 : w3) * al);
+                    st.r_mul = j == 1 ? (float)w2 : 1.0f;
+                }
                 st.gate = stage_gate;
                 p.steps[n++] = st;
                 c = dst;
-                ++k_done;
             }
-            bound *= std::pow(al, m);
-            cs_next = si + 1 < n_total ? scale_for(plan[si + 1]) : 1.0f;
+            bound *= norm_contraction(si);
+            cs_next = si + 1 < n_total ? scale_for(si + 1) : 1.0f;
         }
         p.stage_inv[si] = 1.0f / cs;
-        ++k_done;
+        shrunk *= si == 0 ? al : model_contraction(si);
         if (si >= n_stage - 1) {
             // the stage may be the last one: final sweep variant j (passage rows only) measures the update it applies;
             // decision j follows it (ppr8_decide_kernel): while that update is above the tolerance, the boundary below
@@ -178,10 +263,12 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
             const int y = (rt >= 0 && c != rt) ? rt : (c + 1) % 3;
             // residual form: fp32 while it is large; (rt + fp16 remainder) once damping^k <= 2^-6, where the
             // 2^-15 relative error of that form is below 5e-7 of the solution (ppr8.hip finish_row)
-            const bool out16 = si > 0 && std::pow(al, k_done) <= 1.0 / 64.0;
+            const bool out16 = si > 0 && shrunk <= 1.0 / 64.0;
             const int rio = (r16 ? 1 : 0) | (out16 ? 2 : 0);
             Ppr8Step st{si == 0 ? kP8ModeB0 : kP8ModeB, si, c, y, rt, 1.0f / cs, cs_next, rio};
             if (si >= n_stage - 1) st.gate = si - (n_stage - 1);   // closes a stage that could have been the last
+            // accelerated plan: this boundary's measured maximum fixes the scale of stage si + 2 (if there is one)
+            if (si + 2 < n_total) st.kappa_growth = (float)(norm_contraction(si + 1) * growth_of(si + 2));
             p.steps[n++] = st;
             r16 = out16;
             rt = y;
@@ -203,6 +290,7 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
         // matrix, the row -> teleport-row map and the column bitmap from their static parts
         BlitList z;
         if (est) z.zero(e->d_est_f, (int64_t)batch * sizeof(int32_t));
+        if (accel) z.zero(e->d_mmax_ws, e->mmax_slots * (int64_t)sizeof(float));   // slots a launch geometry never writes stay 0
         z.zero(e->d_ctl, (int64_t)(kP8MaxExt + 1) * sizeof(int32_t));
         z.zero(e->d_tele16 + (size_t)e->p_rows * 64, (int64_t)batch * kMaxSeeds * 64 * sizeof(float), l64.n_slabs,
                (int64_t)e->tele16_rows * 64 * sizeof(float));
@@ -213,6 +301,9 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     HRAG_TRY(launch_ppr16_seed_rows(seed_vtx, seed_w, seed_cnt, e->d_qscale, batch, e->p_rows, e->V, e->d_row_slot,
                                     e->d_tele16, e->tele16_rows, 64, s, e->row_offset, e->n_rows));
     HRAG_TRY(launch_ppr8_mask_seeds(seed_vtx, seed_cnt, batch, e->V, e->d_colmask, s));
+    if (accel)   // the two scales known before anything is measured: c_0's and the first stage's
+        HRAG_TRY(launch_ppr8_next_scale(nullptr, 0, e->d_mmax_word, e->d_dyn, 0, 0.f, 1, kP8C0Scale, p.steps[0].cs_next,
+                                        nullptr, 0, s));
     // ---- c_0 = Q(v/d * 2^7) on the owned rows of every group
     Ppr8Args a = base_args(e);
     a.y = p.buf[0];
@@ -235,9 +326,18 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
     }
     a.x = p.buf[st.x];
     a.inv_cs = st.inv_cs; a.cs_next = st.cs_next;
+    const bool boundary = st.mode == kP8ModeB || st.mode == kP8ModeB0;
+    if (p.accel && st.mode != kP8ModeC) {     // measured stage scales (HRAG_OPT_ACCEL)
+        a.dyn = e->d_dyn; a.dyn_stage = st.stage;
+        if (boundary) {
+            a.mmax_ws = e->d_mmax_ws; a.mmax_atomic = e->d_mmax_word;
+            a.mmax_units = a.n_slabs; a.mmax_slab0 = a.slab0;
+        }
+    }
     if (st.mode == kP8ModeC) {
         a.y = p.buf[st.y];
         a.rt = p.buf[st.rt];
+        a.c_mul = st.c_mul; a.r_mul = st.r_mul;
     } else if (st.mode == kP8ModeB || st.mode == kP8ModeB0) {
         a.y = p.buf[st.y];
         a.rt = st.rt >= 0 ? p.buf[st.rt] : nullptr;
@@ -254,7 +354,11 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
         if (p.want_est) { a.est = e->d_est_f; a.est_ws = e->d_est_ws; }
     }
     if (exchange) *exchange = st.y;
-    return launch_ppr8_sweep(a, st.mode, false, s);
+    HRAG_TRY(launch_ppr8_sweep(a, st.mode, false, s));
+    if (p.accel && boundary && st.kappa_growth > 0.f)   // this boundary's maximum -> the scale of the stage after next
+        HRAG_TRY(launch_ppr8_next_scale(e->d_mmax_ws, (int32_t)std::min<int64_t>(e->mmax_slots, (int64_t)e->sell.n_chunks * a.mmax_units),
+                                        e->d_mmax_word, e->d_dyn, st.stage, st.kappa_growth, 0, 0.f, 0.f, a.gate, a.gate_want, s));
+    return HRAG_OK;
 }
 
 hrag_status ppr8_decide(hrag_engine *e, int32_t i, hipStream_t s) {
@@ -479,8 +583,8 @@ hrag_status hrag_engine_gather_embeddings(hrag_engine *e, int32_t which, const i
 hrag_status hrag_engine_set_flags(hrag_engine *e, int32_t flags, int32_t on) {
     HRAG_REQUIRE(e != nullptr, "engine is NULL");
     const int32_t runtime = HRAG_OPT_NO_FP8 | HRAG_OPT_NT_CSR | HRAG_OPT_NT_STORE | HRAG_OPT_TEMPORAL16 | HRAG_OPT_SLABS_PER_WG_1 |
-                            HRAG_OPT_NO_F16 | HRAG_OPT_XCD_BLOCKED;
-    HRAG_REQUIRE((flags & ~runtime) == 0, "only HRAG_OPT_NO_FP8 / NO_F16 / NT_CSR / NT_STORE / TEMPORAL16 / SLABS_PER_WG_1 can change after creation");
+                            HRAG_OPT_NO_F16 | HRAG_OPT_XCD_BLOCKED | HRAG_OPT_ACCEL;
+    HRAG_REQUIRE((flags & ~runtime) == 0, "only HRAG_OPT_NO_FP8 / NO_F16 / ACCEL / NT_CSR / NT_STORE / TEMPORAL16 / SLABS_PER_WG_1 / XCD_BLOCKED can change after creation");
     if (on) e->opt_flags |= flags; else e->opt_flags &= ~flags;
     return HRAG_OK;
 }

@@ -31,6 +31,7 @@ from __future__ import annotations
 
 import json
 import os
+import sys
 import time
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -757,7 +758,23 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
         from .launch import free_port
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # RCCL prints its version banner on the C-level stdout when the first communicator comes up: send that to stderr so
+    # that the ONE JSON line is the only thing rank 0 ever writes to stdout (an external launcher does not filter)
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.barrier()
+        torch.cuda.synchronize()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    finally:
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     V, E, D, seed = cfg["V"], cfg["E"], cfg["D"], cfg["seed"]
     # per-GPU batch: fixed (weak scaling), or the fixed global batch dealt to the GPUs (strong scaling, configs[3])
     B = args.batch or (cfg["global_batch"] // world if strong else cfg["B"])

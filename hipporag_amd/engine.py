@@ -361,6 +361,16 @@ class HippoRAGEngine:
 
         out = run()
         flags = out.flags.cpu().numpy()
+        if (flags & FLAG_FP8_SATURATED).any() and (self.opt_flags & _lib.OPT_ACCEL):
+            # accelerated stages (HRAG_OPT_ACCEL): a violated scale bound falls back to the plain plan first
+            logger.warning("fp8 PPR state saturated under HRAG_OPT_ACCEL for %d queries: repeating the batch on the plain plan",
+                           int(((flags & FLAG_FP8_SATURATED) != 0).sum()))
+            self.set_flags(_lib.OPT_ACCEL, False)
+            try:
+                out = run()
+            finally:
+                self.set_flags(_lib.OPT_ACCEL, True)
+            flags = out.flags.cpu().numpy()
         if (flags & FLAG_FP8_SATURATED).any():
             logger.warning("fp8 PPR state saturated for %d queries: repeating the batch on the wider state",
                            int(((flags & FLAG_FP8_SATURATED) != 0).sum()))

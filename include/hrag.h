@@ -152,6 +152,25 @@ typedef struct hrag_fact_desc {
                                       /* eighth chunk group): with hrag_opts.sell_sigma on a graph with locality the rows     */
                                       /* that share in-neighbours then meet in ONE L2                                          */
 
+#define HRAG_OPT_ACCEL 4096           /* sweep-count acceleration of the fp8-state PPR on an UNDIRECTED graph (HippoRAG's:    */
+                                      /* is_directed_graph = False, config_utils.py:176): the stages run three Chebyshev      */
+                                      /* steps on the real spectrum [-damping, damping] of the sweep operator instead of      */
+                                      /* three Richardson sweeps (csrc/shard.hip ppr8_plan_accel).  `ppr_iters` then names an */
+                                      /* ACCURACY -- the truncation error of that many plain sweeps -- and fewer sweeps run   */
+                                      /* (damping 0.5, ppr_iters 20: 16; with ppr_tol > 0: 17, the last one plain so that the */
+                                      /* convergence measure reads what it reads without the flag; iters_out reports them).   */
+                                      /* The reference's PRPACK solve is tolerance-driven (HippoRAG.py:1736-1743): any sweep  */
+                                      /* count that meets the tolerance is the same answer.  Guarantees: the static e4m3      */
+                                      /* scales rest on the max-norm bound of the Chebyshev polynomial (no saturation by      */
+                                      /* construction; HRAG_FLAG_FP8_SATURATED would still report a violation -- clear the    */
+                                      /* flag and repeat); every boundary forms the TRUE residual, so refinement stays exact  */
+                                      /* and the extension stages of the contract (plain) apply unchanged.  With ppr_tol = 0  */
+                                      /* the accuracy is that of ppr_iters plain sweeps on well-mixing graphs (cfg 3: 4.4e-7  */
+                                      /* against 5.5e-7) and up to 3x their truncation error on small hub-heavy ones: use the */
+                                      /* contract where a bound is needed.  Off by default: ppr_iters is then the literal     */
+                                      /* sweep count (BASELINE.json's 20).  Runtime-switchable.  No effect on the other state */
+                                      /* types (batch <= 64)                                                                  */
+
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */
     int32_t max_topk;     /* largest k_p (retrieval_top_k); <= 2048                              */

@@ -153,6 +153,10 @@ struct Ppr16Args {
     int32_t *est = nullptr;
     float *est_ws = nullptr;   // scratch [n_slabs][n_chunks][64]: every wavefront's maximum (reduced by launch_est_reduce)
     int32_t batch = 0;
+    // HRAG_OPT_ACCEL, modes H / C: the sweep is a Chebyshev step y = omega (plain result) + (1 - omega) prev, prev = the
+    // iterate before x (own row; may alias y: a row is read before it is written, by its one owner; nullptr: zero)
+    float omega = 1.f;
+    const uint16_t *prev = nullptr;
 };
 // nt: bit0 non-temporal (col, val) loads, bit1 non-temporal state stores
 hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, int nt, bool main_only,
@@ -326,6 +330,9 @@ struct PprSvArgs {
     int32_t *est = nullptr;
     float *est_ws = nullptr;   // scratch [n_chunks][BP]: every wavefront's maximum (reduced by launch_est_reduce)
     int32_t batch = 0;
+    // HRAG_OPT_ACCEL, fp16 state, modes plain (H) / correction: Chebyshev step, see Ppr16Args
+    float omega = 1.f;
+    const uint16_t *prev = nullptr;
 };
 hrag_status launch_ppr_sv_sweep(const PprSvArgs &a, int bp, bool main_only, hipStream_t s);
 hrag_status launch_ppr_sv_init(const PprSvArgs &a, int bp, hipStream_t s);

@@ -271,19 +271,61 @@ Ppr16Args ppr16_args(const hrag_engine *e, const uint16_t *x, uint16_t *y, const
     return a;
 }
 
+// HRAG_OPT_ACCEL on the two-stage fp16 states (ppr16.hip, ppr_sv.hip).  Both stages solve (I - G) y = rhs, G = a P, and
+// on an undirected graph the spectrum of G is real, inside [-a, a]: the sweeps of a stage become Chebyshev steps
+//     y_1 = G y_0 + rhs,   y_{k+1} = w_{k+1} (G y_k + rhs - y_{k-1}) + y_{k-1},   w_2 = 1 / (1 - a^2 / 2), w_{k+1} = 1 / (1 - a^2 w_k / 4)
+// (y_{k+1} overwrites y_{k-1}: the ping-pong buffers are the history).  Stage 1: K1 steps on h from h_0 = v; the residual
+// sweep is step 1 of stage 2 (c_0 = 0, c_1 = r); K2 more steps on c; then ONE plain correction sweep and the plain final
+// sweep over the passage rows, so that (i) the mass of the result is the closed form of the plain iteration (the error
+// polynomial vanishes at 0) and (ii) the convergence measure reads the update of a plain sweep that FOLLOWS a plain
+// sweep -- the quantity it reads without the flag (csrc/shard.hip ppr8_plan_accel on why).  Error bound of the plan:
+// 1 / (T_K1(1/a) T_{K2+1}(1/a)) a^2, each Chebyshev factor capped at 2^11 (the fp16 rounding of the stage's iterate);
+// the smallest K1 + K2 that reaches a^iters / 4 is taken: a = 0.5, iters = 20 -> K1 = 6, K2 = 5, 14 sweeps.  Only with
+// ppr_tol = 0 (`ppr_iters` names an accuracy): these states do not extend on the device, and a tolerance-driven caller is
+// better served by the plain plan, which converges faster than its bound where the graph mixes well.
+static double accel_omega(int k, double rho) {    // w_k of the recurrence above
+    double w = 1.0;
+    for (int j = 2; j <= k; ++j) w = j == 2 ? 1.0 / (1.0 - rho * rho / 2.0) : 1.0 / (1.0 - rho * rho * w / 4.0);
+    return w;
+}
+static bool accel_plan16(int iters, float damping, int *k1_out, int *k2_out) {
+    const double al = (double)damping;
+    if (!(al >= 0.2) || al >= 1.0 || iters < 16) return false;
+    // x4: the plain iteration beats its own bound a^iters on well-mixing graphs (16k-vertex test graphs: 2e-7 after 20
+    // sweeps, bound 9.5e-7) while a Chebyshev plan sits ON its bound (equi-oscillation); the margin keeps the accelerated
+    // result within ~5x of the plain one there (measured 1.1e-6 .. 5e-6 without it)
+    const double target = 4.0 * std::pow(al, -(double)iters), cap = 2048.0;
+    int best = iters, bk1 = 0, bk2 = 0;
+    for (int k1 = 3; k1 <= 14; ++k1)
+        for (int k2 = 2; k2 <= 14; ++k2) {
+            const double f = std::min(cheb_T(k1, 1.0 / al), cap) * std::min(cheb_T(k2 + 1, 1.0 / al), cap) / (al * al);
+            const int total = k1 + 1 + k2 + 2;
+            if (f >= target && total < best) { best = total; bk1 = k1; bk2 = k2; }
+        }
+    if (best >= iters) return false;
+    *k1_out = bk1; *k2_out = bk2;
+    return true;
+}
+
 // h_0 = f16(v); K1 sweeps on h (the first one gathers only the columns where h_0 is non-zero: d_colmask); the
 // residual sweep; K2 sweeps on the correction, the last of them over the passage rows only (fsell), writing
 // x = h + c / cs in fp32 at the passages (d_xp8, passage order) -- nothing else is read afterwards
 // (HippoRAG.py:1745).  Buffers: d_h16[0], [1] ping-pong for h; [2] = r; the free h buffer and [3] ping-pong for c.
-hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipStream_t s, int32_t *est = nullptr) {
+// *sweeps_out: the sweeps that ran (HRAG_OPT_ACCEL: fewer than `iters`, which then names the accuracy)
+hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipStream_t s, int32_t *est = nullptr,
+                      int *sweeps_out = nullptr, bool allow_accel = false) {
     const int ns = n_slabs64(batch);
     const int nt = (e->opt_flags & HRAG_OPT_TEMPORAL16) ? 0 : 3;
-    const int k1 = iters / 2, k2 = iters - k1 - 1;
+    int k1 = iters / 2, k2 = iters - k1 - 1, kc = 0;   // kc: Chebyshev steps among the k2 correction sweeps
+    const bool accel = allow_accel && (e->opt_flags & HRAG_OPT_ACCEL) && accel_plan16(iters, damping, &k1, &kc);
+    if (accel) k2 = kc + 2;                            // + one plain correction sweep + the final sweep
+    if (sweeps_out) *sweeps_out = k1 + 1 + k2;
     uint16_t *h = e->d_h16[0], *hn = e->d_h16[1], *r = e->d_h16[2];
     HRAG_TRY(launch_ppr16_init(ppr16_args(e, nullptr, h, nullptr, damping), ns, s));
     for (int it = 0; it < k1; ++it) {
         Ppr16Args a = ppr16_args(e, h, hn, nullptr, damping);
         if (it == 0) { a.colmask = e->d_colmask; a.colmask_bytes = (uint32_t)(e->colmask_words * 4); }
+        if (accel && it > 0) { a.omega = (float)accel_omega(it + 1, damping); a.prev = hn; }   // h_{it+1} over h_{it-1}
         HRAG_TRY(launch_ppr16_sweep(a, kPprModeH, ns, nt, false, s));
         std::swap(h, hn);
     }
@@ -293,6 +335,10 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
     for (int it = 0; it < k2; ++it) {
         const bool last = it + 1 == k2;
         Ppr16Args a = ppr16_args(e, c, cn, r, damping);
+        if (accel && it < kc) {       // step it + 2 of stage 2: c_0 = 0 (no history), c_1 = r, then the ping-pong buffers
+            a.omega = (float)accel_omega(it + 2, damping);
+            a.prev = it == 0 ? nullptr : it == 1 ? r : cn;
+        }
         if (last) {
             const Sell8Store &m = e->fsell;
             a.pairs = m.pairs; a.pairs_bytes = m.pairs_bytes(); a.chunk_meta = m.chunk_meta; a.vrow = m.vrow;
@@ -353,7 +399,9 @@ hrag_status ppr_sv_run_full(hrag_engine *e, const int32_t *row_slot, const float
 // (d_colmask), the last one runs over the passage rows only and leaves x (fp32 [V][bp], passage rows valid) in
 // e->d_x; with >= 16 sweeps the state in between is the two-stage fp16 one (v must carry the per-query scale).
 hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tele, int bp, float damping,
-                       int iters, hipStream_t s, int32_t *est = nullptr, int batch = 0) {
+                       int iters, hipStream_t s, int32_t *est = nullptr, int batch = 0, int *sweeps_out = nullptr,
+                       bool allow_accel = false) {
+    if (sweeps_out) *sweeps_out = iters;
     if (iters < 1) return ppr_sv_run_full(e, row_slot, tele, bp, damping, iters, s);
     if (!use_sv_half(e, iters)) {
         float *x = e->d_x, *y = e->d_y;
@@ -368,7 +416,10 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
         if (x != e->d_x) std::swap(e->d_x, e->d_y);
         return HRAG_OK;
     }
-    const int k1 = iters / 2, k2 = iters - k1 - 1;
+    int k1 = iters / 2, k2 = iters - k1 - 1, kc = 0;   // the plan of ppr16_run, Chebyshev steps included (accel_plan16)
+    const bool accel = allow_accel && (e->opt_flags & HRAG_OPT_ACCEL) && accel_plan16(iters, damping, &k1, &kc);
+    if (accel) k2 = kc + 2;
+    if (sweeps_out) *sweeps_out = k1 + 1 + k2;
     uint16_t *h = e->d_sv16[0], *hn = e->d_sv16[1], *r = e->d_sv16[2];
     {
         PprSvArgs a = ppr_sv_args(e, e->sell, nullptr, h, row_slot, tele, damping);
@@ -378,6 +429,7 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
     for (int it = 0; it < k1; ++it) {
         PprSvArgs a = ppr_sv_args(e, e->sell, h, hn, row_slot, tele, damping);
         a.half_state = 1; a.mode = 0; a.colmask = it == 0 ? e->d_colmask : nullptr;
+        if (accel && it > 0) { a.omega = (float)accel_omega(it + 1, damping); a.prev = hn; }
         HRAG_TRY(launch_ppr_sv_sweep(a, bp, false, s));
         std::swap(h, hn);
     }
@@ -393,6 +445,10 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
         PprSvArgs a = ppr_sv_args(e, last ? e->fsell : e->sell, c, cn, row_slot, tele, damping);
         a.half_state = 1; a.mode = last ? 3 : 2; a.aux16 = r; a.cscale = kPpr16CScale;
         a.h16 = h; a.xout = e->d_x;
+        if (accel && j < kc) {
+            a.omega = (float)accel_omega(j + 2, damping);
+            a.prev = j == 0 ? nullptr : j == 1 ? r : cn;
+        }
         if (last) { a.est = est; a.est_ws = e->d_est_ws; a.batch = batch; }
         HRAG_TRY(launch_ppr_sv_sweep(a, bp, false, s));
         c = cn;
@@ -994,6 +1050,7 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
 
     // convergence contract on the fp16 / small-batch / fp32 states: the fixed count runs, the last sweep measures the
     // relative update of the passage scores (residual_out, flags bit 4); only the fp8 state extends on the device
+    int sweeps_run = ppr_iters;   // fp16 states under HRAG_OPT_ACCEL: fewer (ppr_iters then names the accuracy)
     const bool want_est = residual_out != nullptr || ppr_tol > 0.f;
     int32_t *est = (want_est && !f8 && ppr_iters >= 1) ? e->d_est_f : nullptr;
     {
@@ -1090,9 +1147,9 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
             HRAG_TRY(ppr8_decide(e, it, s));
         }
     } else if (f16) {
-        HRAG_TRY(ppr16_run(e, batch, damping, ppr_iters, s, est));
+        HRAG_TRY(ppr16_run(e, batch, damping, ppr_iters, s, est, &sweeps_run, ppr_tol == 0.f));
     } else if (sv) {
-        HRAG_TRY(ppr_sv_run(e, e->d_row_slot, e->d_tele_sv, bp, damping, ppr_iters, s, est, batch));
+        HRAG_TRY(ppr_sv_run(e, e->d_row_slot, e->d_tele_sv, bp, damping, ppr_iters, s, est, batch, &sweeps_run, ppr_tol == 0.f));
     } else {
         float *x = e->d_x, *y = e->d_y;
         HRAG_TRY(ppr_init(e, e->d_tele, e->n_passages, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w,
@@ -1135,7 +1192,7 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
                              doc_score_out, nullptr, nullptr, s, e->d_topk_ws, kTopkWsBytes));
     const bool measured = f8 || est != nullptr;
     if (!f8 && est)
-        HRAG_TRY(launch_ppr8_finalize(est, e->d_flags, batch, damping / (1.0f - damping), ppr_tol, ppr_iters, e->d_ctl,
+        HRAG_TRY(launch_ppr8_finalize(est, e->d_flags, batch, damping / (1.0f - damping), ppr_tol, sweeps_run, e->d_ctl,
                                       0, nullptr, 0, e->d_sums, e->d_resid, e->d_iters_used, s));
     {
         BlitList out;   // the per-query results in one launch
@@ -1148,7 +1205,7 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
     }
     if (!measured) {   // no sweep measured anything (ppr_iters == 0, or nothing asked for): -1 / the count as given
         if (residual_out) HRAG_TRY(launch_fill_i32(reinterpret_cast<int32_t *>(residual_out), (int32_t)0xbf800000u, batch, s));
-        if (iters_out) HRAG_TRY(launch_fill_i32(iters_out, ppr_iters, batch, s));
+        if (iters_out) HRAG_TRY(launch_fill_i32(iters_out, sweeps_run, batch, s));
     }
     if (prof) {
         HRAG_HIP_TRY(hipEventRecord(e->ev[EV_RANK], s));

@@ -290,6 +290,7 @@ int ppr8_plan(int iters, int *plan);
 // then reads a plain sweep's update) standing for the accuracy of `iters` plain sweeps; kind[i] = 1 marks a stage whose
 // sweeps are Chebyshev steps.  Returns the number of stages, 0 when the variant saves no sweep
 int ppr8_plan_accel(int iters, float damping, bool measured, int *plan, int *kind);
+double cheb_T(int m, double x);   // Chebyshev polynomial T_m(x), x >= 1
 // layout of the state buffers for `batch` queries in `want_groups` exchange groups (0 = the narrowest groups: slab
 // pairs; the group width is kept even, see hrag.h)
 hrag_status ppr8_layout(const hrag_engine *e, int32_t batch, int32_t want_groups, hrag_shard_layout *out);

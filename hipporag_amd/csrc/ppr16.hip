@@ -133,6 +133,7 @@ struct RowIn {
     f32x4_t t0, t1;     // H, R: teleport row (zero without one)
     half8_t h;          // R: a.x own row; F: a.hfin own row
     half8_t r;          // C, F: a.aux own row
+    half8_t p;          // H, C with a.prev: the iterate before x, own row (Chebyshev step)
     int slot;           // F: passage number
 };
 template <int MODE>
@@ -140,6 +141,10 @@ __device__ __forceinline__ void load_row_in(const Ppr16Args &a, int slab, int ro
     const size_t state_off = ((size_t)slab * a.num_vertices + (size_t)row) * 64 + (size_t)gl * 8;
     in.t0 = in.t1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
     in.slot = -1;
+    if constexpr (MODE == kPprModeH || MODE == kPprModeC) {
+        in.p = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        if (a.prev) in.p = *reinterpret_cast<const half8_t *>(a.prev + state_off);   // wave-uniform branch
+    }
     if constexpr (MODE == kPprModeH || MODE == kPprModeR) {
         const int slot = a.row_slot[row];
         if (slot >= 0) {
@@ -196,6 +201,13 @@ __device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row
                     er[j] = xs[j] > 0.f ? fabsf(out[j] - (float)cold[j]) * ics / xs[j] : 0.f;
             }
             return;
+        }
+    }
+    if constexpr (MODE == kPprModeH || MODE == kPprModeC) {
+        if (a.omega != 1.f) {   // wave-uniform: Chebyshev step (HRAG_OPT_ACCEL), omega (plain result - prev) + prev
+            const float om = a.omega, om1 = 1.f - a.omega;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] = fmaf(om, out[j], om1 * (float)in.p[j]);
         }
     }
     half8_t o;

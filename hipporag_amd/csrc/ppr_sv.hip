@@ -102,6 +102,10 @@ __device__ __forceinline__ float sv_finish(const PprSvArgs &a, int row, int gl, 
         if (slot >= 0) t = a.tele[(size_t)slot * BP + gl];
         float out = fmaf(a.alpha, sum, a.beta * t);
         if constexpr (MODE == kSvResid) out = (out - (float)static_cast<const T *>(a.x)[at]) * a.cscale;
+        if constexpr (MODE == kSvPlain && sizeof(T) == 2) {
+            if (a.omega != 1.f)   // Chebyshev step (HRAG_OPT_ACCEL): omega (plain result - prev) + prev
+                out = fmaf(a.omega, out, (1.f - a.omega) * (a.prev ? (float)reinterpret_cast<const _Float16 *>(a.prev)[at] : 0.f));
+        }
         if constexpr (MODE == kSvPlain && sizeof(T) == 4) {
             if (a.est && gl < a.batch)    // last sweep of the fp32 state: relative size of the update
                 er = out > 0.f ? fabsf(out - static_cast<const float *>(a.x)[at]) / out : 0.f;
@@ -109,8 +113,10 @@ __device__ __forceinline__ float sv_finish(const PprSvArgs &a, int row, int gl, 
         if constexpr (sizeof(T) == 2) static_cast<_Float16 *>(a.y)[at] = to_half(out);
         else static_cast<float *>(a.y)[at] = out;
     } else {
-        const float c = fmaf(a.alpha, sum, (float)reinterpret_cast<const _Float16 *>(a.aux16)[at]);
+        float c = fmaf(a.alpha, sum, (float)reinterpret_cast<const _Float16 *>(a.aux16)[at]);
         if constexpr (MODE == kSvCorr) {
+            if (a.omega != 1.f)
+                c = fmaf(a.omega, c, (1.f - a.omega) * (a.prev ? (float)reinterpret_cast<const _Float16 *>(a.prev)[at] : 0.f));
             static_cast<_Float16 *>(a.y)[at] = to_half(c);
         } else {
             const float x = fmaf(c, 1.0f / a.cscale, (float)reinterpret_cast<const _Float16 *>(a.h16)[at]);

@@ -43,17 +43,22 @@ int ppr8_plan(int iters, int *plan) {
 //   * Mass.  T_3 is odd, so the error polynomial of every stage vanishes at 0 like the plain one: the mass of the
 //     result is M - a S from the first sweep on, whatever the polynomial (ppr8_scale_kernel's closed form holds).
 //   * Scales.  A Chebyshev residual polynomial is NOT a contraction by 1/T_3 in the max norm: p_3(G) = (4 G^3 / a^3 -
-//     3 G / a) / T_3(1/a) has max-norm <= 7 / T_3(1/a) (0.27 at a = 0.5, against the spectral 0.038).  The static
-//     power-of-two stage scales are built on THAT bound (ppr8_begin), so the e4m3 range cannot be left on any graph for the
-//     same reason as on the plain plan; values sit lower in the range than they need to on well-mixing graphs (a factor
-//     ~2.5 per stage: 2 of e4m3's 15 binades after five stages).
+//     3 G / a) / T_3(1/a) has max-norm <= 7 / T_3(1/a) (0.27 at a = 0.5, against the spectral 0.038).  A STATIC chain of
+//     scales cannot serve both: built on the spectral factor it leaves the e4m3 range on ring / star / barbell graphs
+//     (round 3), built on the max-norm bound the values sink ~2.5x per stage below where e4m3 resolves them (measured at
+//     cfg 3: 1.8e-6 instead of 4.3e-7, 26 sweeps under the contract).  The accelerated plan therefore MEASURES: every
+//     boundary reports the batch's max |R| (one float per wavefront + a 1-block reduction, ~5 us), and the scale of the
+//     stage after next is the power of two that maps (max-norm contraction of the next stage) x (that maximum) x (growth
+//     of the iterate) to half the range -- rigorous like the static chain, but re-anchored at every stage
+//     (ppr8.hip ppr8_next_scale_kernel).  Measured: cfg 3 4.3e-7 = the plain plan's error, 16k-vertex graphs 2.2e-7 ..
+//     2.4e-7 (plain: 2.2e-7), the adversarial suite without a single saturated value.
 //   * Convergence measure.  The contract's measure is the size of the update a PLAIN sweep applies: after Chebyshev
 //     stages the true residual is spread over the whole spectrum (equi-oscillation) and its mid-spectrum part, which the
 //     next plain sweep annihilates, makes the measure read 60x the true error (cfg 3, round 3).  With `measured` the plan
 //     therefore ends on a plain stage of ONE sweep (its boundary + the passage-row final sweep: the measure then reads
 //     what is left after a plain sweep, the quantity the a-posteriori bound a / (1 - a) |update| is about), and the
 //     extension stages are plain.
-static double cheb_T(int m, double x) {          // Chebyshev polynomial T_m(x), x >= 1
+double cheb_T(int m, double x) {                 // Chebyshev polynomial T_m(x), x >= 1
     double t0 = 1.0, t1 = x;
     if (m == 0) return 1.0;
     for (int k = 1; k < m; ++k) { const double t2 = 2.0 * x * t1 - t0; t0 = t1; t1 = t2; }
@@ -65,8 +70,7 @@ int ppr8_plan_accel(int iters, float damping, bool measured, int *plan, int *kin
     const double al = (double)damping;
     if (!(al >= 0.2) || al >= 1.0 || iters < 8) return 0;   // small damping: the plain stages sit on the floor already
     const double k3 = std::max(1.0 / cheb_T(3, 1.0 / al), kAccelFloor);
-    int n3 = (int)std::ceil((double)(iters - 1) * std::log(1.0 / al) / std::log(1.0 / k3) - 1e-9);
-    { const char *v = getenv("HRAG_ACCEL_N3"); if (v && atoi(v) > 0) n3 = atoi(v); }   // experiment
+    const int n3 = (int)std::ceil((double)(iters - 1) * std::log(1.0 / al) / std::log(1.0 / k3) - 1e-9);
     const int total = 1 + 3 * n3 + (measured ? 1 : 0);
     if (n3 < 2 || total >= iters || n3 + 1 + (measured ? 1 : 0) > kP8MaxStages) return 0;
     int n = 0;
@@ -210,9 +214,7 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     };
     // max-norm contraction of the true residual over stage si (the static scales rest on it) and the modelled one (when
     // the 3-byte residual form is precise enough): plain a^m for both; accelerated 7 / T_3(1/a) against 1 / T_3(1/a)
-    static const double accel_norm = [] { const char *v = getenv("HRAG_ACCEL_NORM"); return v ? atof(v) : 0.0; }();   // experiment
     auto norm_contraction = [&](int si) {
-        if (kind[si] && accel_norm > 0.0) return accel_norm;
         return kind[si] ? std::min(1.0, 7.0 / cheb_T(plan[si], 1.0 / al)) : std::pow(al, plan[si]);
     };
     auto model_contraction = [&](int si) {

@@ -84,10 +84,11 @@ def index_arrays_from_reference(rag) -> dict:
             "subj_vertex": subj, "obj_vertex": obj, "num_chunks": nchunks, "facts": facts}
 
 
-def build_engine_from_reference(rag, *, max_batch: int = 256, embedding_precision: str = "f32"):
+def build_engine_from_reference(rag, *, max_batch: int = 256, embedding_precision: str = "f32", accel: bool = True):
     """Device index from the reference object's host state (prepare_retrieval_objects must have run).
     embedding_precision "f32" (default): the reference's fp32 matrices as they are (HippoRAG.py:1342-1345) on the
     fp32-faithful engine (HRAG_F32_SPLIT); "bf16": rounded to bf16, a third of the embedding stream."""
+    from . import _lib
     from .engine import HippoRAGEngine
     a = index_arrays_from_reference(rag)
     facts = a["facts"]
@@ -102,6 +103,7 @@ def build_engine_from_reference(rag, *, max_batch: int = 256, embedding_precisio
                          conv(a["fact_emb"]) if has_facts else None,
                          a["subj_vertex"] if has_facts else None, a["obj_vertex"] if has_facts else None,
                          a["num_chunks"] if has_facts else None, max_batch=max_batch, locality="auto",
+                         flags=_lib.OPT_ACCEL if accel else 0,   # Chebyshev steps in the fp8 stages (undirected graph: :236)
                          max_topk=int(min(2048, max(1, min(cfg.retrieval_top_k, len(pv))))))
     return eng, facts
 

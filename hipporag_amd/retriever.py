@@ -149,6 +149,11 @@ class RetrievalConfig:
     ppr_tol: float = 1.5e-6
     ppr_max_iters: int = 400             # bound on the sweeps a slowly mixing graph may cost (fp8 state: 30, then
                                          # the flagged queries are repeated on the wider state)
+    ppr_accel: bool = True               # HRAG_OPT_ACCEL (include/hrag.h): wide batches (> 64 queries) run Chebyshev steps
+                                         # inside the fp8 stages -- 17 sweeps + what the measured residual asks for
+                                         # instead of 20 + ...; the answer is tolerance-driven either way, like the
+                                         # reference's PRPACK solve (HippoRAG.py:1736-1743).  HippoRAG graphs are
+                                         # undirected (config_utils.py:176), which is what the polynomial needs
     max_batch: int = 256
     slab_width: int = 0
 
@@ -474,6 +479,7 @@ class HippoRAG:
         """Stage the index on the device.  After an incremental index() / delete() the embedding rows the old
         engine already holds are gathered device-side into the new matrices (hrag_engine_gather_embeddings):
         only the rows that are new cross PCIe, the graph (CSR -> SELL-8) is recompiled from the edge list."""
+        from . import _lib
         from .engine import HippoRAGEngine
         if self._arrays is None:
             raise RuntimeError("nothing indexed yet")
@@ -511,7 +517,8 @@ class HippoRAG:
                                   max_batch=self.global_config.max_batch,
                                   max_topk=min(2048, max(self.global_config.retrieval_top_k, 1)),
                                   slab_width=self.global_config.slab_width,
-                                  flags=0, locality=self.global_config.locality)
+                                  flags=_lib.OPT_ACCEL if self.global_config.ppr_accel else 0,
+                                  locality=self.global_config.locality)
         try:
             engine = build(pe, fe)
         except Exception as exc:

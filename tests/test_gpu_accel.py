@@ -120,3 +120,63 @@ def test_accelerated_valid_inputs_never_saturate_and_small_damping_keeps_the_pla
             assert eng.timings()["slab_width"] == 128 and np.all(out.flags.cpu().numpy() == 0), damping
             assert int(out.iters_used.min()) == int(out.iters_used.max()) == accel_sweeps(iters, damping), damping
     assert accel_sweeps(16, 0.3) == 16 and accel_sweeps(28, 0.6) == 19
+
+
+@pytest.mark.parametrize("b", [1, 4, 8, 40, 64])
+def test_accelerated_fp16_states_fourteen_sweeps_stand_for_twenty(gpu_device, b):
+    """HRAG_OPT_ACCEL on the two-stage fp16 states (B <= 8: ppr_sv.hip; 9 .. 64: ppr16.hip): Chebyshev steps in both
+    stages, then a plain correction sweep and the plain final sweep (csrc/engine.hip accel_plan16): 14 sweeps for the
+    accuracy of 20 plain ones at damping 0.5 -- with ppr_tol = 0 only: under a tolerance these states keep the plain
+    plan (they do not extend on the device, and the plain iteration beats its bound where the graph mixes well).  Same
+    bars as the plain path; the flag is a runtime switch; the measure still reads a plain sweep's update."""
+    import torch
+    from hipporag_amd._lib import OPT_ACCEL
+    from hipporag_amd.engine import HippoRAGEngine
+    from tests.helpers import make_case
+    kg, pass_bits, fact_bits, index = make_case(16000, 160000, 64, seed=77, power_law=(b % 2 == 0))
+    n_p = kg.n_passages
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=5)
+    qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=6)
+    got = {}
+    with HippoRAGEngine(kg.csr, kg.passage_vertex, pass_bits, fact_bits, kg.subj_vertex, kg.obj_vertex, kg.num_chunks,
+                        max_batch=b, max_topk=n_p) as eng:
+        idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
+        cnt = _t(np.full(b, 5, np.int32), gpu_device)
+        for acc in (False, True, False):
+            eng.set_flags(OPT_ACCEL, acc)
+            out = eng.retrieve(_bf16(qp_bits, gpu_device), idx, sc, cnt, ppr_iters=20, k=n_p)
+            torch.cuda.synchronize()
+            assert eng.timings()["slab_width"] != 128      # an fp16 state served the call
+            used, flags = out.iters_used.cpu().numpy(), out.flags.cpu().numpy()
+            assert np.all(flags == 0), np.unique(flags)
+            assert np.all(used == (14 if acc else 20)), used
+            res = (out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy(), out.residual.cpu().numpy())
+            if acc in got:
+                assert all(np.array_equal(x, y) for x, y in zip(got[acc], res))
+            got[acc] = res
+        eng.set_flags(OPT_ACCEL, True)
+        tol_used = int(eng.retrieve(_bf16(qp_bits, gpu_device), idx, sc, cnt, ppr_iters=20, k=n_p, ppr_tol=1.5e-6,
+                                    ppr_max_iters=30).iters_used.max())
+    qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+    worst = {False: 0.0, True: 0.0}
+    under = 0.0
+    for q in range(0, b, max(1, b // 8)):
+        want = oracle.retrieve_one(index, qf[q], qp[q]).x[index.passage_vertex]
+        allow = prior_noise_allowance(index, qp[q])
+        nz = want > 0
+        for acc, (ids, scs, res) in got.items():
+            full = np.empty(n_p)
+            full[ids[q]] = scs[q]
+            e = float((np.abs(full[nz] / want[nz] - 1) - allow[nz]).max())
+            worst[acc] = max(worst[acc], e)
+            if acc:
+                under = max(under, e / max(float(res[q]), 1e-30))
+    write_test_report(f"accel_fp16_state_b{b}", {"worst_rel_err_plain20": worst[False], "worst_rel_err_accel14": worst[True],
+                                                  "residual_max_plain20": float(got[False][2].max()),
+                                                  "residual_max_accel14": float(got[True][2].max()),
+                                                  "max_true_error_over_reported_residual_accel": under})
+    assert worst[False] < 1e-5 and worst[True] < 1e-5, worst
+    assert worst[True] < 3e-6, worst                           # well inside the bar (the plain plan beats its bound here)
+    assert float(got[True][2].max()) < 2e-5                    # the measure stays a plain sweep's update: no 60x over-read
+    # under a tolerance the flag changes nothing on these states
+    assert tol_used == 20

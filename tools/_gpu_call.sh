@@ -1,4 +1,5 @@
-set -x
-mkdir -p gpurun_out/r04g
-python -m pytest tests/test_gpu_accel.py -m gpu -q 2>&1 | tail -40 > gpurun_out/r04g/tests_accel.log
-tail -n 30 gpurun_out/r04g/tests_accel.log
+mkdir -p gpurun_out/r04i
+for args in "1048576 20 0 8 1 32768" "1048576 20 0 8 0 32768" "1048576 20 64 16 1 32768" "1048576 20 0 4 1 32768"; do
+timeout 300 tools/_bin/spmv_lds_bench $args >> gpurun_out/r04i/spmv_lds2.txt 2>&1
+done
+cat gpurun_out/r04i/spmv_lds2.txt

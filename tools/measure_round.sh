@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 3 measurement pass: whole GPU suite, the bench line of every configuration (CPU baselines included), small-batch
-# latencies, rocprofv3 kernel stats + PMC passes of the cfg 3 command
+# measurement pass of a round: whole GPU suite, the bench line of every configuration (CPU baselines included), the
+# N > 1 code path on one GPU (world 1), small-batch latencies, rocprofv3 kernel stats + PMC passes of the cfg 3 command
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03z}
+TAG=${1:-r04z}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$REPO"
@@ -15,6 +15,8 @@ for CFG in cfg1s cfg2; do
   timeout 600 python bench.py --config $CFG --steps 50 --warmup 5 --cpu-queries 16 > "$OUT/bench_$CFG.json" 2> "$OUT/bench_$CFG.err"
   tail -c 200 "$OUT/bench_$CFG.json"; echo
 done
+HRAG_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_dist_world1.json" 2> "$OUT/bench_dist_world1.err"
+HRAG_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --config cfg4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_cfg4_world1.json" 2> "$OUT/bench_cfg4_world1.err"
 timeout 600 python tools/sweep_smallb.py --batches 1,2,4,8,16,32 --out "$OUT/sweep_smallb.json" > "$OUT/sweep_smallb.log" 2> "$OUT/sweep_smallb.err"
 cut -c1-80 "$OUT/sweep_smallb.log"
 bash tools/gpu_profile.sh "$TAG/prof" --steps 5 --warmup 1 > "$OUT/profile.log" 2>&1

@@ -131,6 +131,85 @@ __global__ __launch_bounds__(kThreads) void spmv_lds_kernel(Tiles t, const _Floa
     }
 }
 
+// v2: the block image is double-buffered (2 x kCB2 columns) and the copy of block p + 1 AND the first entries of phase
+// p + 1 are in flight while phase p is processed: one barrier per phase, no exposed HBM latency in the steady state.
+constexpr int kCB2 = 32768;
+template <int UNROLL>
+__global__ __launch_bounds__(kThreads) void spmv_lds2_kernel(Tiles t, const _Float16 *__restrict__ x, _Float16 *__restrict__ y,
+                                                             const float *__restrict__ tele, float alpha, float beta, int rotate) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16 *xs = reinterpret_cast<_Float16 *>(smem);                       // [2][kCB2]
+    float *yacc = reinterpret_cast<float *>(smem + (size_t)kCB2 * 2 * 2);
+    const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < kYMax; i += kThreads) yacc[i] = 0.f;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int2 *>(t.stream), 0, (int)t.stream_bytes, 0x00020000);
+    const uint32_t xs_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)xs;
+    const int np = t.n_phase;
+    auto phase_of = [&](int pp) { return rotate ? (pp + wg) % np : pp; };
+    auto copy_block = [&](int ph, int buf) {
+        const char *src = reinterpret_cast<const char *>(x) + (size_t)ph * kCB2 * 2;
+#pragma unroll
+        for (int i = 0; i < (kCB2 * 2) / (kThreads * 16); ++i) {
+            const int chunk = i * kWaves + wave;   // 1 KB per wavefront instruction
+            lds_dma16(__builtin_amdgcn_readfirstlane(xs_addr + (uint32_t)buf * (kCB2 * 2) + (uint32_t)chunk * 1024u),
+                      src + (size_t)chunk * 1024 + lane * 16);
+        }
+    };
+    const unsigned voff = (unsigned)lane * 8u;
+    int2 m = t.meta[((size_t)wg * np + phase_of(0)) * kWaves + wave];
+    v2i_t e[UNROLL];
+    copy_block(phase_of(0), 0);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) e[u] = __builtin_amdgcn_raw_buffer_load_b64(srs, voff + (unsigned)u * 512u, (unsigned)m.x * 512u, 2);
+    for (int pp = 0; pp < np; ++pp) {
+        const int buf = pp & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this phase's block image and first entries have landed
+        __syncthreads();                                    // ... for everybody; the other buffer is free again
+        int2 mn = make_int2(0, 0);
+        v2i_t en[UNROLL];
+        if (pp + 1 < np) {                                   // next phase: block copy + first entries, in flight from here
+            copy_block(phase_of(pp + 1), buf ^ 1);
+            mn = t.meta[((size_t)wg * np + phase_of(pp + 1)) * kWaves + wave];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) en[u] = __builtin_amdgcn_raw_buffer_load_b64(srs, voff + (unsigned)u * 512u, (unsigned)mn.x * 512u, 2);
+        }
+        const _Float16 *xb = xs + (size_t)buf * kCB2;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (u < m.y && e[u].y != 0) {
+                const unsigned key = (unsigned)e[u].x;
+                const unsigned r = key >> 16;
+                yacc[r] = fmaf(__int_as_float(e[u].y), (float)xb[key & 0xffffu], yacc[r]);
+            }
+        }
+        for (int s0 = UNROLL; s0 < m.y; ++s0) {              // rare: a wavefront with more than UNROLL steps in a phase
+            const v2i_t ex = __builtin_amdgcn_raw_buffer_load_b64(srs, voff + (unsigned)s0 * 512u, (unsigned)m.x * 512u, 2);
+            if (ex.y != 0) {
+                const unsigned key = (unsigned)ex.x;
+                const unsigned r = key >> 16;
+                yacc[r] = fmaf(__int_as_float(ex.y), (float)xb[key & 0xffffu], yacc[r]);
+            }
+        }
+        m = mn;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) e[u] = en[u];
+    }
+    __syncthreads();
+    const int nvt = t.n_vt[wg];
+    for (int i = tid; i < nvt; i += kThreads) {
+        const int32_t *v = t.vt + ((size_t)wg * kVtMax + i) * 3;
+        float a = yacc[v[0]];
+        for (int k = 0; k < v[2]; ++k) a += yacc[v[1] + k];
+        yacc[v[0]] = a;
+    }
+    __syncthreads();
+    const int nr = t.n_real[wg];
+    for (int i = tid; i < nr; i += kThreads) {
+        const int row = t.row_of[(size_t)wg * kYMax + i];
+        y[row] = (_Float16)fmaf(alpha, yacc[i], beta * tele[row]);
+    }
+}
+
 // reference gather kernel from global memory (the structure of csrc/ppr_sv.hip at its simplest: CSR, 8 lanes per row)
 __global__ __launch_bounds__(256) void spmv_ref_kernel(const int *__restrict__ rp, const int *__restrict__ ci, const float *__restrict__ va,
                                                        const _Float16 *__restrict__ x, float *__restrict__ y, int n) {
@@ -148,8 +227,9 @@ int main(int argc, char **argv) {
     const int hubs = argc > 3 ? atoi(argv[3]) : 64;
     const int cap = argc > 4 ? atoi(argv[4]) : 16;
     const int rotate = argc > 5 ? atoi(argv[5]) : 1;
-    if (V % kCB) { fprintf(stderr, "V must be a multiple of %d\n", kCB); return 1; }
-    const int n_phase = V / kCB;
+    const int cb = argc > 6 ? atoi(argv[6]) : kCB;   // columns per block: 65536 (v1 kernels) or 32768 (v2, double-buffered)
+    if (V % cb || (cb != kCB && cb != kCB2)) { fprintf(stderr, "V must be a multiple of the block size %d\n", cb); return 1; }
+    const int n_phase = V / cb;
     std::mt19937_64 rng(12345);
     // ---- graph: Poisson(deg) rows + `hubs` rows of 2000..20000 entries, uniform columns
     std::vector<int> rp(V + 1, 0);
@@ -166,7 +246,7 @@ int main(int argc, char **argv) {
         const float w = 1.0f / (float)(rp[r + 1] - rp[r]);
         for (int k = rp[r]; k < rp[r + 1]; ++k) { ci[k] = (int)(rng() % V); va[k] = w * (0.5f + (float)(rng() % 1000) / 1000.f); }
     }
-    printf("V=%d nnz=%lld phases=%d cap=%d rotate=%d\n", V, (long long)nnz, n_phase, cap, rotate);
+    printf("V=%d nnz=%lld block=%d phases=%d cap=%d rotate=%d\n", V, (long long)nnz, cb, n_phase, cap, rotate);
 
     // ---- tiles.  Rows sorted by length and dealt round-robin to the workgroups
     std::vector<int> order(V);
@@ -188,7 +268,7 @@ int main(int argc, char **argv) {
         // bucket the entries of this workgroup's rows by column block
         std::vector<std::vector<std::pair<int, int>>> by_phase(n_phase);   // (lrow, k)
         for (int i = 0; i < nr; ++i)
-            for (int k = rp[rows[i]]; k < rp[rows[i] + 1]; ++k) by_phase[ci[k] / kCB].push_back({i, k});
+            for (int k = rp[rows[i]]; k < rp[rows[i] + 1]; ++k) by_phase[ci[k] / cb].push_back({i, k});
         // a (row, block) group of more than `cap` entries is cut: the extra parts accumulate in virtual slots, ONE
         // contiguous range per row (added to the row in slot order by one thread of the epilogue)
         std::vector<int> vbase(nr, 0), vnext(nr, 0);
@@ -259,7 +339,7 @@ int main(int argc, char **argv) {
                             int bits;
                             memcpy(&bits, &v, 4);
                             if (bits == 0) bits = 1;   // a true zero weight would look like padding: make it a denormal
-                            stream[at0 + (size_t)s * 64 + l] = make_int2((g.slot << 16) | (ci[kk] % kCB), bits);
+                            stream[at0 + (size_t)s * 64 + l] = make_int2((g.slot << 16) | (ci[kk] % cb), bits);
                         }
                     }
                     real_steps += s;
@@ -330,9 +410,15 @@ int main(int argc, char **argv) {
                stream.size() * 8 / (ms * 1e-3 / n) / 1e12);
         CK(hipMemcpy(d_x, hx.data(), (size_t)V * 2, hipMemcpyHostToDevice));
     };
-    run(spmv_lds_kernel<true, 4>, "lds-blocked, DMA copy, unroll 4");
-    run(spmv_lds_kernel<true, 8>, "lds-blocked, DMA copy, unroll 8");
-    run(spmv_lds_kernel<false, 4>, "lds-blocked, register copy, unroll 4");
+    if (cb == kCB) {
+        run(spmv_lds_kernel<true, 4>, "lds-blocked, DMA copy, unroll 4");
+        run(spmv_lds_kernel<true, 8>, "lds-blocked, DMA copy, unroll 8");
+        run(spmv_lds_kernel<false, 4>, "lds-blocked, register copy, unroll 4");
+    } else {
+        run(spmv_lds2_kernel<4>, "v2 double-buffered, prefetch 4");
+        run(spmv_lds2_kernel<6>, "v2 double-buffered, prefetch 6");
+        run(spmv_lds2_kernel<8>, "v2 double-buffered, prefetch 8");
+    }
     {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

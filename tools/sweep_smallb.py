@@ -71,6 +71,18 @@ def main():
         torch.cuda.synchronize()
         ph = eng.timings()
         eng.set_profiling(False)
+        # HRAG_OPT_ACCEL (tolerance 0: ppr_iters names the accuracy; 14 sweeps on the fp16 states)
+        from hipporag_amd._lib import OPT_ACCEL
+        eng.set_flags(OPT_ACCEL, True)
+        for _ in range(3):
+            used = int(step().iters_used.max())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        accel_ms = (time.perf_counter() - t0) * 1e3 / n
+        eng.set_flags(OPT_ACCEL, False)
         kw = dict(small=True) if B <= 8 else dict(f16=True)
         eng.ppr_sweeps(B, 4, 0.5, **kw)
         e0.record()
@@ -83,7 +95,8 @@ def main():
                       qps=B / lat_ms * 1e3, sweep_us=sweep_us,
                       sweep_alg_gbs=alg / (sweep_us * 1e-6) / 1e9,
                       phases={k: ph[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")},
-                      slab_width=ph["slab_width"])
+                      slab_width=ph["slab_width"],
+                      accel={"latency_ms": accel_ms, "qps": B / accel_ms * 1e3, "sweeps": used})
         print(B, json.dumps(res[B]), flush=True)
         eng.close()
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)

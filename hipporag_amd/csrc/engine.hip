@@ -825,10 +825,10 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         e->mmax_slots = (int64_t)(e->sell.n_chunks + 8) * n_slabs128(B);
         E_TRY(dev_alloc(&e->d_dyn, 2 * kP8DynInv));
         E_TRY(dev_alloc(&e->d_mmax_ws, e->mmax_slots));
-        E_TRY(dev_alloc(&e->d_mmax_word, 1));
+        E_TRY(dev_alloc(&e->d_mmax_word, 2));   // [0] running maximum (float bits), [1] arrival counter of the reduction
         E_HIP(hipMemset(e->d_dyn, 0, 2 * kP8DynInv * sizeof(float)));
         E_HIP(hipMemset(e->d_mmax_ws, 0, (size_t)e->mmax_slots * sizeof(float)));
-        E_HIP(hipMemset(e->d_mmax_word, 0, sizeof(int32_t)));
+        E_HIP(hipMemset(e->d_mmax_word, 0, 2 * sizeof(int32_t)));
     }
     {
         char *ws = nullptr;

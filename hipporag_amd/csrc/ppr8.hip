@@ -973,43 +973,48 @@ __global__ void ppr8_finalize_kernel(const int32_t *__restrict__ est_f, int32_t 
 //   stage after it grows its iterate by at most `growth`: dyn[stage + 2] = the power of two that maps kappa M growth to
 //   <= 224 (half the e4m3 range, like the static chain).  M = 0 (nothing left) keeps the previous scale.
 // seed = 1: write dyn[0] = cs0, dyn[1] = cs1 (the two scales known before anything was measured) and return.
-__global__ __launch_bounds__(1024) void ppr8_next_scale_kernel(const float *__restrict__ ws, int32_t n_slots, int32_t *word,
-                                                               float *dyn, int32_t stage, float kappa_growth, int32_t seed,
-                                                               float cs0, float cs1, const int32_t *gate, int32_t gate_want) {
+__global__ __launch_bounds__(256) void ppr8_next_scale_kernel(const float *__restrict__ ws, int32_t n_slots, int32_t *word,
+                                                              float *dyn, int32_t stage, float kappa_growth, int32_t seed,
+                                                              float cs0, float cs1, const int32_t *gate, int32_t gate_want) {
     if (gate && *gate != gate_want) return;
     if (seed) {
-        if (threadIdx.x == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
             dyn[0] = cs0; dyn[kP8DynInv + 0] = 1.0f / cs0;
             dyn[1] = cs1; dyn[kP8DynInv + 1] = 1.0f / cs1;
-            *word = 0;
+            word[0] = 0; word[1] = 0;
         }
         return;
     }
-    __shared__ float red[1024];
+    // word[0]: running maximum (bits of a non-negative float: integer atomicMax is order-preserving and independent of
+    // the arrival order); word[1]: blocks that have arrived -- the last one turns the maximum into the scale
+    __shared__ float red[256];
     float m = 0.f;
-    for (int i = threadIdx.x; i < n_slots; i += 1024) m = fmaxf(m, ws[i]);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_slots; i += gridDim.x * 256) m = fmaxf(m, ws[i]);
     red[threadIdx.x] = m;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const float mq = fmaxf(red[0], __int_as_float(*word));
-        *word = 0;
-        const float cs_used = dyn[stage + 1];
-        float cs = cs_used;                       // nothing measured: keep the scale
-        const float bound = mq / cs_used * kappa_growth;
-        if (bound > 0.f && bound < 3e38f) {
-            int ex = (int)floorf(log2f(224.0f / bound));
-            // floorf(log2f()) can be one off at exact powers of two: never let the bound exceed 224
-            if (ldexpf(1.0f, ex) * bound > 224.0f) --ex;
-            ex = ex < -60 ? -60 : (ex > 60 ? 60 : ex);
-            cs = ldexpf(1.0f, ex);
-        }
-        dyn[stage + 2] = cs;
-        dyn[kP8DynInv + stage + 2] = 1.0f / cs;
+    if (threadIdx.x != 0) return;
+    if (red[0] > 0.f) __hip_atomic_fetch_max(&word[0], __float_as_int(red[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int before = __hip_atomic_fetch_add(&word[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before != (int)gridDim.x - 1) return;
+    const float mq = __int_as_float(__hip_atomic_load(&word[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __hip_atomic_store(&word[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&word[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float cs_used = dyn[stage + 1];
+    float cs = cs_used;                       // nothing measured: keep the scale
+    const float bound = mq / cs_used * kappa_growth;
+    if (bound > 0.f && bound < 3e38f) {
+        int ex = (int)floorf(log2f(224.0f / bound));
+        // floorf(log2f()) can be one off at exact powers of two: never let the bound exceed 224
+        if (ldexpf(1.0f, ex) * bound > 224.0f) --ex;
+        ex = ex < -60 ? -60 : (ex > 60 ? 60 : ex);
+        cs = ldexpf(1.0f, ex);
     }
+    dyn[stage + 2] = cs;
+    dyn[kP8DynInv + stage + 2] = 1.0f / cs;
 }
 
 __global__ void ppr8_mask_seeds_kernel(const int32_t *__restrict__ seed_vtx, const int32_t *__restrict__ seed_cnt,
@@ -1173,7 +1178,8 @@ hrag_status launch_ppr8_mask_seeds(const int32_t *seed_vtx, const int32_t *seed_
 hrag_status launch_ppr8_next_scale(const float *ws, int32_t n_slots, int32_t *word, float *dyn, int32_t stage,
                                    float kappa_growth, int32_t seed, float cs0, float cs1, const int32_t *gate,
                                    int32_t gate_want, hipStream_t s) {
-    hipLaunchKernelGGL(ppr8_next_scale_kernel, dim3(1), dim3(1024), 0, s, ws, n_slots, word, dyn, stage, kappa_growth, seed,
+    const unsigned blocks = seed ? 1u : (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, ceil_div(n_slots, 4096)));
+    hipLaunchKernelGGL(ppr8_next_scale_kernel, dim3(blocks), dim3(256), 0, s, ws, n_slots, word, dyn, stage, kappa_growth, seed,
                        cs0, cs1, gate, gate_want);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;

@@ -1,5 +1,4 @@
-mkdir -p gpurun_out/r04i
-for args in "1048576 20 0 8 1 32768" "1048576 20 0 8 0 32768" "1048576 20 64 16 1 32768" "1048576 20 0 4 1 32768"; do
-timeout 300 tools/_bin/spmv_lds_bench $args >> gpurun_out/r04i/spmv_lds2.txt 2>&1
-done
-cat gpurun_out/r04i/spmv_lds2.txt
+mkdir -p gpurun_out/r04j
+python -m pytest tests/test_gpu_accel.py tests/test_gpu_fp8_adversarial.py -m gpu -q -x 2>&1 | tail -5 > gpurun_out/r04j/tests.log
+python bench.py --steps 10 --warmup 2 --cpu-queries 8 --cpu-budget-s 8 --cpu-vec-queries 8 > gpurun_out/r04j/bench_cfg3.json 2> gpurun_out/r04j/bench_cfg3.err
+cat gpurun_out/r04j/tests.log

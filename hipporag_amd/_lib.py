@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libhrag.so")
 
 HRAG_OK, HRAG_EINVAL, HRAG_ENOMEM, HRAG_EHIP, HRAG_EBUSY, HRAG_ECAPACITY = range(6)
 SEED_STRIDE = 32
-HRAG_VERSION = 4      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
+HRAG_VERSION = 5      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
 FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, FLAG_FP8_SATURATED, FLAG_NOT_CONVERGED = 1, 2, 4, 8, 16
 # hrag_opts.flags (include/hrag.h HRAG_OPT_*)
 OPT_NATURAL_ROW_ORDER, OPT_NT_CSR, OPT_NT_STORE, OPT_F32_STATE, OPT_TEMPORAL16, OPT_NO_FP8 = 1, 2, 4, 8, 16, 32

@@ -206,6 +206,13 @@ class HippoRAGEngine:
             fdesc = EmbedDesc(f_rows, fact_offset, dim, f_dt, _ptr(f_obj))
             fd = FactDesc(self.n_facts, _ptr(sv), _ptr(ov), _ptr(nc))
             keep += [f_obj, sv, ov, nc]
+        # HRAG_OPT_ACCEL needs an undirected graph (real spectrum of the sweep operator): checked where the graph is at
+        # hand (row sums of the adjacency == its column sums); a directed graph keeps the plain plan, loudly
+        from .graph import looks_undirected
+        self._undirected = looks_undirected(graph) if (row_offset == 0 and n_rows == graph.num_vertices) else False
+        if (flags & _lib.OPT_ACCEL) and not self._undirected:
+            logger.warning("HRAG_OPT_ACCEL dropped: the graph does not look undirected (or has no col_sum / is a row shard)")
+            flags &= ~_lib.OPT_ACCEL
         self.opt_flags = int(flags)      # HRAG_OPT_* bits as set_flags leaves them
         opts = Opts(max_batch, max_topk, slab_width, long_row_nnz, self.device.index, flags, segment_nnz, sell_seg_len, sell_sigma)
         with torch.cuda.device(self.device):
@@ -461,6 +468,9 @@ class HippoRAGEngine:
 
     def set_flags(self, flags: int, on: bool = True):
         """Set / clear HRAG_OPT_* bits after creation (e.g. _lib.OPT_NO_FP8 to rerun a saturated batch)."""
+        if on and (flags & _lib.OPT_ACCEL) and not getattr(self, "_undirected", False):
+            raise ValueError("HRAG_OPT_ACCEL needs an undirected graph with col_sum on an unsharded engine "
+                             "(hipporag_amd.graph.looks_undirected): this engine's graph does not qualify")
         check(self._lib.hrag_engine_set_flags(self._handle, flags, 1 if on else 0))
         self.opt_flags = (self.opt_flags | flags) if on else (self.opt_flags & ~flags)
 

@@ -42,6 +42,24 @@ class CSRGraph:
                         self.col_idx[a:b], self.val[a:b], self.raw[a:b], self.col_sum)
 
 
+def looks_undirected(g: CSRGraph, rtol: float = 1e-5) -> bool:
+    """Necessary condition for the adjacency behind a column-normalised CSR to be symmetric (what HRAG_OPT_ACCEL's
+    Chebyshev steps need: a real spectrum): with A_ij = P_ij d_j the ROW sums of A must equal its column sums d.
+    O(nnz); catches a directed graph handed to the C ABI, not every asymmetric weighting (build_csr symmetrises by
+    construction, like the reference's undirected igraph, HippoRAG.py:236).  Unsharded graphs with col_sum only."""
+    if g.col_sum is None or g.row_ptr.shape[0] - 1 != g.num_vertices:
+        return False
+    d = np.asarray(g.col_sum, dtype=np.float64)
+    if g.nnz == 0:
+        return True
+    a = np.asarray(g.val, dtype=np.float64) * d[np.asarray(g.col_idx, dtype=np.int64)]
+    rp = np.asarray(g.row_ptr, dtype=np.int64)
+    row_sum = np.zeros(g.num_vertices)
+    nz = rp[1:] > rp[:-1]
+    row_sum[nz] = np.add.reduceat(a, rp[:-1][nz])
+    return bool(np.all(np.abs(row_sum - d) <= rtol * np.maximum(d, 1e-300)))
+
+
 def build_csr(num_vertices: int, src, dst, weight) -> CSRGraph:
     src = np.asarray(src, dtype=np.int64)
     dst = np.asarray(dst, dtype=np.int64)

@@ -41,7 +41,7 @@ extern "C" {
 #endif
 
 #define HRAG_VERSION_MAJOR 0
-#define HRAG_VERSION_MINOR 4
+#define HRAG_VERSION_MINOR 5
 
 typedef enum hrag_status {
     HRAG_OK = 0,
@@ -168,8 +168,12 @@ typedef struct hrag_fact_desc {
                                       /* the accuracy is that of ppr_iters plain sweeps on well-mixing graphs (cfg 3: 4.4e-7  */
                                       /* against 5.5e-7) and up to 3x their truncation error on small hub-heavy ones: use the */
                                       /* contract where a bound is needed.  Off by default: ppr_iters is then the literal     */
-                                      /* sweep count (BASELINE.json's 20).  Runtime-switchable.  No effect on the other state */
-                                      /* types (batch <= 64)                                                                  */
+                                      /* sweep count (BASELINE.json's 20).  Runtime-switchable.  The two-stage fp16 states    */
+                                      /* (batch <= 64) accelerate too (14 sweeps for 20), with ppr_tol = 0 only.  The library */
+                                      /* cannot see whether the CSR it was given came from a symmetric adjacency: setting the */
+                                      /* flag on a DIRECTED graph is a caller error (complex spectrum: the steps may converge */
+                                      /* more slowly than the plan assumes; the contract would flag it, ppr_tol = 0 would     */
+                                      /* not) -- the Python wrapper checks row sums == column sums of A and refuses           */
 
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */

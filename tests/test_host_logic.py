@@ -151,3 +151,19 @@ def test_retrieve_converged_repeats_a_saturated_batch_and_leaves_a_flag_that_ppr
     eng = _ScriptedEngine(script)
     eng.retrieve_converged(q, k, k.float(), cnt, ppr_tol=0.0)
     assert len(eng.calls) == 1
+
+
+def test_looks_undirected_is_what_the_accelerated_plan_is_gated_on():
+    """HRAG_OPT_ACCEL (Chebyshev steps: real spectrum) is only honoured on an undirected graph: the wrapper checks that
+    the row sums of the adjacency behind the column-normalised CSR equal its column sums (hipporag_amd.graph.
+    looks_undirected) -- true for everything build_csr makes (it symmetrises, like the reference's undirected igraph,
+    HippoRAG.py:236), false for a CSR whose weights were made asymmetric, for a row shard and without col_sum."""
+    from hipporag_amd import synth
+    from hipporag_amd.graph import CSRGraph, looks_undirected
+    g = synth.make_kg(3000, 30000, 5).csr
+    assert looks_undirected(g)
+    v = g.val.copy()
+    v[g.row_ptr[7]:g.row_ptr[8]] *= 1.5                       # one row re-weighted: A is no longer symmetric
+    assert not looks_undirected(CSRGraph(g.num_vertices, g.row_ptr, g.col_idx, v, g.raw, g.col_sum))
+    assert not looks_undirected(CSRGraph(g.num_vertices, g.row_ptr, g.col_idx, g.val, g.raw, None))
+    assert not looks_undirected(g.rows(0, 1500))

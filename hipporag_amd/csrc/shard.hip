@@ -168,7 +168,6 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     // of m sweeps grows its iterate by at most (1 - a^m) / (1 - a).  cs = the power of two that maps that bound
     // to <= 224 (half the e4m3 range: the bound ignores rounding noise; a clamped value raises flags bit 3).
     int plan[kP8MaxStages + 4], kind[kP8MaxStages + 4] = {};
-    const int asked = iters;
     // accelerated stages need the measured scale chain: the single-GPU engine only (a row shard would have to all-reduce
     // one float per boundary; the shard entry points run the plain plan)
     const bool may_accel = allow_accel && (e->opt_flags & HRAG_OPT_ACCEL) && e->d_dyn && e->n_rows == e->V;
@@ -181,7 +180,6 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
         p.iters = iters;
     }
     p.accel = accel;
-    (void)asked;
     HRAG_REQUIRE(n_stage >= 2 && n_stage <= kP8MaxStages, "ppr_iters=%d needs %d fp8 stages (2..%d)", iters, n_stage,
                  kP8MaxStages);
     // ---- convergence contract (reference: PRPACK iterates until its residual is below 1e-10, HippoRAG.py:1736-1743;

@@ -157,6 +157,10 @@ struct Ppr16Args {
     // iterate before x (own row; may alias y: a row is read before it is written, by its one owner; nullptr: zero)
     float omega = 1.f;
     const uint16_t *prev = nullptr;
+    // convergence contract: a launch whose gate word differs from gate_want returns at once (the extension stages are
+    // enqueued unconditionally and the DEVICE decides which of them run: ppr8.hip ppr8_decide_kernel)
+    const int32_t *gate = nullptr;
+    int32_t gate_want = 0;
 };
 // nt: bit0 non-temporal (col, val) loads, bit1 non-temporal state stores
 hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, int nt, bool main_only,
@@ -333,6 +337,9 @@ struct PprSvArgs {
     // HRAG_OPT_ACCEL, fp16 state, modes plain (H) / correction: Chebyshev step, see Ppr16Args
     float omega = 1.f;
     const uint16_t *prev = nullptr;
+    // convergence contract: conditional launch (see Ppr16Args)
+    const int32_t *gate = nullptr;
+    int32_t gate_want = 0;
 };
 hrag_status launch_ppr_sv_sweep(const PprSvArgs &a, int bp, bool main_only, hipStream_t s);
 hrag_status launch_ppr_sv_init(const PprSvArgs &a, int bp, hipStream_t s);

@@ -281,8 +281,12 @@ Ppr16Args ppr16_args(const hrag_engine *e, const uint16_t *x, uint16_t *y, const
 // sweep -- the quantity it reads without the flag (csrc/shard.hip ppr8_plan_accel on why).  Error bound of the plan:
 // 1 / (T_K1(1/a) T_{K2+1}(1/a)) a^2, each Chebyshev factor capped at 2^11 (the fp16 rounding of the stage's iterate);
 // the smallest K1 + K2 that reaches a^iters / 4 is taken: a = 0.5, iters = 20 -> K1 = 6, K2 = 5, 14 sweeps.  Only with
-// ppr_tol = 0 (`ppr_iters` names an accuracy): these states do not extend on the device, and a tolerance-driven caller is
-// better served by the plain plan, which converges faster than its bound where the graph mixes well.
+// ppr_tol = 0 (`ppr_iters` names an accuracy).  Under a tolerance these states keep the plain plan (+ its device-side
+// extension): after a Chebyshev stage h is less converged ELEMENTWISE than after as many plain sweeps (equi-oscillation
+// puts error into every mode), the correction c is correspondingly larger, and its fp16 rounding (2^-11 |c| / 64) puts a
+// floor of 3e-6 .. 1e-5 under the measured residual that no further correction sweep removes (measured: all four extension
+// stages ran and the residual stayed there) -- above the mirror's tolerance, so every query would be flagged; the plain
+// plan reads 2e-7 after 20 sweeps on the same graphs.
 static double accel_omega(int k, double rho) {    // w_k of the recurrence above
     double w = 1.0;
     for (int j = 2; j <= k; ++j) w = j == 2 ? 1.0 / (1.0 - rho * rho / 2.0) : 1.0 / (1.0 - rho * rho * w / 4.0);
@@ -311,15 +315,29 @@ static bool accel_plan16(int iters, float damping, int *k1_out, int *k2_out) {
 // residual sweep; K2 sweeps on the correction, the last of them over the passage rows only (fsell), writing
 // x = h + c / cs in fp32 at the passages (d_xp8, passage order) -- nothing else is read afterwards
 // (HippoRAG.py:1745).  Buffers: d_h16[0], [1] ping-pong for h; [2] = r; the free h buffer and [3] ping-pong for c.
-// *sweeps_out: the sweeps that ran (HRAG_OPT_ACCEL: fewer than `iters`, which then names the accuracy)
+// Extension stages the contract may add on the two-stage fp16 states (round 4): stage j + 1 of 1, 2, 3, 3 sweeps (the
+// schedule of the fp8 state, p8_ext_sweeps) = that many plain correction sweeps over ALL rows -- the first one redoes,
+// on every row, the sweep the previous final sweep did on the passage rows -- followed by a final sweep over the passage
+// rows that measures again.  All of them are enqueued; ctl[j] (ppr8_decide_kernel after final sweep j) gates them.
+static int ext_stages_for(int sweeps, int max_iters, float tol) {
+    int e_max = 0;
+    if (tol > 0.f)
+        while (e_max < kP8MaxExt && sweeps + p8_ext_sweeps(e_max + 1) <= max_iters) ++e_max;
+    return e_max;
+}
+
+// *sweeps_out: the sweeps of the base plan (HRAG_OPT_ACCEL: fewer than `iters`, which then names the accuracy);
+// tol > 0 with est: up to *e_max_out extension stages follow, decided on the device (no host synchronisation)
 hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipStream_t s, int32_t *est = nullptr,
-                      int *sweeps_out = nullptr, bool allow_accel = false) {
+                      int *sweeps_out = nullptr, bool allow_accel = false, float tol = 0.f, int max_iters = 0,
+                      int *e_max_out = nullptr) {
     const int ns = n_slabs64(batch);
     const int nt = (e->opt_flags & HRAG_OPT_TEMPORAL16) ? 0 : 3;
     int k1 = iters / 2, k2 = iters - k1 - 1, kc = 0;   // kc: Chebyshev steps among the k2 correction sweeps
     const bool accel = allow_accel && (e->opt_flags & HRAG_OPT_ACCEL) && accel_plan16(iters, damping, &k1, &kc);
     if (accel) k2 = kc + 2;                            // + one plain correction sweep + the final sweep
-    if (sweeps_out) *sweeps_out = k1 + 1 + k2;
+    const int sweeps = k1 + 1 + k2;
+    if (sweeps_out) *sweeps_out = sweeps;
     uint16_t *h = e->d_h16[0], *hn = e->d_h16[1], *r = e->d_h16[2];
     HRAG_TRY(launch_ppr16_init(ppr16_args(e, nullptr, h, nullptr, damping), ns, s));
     for (int it = 0; it < k1; ++it) {
@@ -332,24 +350,38 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
     HRAG_TRY(launch_ppr16_sweep(ppr16_args(e, h, r, nullptr, damping), kPprModeR, ns, nt, false, s));
     const uint16_t *c = r;            // c_{K1+1} = r
     uint16_t *cn = hn, *cn2 = e->d_h16[3];
-    for (int it = 0; it < k2; ++it) {
-        const bool last = it + 1 == k2;
+    // a correction sweep over all rows (c -> cn) / the final sweep over the passage rows from c (x = h + c' / cs, measured)
+    auto sweep_c = [&](float omega, const uint16_t *prev, const int32_t *gate) {
         Ppr16Args a = ppr16_args(e, c, cn, r, damping);
-        if (accel && it < kc) {       // step it + 2 of stage 2: c_0 = 0 (no history), c_1 = r, then the ping-pong buffers
-            a.omega = (float)accel_omega(it + 2, damping);
-            a.prev = it == 0 ? nullptr : it == 1 ? r : cn;
-        }
-        if (last) {
-            const Sell8Store &m = e->fsell;
-            a.pairs = m.pairs; a.pairs_bytes = m.pairs_bytes(); a.chunk_meta = m.chunk_meta; a.vrow = m.vrow;
-            a.n_chunks = m.n_chunks; a.lrow_row = m.lrow_row; a.lrow_first = m.lrow_first; a.lrow_cnt = m.lrow_cnt;
-            a.n_lrow = m.n_lrow; a.n_partial = m.n_partial; a.seg_lrow = m.seg_lrow; a.lcount = m.lcount;
-            a.hfin = h; a.out = e->d_xp8; a.p_rows = e->p_rows;
-            a.est = est; a.est_ws = e->d_est_ws; a.batch = batch;
-        }
-        HRAG_TRY(launch_ppr16_sweep(a, last ? kPprModeF : kPprModeC, ns, nt, false, s));
+        a.omega = omega; a.prev = prev; a.gate = gate; a.gate_want = 1;
+        const hrag_status st = launch_ppr16_sweep(a, kPprModeC, ns, nt, false, s);
         c = cn;
         std::swap(cn, cn2);
+        return st;
+    };
+    auto sweep_f = [&](const int32_t *gate) {
+        Ppr16Args a = ppr16_args(e, c, cn, r, damping);
+        const Sell8Store &m = e->fsell;
+        a.pairs = m.pairs; a.pairs_bytes = m.pairs_bytes(); a.chunk_meta = m.chunk_meta; a.vrow = m.vrow;
+        a.n_chunks = m.n_chunks; a.lrow_row = m.lrow_row; a.lrow_first = m.lrow_first; a.lrow_cnt = m.lrow_cnt;
+        a.n_lrow = m.n_lrow; a.n_partial = m.n_partial; a.seg_lrow = m.seg_lrow; a.lcount = m.lcount;
+        a.hfin = h; a.out = e->d_xp8; a.p_rows = e->p_rows;
+        a.est = est; a.est_ws = e->d_est_ws; a.batch = batch;
+        a.gate = gate; a.gate_want = 1;
+        return launch_ppr16_sweep(a, kPprModeF, ns, nt, false, s);
+    };
+    for (int it = 0; it + 1 < k2; ++it) {
+        // accelerated: step it + 2 of stage 2 -- c_0 = 0 (no history), c_1 = r, then the ping-pong buffers
+        const bool cheb = accel && it < kc;
+        HRAG_TRY(sweep_c(cheb ? (float)accel_omega(it + 2, damping) : 1.f, !cheb || it == 0 ? nullptr : it == 1 ? r : cn, nullptr));
+    }
+    HRAG_TRY(sweep_f(nullptr));
+    const int e_max = est ? ext_stages_for(sweeps, max_iters, tol) : 0;
+    if (e_max_out) *e_max_out = e_max;
+    for (int j = 0; j < e_max; ++j) {
+        HRAG_TRY(launch_ppr8_decide(est, e->d_flags, batch, damping / (1.0f - damping), tol, j, e_max, e->d_ctl, s));
+        for (int i = p8_ext_sweeps(j); i < p8_ext_sweeps(j + 1); ++i) HRAG_TRY(sweep_c(1.f, nullptr, e->d_ctl + j));
+        HRAG_TRY(sweep_f(e->d_ctl + j));
     }
     if (h != e->d_h16[0]) std::swap(e->d_h16[0], e->d_h16[1]);  // keep h in [0] for hrag_ppr_sweeps
     return HRAG_OK;
@@ -400,8 +432,9 @@ hrag_status ppr_sv_run_full(hrag_engine *e, const int32_t *row_slot, const float
 // e->d_x; with >= 16 sweeps the state in between is the two-stage fp16 one (v must carry the per-query scale).
 hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tele, int bp, float damping,
                        int iters, hipStream_t s, int32_t *est = nullptr, int batch = 0, int *sweeps_out = nullptr,
-                       bool allow_accel = false) {
+                       bool allow_accel = false, float tol = 0.f, int max_iters = 0, int *e_max_out = nullptr) {
     if (sweeps_out) *sweeps_out = iters;
+    if (e_max_out) *e_max_out = 0;
     if (iters < 1) return ppr_sv_run_full(e, row_slot, tele, bp, damping, iters, s);
     if (!use_sv_half(e, iters)) {
         float *x = e->d_x, *y = e->d_y;
@@ -419,7 +452,8 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
     int k1 = iters / 2, k2 = iters - k1 - 1, kc = 0;   // the plan of ppr16_run, Chebyshev steps included (accel_plan16)
     const bool accel = allow_accel && (e->opt_flags & HRAG_OPT_ACCEL) && accel_plan16(iters, damping, &k1, &kc);
     if (accel) k2 = kc + 2;
-    if (sweeps_out) *sweeps_out = k1 + 1 + k2;
+    const int sweeps = k1 + 1 + k2;
+    if (sweeps_out) *sweeps_out = sweeps;
     uint16_t *h = e->d_sv16[0], *hn = e->d_sv16[1], *r = e->d_sv16[2];
     {
         PprSvArgs a = ppr_sv_args(e, e->sell, nullptr, h, row_slot, tele, damping);
@@ -440,19 +474,34 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
     }
     const uint16_t *c = r;                 // c_{K1+1} = r
     uint16_t *cn = hn, *cn2 = e->d_sv16[3];
-    for (int j = 0; j < k2; ++j) {
-        const bool last = j + 1 == k2;
-        PprSvArgs a = ppr_sv_args(e, last ? e->fsell : e->sell, c, cn, row_slot, tele, damping);
-        a.half_state = 1; a.mode = last ? 3 : 2; a.aux16 = r; a.cscale = kPpr16CScale;
-        a.h16 = h; a.xout = e->d_x;
-        if (accel && j < kc) {
-            a.omega = (float)accel_omega(j + 2, damping);
-            a.prev = j == 0 ? nullptr : j == 1 ? r : cn;
-        }
-        if (last) { a.est = est; a.est_ws = e->d_est_ws; a.batch = batch; }
-        HRAG_TRY(launch_ppr_sv_sweep(a, bp, false, s));
+    // a correction sweep over all rows (c -> cn) / the final sweep over the passage rows from c (see ppr16_run)
+    auto sweep_c = [&](float omega, const uint16_t *prev, const int32_t *gate) {
+        PprSvArgs a = ppr_sv_args(e, e->sell, c, cn, row_slot, tele, damping);
+        a.half_state = 1; a.mode = 2; a.aux16 = r; a.cscale = kPpr16CScale; a.h16 = h; a.xout = e->d_x;
+        a.omega = omega; a.prev = prev; a.gate = gate; a.gate_want = 1;
+        const hrag_status st = launch_ppr_sv_sweep(a, bp, false, s);
         c = cn;
         std::swap(cn, cn2);
+        return st;
+    };
+    auto sweep_f = [&](const int32_t *gate) {
+        PprSvArgs a = ppr_sv_args(e, e->fsell, c, cn, row_slot, tele, damping);
+        a.half_state = 1; a.mode = 3; a.aux16 = r; a.cscale = kPpr16CScale; a.h16 = h; a.xout = e->d_x;
+        a.est = est; a.est_ws = e->d_est_ws; a.batch = batch;
+        a.gate = gate; a.gate_want = 1;
+        return launch_ppr_sv_sweep(a, bp, false, s);
+    };
+    for (int j = 0; j + 1 < k2; ++j) {
+        const bool cheb = accel && j < kc;
+        HRAG_TRY(sweep_c(cheb ? (float)accel_omega(j + 2, damping) : 1.f, !cheb || j == 0 ? nullptr : j == 1 ? r : cn, nullptr));
+    }
+    HRAG_TRY(sweep_f(nullptr));
+    const int e_max = est ? ext_stages_for(sweeps, max_iters, tol) : 0;
+    if (e_max_out) *e_max_out = e_max;
+    for (int j = 0; j < e_max; ++j) {   // extension stages of the contract, decided on the device (ppr16_run)
+        HRAG_TRY(launch_ppr8_decide(est, e->d_flags, batch, damping / (1.0f - damping), tol, j, e_max, e->d_ctl, s));
+        for (int i = p8_ext_sweeps(j); i < p8_ext_sweeps(j + 1); ++i) HRAG_TRY(sweep_c(1.f, nullptr, e->d_ctl + j));
+        HRAG_TRY(sweep_f(e->d_ctl + j));
     }
     return HRAG_OK;
 }
@@ -1051,6 +1100,7 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
     // convergence contract on the fp16 / small-batch / fp32 states: the fixed count runs, the last sweep measures the
     // relative update of the passage scores (residual_out, flags bit 4); only the fp8 state extends on the device
     int sweeps_run = ppr_iters;   // fp16 states under HRAG_OPT_ACCEL: fewer (ppr_iters then names the accuracy)
+    int ext_max = 0;              // fp16 states: extension stages enqueued (the device decides which of them run)
     const bool want_est = residual_out != nullptr || ppr_tol > 0.f;
     int32_t *est = (want_est && !f8 && ppr_iters >= 1) ? e->d_est_f : nullptr;
     {
@@ -1147,9 +1197,10 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
             HRAG_TRY(ppr8_decide(e, it, s));
         }
     } else if (f16) {
-        HRAG_TRY(ppr16_run(e, batch, damping, ppr_iters, s, est, &sweeps_run, ppr_tol == 0.f));
+        HRAG_TRY(ppr16_run(e, batch, damping, ppr_iters, s, est, &sweeps_run, ppr_tol == 0.f, ppr_tol, ppr_max_iters, &ext_max));
     } else if (sv) {
-        HRAG_TRY(ppr_sv_run(e, e->d_row_slot, e->d_tele_sv, bp, damping, ppr_iters, s, est, batch, &sweeps_run, ppr_tol == 0.f));
+        HRAG_TRY(ppr_sv_run(e, e->d_row_slot, e->d_tele_sv, bp, damping, ppr_iters, s, est, batch, &sweeps_run, ppr_tol == 0.f,
+                            ppr_tol, ppr_max_iters, &ext_max));
     } else {
         float *x = e->d_x, *y = e->d_y;
         HRAG_TRY(ppr_init(e, e->d_tele, e->n_passages, e->d_row_to_tele, e->d_seed_vtx, e->d_seed_w,
@@ -1193,7 +1244,7 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
     const bool measured = f8 || est != nullptr;
     if (!f8 && est)
         HRAG_TRY(launch_ppr8_finalize(est, e->d_flags, batch, damping / (1.0f - damping), ppr_tol, sweeps_run, e->d_ctl,
-                                      0, nullptr, 0, e->d_sums, e->d_resid, e->d_iters_used, s));
+                                      ext_max, nullptr, 0, e->d_sums, e->d_resid, e->d_iters_used, s));
     {
         BlitList out;   // the per-query results in one launch
         out.copy(flags_out, e->d_flags, (int64_t)batch * sizeof(int32_t));

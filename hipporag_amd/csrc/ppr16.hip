@@ -222,6 +222,7 @@ __device__ __forceinline__ void finish_row(const Ppr16Args &a, int slab, int row
 
 template <int MODE, bool NT, bool NT_ST, bool MASK = false>
 __global__ __launch_bounds__(256, 6) void ppr16_kernel(const Ppr16Args a) {
+    if (a.gate && *a.gate != a.gate_want) return;   // a conditional step the device decided not to run
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
     const int slab = blockIdx.y;
@@ -446,7 +447,7 @@ hrag_status launch_ppr16_sweep(const Ppr16Args &a, int mode, int n_slabs, int nt
         case kPprModeF:
             HRAG_TRY(sweep_mode<kPprModeF>(a, n_slabs, nt_pairs, main_only, s));
             if (a.est && a.n_chunks > 0)
-                return launch_est_reduce(a.est_ws, a.n_chunks, 64, 0, n_slabs, a.batch, a.est, nullptr, 0, s);
+                return launch_est_reduce(a.est_ws, a.n_chunks, 64, 0, n_slabs, a.batch, a.est, a.gate, a.gate_want, s);
             return HRAG_OK;
         default: set_error("bad ppr16 mode %d", mode); return HRAG_EINVAL;
     }

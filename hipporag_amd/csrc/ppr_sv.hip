@@ -131,6 +131,7 @@ __device__ __forceinline__ float sv_finish(const PprSvArgs &a, int row, int gl, 
 // MASK: the gathers of columns whose bit is clear in a.colmask are skipped (first sweep: x_0 = v is zero there)
 template <int BP, bool NT, int MODE, typename T, bool MASK>
 __global__ __launch_bounds__(256) void ppr_sv_kernel(const PprSvArgs a) {
+    if (a.gate && *a.gate != a.gate_want) return;   // a conditional step the device decided not to run
     const int lane = threadIdx.x & 63;
     const int gl = lane & 7, grp = lane >> 3;
     const int chunk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -403,7 +404,7 @@ hrag_status sv_sweep_one(const PprSvArgs &a, bool main_only, hipStream_t s) {
         if (a.nt) hipLaunchKernelGGL((ppr_sv_kernel<BP, true, MODE, T, MASK>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((ppr_sv_kernel<BP, false, MODE, T, MASK>), grid, dim3(256), 0, s, a);
         HRAG_LAUNCH_CHECK();
-        if (a.est) HRAG_TRY(launch_est_reduce(a.est_ws, a.n_chunks, BP, 0, 1, a.batch, a.est, nullptr, 0, s));
+        if (a.est) HRAG_TRY(launch_est_reduce(a.est_ws, a.n_chunks, BP, 0, 1, a.batch, a.est, a.gate, a.gate_want, s));
     }
     (void)main_only;   // long rows are finished inside the sweep kernel (last-arriving segment)
     return HRAG_OK;

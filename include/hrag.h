@@ -262,8 +262,10 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q_fact_dev, int32_t
  *                   is above ppr_tol for some query of the batch and fewer than ppr_max_iters sweeps ran.  The
  *                   fp8-state path (batch > 64) extends in stages of 1, 2, 3, 3 sweeps up to 30 (the final sweep of a
  *                   stage runs over the passage rows only and measures; the launches of the next stage are enqueued
- *                   and skip themselves when a control word says so); the other state types run the fixed count
- *                   and report.
+ *                   and skip themselves when a control word says so); the two-stage fp16 states (batch <= 64) extend
+ *                   the same way by up to 9 sweeps beyond ppr_iters (stages of 1, 2, 3, 3 plain correction sweeps, each
+ *                   closed by a measuring passage-row sweep); the fp32 states (other sweep counts / damping, the repeat
+ *                   path) run the fixed count and report.
  *   ppr_max_iters   upper bound on the sweeps (>= ppr_iters; ignored when ppr_tol == 0)
  *   residual_out_dev fp32 [B] (may be NULL): the residual above for the sweeps that ran (0 on the DPR fallback)
  *   iters_out_dev   int32 [B] (may be NULL): sweeps that ran for the query's batch

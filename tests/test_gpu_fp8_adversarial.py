@@ -298,13 +298,14 @@ def test_the_device_extends_exactly_when_the_measured_residual_is_above_the_tole
 
 
 @pytest.mark.parametrize("b", [1, 8, 40])
-def test_the_other_state_types_run_the_fixed_count_flag_and_leave_the_repeat_to_the_caller(gpu_device, b):
-    """hrag_retrieve extends in-kernel on the fp8 state only (batch > 64).  The small-batch (B <= 8), fp16 (B <= 64)
-    and fp32 states run exactly ppr_iters sweeps, MEASURE the same residual in their last sweep and, when ppr_tol > 0
-    and it is above the tolerance, set HRAG_FLAG_NOT_CONVERGED: a raw caller of the C ABI gets a flag, never silently
-    unconverged scores; HippoRAGEngine.retrieve_converged (what the mirror and the adapter call) repeats the flagged
-    queries with the sweeps their residual asks for.  Ring graph: 20 sweeps leave ~1e-3."""
-    import dataclasses
+def test_the_fp16_states_extend_on_the_device_then_flag_and_leave_the_repeat_to_the_caller(gpu_device, b):
+    """The contract on the two-stage fp16 states (B <= 8: ppr_sv.hip; 9 .. 64: ppr16.hip), round 4: like the fp8 state they
+    extend ON THE DEVICE -- stages of 1, 2, 3, 3 plain correction sweeps, each closed by a passage-row final sweep that
+    measures again, gated by the control words a 1-block decision kernel sets (csrc/engine.hip ppr16_run) -- up to 9 sweeps
+    beyond ppr_iters; a query still above the tolerance then gets HRAG_FLAG_NOT_CONVERGED (never silently unconverged
+    scores for a raw caller of the C ABI) and HippoRAGEngine.retrieve_converged repeats it with the sweeps its residual
+    asks for.  Ring graph: 20 sweeps leave ~1e-3, 29 leave ~2e-6 (some queries above the tolerance, some below): the former are
+    flagged and repeated; everybody ends inside the bar with margin."""
     import torch
     from hipporag_amd._lib import FLAG_NOT_CONVERGED
     from hipporag_amd.engine import HippoRAGEngine
@@ -318,12 +319,24 @@ def test_the_other_state_types_run_the_fixed_count_flag_and_leave_the_repeat_to_
                         index.num_chunks, max_batch=b, max_topk=n_p) as eng:
         idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
         cnt = _t(np.full(b, 5, np.int32), gpu_device)
+        fixed = eng.retrieve(_bf16(qp_bits, gpu_device), idx, sc, cnt, ppr_iters=20, k=n_p)
         raw = eng.retrieve(_bf16(qp_bits, gpu_device), idx, sc, cnt, ppr_iters=20, k=n_p, ppr_tol=tol, ppr_max_iters=400)
+        short = eng.retrieve(_bf16(qp_bits, gpu_device), idx, sc, cnt, ppr_iters=20, k=n_p, ppr_tol=tol, ppr_max_iters=23)
         torch.cuda.synchronize()
         assert eng.timings()["slab_width"] != 128         # NOT the fp8 state
-        assert np.all(raw.iters_used.cpu().numpy() == 20)                      # no in-kernel extension on these states
-        assert np.all(raw.flags.cpu().numpy() & FLAG_NOT_CONVERGED)            # ... but every query says so
-        assert float(raw.residual.min()) > tol
+        assert np.all(fixed.iters_used.cpu().numpy() == 20) and np.all(fixed.flags.cpu().numpy() == 0)   # tolerance 0
+        raw_flags, raw_res = raw.flags.cpu().numpy(), raw.residual.cpu().numpy()
+        assert np.all(raw.iters_used.cpu().numpy() == 29)                      # every extension stage ran ...
+        assert np.all(((raw_flags & FLAG_NOT_CONVERGED) != 0) == (raw_res > tol))   # ... and whoever is still above the
+        assert b == 1 or (raw_flags & FLAG_NOT_CONVERGED).any()                # tolerance says so (the ring after 29 sweeps:
+                                                                              # 4e-7 .. 1.5e-4 from query to query)
+        write_test_report(f"fp16_state_extension_ring_b{b}", {"residual_max_after_20": float(fixed.residual.max()),
+                                                              "residual_max_after_29": float(raw_res.max()),
+                                                              "residual_min_after_29": float(raw_res.min()),
+                                                              "flagged": int(((raw_flags & FLAG_NOT_CONVERGED) != 0).sum())})
+        assert float(raw_res.max()) < 0.1 * float(fixed.residual.max())        # nine more sweeps (the worst passage changes
+                                                                              # from sweep to sweep on the ring: 0.03 .. 0.06)
+        assert np.all(short.iters_used.cpu().numpy() == 23)                    # ppr_max_iters bounds the extension
         out = eng.retrieve_converged(_bf16(qp_bits, gpu_device), idx, sc, cnt, ppr_iters=20, k=n_p, ppr_tol=tol,
                                      ppr_max_iters=400)
         torch.cuda.synchronize()
@@ -335,6 +348,37 @@ def test_the_other_state_types_run_the_fixed_count_flag_and_leave_the_repeat_to_
         allow = prior_noise_allowance(index, qp[q])       # q = 12: the oracle's OWN two dot variants differ by 1.5e-5
         worst = max(worst, float((np.abs(got_sc[q] / want[got_idx[q]] - 1) - allow[got_idx[q]]).max()))
     assert worst < 1e-5 / 1.5, (b, worst)
+
+
+@pytest.mark.parametrize("b", [4, 48])
+def test_the_fp16_states_stop_extending_as_soon_as_the_measured_residual_is_under_the_tolerance(gpu_device, b):
+    """The device decision on the fp16 states, like the fp8 one: a tolerance just above what the base sweeps leave costs
+    nothing (bit-identical to the fixed count), one just below it buys whole extension stages until the MEASURED residual
+    is under it, and nothing is flagged."""
+    import torch
+    from hipporag_amd.engine import HippoRAGEngine
+    # the ring: 20 sweeps leave a residual ~1e-3, far above the ~1e-7 the fp16 rounding of the correction puts under it
+    n, src, dst, w, pv, pinned = _ring()
+    csr, pass_bits, fact_bits, index = _index(n, src, dst, w, pv, 64, seed=11)
+    qf = _bf16(synth.make_queries_np(fact_bits, b, seed=5)[0], gpu_device)
+    qp = _bf16(synth.make_queries_np(pass_bits, b, seed=6)[0], gpu_device)
+    with HippoRAGEngine(csr, index.passage_vertex, pass_bits, fact_bits, index.subj_vertex, index.obj_vertex,
+                        index.num_chunks, max_batch=b, max_topk=50) as eng:
+        idx, sc = eng.score_facts(qf, k=5)
+        cnt = _t(np.full(b, 5, np.int32), gpu_device)
+        fixed = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50)
+        torch.cuda.synchronize()
+        assert eng.timings()["slab_width"] != 128
+        r20 = float(fixed.residual.max())
+        assert r20 > 1e-5 and int(fixed.iters_used.max()) == 20
+        above = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50, ppr_tol=1.05 * r20, ppr_max_iters=30)
+        below = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50, ppr_tol=0.2 * r20, ppr_max_iters=30)
+        torch.cuda.synchronize()
+        assert int(above.iters_used.max()) == 20 and np.all(above.flags.cpu().numpy() == 0)
+        assert torch.equal(above.doc_score, fixed.doc_score) and torch.equal(above.doc_idx, fixed.doc_idx)
+        used = int(below.iters_used.min())
+        assert used == int(below.iters_used.max()) and used in (21, 23, 26), used       # whole stages of 1, 2, 3 sweeps
+        assert float(below.residual.max()) <= 0.2 * r20 and np.all(below.flags.cpu().numpy() == 0)
 
 
 def test_on_a_bipartite_graph_the_passage_only_measure_still_reads_every_sweep(gpu_device):

@@ -12,6 +12,7 @@ LAST line (the JSON line of bench.py) as the last line of its own stdout.  A ran
 from __future__ import annotations
 
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -60,6 +61,14 @@ def spawn_ranks(world: int, cmd: Sequence[str], *, timeout_s: Optional[float] = 
     procs: List[subprocess.Popen] = []
     lines0: List[str] = []
     pumps: List[threading.Thread] = []
+
+    def on_signal(signum, frame):            # the launcher is being stopped (a driver-side timeout): take the ranks along
+        raise KeyboardInterrupt(f"signal {signum}")
+
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            old_handlers[sig] = signal.signal(sig, on_signal)
     try:
         for r in range(world):
             p = subprocess.Popen(list(cmd), env=rank_env(r, world, port, env), stdout=subprocess.PIPE, stderr=None,
@@ -102,6 +111,8 @@ def spawn_ranks(world: int, cmd: Sequence[str], *, timeout_s: Optional[float] = 
                 p.wait()
         for t in pumps:
             t.join(timeout=5)
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
         body = [ln for ln in lines0 if ln.strip()]
         for ln in body[:-1]:
             err.write(ln)

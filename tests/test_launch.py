@@ -88,3 +88,40 @@ def test_value_leg_prefers_a_parity_green_corpus_sharded_leg():
     assert pick_value_leg("rowshard", green, green) == "rowshard"
     assert pick_value_leg("hybrid", red, green) == "replica"
     assert pick_value_leg("replica", green, green) == "replica"
+
+
+def test_a_stopped_launcher_takes_its_ranks_along(tmp_path):
+    """SIGTERM to the launcher (a driver-side timeout) must not leave N orphaned ranks holding the GPUs."""
+    import signal
+    import time
+    pidfile = tmp_path / "pids"
+    worker = tmp_path / "worker.py"
+    worker.write_text(textwrap.dedent(f"""
+        import os, time
+        open({str(pidfile)!r}, "a").write(str(os.getpid()) + "\\n")
+        time.sleep(600)
+    """))
+    driver = tmp_path / "driver.py"
+    driver.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        from hipporag_amd import launch
+        sys.exit(launch.spawn_ranks(2, [sys.executable, {str(worker)!r}]))
+    """))
+    p = subprocess.Popen([sys.executable, str(driver)], stderr=subprocess.DEVNULL)
+    for _ in range(200):
+        if pidfile.exists() and len(pidfile.read_text().split()) == 2:
+            break
+        time.sleep(0.05)
+    pids = [int(x) for x in pidfile.read_text().split()]
+    assert len(pids) == 2
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=30)
+    time.sleep(0.3)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive, pid

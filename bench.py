@@ -649,6 +649,16 @@ def main():
         "ppr_contract": contract, "with_convergence_contract": contract_c, "with_accelerated_stages": accel,
         "phases_ms": {k: phases[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")},
         "sim_algorithmic_bytes": sim_algorithmic_bytes(kg.n_facts, kg.n_passages, D, B),
+        # the similarity stage against ITS roofline -- max(HBM time, MFMA time) of the algorithmic
+        # bytes / flops over the measured fact + passage phases (GEMMs + min/max + fused top-k)
+        "similarity_roofline": (lambda sb, fl, ms: {
+            "bound": "hbm" if sb / (HBM_PEAK_GBS * 1e9) >= fl / 2.5e15 else "mfma",
+            "algorithmic_bytes": sb, "flops": fl, "phase_ms": ms,
+            "achieved_gbs": sb / (ms * 1e-3) / 1e9, "achieved_tflops": fl / (ms * 1e-3) / 1e12,
+            "frac": max(sb / (HBM_PEAK_GBS * 1e9), fl / 2.5e15) / (ms * 1e-3),
+            "peaks": "8.0 TB/s HBM, 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)"})(
+                sim_algorithmic_bytes(kg.n_facts, kg.n_passages, D, B), 2.0 * B * (kg.n_facts + kg.n_passages) * D,
+                phases["fact_sim_ms"] + phases["pass_sim_ms"]),
         "n_long_rows": phases["n_long_rows"], "setup_s": setup_s,
     }
     if not args.no_cpu_baseline:

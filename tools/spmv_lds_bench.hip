@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void spmv_lds_kernel(Tiles t, const _Floa
 // v2: the block image is double-buffered (2 x kCB2 columns) and the copy of block p + 1 AND the first entries of phase
 // p + 1 are in flight while phase p is processed: one barrier per phase, no exposed HBM latency in the steady state.
 constexpr int kCB2 = 32768;
-template <int UNROLL>
+template <int UNROLL, bool DO_COPY = true, bool DO_ENTRIES = true>
 __global__ __launch_bounds__(kThreads) void spmv_lds2_kernel(Tiles t, const _Float16 *__restrict__ x, _Float16 *__restrict__ y,
                                                              const float *__restrict__ tele, float alpha, float beta, int rotate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -158,9 +158,9 @@ __global__ __launch_bounds__(kThreads) void spmv_lds2_kernel(Tiles t, const _Flo
     const unsigned voff = (unsigned)lane * 8u;
     int2 m = t.meta[((size_t)wg * np + phase_of(0)) * kWaves + wave];
     v2i_t e[UNROLL];
-    copy_block(phase_of(0), 0);
+    if constexpr (DO_COPY) copy_block(phase_of(0), 0);
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) e[u] = __builtin_amdgcn_raw_buffer_load_b64(srs, voff + (unsigned)u * 512u, (unsigned)m.x * 512u, 2);
+    for (int u = 0; u < UNROLL; ++u) e[u] = DO_ENTRIES ? __builtin_amdgcn_raw_buffer_load_b64(srs, voff + (unsigned)u * 512u, (unsigned)m.x * 512u, 2) : v2i_t{0, 0};
     for (int pp = 0; pp < np; ++pp) {
         const int buf = pp & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this phase's block image and first entries have landed
@@ -168,10 +168,10 @@ __global__ __launch_bounds__(kThreads) void spmv_lds2_kernel(Tiles t, const _Flo
         int2 mn = make_int2(0, 0);
         v2i_t en[UNROLL];
         if (pp + 1 < np) {                                   // next phase: block copy + first entries, in flight from here
-            copy_block(phase_of(pp + 1), buf ^ 1);
+            if constexpr (DO_COPY) copy_block(phase_of(pp + 1), buf ^ 1);
             mn = t.meta[((size_t)wg * np + phase_of(pp + 1)) * kWaves + wave];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) en[u] = __builtin_amdgcn_raw_buffer_load_b64(srs, voff + (unsigned)u * 512u, (unsigned)mn.x * 512u, 2);
+            for (int u = 0; u < UNROLL; ++u) en[u] = DO_ENTRIES ? __builtin_amdgcn_raw_buffer_load_b64(srs, voff + (unsigned)u * 512u, (unsigned)mn.x * 512u, 2) : v2i_t{0, 0};
         }
         const _Float16 *xb = xs + (size_t)buf * kCB2;
 #pragma unroll
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void spmv_lds2_kernel(Tiles t, const _Flo
                 yacc[r] = fmaf(__int_as_float(e[u].y), (float)xb[key & 0xffffu], yacc[r]);
             }
         }
-        for (int s0 = UNROLL; s0 < m.y; ++s0) {              // rare: a wavefront with more than UNROLL steps in a phase
+        for (int s0 = UNROLL; DO_ENTRIES && s0 < m.y; ++s0) { // rare: a wavefront with more than UNROLL steps in a phase
             const v2i_t ex = __builtin_amdgcn_raw_buffer_load_b64(srs, voff + (unsigned)s0 * 512u, (unsigned)m.x * 512u, 2);
             if (ex.y != 0) {
                 const unsigned key = (unsigned)ex.x;
@@ -381,9 +381,10 @@ int main(int argc, char **argv) {
     const size_t smem = (size_t)kCB * 2 + (size_t)kYMax * 4;
     const float alpha = 0.5f, beta = 0.5f;
 
+    int grid_wgs = kWG;
     auto run = [&](auto kern, const char *name) {
         CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, dim3(kWG), dim3(kThreads), smem, 0, t, d_x, d_y, d_tele, alpha, beta, rotate);
+        hipLaunchKernelGGL(kern, dim3(grid_wgs), dim3(kThreads), smem, 0, t, d_x, d_y, d_tele, alpha, beta, rotate);
         CK(hipGetLastError());
         CK(hipDeviceSynchronize());
         // check against the CPU (double)
@@ -399,9 +400,9 @@ int main(int argc, char **argv) {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const int n = 40;
-        for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(kern, dim3(kWG), dim3(kThreads), smem, 0, t, (i & 1) ? d_y : d_x, (i & 1) ? d_x : d_y, d_tele, alpha, beta, rotate);
+        for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(kern, dim3(grid_wgs), dim3(kThreads), smem, 0, t, (i & 1) ? d_y : d_x, (i & 1) ? d_x : d_y, d_tele, alpha, beta, rotate);
         CK(hipEventRecord(e0));
-        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(kern, dim3(kWG), dim3(kThreads), smem, 0, t, (i & 1) ? d_y : d_x, (i & 1) ? d_x : d_y, d_tele, alpha, beta, rotate);
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(kern, dim3(grid_wgs), dim3(kThreads), smem, 0, t, (i & 1) ? d_y : d_x, (i & 1) ? d_x : d_y, d_tele, alpha, beta, rotate);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms = 0;
@@ -415,6 +416,11 @@ int main(int argc, char **argv) {
         run(spmv_lds_kernel<true, 8>, "lds-blocked, DMA copy, unroll 8");
         run(spmv_lds_kernel<false, 4>, "lds-blocked, register copy, unroll 4");
     } else {
+        run(spmv_lds2_kernel<4, true, false>, "v2 COPY ONLY (no entries)");
+        grid_wgs = 128; run(spmv_lds2_kernel<4, true, false>, "v2 COPY ONLY, 128 workgroups");
+        grid_wgs = 64; run(spmv_lds2_kernel<4, true, false>, "v2 COPY ONLY, 64 workgroups");
+        grid_wgs = kWG;
+        run(spmv_lds2_kernel<4, false, true>, "v2 ENTRIES ONLY (no block copies)");
         run(spmv_lds2_kernel<4>, "v2 double-buffered, prefetch 4");
         run(spmv_lds2_kernel<6>, "v2 double-buffered, prefetch 6");
         run(spmv_lds2_kernel<8>, "v2 double-buffered, prefetch 8");

@@ -11,9 +11,9 @@
 //     cycles of 130 M LDS-active ones), and two waves per SIMD so that one wave's LDS reads / barrier waits
 //     hide behind the other's MFMAs (4 waves of 128 x 128: 0.48 ms; 8 waves: 0.35 ms);
 //   * global -> LDS by LDS-direct loads (global_load_lds_dwordx4, non-temporal for the embedding stream,
-//     which every byte of is read once): no VGPR staging, no ds_write pass; two LDS stages of BK = 64, the
-//     next stage's loads in flight during the MFMAs of the current one (deeper / finer pipelines measured
-//     slower);
+//     which every byte of is read once): no VGPR staging, no ds_write pass; stages of BK = 64 in an ASYMMETRIC
+//     pipeline (round 4): three for the embedding rows (HBM, prefetch distance 2), two for the query tile (L2) --
+//     160 KB, the whole LDS of a CU at 256 queries (symmetric deeper / finer pipelines measured slower);
 //   * LDS image: [rows][8 chunks of 16 B], chunk c of row r stored at chunk c ^ (r & 7) -- no bank conflicts
 //     (PMC: SQ_LDS_BANK_CONFLICT = 0).  An LDS-direct load writes wave-uniform base + lane * 16, so the
 //     swizzle is applied on the GLOBAL side: lane l fetches logical chunk (l & 7) ^ ((l >> 3) & 7) of row
@@ -83,8 +83,13 @@ __global__ __launch_bounds__(512, 1) void sim_gemm256_kernel(const uint16_t *__r
                                                              float *__restrict__ tmin) {
     constexpr int MI = 4, WGM = 4, WGN = 2, NW = WGM * WGN;
     constexpr int BN = WGN * NJ * 16;
-    constexpr int A_BYTES = BM2 * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 stages
+    constexpr int A_BYTES = BM2 * 128, B_BYTES = BN * 128;
+    constexpr int A_LOADS = BM2 / 8 / NW;   // LDS-direct loads per wave and embedding stage
+    // Asymmetric pipeline (round 4; measured in tools/gemm_bench.hip: 0.341 -> 0.326 ms on the cfg 3 shape): THREE stages for
+    // the embedding rows -- the HBM stream, prefetch distance 2 -- and TWO for the query tile (L2): 3 * 32 KB + 2 * 32 KB =
+    // 160 KB at a 256 x 256 tile, the whole LDS of a CU.  Issue order per step: B(k + 1) then A(k + 2), so that
+    // `s_waitcnt vmcnt(A_LOADS)` leaves exactly A(k + 2) in flight.  The MFMA chain of every score is untouched.
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [3][A_BYTES] then [2][B_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -101,21 +106,24 @@ __global__ __launch_bounds__(512, 1) void sim_gemm256_kernel(const uint16_t *__r
     const int lrow = lane >> 3;
     const int lchunk = (lane & 7) ^ (lrow & 7);          // logical 16-byte chunk this lane fetches
     const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    auto issue = [&](int stage, int k0) {
-        const uint32_t sa = smem_base + (uint32_t)(stage * STAGE);
+    auto issue_a = [&](int stage, int k0) {
+        const uint32_t sa = smem_base + (uint32_t)(stage * A_BYTES);
 #pragma unroll
-        for (int i = 0; i < BM2 / 8 / NW; ++i) {
-            const int blk = wave * (BM2 / 8 / NW) + i;
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int blk = wave * A_LOADS + i;
             int64_t r = m0 + blk * 8 + lrow;
             r = r < rows ? r : rows - 1;                 // rows beyond the matrix: any valid row (never stored)
             glds16<true>(emb + (size_t)r * dim + k0 + lchunk * 8, sa + (uint32_t)(blk * 1024));
         }
+    };
+    auto issue_b = [&](int stage, int k0) {
+        const uint32_t sb = smem_base + (uint32_t)(3 * A_BYTES + stage * B_BYTES);
 #pragma unroll
         for (int i = 0; i < BN / 8 / NW; ++i) {
             const int blk = wave * (BN / 8 / NW) + i;
             int r = b0 + blk * 8 + lrow;
             r = r < batch ? r : batch - 1;
-            glds16<false>(q + (size_t)r * dim + k0 + lchunk * 8, sa + (uint32_t)(A_BYTES + blk * 1024));
+            glds16<false>(q + (size_t)r * dim + k0 + lchunk * 8, sb + (uint32_t)(blk * 1024));
         }
     };
 
@@ -127,14 +135,20 @@ __global__ __launch_bounds__(512, 1) void sim_gemm256_kernel(const uint16_t *__r
 
     const int frow = lane & 15, fk = lane >> 4;           // fragment row and 8-element k group of this lane
     const int nk = dim / BK2;
-    issue(0, 0);
+    issue_b(0, 0);
+    issue_a(0, 0);
+    if (nk > 1) issue_a(1, BK2);
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage kt has landed (the LDS-direct loads are not
-        __syncthreads();                                   // tracked by the compiler) -- for every wave; and
-                                                           // everybody is done reading the other stage
-        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * BK2);     // in flight during the MFMAs below
-        const unsigned char *sa = smem + (kt & 1) * STAGE;
-        const unsigned char *sb = sa + A_BYTES;
+        // A(kt) and B(kt) have landed (the LDS-direct loads are not tracked by the compiler; they retire in order, so
+        // allowing the A_LOADS youngest = A(kt + 1) to stay in flight is exact)
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // ... for every wave; and everybody is done reading the
+                                                           // stages about to be refilled
+        if (kt + 1 < nk) issue_b((kt + 1) & 1, (kt + 1) * BK2);   // in flight during the MFMAs below
+        if (kt + 2 < nk) issue_a((kt + 2) % 3, (kt + 2) * BK2);
+        const unsigned char *sa = smem + (kt % 3) * A_BYTES;
+        const unsigned char *sb = smem + 3 * A_BYTES + (kt & 1) * B_BYTES;
 #pragma unroll
         for (int s = 0; s < BK2 / 32; ++s) {
             const int c = s * 4 + fk;
@@ -220,7 +234,7 @@ template <int NJ, bool TILEMAX, bool F16>
 hrag_status launch256(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch, float *out,
                       int64_t ld, float *tmax, float *tmin, hipStream_t s) {
     constexpr int BN = NJ * 32;
-    constexpr int lds_bytes = 2 * (BM2 * 128 + BN * 128);
+    constexpr int lds_bytes = 3 * BM2 * 128 + 2 * BN * 128;   // three embedding stages, two query stages
     static_assert(lds_bytes >= 2 * 4 * BN * (int)sizeof(float), "the tile-max reduction reuses the stage memory");
     static bool configured = false;
     auto kernel = sim_gemm256_kernel<NJ, TILEMAX, F16>;

@@ -96,6 +96,104 @@ class RetrieveOutput:
 logger = logging.getLogger(__name__)
 
 
+def host_copy_async(t):
+    """(host tensor, event): the copy of device tensor `t` to pinned host memory, enqueued on the current stream; the
+    event (None for a tensor that already lives on the host) completes when the copy has.  Waiting for the event does
+    not wait for anything enqueued after it -- what a pipeline over batches needs (t.cpu() drains the stream)."""
+    torch = _torch()
+    if not t.is_cuda:
+        return t, None
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return h, ev
+
+
+def host_wait(pair):
+    """The numpy view of a host_copy_async() result, once its copy has completed."""
+    h, ev = pair
+    if ev is not None:
+        ev.synchronize()
+    return h.numpy()
+
+
+class PendingRetrieve:
+    """A batch that HippoRAGEngine.retrieve_converged_start() enqueued.  finish() is the host half of the convergence
+    contract (see retrieve_converged); `repeated` tells whether anything was run again (the output tensors then
+    differ from what was enqueued first)."""
+
+    def __init__(self, eng, run, out, flags_h, damping, ppr_iters, ppr_tol, ppr_max_iters, want_all_scores):
+        self.eng, self.run, self.out, self.flags_h = eng, run, out, flags_h
+        self.damping, self.ppr_iters, self.ppr_tol, self.ppr_max_iters = damping, ppr_iters, ppr_tol, ppr_max_iters
+        self.want_all_scores = want_all_scores
+        self.repeated, self.flags = False, None
+
+    def finish(self) -> RetrieveOutput:
+        torch = _torch()
+        from ._lib import FLAG_FP8_SATURATED, FLAG_NOT_CONVERGED, OPT_NO_F16, OPT_NO_FP8
+        eng, run, out = self.eng, self.run, self.out
+        damping, ppr_iters, ppr_tol, ppr_max_iters = self.damping, self.ppr_iters, self.ppr_tol, self.ppr_max_iters
+
+        def on_wider_state(fn, bits=OPT_NO_FP8):
+            had = eng.opt_flags & bits               # restore what the engine was created with
+            eng.set_flags(bits, True)
+            try:
+                return fn()
+            finally:
+                if bits & ~had:
+                    eng.set_flags(bits & ~had, False)
+
+        flags = host_wait(self.flags_h).copy()
+        if (flags & FLAG_FP8_SATURATED).any() and (eng.opt_flags & _lib.OPT_ACCEL):
+            # accelerated stages (HRAG_OPT_ACCEL): a violated scale bound falls back to the plain plan first
+            logger.warning("fp8 PPR state saturated under HRAG_OPT_ACCEL for %d queries: repeating the batch on the plain plan",
+                           int(((flags & FLAG_FP8_SATURATED) != 0).sum()))
+            eng.set_flags(_lib.OPT_ACCEL, False)
+            try:
+                out = run()
+            finally:
+                eng.set_flags(_lib.OPT_ACCEL, True)
+            self.repeated = True
+            flags = out.flags.cpu().numpy()
+        if (flags & FLAG_FP8_SATURATED).any():
+            logger.warning("fp8 PPR state saturated for %d queries: repeating the batch on the wider state",
+                           int(((flags & FLAG_FP8_SATURATED) != 0).sum()))
+            out = on_wider_state(run)
+            self.repeated = True
+            flags = out.flags.cpu().numpy()
+        self.out, self.flags = out, flags            # flags: the final flag words on the host (numpy)
+        if ppr_tol <= 0 or not (flags & FLAG_NOT_CONVERGED).any():
+            return out
+        self.repeated = True
+        resid, used = out.residual.cpu().numpy(), out.iters_used.cpu().numpy()
+        for _ in range(6):
+            rows = np.flatnonzero(flags & FLAG_NOT_CONVERGED)
+            if not len(rows):
+                break
+            done = int(used[rows].max())
+            need = done + int(np.ceil(np.log(max(float(resid[rows].max()) / ppr_tol, 1.0)) / -np.log(damping))) + 4
+            need = min(max(need, done + 4), max(ppr_max_iters, ppr_iters))
+            if need <= done:
+                break                                   # ppr_max_iters reached: the flag stays
+            logger.info("PPR not converged for %d queries after %d sweeps (residual %.2g > %.2g): repeating them "
+                        "with %d sweeps", len(rows), done, float(resid[rows].max()), ppr_tol, need)
+            rt = torch.as_tensor(rows, device=eng.device)
+            # fp32 state: the scores that converge last are orders of magnitude below the largest one
+            o2 = on_wider_state(lambda: run(rt, need, need), OPT_NO_FP8 | OPT_NO_F16)
+            out.doc_idx[rt], out.doc_score[rt] = o2.doc_idx, o2.doc_score
+            out.flags[rt], out.residual[rt], out.iters_used[rt] = o2.flags, o2.residual, o2.iters_used
+            if self.want_all_scores:
+                out.all_scores[rt] = o2.all_scores
+            flags[rows], resid[rows], used[rows] = (o2.flags.cpu().numpy(), o2.residual.cpu().numpy(),
+                                                    o2.iters_used.cpu().numpy())
+        left = (flags & FLAG_NOT_CONVERGED) != 0
+        if left.any():
+            logger.warning("PPR residual above ppr_tol=%.2g for %d queries after ppr_max_iters=%d sweeps (max %.2g)",
+                           ppr_tol, int(left.sum()), ppr_max_iters, float(resid[left].max()))
+        return out
+
+
 class HippoRAGEngine:
     """Device-resident retrieval state: CSR graph, bf16 fact / passage embeddings, lookup arrays.
 
@@ -343,9 +441,19 @@ class HippoRAGEngine:
         HRAG_FLAG_NOT_CONVERGED -- its sweep budget did not reach ppr_tol: a slowly mixing graph -- are repeated,
         those queries only, on the wider state with the sweeps their residual asks for (it contracts by `damping`
         per sweep), up to ppr_max_iters.  The reference's PRPACK does the same thing implicitly: it iterates to
-        1e-10 whatever the graph (HippoRAG.py:1736-1743).  A flag that survives means ppr_max_iters was too small."""
-        torch = _torch()
-        from ._lib import FLAG_FP8_SATURATED, FLAG_NOT_CONVERGED, OPT_NO_F16, OPT_NO_FP8
+        1e-10 whatever the graph (HippoRAG.py:1736-1743).  A flag that survives means ppr_max_iters was too small.
+
+        = retrieve_converged_start(...).finish(); callers that have host work to do while the batch runs (the mirror's
+        batch pipeline, retriever.iter_batched_retrieve) use the two halves."""
+        return self.retrieve_converged_start(q_pass, kept_idx, kept_score, kept_count, damping=damping, ppr_iters=ppr_iters,
+                                             ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters,
+                                             want_all_scores=want_all_scores, **kw).finish()
+
+    def retrieve_converged_start(self, q_pass, kept_idx, kept_score, kept_count, *, damping: float = 0.5,
+                                 ppr_iters: int = 20, ppr_tol: float = 1.5e-6, ppr_max_iters: int = 400,
+                                 want_all_scores: bool = False, **kw) -> "PendingRetrieve":
+        """Enqueue the batch and the copy of its flag words to (pinned) host memory; nothing waits.  .finish() waits for
+        the flags -- not for whatever was enqueued behind them -- and does the host half of the contract."""
         q = self._q(q_pass)
         kept_idx, kept_score, kept_count = (t.to(self.device) for t in (kept_idx, kept_score, kept_count))
 
@@ -357,60 +465,9 @@ class HippoRAGEngine:
                 o.all_scores = self.last_doc_scores(o.doc_idx.shape[0])
             return o
 
-        def on_wider_state(fn, bits=OPT_NO_FP8):
-            had = self.opt_flags & bits               # restore what the engine was created with
-            self.set_flags(bits, True)
-            try:
-                return fn()
-            finally:
-                if bits & ~had:
-                    self.set_flags(bits & ~had, False)
-
         out = run()
-        flags = out.flags.cpu().numpy()
-        if (flags & FLAG_FP8_SATURATED).any() and (self.opt_flags & _lib.OPT_ACCEL):
-            # accelerated stages (HRAG_OPT_ACCEL): a violated scale bound falls back to the plain plan first
-            logger.warning("fp8 PPR state saturated under HRAG_OPT_ACCEL for %d queries: repeating the batch on the plain plan",
-                           int(((flags & FLAG_FP8_SATURATED) != 0).sum()))
-            self.set_flags(_lib.OPT_ACCEL, False)
-            try:
-                out = run()
-            finally:
-                self.set_flags(_lib.OPT_ACCEL, True)
-            flags = out.flags.cpu().numpy()
-        if (flags & FLAG_FP8_SATURATED).any():
-            logger.warning("fp8 PPR state saturated for %d queries: repeating the batch on the wider state",
-                           int(((flags & FLAG_FP8_SATURATED) != 0).sum()))
-            out = on_wider_state(run)
-            flags = out.flags.cpu().numpy()
-        if ppr_tol <= 0 or not (flags & FLAG_NOT_CONVERGED).any():
-            return out
-        resid, used = out.residual.cpu().numpy(), out.iters_used.cpu().numpy()
-        for _ in range(6):
-            rows = np.flatnonzero(flags & FLAG_NOT_CONVERGED)
-            if not len(rows):
-                break
-            done = int(used[rows].max())
-            need = done + int(np.ceil(np.log(max(float(resid[rows].max()) / ppr_tol, 1.0)) / -np.log(damping))) + 4
-            need = min(max(need, done + 4), max(ppr_max_iters, ppr_iters))
-            if need <= done:
-                break                                   # ppr_max_iters reached: the flag stays
-            logger.info("PPR not converged for %d queries after %d sweeps (residual %.2g > %.2g): repeating them "
-                        "with %d sweeps", len(rows), done, float(resid[rows].max()), ppr_tol, need)
-            rt = torch.as_tensor(rows, device=self.device)
-            # fp32 state: the scores that converge last are orders of magnitude below the largest one
-            o2 = on_wider_state(lambda: run(rt, need, need), OPT_NO_FP8 | OPT_NO_F16)
-            out.doc_idx[rt], out.doc_score[rt] = o2.doc_idx, o2.doc_score
-            out.flags[rt], out.residual[rt], out.iters_used[rt] = o2.flags, o2.residual, o2.iters_used
-            if want_all_scores:
-                out.all_scores[rt] = o2.all_scores
-            flags[rows], resid[rows], used[rows] = (o2.flags.cpu().numpy(), o2.residual.cpu().numpy(),
-                                                    o2.iters_used.cpu().numpy())
-        left = (flags & FLAG_NOT_CONVERGED) != 0
-        if left.any():
-            logger.warning("PPR residual above ppr_tol=%.2g for %d queries after ppr_max_iters=%d sweeps (max %.2g)",
-                           ppr_tol, int(left.sum()), ppr_max_iters, float(resid[left].max()))
-        return out
+        return PendingRetrieve(self, run, out, host_copy_async(out.flags), damping, ppr_iters, ppr_tol, ppr_max_iters,
+                               want_all_scores)
 
     def last_doc_scores(self, batch: int):
         """fp32 [batch, Np]: the scores of ALL passages behind the last retrieve() / retrieve_scored() (hrag_last_doc_scores)."""

@@ -170,21 +170,23 @@ def attach(rag, *, max_batch: int = 256, ppr_iters: Optional[int] = None, batche
                                doc_metadata=meta, graph_seeds=seeds or [])
 
     def retrieve(queries: List[str], num_to_retrieve: Optional[int] = None, gold_docs=None):   # :413-499
-        from .retriever import batched_retrieve
+        from .retriever import gc_paused, iter_batched_retrieve
         t_start = time.time()
         if num_to_retrieve is None:
             num_to_retrieve = cfg.retrieval_top_k
         rag.get_query_embeddings(queries)
-        rows = batched_retrieve(eng, queries, q_tensor, facts, rag.rerank_filter,
-                                linking_top_k=int(cfg.linking_top_k), damping=cfg.damping,
-                                passage_node_weight=cfg.passage_node_weight, ppr_iters=sweeps,
-                                num_to_retrieve=int(num_to_retrieve), n_passages=len(rag.passage_node_keys),
-                                timers=rag, ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters)
         results = []
-        for q, (d_idx, d_sc, seeds) in zip(queries, rows):
-            r = build_result(q, d_idx, d_sc, num_to_retrieve, seeds)
-            results.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
-                                         doc_metadata=r.doc_metadata, graph_seeds=r.graph_seeds))
+        # batch by batch: one batch's document lists are built while the device works on the next one
+        for lo, rows in iter_batched_retrieve(eng, queries, q_tensor, facts, rag.rerank_filter,
+                                              linking_top_k=int(cfg.linking_top_k), damping=cfg.damping,
+                                              passage_node_weight=cfg.passage_node_weight, ppr_iters=sweeps,
+                                              num_to_retrieve=int(num_to_retrieve), n_passages=len(rag.passage_node_keys),
+                                              timers=rag, ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters):
+            with gc_paused():
+                for q, (d_idx, d_sc, seeds) in zip(queries[lo: lo + len(rows)], rows):
+                    r = build_result(q, d_idx, d_sc, num_to_retrieve, seeds)
+                    results.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
+                                                 doc_metadata=r.doc_metadata, graph_seeds=r.graph_seeds))
         rag.all_retrieval_time = getattr(rag, "all_retrieval_time", 0.0) + time.time() - t_start
         if gold_docs is not None:
             try:

@@ -24,6 +24,8 @@ Differences to the reference, all deliberate:
 
 from __future__ import annotations
 
+import contextlib
+import gc
 import logging
 import re
 import time
@@ -164,19 +166,60 @@ def identity_rerank_filter(query, candidate_items, candidate_indices, len_after_
     return list(candidate_indices)[:n], list(candidate_items)[:n], {"confidence": None}
 
 
-def batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Sequence, rerank_filter: Callable, *,
-                     linking_top_k: int, damping: float, passage_node_weight: float, ppr_iters: int,
-                     num_to_retrieve: int, n_passages: int, timers=None, ppr_tol: float = 0.0,
-                     ppr_max_iters: int = 0):
-    """The body of retrieve() (HippoRAG.py:459-480) for all queries at once, shared by the mirror class below
-    and by reference_adapter.attach(): phase A on the device, the recognition-memory filter on the host
-    (rerank_facts :1659-1707), phase B on the device.  Returns one (doc ids, doc scores, kept facts) per
-    query; raises where the reference's asserts would (:1541, :1644).  timers: object whose rerank_time /
-    ppr_time attributes are advanced like the reference's accumulators (:184-186).
+@contextlib.contextmanager
+def gc_paused():
+    """Materialising a batch allocates ~50 k small containers (lists of document strings, one metadata dict per
+    document, HippoRAG.py:501-507); none of them can be part of a cycle, but they trip the cyclic collector every 700
+    allocations and, every so often, a full pass over everything the process holds (the fact and passage tables: tens of
+    milliseconds at 1 M facts).  retrieve() pauses the collector while it builds a batch's results: 7 -> 4 ms per
+    256 x 200 documents."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
+class BatchRows(list):
+    """What iter_batched_retrieve yields for a batch: the list of (doc ids, doc scores, kept facts) per query, plus the
+    batch's arrays themselves (doc_idx int32 [b, k], doc_score fp32 [b, k]) for consumers that work on whole batches."""
+    doc_idx = None
+    doc_score = None
+
+
+def batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Sequence, rerank_filter: Callable, **kw):
+    """The body of retrieve() (HippoRAG.py:459-480) for all queries at once: one (doc ids, doc scores, kept facts) per
+    query.  See iter_batched_retrieve, which this flattens."""
+    out_rows = []
+    for _, rows in iter_batched_retrieve(eng, queries, q_tensor, facts, rerank_filter, **kw):
+        out_rows.extend(rows)
+    return out_rows
+
+
+def iter_batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Sequence, rerank_filter: Callable, *,
+                          linking_top_k: int, damping: float, passage_node_weight: float, ppr_iters: int,
+                          num_to_retrieve: int, n_passages: int, timers=None, ppr_tol: float = 0.0,
+                          ppr_max_iters: int = 0):
+    """The body of retrieve() (HippoRAG.py:459-480), shared by the mirror class below and by
+    reference_adapter.attach(): phase A on the device, the recognition-memory filter on the host (rerank_facts
+    :1659-1707), phase B on the device, in batches of eng.max_batch queries.  Yields (offset of the batch, [(doc ids,
+    doc scores, kept facts) per query]) batch by batch, in order; raises where the reference's asserts would (:1541,
+    :1644).  timers: object whose rerank_time / ppr_time attributes are advanced like the reference's accumulators
+    (:184-186).
+
+    The batches are PIPELINED against the host: phase A of batch i + 1 is enqueued before the filter loop of batch i
+    runs, and batch i's results are waited for (events on the copies to pinned memory, not a drain of the stream) only
+    after batch i + 1's phase B was enqueued -- so the filter loop and whatever the consumer does with a yielded batch
+    (the mirror builds its lists of document strings) run while the device works on the next batch.  The device sees
+    A(0) A(1) B(0) A(2) B(1) ...; phase B takes everything it needs from its arguments, so the order is free.
+
     ppr_tol / ppr_max_iters: the convergence contract (RetrievalConfig): queries the engine flags as not converged
     within its sweep budget are repeated -- those queries only -- on the wider state with the sweeps their
     residual asks for, so a slowly mixing graph costs time, never accuracy."""
     import torch
+    from .engine import host_copy_async, host_wait
     k_f = int(linking_top_k)
     want = max(1, min(int(num_to_retrieve), n_passages))
     k_docs = min(want, eng.max_topk)
@@ -186,57 +229,112 @@ def batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Sequenc
     if k_docs < want and not beyond:
         logger.warning("num_to_retrieve=%d exceeds the engine's max_topk=%d: %d documents per query are returned "
                        "(create the engine with a larger retrieval_top_k, <= 2048)", num_to_retrieve, eng.max_topk, k_docs)
-    out_rows = []
-    for lo in range(0, len(queries), eng.max_batch):
-        qs = queries[lo: lo + eng.max_batch]
+    use_facts = len(facts) > 0 and k_f > 0
+    two_halves = hasattr(eng, "retrieve_converged_start")
+    starts = list(range(0, len(queries), eng.max_batch))
+
+    def tick(name, t0):
+        if timers is not None:
+            setattr(timers, name, getattr(timers, name, 0.0) + time.time() - t0)
+
+    class Batch:
+        pass
+
+    def start_a(lo):                                                                   # phase A, enqueued
+        bt = Batch()
+        bt.lo, bt.qs = lo, queries[lo: lo + eng.max_batch]
+        bt.a = None
+        if use_facts:
+            t0 = time.time()
+            idx, sc = eng.score_facts(q_tensor(bt.qs, "triple"), k=k_f)
+            bt.a = (host_copy_async(idx), host_copy_async(sc))
+            tick("rerank_time", t0)
+        return bt
+
+    def filter_and_start_b(bt):                                                        # host: LLM filter; phase B, enqueued
+        qs = bt.qs
         b = len(qs)
         kept_idx = np.full((b, max(k_f, 1)), -1, np.int32)
         kept_sc = np.zeros((b, max(k_f, 1)), np.float32)
         kept_cnt = np.zeros(b, np.int32)
-        seeds: List[List[Tuple]] = [[] for _ in range(b)]
-        t_r = time.time()
-        if len(facts) > 0 and k_f > 0:
-            idx, sc = eng.score_facts(q_tensor(qs, "triple"), k=k_f)                   # phase A
-            idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
-            for i, q in enumerate(qs):                                                 # host: LLM filter
-                cand = [int(j) for j in idx_h[i] if j >= 0]
+        bt.seeds = [[] for _ in range(b)]
+        t0 = time.time()
+        if bt.a is not None:
+            idx_l, sc_l = host_wait(bt.a[0]).tolist(), host_wait(bt.a[1]).tolist()     # python ints / floats, once
+            for i, q in enumerate(qs):
+                row, srow = idx_l[i], sc_l[i]
+                cand = [j for j in row if j >= 0]
                 try:
                     kidx, kfacts, _ = rerank_filter(q, [facts[j] for j in cand], cand, len_after_rerank=k_f)
                 except Exception as exc:                                               # :1705-1707
                     logger.error("Error in rerank_facts: %s", exc)
                     kidx, kfacts = [], []
-                score_of = {int(j): sc_h[i][p] for p, j in enumerate(idx_h[i]) if j >= 0}
-                kidx = [int(j) for j in kidx if int(j) in score_of][:k_f]
-                kept_idx[i, :len(kidx)] = kidx
-                kept_sc[i, :len(kidx)] = [score_of[j] for j in kidx]
-                kept_cnt[i] = len(kidx)
-                seeds[i] = list(kfacts)
-        if timers is not None:
-            timers.rerank_time = getattr(timers, "rerank_time", 0.0) + time.time() - t_r
-        t_p = time.time()
+                score_of = {j: srow[p] for p, j in enumerate(row) if j >= 0}
+                kidx = [j for j in map(int, kidx) if j in score_of][:k_f]
+                n = len(kidx)
+                if n:
+                    kept_idx[i, :n] = kidx
+                    kept_sc[i, :n] = [score_of[j] for j in kidx]
+                kept_cnt[i] = n
+                bt.seeds[i] = list(kfacts)
+        tick("rerank_time", t0)
+        t0 = time.time()
+        args = (q_tensor(qs, "passage"), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc), torch.from_numpy(kept_cnt))
+        kw = dict(link_top_k=k_f, damping=damping, passage_node_weight=passage_node_weight, ppr_iters=ppr_iters,
+                  k=k_docs, ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters, **({"want_all_scores": True} if beyond else {}))
+        if two_halves:
+            bt.pending = eng.retrieve_converged_start(*args, **kw)
+            o = bt.pending.out
+            bt.copies = (host_copy_async(o.doc_idx), host_copy_async(o.doc_score))
+        else:                                       # an engine with the one-call form only (test doubles)
+            bt.pending, bt.out = None, eng.retrieve_converged(*args, **kw)
+        tick("ppr_time", t0)
 
-        out = eng.retrieve_converged(q_tensor(qs, "passage"), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc),
-                                     torch.from_numpy(kept_cnt), link_top_k=k_f, damping=damping,
-                                     passage_node_weight=passage_node_weight, ppr_iters=ppr_iters, k=k_docs,
-                                     ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters,
-                                     **({"want_all_scores": True} if beyond else {}))
-        flags = out.flags.cpu().numpy()
-        d_idx, d_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+    def finish(bt):
+        t0 = time.time()
+        if bt.pending is not None:
+            out = bt.pending.finish()
+            if bt.pending.repeated:                 # something was run again: take what the tensors hold now
+                d_idx, d_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+            else:
+                d_idx, d_sc = host_wait(bt.copies[0]), host_wait(bt.copies[1])
+            flags = bt.pending.flags                # host copy: reading out.flags would drain the stream
+        else:
+            out = bt.out
+            d_idx, d_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
+            flags = out.flags.cpu().numpy()
         if beyond:
             full = out.all_scores.cpu().numpy()
             d_idx = np.stack([np.argsort(r, kind="stable")[::-1][:want] for r in full]).astype(np.int32)
             d_sc = np.take_along_axis(full, d_idx.astype(np.int64), axis=1)
-        if timers is not None:
-            timers.ppr_time = getattr(timers, "ppr_time", 0.0) + time.time() - t_p
-        for i in range(b):
+        tick("ppr_time", t0)
+        rows = BatchRows()
+        rows.doc_idx, rows.doc_score = d_idx, d_sc
+        for i in range(len(bt.qs)):
             if flags[i] & 4:      # :1541
                 raise AssertionError("count_nonzero(all_phrase_weights) != len(linking_score_map)")
             if flags[i] & 2:      # :1644
-                raise AssertionError(f"No phrases found in the graph for the given facts: {seeds[i]}")
+                raise AssertionError(f"No phrases found in the graph for the given facts: {bt.seeds[i]}")
             if flags[i] & 1:
                 logger.info("No facts found after reranking, return DPR results")      # :468
-            out_rows.append((d_idx[i], d_sc[i], seeds[i]))
-    return out_rows
+            rows.append((d_idx[i], d_sc[i], bt.seeds[i]))
+        return bt.lo, rows
+
+    if not starts:
+        return
+    nxt, prev = start_a(starts[0]), None
+    for n, lo in enumerate(starts):
+        cur = nxt
+        if bt_wait := cur.a:                        # batch n's fact candidates are needed on the host now
+            t0 = time.time()
+            host_wait(bt_wait[0])
+            tick("rerank_time", t0)
+        nxt = start_a(starts[n + 1]) if n + 1 < len(starts) else None
+        filter_and_start_b(cur)
+        if prev is not None:
+            yield finish(prev)
+        prev = cur
+    yield finish(prev)
 
 
 class HippoRAG:
@@ -616,16 +714,8 @@ class HippoRAG:
             num_to_retrieve = cfg.retrieval_top_k
         self._ensure_ready()
         self.get_query_embeddings(queries)
-        rows = batched_retrieve(self.engine, queries, self._q_tensor, self.facts if self.fact_node_keys else [],
-                                self.rerank_filter, linking_top_k=cfg.linking_top_k, damping=cfg.damping,
-                                passage_node_weight=cfg.passage_node_weight, ppr_iters=self._ppr_iters(),
-                                ppr_tol=cfg.ppr_tol, ppr_max_iters=cfg.ppr_max_iters,
-                                num_to_retrieve=num_to_retrieve, n_passages=len(self.passage_node_keys), timers=self)
         results: List[QuerySolution] = []
-        for q, (d_idx, d_sc, seeds) in zip(queries, rows):
-            r = self._build_retrieval_result(q, d_idx, d_sc, num_to_retrieve, seeds)
-            results.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
-                                         doc_metadata=r.doc_metadata, graph_seeds=r.graph_seeds))
+        self._retrieve_into(results, queries, num_to_retrieve)
         self.all_retrieval_time += time.time() - t_start
         logger.info("Total Retrieval Time %.2fs", self.all_retrieval_time)
         logger.info("Total Recognition Memory Time %.2fs", self.rerank_time)
@@ -633,6 +723,18 @@ class HippoRAG:
         if gold_docs is not None:
             return results, self._recall(gold_docs, [r.docs for r in results])
         return results
+
+    def _retrieve_into(self, results, queries, num_to_retrieve):
+        cfg = self.global_config
+        # batch by batch: the lists of document strings of one batch are built while the device works on the next
+        for lo, rows in iter_batched_retrieve(self.engine, queries, self._q_tensor, self.facts if self.fact_node_keys else [],
+                                              self.rerank_filter, linking_top_k=cfg.linking_top_k, damping=cfg.damping,
+                                              passage_node_weight=cfg.passage_node_weight, ppr_iters=self._ppr_iters(),
+                                              ppr_tol=cfg.ppr_tol, ppr_max_iters=cfg.ppr_max_iters,
+                                              num_to_retrieve=num_to_retrieve, n_passages=len(self.passage_node_keys),
+                                              timers=self):
+            with gc_paused():       # around the materialisation only: the filter (an LLM call in production) runs outside
+                results.extend(self._build_query_solutions(queries[lo: lo + len(rows)], rows, num_to_retrieve))
 
     # ------------------------------------------------------------------ retrieve_ircot :509-558
     def retrieve_ircot(self, queries: List[str], max_qa_steps: int, num_to_retrieve: Optional[int] = None,
@@ -695,6 +797,25 @@ class HippoRAG:
             keys[:] = self.passage_node_keys
             t = self._tables = (self.passage_texts, len(self.passage_texts), texts, keys)
         return t[2], t[3]
+
+    def _build_query_solutions(self, queries, rows, num_to_retrieve) -> List[QuerySolution]:
+        """_build_retrieval_result + the QuerySolution of retrieve() (:471-480) for one batch.  When every query of the
+        batch has a full list of valid ids (the usual case) and there is no chunk metadata, the document strings of the
+        whole batch come from ONE fancy index into the text table."""
+        ids = None if rows.doc_idx is None else np.asarray(rows.doc_idx)[:, :num_to_retrieve]
+        if ids is None or self.chunk_metadata or ids.size == 0 or int(ids.min()) < 0:
+            out = []
+            for q, (d_idx, d_sc, seeds) in zip(queries, rows):
+                r = self._build_retrieval_result(q, d_idx, d_sc, num_to_retrieve, seeds)
+                out.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
+                                         doc_metadata=r.doc_metadata, graph_seeds=r.graph_seeds))
+            return out
+        texts, _ = self._result_tables()
+        docs = texts[ids].tolist()
+        n = ids.shape[1]
+        return [QuerySolution(question=q, docs=docs[i], doc_scores=np.asarray(rows[i][1][:n]),
+                              doc_metadata=[{} for _ in range(n)], graph_seeds=rows[i][2] or [])
+                for i, q in enumerate(queries)]
 
     def _build_retrieval_result(self, query, sorted_doc_ids, sorted_doc_scores, num_to_retrieve, graph_seeds=None):
         ids = np.asarray(sorted_doc_ids[:num_to_retrieve], dtype=np.int64)                  # :501-507

@@ -167,3 +167,132 @@ def test_looks_undirected_is_what_the_accelerated_plan_is_gated_on():
     assert not looks_undirected(CSRGraph(g.num_vertices, g.row_ptr, g.col_idx, v, g.raw, g.col_sum))
     assert not looks_undirected(CSRGraph(g.num_vertices, g.row_ptr, g.col_idx, g.val, g.raw, None))
     assert not looks_undirected(g.rows(0, 1500))
+
+
+# ------------------------------------------------------------------ the mirror's batch pipeline (retriever.iter_batched_retrieve)
+class _PipelineEngine:
+    """Records the order in which the mirror enqueues its device calls.  Phase A answers fact j = 10 * tag + slot for
+    the query tagged `tag`; phase B answers documents (tag, kept fact 0, kept count): every row stays traceable."""
+    max_batch, max_topk = 4, 3
+
+    def __init__(self, two_halves=True, flag_for=None):
+        import torch
+        self.log, self.device, self.flag_for = [], torch.device("cpu"), flag_for or {}
+        if two_halves:
+            self.retrieve_converged_start = self._start
+
+    def score_facts(self, q, k):
+        import torch
+        self.log.append(("A", q[:, 0].int().tolist()))
+        idx = (q[:, :1].int() * 10 + torch.arange(k, dtype=torch.int32)[None, :]).to(torch.int32)
+        return idx, torch.linspace(1.0, 0.5, k).repeat(q.shape[0], 1)
+
+    def _answer(self, q, kept_idx, kept_score, kept_count, **kw):
+        import torch
+        from hipporag_amd.engine import RetrieveOutput
+        self.log.append(("B", q[:, 0].int().tolist()))
+        tag = q[:, 0].int()
+        ids = torch.stack([tag, kept_idx[:, 0], kept_count], 1).to(torch.int32)
+        flags = torch.tensor([self.flag_for.get(int(t), 0) for t in tag], dtype=torch.int32)
+        return RetrieveOutput(ids, ids.float(), flags, torch.zeros(len(tag)), torch.full((len(tag),), 20, dtype=torch.int32))
+
+    def retrieve_converged(self, *a, **kw):
+        return self._answer(*a, **kw)
+
+    def _start(self, *a, **kw):
+        from hipporag_amd.engine import PendingRetrieve, host_copy_async
+        out = self._answer(*a, **kw)
+        eng = self
+
+        class P(PendingRetrieve):
+            def finish(self_p):
+                eng.log.append(("wait", out.doc_idx[:, 0].tolist()))
+                self_p.flags = out.flags.numpy()
+                return out
+        return P(self, None, out, host_copy_async(out.flags), 0.5, 20, 0.0, 0, False)
+
+
+def _run_pipeline(eng, n, consume=None, **over):
+    import torch
+    from hipporag_amd.retriever import identity_rerank_filter, iter_batched_retrieve
+    queries = [f"q{i}" for i in range(n)]
+    facts = [("s", "p", str(j)) for j in range(10 * n + 10)]
+    q_tensor = lambda qs, kind: torch.tensor([[float(q[1:])] for q in qs])
+    kw = dict(linking_top_k=2, damping=0.5, passage_node_weight=0.05, ppr_iters=20, num_to_retrieve=3, n_passages=100)
+    kw.update(over)
+    got = []
+    for lo, rows in iter_batched_retrieve(eng, queries, q_tensor, facts, identity_rerank_filter, **kw):
+        if consume:
+            consume(lo)
+        got.append((lo, rows))
+    return got
+
+
+def test_the_batch_pipeline_keeps_the_device_one_batch_ahead_of_the_host():
+    eng = _PipelineEngine()
+    seen = []
+    got = _run_pipeline(eng, 10, consume=lambda lo: seen.append((lo, len(eng.log))))
+    tags = lambda lo, hi: list(range(lo, hi))
+    assert eng.log == [("A", tags(0, 4)), ("A", tags(4, 8)), ("B", tags(0, 4)), ("A", tags(8, 10)), ("B", tags(4, 8)),
+                       ("wait", tags(0, 4)), ("B", tags(8, 10)), ("wait", tags(4, 8)), ("wait", tags(8, 10))]
+    # batch 0 reached the consumer only after batch 1's phase B had been enqueued
+    assert seen[0] == (0, 6) and [lo for lo, _ in got] == [0, 4, 8]
+    for lo, rows in got:
+        for i, (d_idx, d_sc, seeds) in enumerate(rows):
+            tag = lo + i
+            assert d_idx.tolist() == [tag, 10 * tag, 2]                 # its own query, its own best fact, both facts kept
+            assert [f[2] for f in seeds] == [str(10 * tag), str(10 * tag + 1)]
+
+
+def test_the_batch_pipeline_gives_what_the_one_call_form_gives_and_raises_the_references_asserts():
+    from hipporag_amd.retriever import batched_retrieve
+    a = _run_pipeline(_PipelineEngine(two_halves=True), 9)
+    b = _run_pipeline(_PipelineEngine(two_halves=False), 9)      # an engine that only has retrieve_converged (test doubles)
+    assert [lo for lo, _ in a] == [lo for lo, _ in b]
+    for (_, ra), (_, rb) in zip(a, b):
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2]
+    assert _run_pipeline(_PipelineEngine(), 0) == []
+    # flag bit 1 (zero-mass reset vector) of query 5: the reference's assert (:1644), raised when ITS batch is finished
+    with pytest.raises(AssertionError, match="No phrases found"):
+        _run_pipeline(_PipelineEngine(flag_for={5: 2}), 9)
+    # no facts in the index: phase A is skipped, every query goes to phase B with nothing kept
+    import torch
+    from hipporag_amd.retriever import identity_rerank_filter
+    eng = _PipelineEngine()
+    rows = batched_retrieve(eng, ["q1", "q2"], lambda qs, kind: torch.tensor([[float(q[1:])] for q in qs]), [],
+                            identity_rerank_filter, linking_top_k=2, damping=0.5, passage_node_weight=0.05, ppr_iters=20,
+                            num_to_retrieve=3, n_passages=100)
+    assert [k for k, _ in eng.log] == ["B", "wait"] and rows[1][0].tolist() == [2, -1, 0] and rows[1][2] == []
+
+
+def test_batch_materialisation_equals_the_per_query_form():
+    """retriever.HippoRAG._build_query_solutions: the one-fancy-index fast path (full lists of valid ids, no chunk
+    metadata) builds exactly what _build_retrieval_result + QuerySolution build query by query; a batch with a -1
+    (fewer passages than asked for) or with chunk metadata takes the per-query form."""
+    from hipporag_amd.retriever import BatchRows, HippoRAG
+    rag = HippoRAG()
+    rag.passage_texts = [f"text {i}" for i in range(50)]
+    rag.passage_node_keys = [f"chunk-{i}" for i in range(50)]
+    rng = np.random.default_rng(3)
+
+    def rows_of(idx, sc):
+        r = BatchRows((idx[i], sc[i], [("a", "b", str(i))] if i % 2 else []) for i in range(len(idx)))
+        r.doc_idx, r.doc_score = idx, sc
+        return r
+
+    idx = rng.integers(0, 50, (6, 8)).astype(np.int32)
+    sc = np.sort(rng.random((6, 8)).astype(np.float32))[:, ::-1].copy()
+    qs = [f"q{i}" for i in range(6)]
+    for k, meta, hole in ((5, {}, False), (8, {}, False), (20, {}, False), (5, {"chunk-3": {"src": "x"}}, False), (5, {}, True)):
+        rag.chunk_metadata = meta
+        ii = idx.copy()
+        if hole:
+            ii[2, 3:] = -1
+        rows = rows_of(ii, sc)
+        fast = rag._build_query_solutions(qs, rows, k)
+        for q, sol, (d_idx, d_sc, seeds) in zip(qs, fast, rows):
+            r = rag._build_retrieval_result(q, d_idx, d_sc, k, seeds)
+            assert sol.question == q and sol.docs == r.docs and sol.graph_seeds == r.graph_seeds
+            assert np.array_equal(sol.doc_scores, r.scores) and sol.doc_metadata == r.doc_metadata
+            assert len({id(m) for m in sol.doc_metadata}) == len(sol.doc_metadata)      # one dict per document, as in :505

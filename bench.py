@@ -498,13 +498,15 @@ def main():
                     help="N > 1: abandon the row-sharded leg after this long (the primary line still prints)")
     ap.add_argument("--sell-sigma", type=int, default=0, help="hrag_opts.sell_sigma (SELL-C-sigma sorting window; 0 = global)")
     ap.add_argument("--engine-flags", type=int, default=0, help="hrag_opts.flags (HRAG_OPT_*), e.g. 2048 = XCD_BLOCKED")
-    ap.add_argument("--locality", default=None, choices=["auto", "on"],
-                    help="HippoRAGEngine(locality=...): renumber the vertices by the first passage that links them")
+    ap.add_argument("--locality", default="none", choices=["auto", "on", "degree", "none"],
+                    help="HippoRAGEngine(locality=...), the engine's vertex numbering (the caller's ids are kept at the boundary); "
+                         "none = as generated (the benchmark generator has no locality to find)")
     ap.add_argument("--ppr-tol", type=float, default=1.5e-6,
                     help="tolerance of the secondary leg that runs under the convergence contract (the headline runs "
                          "BASELINE.json's fixed 20 sweeps and reports the residual they leave)")
     ap.add_argument("--ppr-max-iters", type=int, default=29)
     args = ap.parse_args()
+    args.locality = None if args.locality == "none" else args.locality
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("HRAG_FORCE_DIST"):
         # the driver's command is plain `python bench.py --gpus N ...`: be our own launcher -- N ranks of this very
@@ -641,7 +643,8 @@ def main():
                    "ppr_state_dtype": ("e4m3 staged corrections + fp32 true residual (fp32 arithmetic)" if f8 else
                                        "f16 hi + f16 correction (fp32 arithmetic)" if f16 else "f32"),
                    "sell_sigma": args.sell_sigma, "engine_flags": args.engine_flags, "locality": args.locality,
-                   "locality_score_after_renumbering": eng.locality_score, "engine_opt_flags": eng.opt_flags,
+                   "locality_score_after_renumbering": eng.locality_score, "vertex_numbering": eng.numbering,
+                   "engine_opt_flags": eng.opt_flags,
                    "parallelism": "1gpu"},
         "roofline": roofline,
         "step_ms_median_hip_events": contract.pop("step_ms_median_hip_events"),

@@ -50,7 +50,23 @@ __device__ __forceinline__ void for_each_in_row(const float *s, int64_t n, int t
     if (vec) {
         const int64_t n4 = n >> 2;
         const float4 *s4 = reinterpret_cast<const float4 *>(s);
-        for (int64_t i = tid; i < n4; i += TK_THREADS) {
+        int64_t i = tid;
+        // four independent 16-byte loads in flight per lane (one per iteration left a 1024-thread workgroup with 16 KB
+        // outstanding: latency-bound at ~1/3 of the stream rate on 125k-long rows); the SET of elements a thread sees is
+        // unchanged, and nothing downstream depends on their order
+        for (; i + 3 * TK_THREADS < n4; i += 4 * TK_THREADS) {
+            const float4 v0 = s4[i], v1 = s4[i + TK_THREADS], v2 = s4[i + 2 * TK_THREADS], v3 = s4[i + 3 * TK_THREADS];
+            const float4 vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t b = (uint32_t)(4 * (i + u * TK_THREADS));
+                f(vv[u].x, b);
+                f(vv[u].y, b + 1);
+                f(vv[u].z, b + 2);
+                f(vv[u].w, b + 3);
+            }
+        }
+        for (; i < n4; i += TK_THREADS) {
             const float4 v = s4[i];
             f(v.x, (uint32_t)(4 * i));
             f(v.y, (uint32_t)(4 * i + 1));

@@ -799,7 +799,8 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
 
     # ---------------- replica mode: every rank serves its own B queries ----------------------
     eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pass_emb, fact_emb, kg.subj_vertex, kg.obj_vertex,
-                         kg.num_chunks, max_batch=B, max_topk=K_P, slab_width=args.slab_width)
+                         kg.num_chunks, max_batch=B, max_topk=K_P, slab_width=args.slab_width,
+                         locality=getattr(args, "locality", None))
     qf = [synth.make_queries_torch(fact_emb, B, seed + 100 + i + 1000 * rank)[0] for i in range(n_batches)]
     qp = [synth.make_queries_torch(pass_emb, B, seed + 500 + i + 1000 * rank)[0] for i in range(n_batches)]
 

@@ -209,11 +209,13 @@ class HippoRAGEngine:
                  n_passages: Optional[int] = None, n_facts: Optional[int] = None,
                  device: Optional[int] = None, flags: int = 0, segment_nnz: int = 0, sell_seg_len: int = 0,
                  dim: Optional[int] = None, sell_sigma: int = 0, locality: Optional[str] = None):
-        """locality ("auto" / "on" / None): the graph compiler's locality numbering (graph.locality_order: vertices
-        renumbered by the first passage that links them; everything the caller sees -- passage positions, fact ids,
-        hrag_ppr's vertex order -- keeps the caller's numbering).  "on" also switches the sweep to SELL-C-sigma windows
-        and the XCD-blocked launch; "auto" does so when the renumbered matrix actually has locality
-        (graph.locality_score >= 0.3).  Unsharded engines only.
+        """locality ("auto" / "on" / "degree" / None): the graph compiler's vertex numbering; everything the caller sees --
+        passage positions, fact ids, hrag_ppr's vertex order -- keeps the caller's numbering.  "on": graph.locality_order
+        (vertices by the first passage that links them) + SELL-C-sigma windows + the XCD-blocked launch; "auto": that
+        numbering, the two switches only when the renumbered matrix actually has locality (graph.locality_score >= 0.3);
+        "degree": graph.degree_order (hubs first) -- an experiment switch, not a default: -4 ... -12 % per call for
+        B <= 8 and +1.2 % for the wide batch on the 1M-vertex benchmark graph, but -6 % on the 100k-vertex one
+        (docs/experiments/README.md).  Unsharded engines only.
 
         passage_emb=None (with dim=...): an engine WITHOUT embeddings -- the PPR side of the hybrid multi-GPU mode
         (dist.HybridRetriever): passage scores arrive through retrieve_scored(), seeds still come from subj_vertex /
@@ -228,14 +230,21 @@ class HippoRAGEngine:
 
         pv = np.ascontiguousarray(passage_vertex, dtype=np.int32)
         self._perm = self._inv_perm = None
-        self.locality_score = None
+        self.locality_score = self.numbering = None
         if locality:
-            if locality not in ("auto", "on"):
-                raise ValueError("locality must be None, 'auto' or 'on'")
+            if locality not in ("auto", "on", "degree"):
+                raise ValueError("locality must be None, 'auto', 'on' or 'degree'")
             if row_offset != 0 or graph.row_ptr.shape[0] - 1 != graph.num_vertices:
                 raise ValueError("the locality numbering is for unsharded engines (dist.shard_index relabels shards)")
-            from .graph import locality_order, locality_score, relabel_csr
-            perm = locality_order(graph, pv)
+            from .graph import degree_order, locality_order, locality_score, relabel_csr
+            windows = False
+            if locality == "degree":
+                perm = degree_order(graph, pv)
+            else:
+                perm = locality_order(graph, pv)
+                self.locality_score = locality_score(graph, perm=perm)       # of the matrix as it will be renumbered
+                windows = locality == "on" or self.locality_score >= 0.3
+            self.numbering = "degree" if locality == "degree" else "locality"
             graph = relabel_csr(graph, perm)
             pv = np.ascontiguousarray(perm[pv], dtype=np.int32)
             if subj_vertex is not None:
@@ -246,8 +255,7 @@ class HippoRAGEngine:
                 nc_ = np.zeros(graph.num_vertices, dtype=np.int32)
                 nc_[perm] = np.asarray(num_chunks, dtype=np.int32)
                 num_chunks = nc_
-            self.locality_score = locality_score(graph)
-            if locality == "on" or self.locality_score >= 0.3:
+            if windows:
                 sell_sigma = sell_sigma or 16384
                 flags |= _lib.OPT_XCD_BLOCKED
             self._perm = torch.from_numpy(perm).to(self.device)              # caller's vertex id -> engine's

@@ -18,6 +18,7 @@ and fp32 values (sums and the division in fp64, rounded once) -- the layout
 from __future__ import annotations
 
 from dataclasses import dataclass
+from typing import Optional
 
 import numpy as np
 
@@ -127,6 +128,23 @@ def locality_order(csr: CSRGraph, passage_vertex) -> np.ndarray:
     return perm
 
 
+def degree_order(csr: CSRGraph, passage_vertex) -> np.ndarray:
+    """perm[old vertex] = new vertex: non-passage vertices by falling entry count (stable), passages after them in passage
+    order.  A numbering for graphs WITHOUT corpus locality: with a narrow state (B <= 8: 2 ... 16 bytes per vertex, 8 ... 64
+    vertices per cache line) the columns that most entries point at then share lines, which the per-CU cache can hold."""
+    v = csr.num_vertices
+    pv = np.asarray(passage_vertex, dtype=np.int64)
+    is_p = np.zeros(v, dtype=bool)
+    is_p[pv] = True
+    deg = np.diff(np.asarray(csr.row_ptr, dtype=np.int64))
+    ents = np.flatnonzero(~is_p)
+    order = ents[np.argsort(-deg[ents], kind="stable")]
+    perm = np.empty(v, dtype=np.int64)
+    perm[order] = np.arange(order.shape[0])
+    perm[pv] = order.shape[0] + np.arange(pv.shape[0])
+    return perm
+
+
 def relabel_csr(csr: CSRGraph, perm: np.ndarray) -> CSRGraph:
     """The same matrix with vertex i renamed perm[i] (rows and columns; columns stay sorted inside a row)."""
     v = csr.num_vertices
@@ -144,13 +162,18 @@ def relabel_csr(csr: CSRGraph, perm: np.ndarray) -> CSRGraph:
                     np.asarray(csr.raw)[order], col_sum)
 
 
-def locality_score(csr: CSRGraph, window: int = 4096) -> float:
+def locality_score(csr: CSRGraph, window: int = 4096, perm: Optional[np.ndarray] = None) -> float:
     """Fraction of the matrix entries whose column lies within `window` ids of their row: how much a numbering gives
-    the sweep to re-use (the benchmark generator: ~1 %; a corpus numbered by locality_order: most of them)."""
+    the sweep to re-use (the benchmark generator: ~1 %; a corpus numbered by locality_order: most of them).
+    perm: score the matrix as it WOULD be under that renumbering (no relabelled copy is built)."""
     rows = np.repeat(np.arange(csr.num_vertices, dtype=np.int64), np.diff(csr.row_ptr))
     if rows.size == 0:
         return 0.0
-    return float(np.mean(np.abs(rows - np.asarray(csr.col_idx, dtype=np.int64)) < window))
+    cols = np.asarray(csr.col_idx, dtype=np.int64)
+    if perm is not None:
+        perm = np.asarray(perm, dtype=np.int64)
+        rows, cols = perm[rows], perm[cols]
+    return float(np.mean(np.abs(rows - cols) < window))
 
 
 def float_to_bf16_bits(x: np.ndarray) -> np.ndarray:

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
+from hipporag_amd import _lib
 from hipporag_amd.graph import bf16_bits_to_float
 from tests.helpers import make_case, ranked_parity, tie_aware_equal, write_test_report
 
@@ -583,6 +584,12 @@ def test_full_size_cfg3_properties_and_spot_parity(gpu_device):
         w256 = eng.timings()["slab_width"]
         deep = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=2048)
         deep_ids, deep_sc = deep.doc_idx.cpu().numpy(), deep.doc_score.cpu().numpy()
+        # what the mirror and the adapter run by default: accelerated stages under the convergence contract
+        eng.set_flags(_lib.OPT_ACCEL, True)
+        acc = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=2048, ppr_tol=1.5e-6, ppr_max_iters=30)
+        eng.set_flags(_lib.OPT_ACCEL, False)
+        acc_ids, acc_sc = acc.doc_idx.cpu().numpy(), acc.doc_score.cpu().numpy()
+        acc_used, acc_resid, acc_flags = (t.cpu().numpy() for t in (acc.iters_used, acc.residual, acc.flags))
         sub = eng.retrieve(qp[:64], idx[:64], sc[:64], cnt[:64], ppr_iters=20, k=200)
         torch.cuda.synchronize()
         assert w256 == 128 and eng.timings()["slab_width"] == 64
@@ -611,7 +618,7 @@ def test_full_size_cfg3_properties_and_spot_parity(gpu_device):
                             subj_vertex=kg.subj_vertex, obj_vertex=kg.obj_vertex, num_chunks=kg.num_chunks,
                             passage_vertex=kg.passage_vertex, p=oracle.column_normalize(a))
     qf_h, qp_h = qf.float().cpu().numpy(), qp.float().cpu().numpy()
-    worst, gap, exact, npos = 0.0, 0.0, 0, 0
+    worst, gap, exact, npos, worst_a, exact_a = 0.0, 0.0, 0, 0, 0.0, 0
     for q in list(range(0, B, 8)):
         ref = oracle.retrieve_one(index, qf_h[q], qp_h[q])
         # the tie window follows the measured error (tests/helpers.ranked_parity): 2e-6 at this size, not 2e-5
@@ -619,10 +626,19 @@ def test_full_size_cfg3_properties_and_spot_parity(gpu_device):
         assert rep["equal"], (q, rep)
         worst, gap = max(worst, rep["worst_rel_err"]), max(gap, rep["rel_gap"])
         exact += rep["exact_positions"]; npos += rep["n"]
+        rep_a = ranked_parity(acc_ids[q], acc_sc[q], ref.sorted_doc_ids, ref.sorted_doc_scores, ref.x[kg.passage_vertex])
+        assert rep_a["equal"], (q, rep_a)
+        worst_a, exact_a = max(worst_a, rep_a["worst_rel_err"]), exact_a + rep_a["exact_positions"]
     write_test_report("cfg3_full_size_parity", {"queries": B // 8, "ranks_per_query": 2048, "max_rel_score_err": worst,
-                                                "exact_id_fraction": exact / npos, "tie_window_rel": gap})
+                                                "exact_id_fraction": exact / npos, "tie_window_rel": gap,
+                                                "accel_contract": {"max_rel_score_err": worst_a, "exact_id_fraction": exact_a / npos,
+                                                                   "sweeps_used_max": int(acc_used.max()),
+                                                                   "residual_max": float(acc_resid.max())}})
     assert worst < 1e-5, worst
     assert gap <= 2.5e-6, gap                     # i.e. the ids agree outside a window 8x narrower than round 3's
+    # accelerated stages + contract: converged (no flag), fewer sweeps than the plain 20, the same parity bar
+    assert np.all(acc_flags == 0) and acc_resid.max() <= 1.5e-6 and 16 <= acc_used.max() < 20, (acc_used.max(), acc_resid.max())
+    assert worst_a < 1e-5, worst_a
 
 
 # ----------------------------------------------------------------------------- full size (BASELINE configs[1])

@@ -168,3 +168,40 @@ def test_gpu_a_call_on_another_stream_is_ordered_behind_the_one_in_flight(gpu_de
         for got, want in ((got_a, want_a), (got_b, want_b)):
             assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
         assert int(got_b[0].min()) >= 0
+
+
+@pytest.mark.gpu
+def test_gpu_pipelined_batches_equal_the_same_batches_one_call_at_a_time(gpu_device):
+    """retrieve() pipelines its batches (phase A of batch i + 1 is enqueued before phase B of batch i, results are waited
+    for through events, retriever.iter_batched_retrieve): five batches of a 37-query call -- the last one ragged -- must
+    give bit for bit what the same five batches give as five separate calls (nothing of batch i + 1's phase A may
+    leak into batch i's phase B through the engine's workspace)."""
+    from hipporag_amd import synth
+    from hipporag_amd.graph import bf16_bits_to_float
+    from tests.helpers import make_case
+
+    class Table:
+        def __init__(self, t):
+            self.t = t
+
+        def batch_encode(self, texts, instruction=None, norm=True):
+            return np.stack([self.t["f" if instruction and "fact" in instruction else "p"][x] for x in texts])
+
+    kg, pass_bits, fact_bits, _ = make_case(6000, 60000, 64, seed=77)
+    n = 37
+    qf, _ = synth.make_queries_np(fact_bits, n, seed=3)
+    qp, _ = synth.make_queries_np(pass_bits, n, seed=4)
+    queries = [f"question {i}" for i in range(n)]
+    table = {"f": dict(zip(queries, bf16_bits_to_float(qf))), "p": dict(zip(queries, bf16_bits_to_float(qp)))}
+    rag = HippoRAG.from_arrays(kg.csr, kg.passage_vertex, pass_bits, fact_bits, kg.subj_vertex, kg.obj_vertex, kg.num_chunks,
+                               global_config=RetrievalConfig(embedding_precision="bf16", max_batch=8),
+                               embedding_model=Table(table))
+    piped = rag.retrieve(queries, num_to_retrieve=20)
+    single = []
+    for lo in range(0, n, 8):
+        single.extend(rag.retrieve(queries[lo: lo + 8], num_to_retrieve=20))
+    assert len(piped) == n
+    for a, b in zip(piped, single):
+        assert a.question == b.question and a.docs == b.docs and a.graph_seeds == b.graph_seeds
+        assert np.array_equal(a.doc_scores, b.doc_scores)
+    assert len({tuple(s.docs) for s in piped}) > n // 2          # the queries really have different answers

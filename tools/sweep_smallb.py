@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batches", default="1,2,4,8,16,32")
     ap.add_argument("--out", default="gpurun_out/sweep_smallb.json")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--locality", default="none", help="engine vertex numbering (HippoRAGEngine(locality=...); none = as generated)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     V, E, D, seed = cfg["V"], cfg["E"], cfg["D"], cfg["seed"]
@@ -34,7 +35,7 @@ def main():
     res = {}
     for B in [int(b) for b in args.batches.split(",")]:
         eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pemb, femb, kg.subj_vertex, kg.obj_vertex,
-                             kg.num_chunks, max_batch=B, max_topk=200, flags=args.flags)
+                             kg.num_chunks, max_batch=B, max_topk=200, flags=args.flags, locality=None if args.locality == "none" else args.locality)
         qf, _ = synth.make_queries_torch(femb, B, 7)
         qp, _ = synth.make_queries_torch(pemb, B, 8)
         cnt = torch.full((B,), 5, dtype=torch.int32, device=dev)

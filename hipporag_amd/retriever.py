@@ -297,7 +297,8 @@ def iter_batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Se
             if bt.pending.repeated:                 # something was run again: take what the tensors hold now
                 d_idx, d_sc = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy()
             else:
-                d_idx, d_sc = host_wait(bt.copies[0]), host_wait(bt.copies[1])
+                # out of the pinned staging buffers: the rows handed out must not keep page-locked memory alive
+                d_idx, d_sc = host_wait(bt.copies[0]).copy(), host_wait(bt.copies[1]).copy()
             flags = bt.pending.flags                # host copy: reading out.flags would drain the stream
         else:
             out = bt.out
@@ -842,15 +843,26 @@ class HippoRAG:
         if k_docs < want:
             logger.warning("num_to_retrieve=%d exceeds the engine's max_topk=%d: %d documents per query are returned",
                            num_to_retrieve, eng.max_topk, k_docs)
+        from .engine import host_copy_async, host_wait
         results = []
-        for lo in range(0, len(queries), eng.max_batch):
+
+        def enqueue(lo):
             qs = queries[lo: lo + eng.max_batch]
             idx, sc = eng.dense_retrieve(self._q_tensor(qs, "passage"), k=k_docs)
-            idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
-            for i, q in enumerate(qs):
-                r = self._build_retrieval_result(q, idx[i], sc[i], num_to_retrieve)
-                results.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
-                                             doc_metadata=r.doc_metadata))
+            return qs, host_copy_async(idx), host_copy_async(sc)
+
+        # one batch ahead of the host, like retrieve(): batch i's lists are built while the device scores batch i + 1
+        starts = list(range(0, len(queries), eng.max_batch))
+        pending = enqueue(starts[0]) if starts else None
+        for n in range(len(starts)):
+            qs, idx_h, sc_h = pending
+            pending = enqueue(starts[n + 1]) if n + 1 < len(starts) else None
+            idx, sc = host_wait(idx_h).copy(), host_wait(sc_h).copy()
+            with gc_paused():
+                for i, q in enumerate(qs):
+                    r = self._build_retrieval_result(q, idx[i], sc[i], num_to_retrieve)
+                    results.append(QuerySolution(question=r.query, docs=r.docs, doc_scores=r.scores,
+                                                 doc_metadata=r.doc_metadata))
         if gold_docs is not None:
             return results, self._recall(gold_docs, [r.docs for r in results])
         return results

@@ -17,6 +17,7 @@ N > 1 without a launcher (no WORLD_SIZE in the environment): bench.py spawns its
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -563,6 +564,8 @@ def main():
         for i in range(args.warmup):
             o = step(i, tol, max_iters)
         torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()                    # no collector pass of the host interpreter inside the timed region
         t0 = time.perf_counter()
         res, used, flg = [], [], []
         for i in range(args.warmup, n_batches):
@@ -570,6 +573,7 @@ def main():
             res.append(o.residual); used.append(o.iters_used); flg.append(o.flags)     # device tensors: no sync
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        gc.enable()
         # SURVEY 8(d)'s median of per-step HIP-event times, in a loop of its own AFTER the wall-clock region (an event
         # per step inside it cost sporadic 7-26 ms stalls on the small configurations); events on torch's current
         # stream = the stream the library launches on

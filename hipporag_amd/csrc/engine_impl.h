@@ -92,6 +92,7 @@ struct Ppr8Session {
     bool active = false;
     int32_t batch = 0, iters = 0, n_steps = 0, n_stage = 0;   // iters: the sweeps of the base plan (accelerated: fewer than asked)
     bool accel = false;
+    bool dyn = false;                    // stage scales measured on the device (accelerated plans; plain plans at small damping)
     int32_t n_slabs = 0, n_groups = 0, spg = 0;
     int64_t group_bytes = 0;
     float damping = 0.f;

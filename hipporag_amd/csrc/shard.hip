@@ -65,6 +65,8 @@ double cheb_T(int m, double x) {                 // Chebyshev polynomial T_m(x),
     return t1;
 }
 constexpr double kAccelFloor = 1.0 / 14.0;       // contraction floor of an e4m3 stage
+constexpr double kP8StageNoise = 0.05;           // what a stage's e4m3 rounding puts back into the residual, per unit of iterate growth
+constexpr double kP8StaticFloor = 0.09;          // per-stage contraction a STATIC chain may assume at small damping
 
 int ppr8_plan_accel(int iters, float damping, bool measured, int *plan, int *kind) {
     const double al = (double)damping;
@@ -163,7 +165,7 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     p.n_slabs = lay.n_slabs; p.n_groups = lay.n_groups; p.spg = lay.slabs_per_group; p.group_bytes = lay.group_bytes;
     for (int i = 0; i < 3; ++i) p.buf[i] = bufs[i];
 
-    // ---- stage plan with static power-of-two scales: the max-norm of the true residual contracts by
+    // ---- stage plan with static power-of-two scales (damping >= 0.46; below: measured, see `dyn` further down): the max-norm of the true residual contracts by
     // `damping` per sweep (At is row-stochastic), |R_0| <= max(a, 1 - a) max(v/d) + the rounding of c_0; a stage
     // of m sweeps grows its iterate by at most (1 - a^m) / (1 - a).  cs = the power of two that maps that bound
     // to <= 224 (half the e4m3 range: the bound ignores rounding noise; a clamped value raises flags bit 3).
@@ -180,6 +182,19 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
         p.iters = iters;
     }
     p.accel = accel;
+    // Small damping: the static chain assumes that the max-norm of the residual contracts by a^m per stage, which ignores
+    // what the e4m3 rounding of a stage puts back (~0.05 .. 0.1 of the residual per stage, whatever a).  At a >= 0.46
+    // (a^3 >= 0.1) the half-range target of the scales absorbs that (worst emulated occupancy 0.63 of the range on a
+    // sparse power-law graph at a = 0.6); below it the real residual outgrows the assumed one stage after stage and
+    // valid inputs saturated (found by tools/soak_random.py at a = 0.3: ring, star forest, sparse power-law graphs;
+    // emulation 3x .. 30x over the range).  There the plain plan MEASURES its scales like the accelerated one (one float per
+    // wavefront per boundary + ppr8_next_scale_kernel): re-anchored at every stage, with the rounding inside the
+    // contraction it multiplies with.  A row shard has no such maximum (it would be an all-reduce per boundary): its static
+    // chain takes max(a^m, 0.09) per stage instead -- no saturation in the emulation, at the price of resolution on
+    // slowly mixing graphs, which the convergence contract then extends.
+    const bool small_al = damping < 0.46f;
+    const bool dyn = accel || (small_al && e->d_dyn && e->n_rows == e->V);
+    p.dyn = dyn;
     HRAG_REQUIRE(n_stage >= 2 && n_stage <= kP8MaxStages, "ppr_iters=%d needs %d fp8 stages (2..%d)", iters, n_stage,
                  kP8MaxStages);
     // ---- convergence contract (reference: PRPACK iterates until its residual is below 1e-10, HippoRAG.py:1736-1743;
@@ -213,7 +228,10 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     // max-norm contraction of the true residual over stage si (the static scales rest on it) and the modelled one (when
     // the 3-byte residual form is precise enough): plain a^m for both; accelerated 7 / T_3(1/a) against 1 / T_3(1/a)
     auto norm_contraction = [&](int si) {
-        return kind[si] ? std::min(1.0, 7.0 / cheb_T(plan[si], 1.0 / al)) : std::pow(al, plan[si]);
+        if (kind[si]) return std::min(1.0, 7.0 / cheb_T(plan[si], 1.0 / al));
+        const double am = std::pow(al, plan[si]);
+        if (!small_al) return am;
+        return dyn ? std::min(1.0, am + kP8StageNoise * growth_of(si)) : std::max(am, kP8StaticFloor);
     };
     auto model_contraction = [&](int si) {
         return kind[si] ? std::max(1.0 / cheb_T(plan[si], 1.0 / al), 1.0 / 16.0) : std::pow(al, plan[si]);
@@ -290,7 +308,7 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
         // matrix, the row -> teleport-row map and the column bitmap from their static parts
         BlitList z;
         if (est) z.zero(e->d_est_f, (int64_t)batch * sizeof(int32_t));
-        if (accel) z.zero(e->d_mmax_ws, e->mmax_slots * (int64_t)sizeof(float));   // slots a launch geometry never writes stay 0
+        if (dyn) z.zero(e->d_mmax_ws, e->mmax_slots * (int64_t)sizeof(float));   // slots a launch geometry never writes stay 0
         z.zero(e->d_ctl, (int64_t)(kP8MaxExt + 1) * sizeof(int32_t));
         z.zero(e->d_tele16 + (size_t)e->p_rows * 64, (int64_t)batch * kMaxSeeds * 64 * sizeof(float), l64.n_slabs,
                (int64_t)e->tele16_rows * 64 * sizeof(float));
@@ -301,7 +319,7 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     HRAG_TRY(launch_ppr16_seed_rows(seed_vtx, seed_w, seed_cnt, e->d_qscale, batch, e->p_rows, e->V, e->d_row_slot,
                                     e->d_tele16, e->tele16_rows, 64, s, e->row_offset, e->n_rows));
     HRAG_TRY(launch_ppr8_mask_seeds(seed_vtx, seed_cnt, batch, e->V, e->d_colmask, s));
-    if (accel)   // the two scales known before anything is measured: c_0's and the first stage's
+    if (dyn)   // the two scales known before anything is measured: c_0's and the first stage's
         HRAG_TRY(launch_ppr8_next_scale(nullptr, 0, e->d_mmax_word, e->d_dyn, 0, 0.f, 1, kP8C0Scale, p.steps[0].cs_next,
                                         nullptr, 0, s));
     // ---- c_0 = Q(v/d * 2^7) on the owned rows of every group
@@ -327,7 +345,7 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
     a.x = p.buf[st.x];
     a.inv_cs = st.inv_cs; a.cs_next = st.cs_next;
     const bool boundary = st.mode == kP8ModeB || st.mode == kP8ModeB0;
-    if (p.accel && st.mode != kP8ModeC) {     // measured stage scales (HRAG_OPT_ACCEL)
+    if (p.dyn && st.mode != kP8ModeC) {     // measured stage scales (HRAG_OPT_ACCEL; plain plans at small damping)
         a.dyn = e->d_dyn; a.dyn_stage = st.stage;
         if (boundary) {
             a.mmax_ws = e->d_mmax_ws; a.mmax_atomic = e->d_mmax_word;
@@ -355,7 +373,7 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
     }
     if (exchange) *exchange = st.y;
     HRAG_TRY(launch_ppr8_sweep(a, st.mode, false, s));
-    if (p.accel && boundary && st.kappa_growth > 0.f)   // this boundary's maximum -> the scale of the stage after next
+    if (p.dyn && boundary && st.kappa_growth > 0.f)   // this boundary's maximum -> the scale of the stage after next
         HRAG_TRY(launch_ppr8_next_scale(e->d_mmax_ws, (int32_t)std::min<int64_t>(e->mmax_slots, (int64_t)e->sell.n_chunks * a.mmax_units),
                                         e->d_mmax_word, e->d_dyn, st.stage, st.kappa_growth, 0, 0.f, 0.f, a.gate, a.gate_want, s));
     return HRAG_OK;

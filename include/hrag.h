@@ -245,9 +245,10 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q_fact_dev, int32_t
  *   flags_out_dev    int32 [B]    bit0: DPR fallback used; bit1: reset vector had no mass
  *                                 bit2: the :1541 assert would fire (kept phrase weight 0)
  *                                 bit3: HRAG_FLAG_FP8_SATURATED -- a value of the fp8-state PPR left the e4m3
- *                                       range (a static scale bound was violated): this query's scores are
- *                                       not trustworthy; rerun the batch after
- *                                       hrag_engine_set_flags(e, HRAG_OPT_NO_FP8, 1)
+ *                                       range (a scale bound was violated; the scales are static powers of two at
+ *                                       damping >= 0.46 and measured per stage below that and under
+ *                                       HRAG_OPT_ACCEL): treat this query's scores as not trustworthy; rerun the
+ *                                       batch after hrag_engine_set_flags(e, HRAG_OPT_NO_FP8, 1)
  *                                 bit4: HRAG_FLAG_NOT_CONVERGED -- ppr_tol > 0 and this query's residual (below)
  *                                       is still above it after ppr_max_iters sweeps: rerun with more sweeps
  *

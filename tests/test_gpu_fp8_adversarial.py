@@ -99,9 +99,21 @@ def _tiny_component():
     return n, src[keep], dst[keep], w[keep], pv, pinned
 
 
+def _sparse_power_law():
+    """The generator's power-law graph at mean degree 6 with 30 % passages (what tools/soak_random.py tripped over): the
+    max-norm of the residual contracts visibly slower than damping^m per stage once the e4m3 rounding is in it."""
+    kg = synth.make_kg(12000, 36000, 31506654, passage_frac=0.3, power_law=True)
+    return kg.num_vertices, kg.src, kg.dst, kg.weight, np.asarray(kg.passage_vertex)[:2000], ()
+
+
 CASES = {"ring": (_ring, 0.5, 20), "stars": (_stars, 0.5, 20), "barbell_wild_weights": (_barbell, 0.5, 20),
          "tiny_component": (_tiny_component, 0.5, 20), "barbell_damping_0.6": (_barbell, 0.6, 28),
-         "tiny_component_24_sweeps": (_tiny_component, 0.5, 24)}
+         "tiny_component_24_sweeps": (_tiny_component, 0.5, 24),
+         # small damping: damping^m per stage is BELOW what the e4m3 rounding of a stage puts back, the static scale chain
+         # drifted out of the range there (round 4, found by the randomised soak); the plan measures its scales instead
+         "ring_damping_0.3": (_ring, 0.3, 16), "stars_damping_0.3": (_stars, 0.3, 16),
+         "sparse_power_law_damping_0.3": (_sparse_power_law, 0.3, 16), "sparse_power_law_damping_0.4": (_sparse_power_law, 0.4, 16),
+         "sparse_power_law": (_sparse_power_law, 0.5, 20)}
 
 
 @pytest.mark.parametrize("b", [65, 256])

@@ -180,3 +180,40 @@ def test_convergence_contract_on_shards_matches_the_single_gpu_engine(gpu_device
     np.testing.assert_array_equal(flags, one.flags.cpu().numpy())
     np.testing.assert_array_equal(d_idx, one.doc_idx.cpu().numpy())
     np.testing.assert_array_equal(d_sc, one.doc_score.cpu().numpy())
+
+
+def test_shards_at_small_damping_keep_inside_the_fp8_range(gpu_device):
+    """Damping 0.3: damping^m per stage is below what a stage's e4m3 rounding puts back into the residual, and a static
+    scale chain built on damping^m alone drifted out of the range (round 4, found by tools/soak_random.py).  The
+    single-GPU engine measures its scales there; a row shard cannot (that maximum would be an all-reduce per boundary),
+    its chain assumes max(damping^m, 0.09) per stage.  Sparse power-law graph, 2 shards, 130 queries: no saturation
+    flag on either path and both within the parity bar of the same-count oracle."""
+    import dataclasses
+    import torch
+    from hipporag_amd import dist as hd
+    from hipporag_amd.engine import HippoRAGEngine
+    world, b, damping, iters = 2, 130, 0.3, 16
+    kg, pass_bits, fact_bits, index = make_case(12000, 36000, 96, seed=31506654, passage_frac=0.3, power_law=True)
+    index = dataclasses.replace(index, damping=damping)
+    sidx = hd.shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=3)
+    qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=4)
+    qf_t, qp_t = _bf16(qf_bits, gpu_device), _bf16(qp_bits, gpu_device)
+    kw = dict(link_top_k=5, damping=damping, passage_node_weight=0.05, ppr_iters=iters, k=100)
+    got = _run_shards(world, sidx, pass_bits, fact_bits, qf_t, qp_t, kw, 1, gpu_device, 100)
+    with HippoRAGEngine(sidx.csr, sidx.passage_vertex, pass_bits, fact_bits, sidx.subj_vertex, sidx.obj_vertex,
+                        sidx.num_chunks, max_batch=b, max_topk=100) as eng:
+        idx, sc = eng.score_facts(qf_t, k=5)
+        out = eng.retrieve(qp_t, idx, sc, torch.full((b,), 5, dtype=torch.int32, device=gpu_device), **kw)
+        torch.cuda.synchronize()
+        one = tuple(t.cpu().numpy() for t in (out.doc_idx, out.doc_score, out.flags))
+        assert eng.timings()["slab_width"] == 128
+    assert np.all(got[4] == 0), np.unique(got[4])                 # the shards: no HRAG_FLAG_FP8_SATURATED
+    assert np.all(one[2] == 0), np.unique(one[2])                 # the single-GPU engine (measured scales): none either
+    qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+    for q in list(range(0, b, 17)) + [b - 1]:
+        ref = oracle.retrieve_one(index, qf[q], qp[q])
+        full = ref.x[kg.passage_vertex]
+        for ids, scs in ((got[2][q], got[3][q]), (one[0][q], one[1][q])):
+            assert float((np.abs(scs - full[ids]) / full[ids]).max()) < 1e-5, q
+            assert tie_aware_equal(ids, ref.sorted_doc_ids[:100], ref.sorted_doc_scores[:100], rel_gap=2e-5), q

@@ -56,7 +56,7 @@ def main():
         power_law = bool(rng.integers(0, 2))
         pfrac = float(rng.choice([0.05, 0.125, 0.3]))
         b = int(rng.choice([1, 2, 3, 5, 8, 9, 17, 40, 64, 65, 100, 128, 130, 256, 300]))
-        damping = float(rng.choice([0.3, 0.5, 0.5, 0.5, 0.6]))
+        damping = float(rng.choice([0.2, 0.3, 0.4, 0.45, 0.5, 0.5, 0.5, 0.55, 0.6, 0.7]))
         iters = sweeps_for_damping(damping)
         accel = bool(rng.integers(0, 2))
         tol = float(rng.choice([0.0, 1.5e-6]))
@@ -67,7 +67,15 @@ def main():
                 "v", "e", "dim", "power_law", "pfrac", "b", "damping", "iters", "accel", "tol", "k_f", "seed"))
         par = dict(v=v, e=e, dim=dim, power_law=power_law, pfrac=pfrac, b=b, damping=damping, iters=iters, accel=accel,
                    tol=tol, k_f=k_f, seed=seed)
-        rng_case = np.random.default_rng(seed ^ 0x5EED)      # filter outcomes and k: a function of the case alone
+        rng_case = np.random.default_rng(seed ^ 0x5EED)      # filter outcomes, k, engine knobs: a function of the case alone
+        # engine knobs that must not change any result beyond the parity bars: vertex numbering, long-row cut, tuning bits
+        locality = [None, None, "auto", "degree"][int(rng_case.integers(0, 4))]
+        seg_len = int(rng_case.choice([0, 0, 64, 128, 512]))
+        tuning = 0
+        for bit in (_lib.OPT_NT_CSR, _lib.OPT_NT_STORE, _lib.OPT_TEMPORAL16, _lib.OPT_SLABS_PER_WG_1, _lib.OPT_XCD_BLOCKED):
+            if rng_case.random() < 0.15:
+                tuning |= bit
+        par.update(locality=locality, seg_len=seg_len, tuning=tuning)
         kg, pass_bits, fact_bits, index = make_case(v, e, dim, seed=seed, passage_frac=pfrac, power_law=power_law)
         index = dataclasses.replace(index, damping=damping, linking_top_k=k_f)
         n_p = kg.n_passages
@@ -77,10 +85,10 @@ def main():
         qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
         # what the recognition-memory filter keeps: all / a random subset / nothing (-> DPR ranking)
         keep_mode = rng_case.integers(0, 3, b)
-        flags_engine = _lib.OPT_ACCEL if accel else 0
+        flags_engine = (_lib.OPT_ACCEL if accel else 0) | tuning
         try:
             with HippoRAGEngine(kg.csr, kg.passage_vertex, pass_bits, fact_bits, kg.subj_vertex, kg.obj_vertex, kg.num_chunks,
-                                max_batch=b, max_topk=k_docs, flags=flags_engine) as eng:
+                                max_batch=b, max_topk=k_docs, flags=flags_engine, locality=locality, sell_seg_len=seg_len) as eng:
                 idx, sc = eng.score_facts(bf16(qf_bits, dev), k=k_f)
                 idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
                 kept_idx = np.full((b, k_f), -1, np.int32)
@@ -104,6 +112,15 @@ def main():
                 d_idx, d_sc, fl = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy(), out.flags.cpu().numpy()
                 used = int(out.iters_used.max()) if out.iters_used is not None else iters
                 width = eng.timings()["slab_width"]
+                # the run_ppr seam: arbitrary reset vectors (a few of them), every vertex's score, caller's numbering
+                nb = min(b, int(rng_case.choice([1, 3, 8, 12])))
+                reset = np.zeros((nb, kg.num_vertices), np.float32)
+                for i in range(nb):
+                    hot = rng_case.choice(kg.num_vertices, int(rng_case.integers(1, 40)), replace=False)
+                    reset[i, hot] = rng_case.random(len(hot)).astype(np.float32) + 1e-3
+                seam_iters = int(rng_case.choice([iters, 2 * iters]))
+                xs, xfl = eng.ppr(torch.from_numpy(reset), damping, seam_iters)
+                xs, xfl = xs.cpu().numpy(), xfl.cpu().numpy()
         except Exception as exc:  # noqa: BLE001
             bad += 1
             par["error"] = f"{type(exc).__name__}: {exc}"
@@ -112,6 +129,12 @@ def main():
             continue
         worst, ok = 0.0, True
         why = ""
+        for i in range(nb):
+            want = oracle.ppr_power(index.p, reset[i].astype(np.float64), damping, seam_iters)
+            nzw = want > 1e-12                      # the bar of tests/test_gpu_locality.py: rtol 2e-5, atol 1e-12
+            seam = float(np.abs(xs[i][nzw] / want[nzw] - 1).max()) if nzw.any() else 0.0
+            if seam >= 2e-5 or xfl[i] != 0 or not np.all(xs[i][want == 0] == 0):
+                ok, why = False, f"ppr seam vector {i}: rel dev {seam:.2e} flags {int(xfl[i])}"
         for q in sorted(set(np.linspace(0, b - 1, min(b, 4)).astype(int).tolist())):
             if cnt[q] == 0:
                 if not (fl[q] & 1):

@@ -60,7 +60,7 @@ def main():
         iters = sweeps_for_damping(damping)
         accel = bool(rng.integers(0, 2))
         tol = float(rng.choice([0.0, 1.5e-6]))
-        k_f = int(rng.choice([1, 3, 5]))
+        k_f = int(rng.choice([1, 3, 5, 5, 10, 16]))
         seed = int(rng.integers(1, 1 << 30))
         if forced is not None:
             v, e, dim, power_law, pfrac, b, damping, iters, accel, tol, k_f, seed = (forced[k] for k in (
@@ -75,9 +75,10 @@ def main():
         for bit in (_lib.OPT_NT_CSR, _lib.OPT_NT_STORE, _lib.OPT_TEMPORAL16, _lib.OPT_SLABS_PER_WG_1, _lib.OPT_XCD_BLOCKED):
             if rng_case.random() < 0.15:
                 tuning |= bit
-        par.update(locality=locality, seg_len=seg_len, tuning=tuning)
+        pw = float(rng_case.choice([0.05, 0.05, 0.05, 0.01, 0.5, 1.0]))       # passage_node_weight (reference default 0.05)
+        par.update(locality=locality, seg_len=seg_len, tuning=tuning, pw=pw)
         kg, pass_bits, fact_bits, index = make_case(v, e, dim, seed=seed, passage_frac=pfrac, power_law=power_law)
-        index = dataclasses.replace(index, damping=damping, linking_top_k=k_f)
+        index = dataclasses.replace(index, damping=damping, linking_top_k=k_f, passage_node_weight=pw)
         n_p = kg.n_passages
         k_docs = int(min(n_p, rng_case.choice([10, 100, 500])))
         qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=seed + 5)
@@ -104,7 +105,7 @@ def main():
                     kept_sc[q, :len(valid)] = sc_h[q, valid]
                     cnt[q] = len(valid)
                 fn = eng.retrieve_converged if tol > 0 else eng.retrieve
-                kw = dict(link_top_k=k_f, damping=damping, passage_node_weight=0.05, ppr_iters=iters, k=k_docs)
+                kw = dict(link_top_k=k_f, damping=damping, passage_node_weight=pw, ppr_iters=iters, k=k_docs)
                 if tol > 0:
                     kw.update(ppr_tol=tol, ppr_max_iters=400)
                 out = fn(bf16(qp_bits, dev), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc), torch.from_numpy(cnt), **kw)

@@ -76,7 +76,8 @@ def main():
             if rng_case.random() < 0.15:
                 tuning |= bit
         pw = float(rng_case.choice([0.05, 0.05, 0.05, 0.01, 0.5, 1.0]))       # passage_node_weight (reference default 0.05)
-        par.update(locality=locality, seg_len=seg_len, tuning=tuning, pw=pw)
+        emb_kind = ["bf16", "bf16", "f32", "fp16"][int(rng_case.integers(0, 4))]     # f32: HRAG_F32_SPLIT (the mirror's default)
+        par.update(locality=locality, seg_len=seg_len, tuning=tuning, pw=pw, emb=emb_kind)
         kg, pass_bits, fact_bits, index = make_case(v, e, dim, seed=seed, passage_frac=pfrac, power_law=power_law)
         index = dataclasses.replace(index, damping=damping, linking_top_k=k_f, passage_node_weight=pw)
         n_p = kg.n_passages
@@ -84,13 +85,28 @@ def main():
         qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=seed + 5)
         qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=seed + 6)
         qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+        pass_arg, fact_arg, to_dev = pass_bits, fact_bits, (lambda bits, x: bf16(bits, dev))
+        if emb_kind != "bf16":
+            # rows / queries that are NOT bf16-representable: fp32 (split into hi + lo fp16 planes by the engine) or fp16
+            def jitter(x, sd):
+                y = x + np.random.default_rng(sd).standard_normal(x.shape).astype(np.float32) * np.float32(2e-3)
+                return (y / np.linalg.norm(y, axis=1, keepdims=True)).astype(np.float32)
+            pe, fe = jitter(index.passage_emb, seed + 11), jitter(index.fact_emb, seed + 12)
+            qf, qp = jitter(qf, seed + 13), jitter(qp, seed + 14)
+            if emb_kind == "fp16":
+                pe, fe = pe.astype(np.float16), fe.astype(np.float16)
+                qf, qp = qf.astype(np.float16).astype(np.float32), qp.astype(np.float16).astype(np.float32)
+            pass_arg, fact_arg = pe, fe
+            index = dataclasses.replace(index, passage_emb=pe.astype(np.float32), fact_emb=fe.astype(np.float32))
+            tdt = torch.float16 if emb_kind == "fp16" else torch.float32
+            to_dev = lambda bits, x: torch.from_numpy(x).to(dev).to(tdt)
         # what the recognition-memory filter keeps: all / a random subset / nothing (-> DPR ranking)
         keep_mode = rng_case.integers(0, 3, b)
         flags_engine = (_lib.OPT_ACCEL if accel else 0) | tuning
         try:
-            with HippoRAGEngine(kg.csr, kg.passage_vertex, pass_bits, fact_bits, kg.subj_vertex, kg.obj_vertex, kg.num_chunks,
+            with HippoRAGEngine(kg.csr, kg.passage_vertex, pass_arg, fact_arg, kg.subj_vertex, kg.obj_vertex, kg.num_chunks,
                                 max_batch=b, max_topk=k_docs, flags=flags_engine, locality=locality, sell_seg_len=seg_len) as eng:
-                idx, sc = eng.score_facts(bf16(qf_bits, dev), k=k_f)
+                idx, sc = eng.score_facts(to_dev(qf_bits, qf), k=k_f)
                 idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
                 kept_idx = np.full((b, k_f), -1, np.int32)
                 kept_sc = np.zeros((b, k_f), np.float32)
@@ -108,7 +124,7 @@ def main():
                 kw = dict(link_top_k=k_f, damping=damping, passage_node_weight=pw, ppr_iters=iters, k=k_docs)
                 if tol > 0:
                     kw.update(ppr_tol=tol, ppr_max_iters=400)
-                out = fn(bf16(qp_bits, dev), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc), torch.from_numpy(cnt), **kw)
+                out = fn(to_dev(qp_bits, qp), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc), torch.from_numpy(cnt), **kw)
                 torch.cuda.synchronize()
                 d_idx, d_sc, fl = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy(), out.flags.cpu().numpy()
                 used = int(out.iters_used.max()) if out.iters_used is not None else iters
@@ -130,6 +146,15 @@ def main():
             continue
         worst, ok = 0.0, True
         why = ""
+        ok_a, why_a = True, ""
+        for q in sorted(set(np.linspace(0, b - 1, min(b, 3)).astype(int).tolist())):      # phase A against the oracle
+            fs = oracle.fact_scores(index.fact_emb, qf[q])
+            cand = oracle.topk_desc(fs, k_f)
+            nf = min(k_f, len(fs))
+            same = tie_aware_equal(idx_h[q][:nf], cand[:nf], fs[cand[:nf]], rel_gap=0.0, abs_gap=4e-6)
+            devf = float(np.abs(sc_h[q][:nf].astype(np.float64) - fs[idx_h[q][:nf]]).max())
+            if not same or devf > 2e-6 or np.any(idx_h[q][nf:] != -1):
+                ok_a, why_a = False, f"q{q} fact top-k: ids {same}, abs score dev {devf:.2e}"
         for i in range(nb):
             want = oracle.ppr_power(index.p, reset[i].astype(np.float64), damping, seam_iters)
             nzw = want > 1e-12                      # the bar of tests/test_gpu_locality.py: rtol 2e-5, atol 1e-12
@@ -177,6 +202,8 @@ def main():
                 ok, why = False, f"q{q}: err {rep['worst_rel_err']:.2e} (allow {allow:.1e}) equal={rep['equal']} gap={rep['rel_gap']:.1e}"
             if fl[q] & ~1:
                 ok, why = False, f"q{q}: flags {int(fl[q])}"
+        if not ok_a:
+            ok, why = False, why_a
         par.update(worst=worst, ok=ok, sweeps=used, width=width, k=k_docs)
         if args.verbose:
             par.update(flags=sorted(set(int(f) for f in fl)), flagged_queries=[int(q) for q in np.flatnonzero(fl & ~1)][:16],

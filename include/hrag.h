@@ -169,7 +169,7 @@ typedef struct hrag_fact_desc {
                                       /* against 5.5e-7) and up to 3x their truncation error on small hub-heavy ones: use the */
                                       /* contract where a bound is needed.  Off by default: ppr_iters is then the literal     */
                                       /* sweep count (BASELINE.json's 20).  Runtime-switchable.  The two-stage fp16 states    */
-                                      /* (batch <= 64) accelerate too (14 sweeps for 20), with ppr_tol = 0 only.  The library */
+                                      /* (batch <= 64) accelerate too (14 sweeps for 20), with ppr_tol = 0 and damping <= 0.62 only.  The library */
                                       /* cannot see whether the CSR it was given came from a symmetric adjacency: setting the */
                                       /* flag on a DIRECTED graph is a caller error (complex spectrum: the steps may converge */
                                       /* more slowly than the plan assumes; the contract would flag it, ppr_tol = 0 would     */

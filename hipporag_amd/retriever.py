@@ -840,14 +840,16 @@ class HippoRAG:
         eng = self.engine
         want = max(1, min(num_to_retrieve, len(self.passage_node_keys)))
         k_docs = min(want, eng.max_topk)
-        if k_docs < want:
-            logger.warning("num_to_retrieve=%d exceeds the engine's max_topk=%d: %d documents per query are returned",
-                           num_to_retrieve, eng.max_topk, k_docs)
+        # more documents than the device top-k holds (:704-714 slices any prefix of the full ranking): the raw scores of all
+        # passages come back and are normalised and ranked here with the library's rule (score desc, larger index first)
+        beyond = k_docs < want
         from .engine import host_copy_async, host_wait
         results = []
 
         def enqueue(lo):
             qs = queries[lo: lo + eng.max_batch]
+            if beyond:
+                return qs, host_copy_async(eng.sim_scores("passages", self._q_tensor(qs, "passage"))), None
             idx, sc = eng.dense_retrieve(self._q_tensor(qs, "passage"), k=k_docs)
             return qs, host_copy_async(idx), host_copy_async(sc)
 
@@ -857,7 +859,13 @@ class HippoRAG:
         for n in range(len(starts)):
             qs, idx_h, sc_h = pending
             pending = enqueue(starts[n + 1]) if n + 1 < len(starts) else None
-            idx, sc = host_wait(idx_h).copy(), host_wait(sc_h).copy()
+            if beyond:
+                raw = host_wait(idx_h)[:, :len(self.passage_node_keys)]
+                full = np.stack([min_max_normalize(r) for r in raw]).astype(np.float32)
+                idx = np.stack([np.argsort(r, kind="stable")[::-1][:want] for r in full]).astype(np.int32)
+                sc = np.take_along_axis(full, idx.astype(np.int64), axis=1)
+            else:
+                idx, sc = host_wait(idx_h).copy(), host_wait(sc_h).copy()
             with gc_paused():
                 for i, q in enumerate(qs):
                     r = self._build_retrieval_result(q, idx[i], sc[i], num_to_retrieve)

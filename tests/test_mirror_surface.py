@@ -135,6 +135,14 @@ def test_gpu_num_to_retrieve_beyond_max_topk_returns_the_full_ranking(gpu_device
         assert len(b.docs) == 7 and b.docs[:3] == a.docs
         np.testing.assert_array_equal(np.asarray(b.doc_scores[:3]), np.asarray(a.doc_scores))
         assert np.all(np.diff(np.asarray(b.doc_scores)) <= 0)
+    # retrieve_dpr likewise (:704-714): the full dense ranking, the device's own top-k as its prefix
+    few_d, many_d = rag.retrieve_dpr(QUERIES, num_to_retrieve=3), rag.retrieve_dpr(QUERIES, num_to_retrieve=7)
+    for q, a, b in zip(QUERIES, few_d, many_d):
+        assert len(b.docs) == 7 and b.docs[:3] == a.docs
+        np.testing.assert_array_equal(np.asarray(b.doc_scores[:3]), np.asarray(a.doc_scores))
+        ids, sc = rag.dense_passage_retrieval(q)                       # the per-method seam: the same ranking
+        assert b.docs == [rag.passage_texts[i] for i in ids[:7]]
+        np.testing.assert_allclose(np.asarray(b.doc_scores), sc[:7], rtol=1e-6)   # B = 1 GEMV vs batch GEMM: other summation order
 
 
 @pytest.mark.gpu

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "soak_random.json"))
     ap.add_argument("--replay", action="append", default=[], help="a case as printed (JSON): run exactly that one; repeatable")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--big", action="store_true", help="50k .. 200k vertices, batches up to 512, up to 2048 documents per query")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     dev = torch.device("cuda", 0)
@@ -50,12 +51,12 @@ def main():
         forced = replay.pop(0) if args.replay else None
         if forced is not None:                      # the case's own stream of random decisions restarts from its seed
             rng = np.random.default_rng(forced["seed"])
-        v = int(rng.choice([600, 1500, 4000, 9000, 20000]))
+        v = int(rng.choice([50000, 100000, 200000] if args.big else [600, 1500, 4000, 9000, 20000]))
         e = int(v * rng.choice([3, 6, 10, 20]))
         dim = int(rng.choice([32, 64, 96, 192]))
         power_law = bool(rng.integers(0, 2))
         pfrac = float(rng.choice([0.05, 0.125, 0.3]))
-        b = int(rng.choice([1, 2, 3, 5, 8, 9, 17, 40, 64, 65, 100, 128, 130, 256, 300]))
+        b = int(rng.choice([1, 8, 33, 64, 130, 256, 384, 512] if args.big else [1, 2, 3, 5, 8, 9, 17, 40, 64, 65, 100, 128, 130, 256, 300]))
         damping = float(rng.choice([0.2, 0.3, 0.4, 0.45, 0.5, 0.5, 0.5, 0.55, 0.6, 0.7]))
         iters = sweeps_for_damping(damping)
         accel = bool(rng.integers(0, 2))
@@ -81,7 +82,7 @@ def main():
         kg, pass_bits, fact_bits, index = make_case(v, e, dim, seed=seed, passage_frac=pfrac, power_law=power_law)
         index = dataclasses.replace(index, damping=damping, linking_top_k=k_f, passage_node_weight=pw)
         n_p = kg.n_passages
-        k_docs = int(min(n_p, rng_case.choice([10, 100, 500])))
+        k_docs = int(min(n_p, rng_case.choice([200, 2048] if args.big else [10, 100, 500])))
         qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=seed + 5)
         qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=seed + 6)
         qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
@@ -161,7 +162,7 @@ def main():
             seam = float(np.abs(xs[i][nzw] / want[nzw] - 1).max()) if nzw.any() else 0.0
             if seam >= 2e-5 or xfl[i] != 0 or not np.all(xs[i][want == 0] == 0):
                 ok, why = False, f"ppr seam vector {i}: rel dev {seam:.2e} flags {int(xfl[i])}"
-        for q in sorted(set(np.linspace(0, b - 1, min(b, 4)).astype(int).tolist())):
+        for q in sorted(set(np.linspace(0, b - 1, min(b, 2 if args.big else 4)).astype(int).tolist())):
             if cnt[q] == 0:
                 if not (fl[q] & 1):
                     ok, why = False, f"q{q}: no DPR flag"

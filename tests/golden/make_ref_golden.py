@@ -146,7 +146,7 @@ def dump_object_state(rag, queries, filter_mode, sols, path):
         pickle.dump(state, f, protocol=4)
 
 
-def run_case(name, docs, triples, queries, filter_mode, model=None, dump_state=False, **cfg):
+def run_case(name, docs, triples, queries, filter_mode, model=None, dump_state=False, save=True, **cfg):
     tmp = tempfile.mkdtemp(prefix="refgold_")
     try:
         rag = rh.build_reference_rag(tmp, docs, triples, model or Bf16Mock(), **cfg)
@@ -200,7 +200,8 @@ def run_case(name, docs, triples, queries, filter_mode, model=None, dump_state=F
         out.update(retrieve_dpr_ids=d_ids, retrieve_dpr_scores=d_sc)
         out["passage_texts"] = np.array([rag.chunk_embedding_store.get_row(k)["content"] for k in rag.passage_node_keys])
         out["queries"] = np.array(list(queries))
-        np.savez_compressed(os.path.join(HERE, f"ref_{name}.npz"), **out)
+        if save:
+            np.savez_compressed(os.path.join(HERE, f"ref_{name}.npz"), **out)
         if dump_state:
             dump_object_state(rag, queries, filter_mode, sols, os.path.join(HERE, f"ref_state_{name}.pkl"))
         n_syn = sum(1 for w in a["edge_w"] if 0.8 <= w < 1.0)

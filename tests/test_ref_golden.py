@@ -368,3 +368,17 @@ def test_bf16_rounding_of_a_real_fp32_store_flips_rankings_the_split_engine_does
     assert stats["split"][0] == nq and stats["split"][1] == nq and stats["split"][2] <= 3e-6, stats
     # the rounded engine is off by the bf16 quantum of the inputs and reorders at least one full DPR ranking
     assert stats["bf16"][2] > 1e-4 and stats["bf16"][1] < nq, stats
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/hipporag"), reason="reference sources not present")
+def test_oracle_against_the_reference_on_fresh_random_corpora():
+    """A short run of tools/soak_oracle_vs_reference.py: corpora the committed fixtures have never seen, indexed and queried
+    by the imported reference package, every stage reproduced by the oracle (profiles/r04_soak_oracle_vs_reference_summary.json:
+    1 000 of them)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_oracle_vs_reference.py"), "--cases", "6", "--seed", "11",
+                        "--out", os.path.join(str(root), "gpurun_out", "soak_oracle_vs_reference_test.json")],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "6 cases; SOAK OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

@@ -93,6 +93,22 @@ def text_processing(text):                                          # misc_utils
     return re.sub("[^A-Za-z0-9 ]", " ", text.lower()).strip()
 
 
+def filter_invalid_triples(triples):                                # llm_utils.py:222-252
+    """What index() applies to every chunk's OpenIE triples before anything else (reformat_openie_results,
+    misc_utils.py:87-108, called at HippoRAG.py:305): triples without exactly three elements are dropped, EXACT duplicates
+    (raw strings, before text_processing) collapse, order is kept.  Two triples that differ in case only stay two -- and
+    count twice in the graph once text_processing has lower-cased them, as in the reference."""
+    seen, out = set(), []
+    for t in triples:
+        if len(t) != 3:
+            continue
+        v = tuple(str(x) for x in t)
+        if v not in seen:
+            seen.add(v)
+            out.append(v)
+    return out
+
+
 def min_max_normalize(x):                                           # misc_utils.py:130-139
     mn, mx = np.min(x), np.max(x)
     rng = mx - mn
@@ -397,7 +413,7 @@ class HippoRAG:
                 meta["source_id"] = ch.source_id
             self.chunk_metadata[key] = meta
             if key not in self._chunk_triples:
-                self._chunk_triples[key] = [tuple(text_processing(list(t))) for t in tr if len(t) == 3]
+                self._chunk_triples[key] = [tuple(text_processing(list(t))) for t in filter_invalid_triples(tr)]
                 self.passage_node_keys.append(key)
                 self.passage_texts.append(ch.content)
                 new_chunk_keys.append(key)

@@ -54,16 +54,10 @@ def load_embedding_store(directory: str, namespace: str):
 
 
 def filter_invalid_triples(triples) -> List[List[str]]:
-    """utils/llm_utils.py:222-254: keep 3-element triples, stringify, drop duplicates, keep order."""
-    seen, out = set(), []
-    for t in triples:
-        if len(t) != 3:
-            continue
-        v = [str(x) for x in t]
-        if tuple(v) not in seen:
-            seen.add(tuple(v))
-            out.append(v)
-    return out
+    """utils/llm_utils.py:222-254: keep 3-element triples, stringify, drop duplicates, keep order (one implementation:
+    retriever.filter_invalid_triples, which index_from_openie applies to every chunk as well)."""
+    from .retriever import filter_invalid_triples as _filter
+    return [list(t) for t in _filter(triples)]
 
 
 def load_openie_results(path: str) -> Dict[str, dict]:

@@ -3,7 +3,7 @@
 package (CPU, authoring container only: needs /root/reference): random synthetic corpora (tests/golden/make_ref_golden.py),
 random life cycles  index(A) -> index(B, overlapping A) -> delete(some) [-> index(C, re-adding deleted documents)], run by
 the reference's own code (tests/golden/ref_harness.py) and by hipporag_amd.retriever.HippoRAG.index_from_openie / delete;
-after EVERY step the two must hold the same thing BY NAME: vertex set, the igraph edge list with parallel edges summed,
+after EVERY step -- and, for the fresh index, once more for the reference's working directory read back by hipporag_amd.loaders -- the two must hold the same thing BY NAME: vertex set, the igraph edge list with parallel edges summed,
 passage store order and texts, fact store contents, the chunk-count divisor of every entity (the assertions of
 tests/test_incremental_index.py::test_mirror_life_cycle_matches_the_reference_by_name).
 
@@ -61,6 +61,32 @@ def compare(rag_ref, rag):
     return ""
 
 
+def same_index(a, b):
+    """Two mirror objects (one indexed in memory and equal to the reference by name, one loaded from the reference's
+    working directory) hold the same index up to the vertex numbering: matrix entries by name, stores, divisors, rows."""
+    def by_name(rag):
+        csr, inv = rag._arrays["csr"], {v: k for k, v in rag.node_name_to_vertex_idx.items()}
+        rows = np.repeat(np.arange(csr.num_vertices), np.diff(csr.row_ptr))
+        return {(inv[int(r)], inv[int(c)]): float(w) for r, c, w in zip(rows, csr.col_idx, csr.raw)}
+    ea, eb = by_name(a), by_name(b)
+    if set(ea) != set(eb) or any(abs(ea[k] - eb[k]) > 1e-9 * max(1.0, abs(ea[k])) for k in ea):
+        return "matrix entries differ by name"
+    if a.passage_node_keys != b.passage_node_keys or a.passage_texts != b.passage_texts:
+        return "passage stores differ"
+    if set(a.facts) != set(b.facts) or set(a.entity_node_keys) != set(b.entity_node_keys):
+        return "fact / entity stores differ"
+    nc = lambda r: {k: int(r._arrays["num_chunks"][v]) for k, v in r.node_name_to_vertex_idx.items() if k.startswith("entity-")}
+    if nc(a) != nc(b):
+        return "chunk-count divisors differ"
+    if not np.array_equal(a._arrays["passage_emb"], b._arrays["passage_emb"]):
+        return "passage embedding rows differ"
+    fa = {f: a._arrays["fact_emb"][i].tobytes() for i, f in enumerate(a.facts)}
+    fb = {f: b._arrays["fact_emb"][i].tobytes() for i, f in enumerate(b.facts)}
+    if fa != fb:
+        return "fact embedding rows differ"
+    return ""
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
@@ -101,6 +127,16 @@ def main():
             mine.index_from_openie([docs[i] for i in step_a], [triples[i] for i in step_a])
             why = compare(ref, mine)
             step = "a"
+            if not why:
+                # the reference's working directory of this FRESH index (parquet stores, OpenIE json, chunk metadata) through
+                # the on-disk loader, which rebuilds the graph from them: the same index by name.  (After an
+                # incremental life cycle the reference's graph carries history the files do not -- surviving edges are not
+                # decremented by delete() -- and the loader then takes the exported edge list of graph.pickle instead.)
+                from hipporag_amd.loaders import load_reference_workdir
+                loaded = load_reference_workdir(tmp, ref.global_config.llm_name, ref.global_config.embedding_model_name,
+                                                synonymy="none", embedding_model=Bf16Mock(),
+                                                global_config=RetrievalConfig(max_batch=4, embedding_precision="bf16"))
+                why, step = same_index(mine, loaded), "a (loader)"
             if not why:
                 ref.global_config.force_openie_from_scratch = False
                 ref.global_config.force_index_from_scratch = False

@@ -87,6 +87,20 @@ class OracleEngine:
 
     retrieve_converged = retrieve
 
+    def dense_retrieve(self, q_pass, k=200):            # the mirror's retrieve_dpr (not used by the adapter)
+        b = q_pass.shape[0]
+        d_idx, d_sc = np.full((b, k), -1, np.int32), np.zeros((b, k), np.float32)
+        for i in range(b):
+            ids, sc = oracle.dense_passage_scores(self.index.passage_emb, q_pass[i].float().numpy())
+            d_idx[i, :min(k, len(ids))], d_sc[i, :min(k, len(ids))] = ids[:k], sc[:k]
+        return torch.from_numpy(d_idx), torch.from_numpy(d_sc)
+
+    f32_split = False
+
+    @property
+    def dim(self):
+        return self.index.passage_emb.shape[1]
+
     def sim_scores(self, which, q):
         emb = self.index.fact_emb if which == "facts" else self.index.passage_emb
         return torch.from_numpy((q.float().numpy().astype(np.float64) @ emb.T.astype(np.float64)).astype(np.float32))

@@ -43,7 +43,7 @@ def compare(rag_ref, rag):
     s, d, ww = mg_.edge_list()
     mine = summed(mg_.names, s.tolist(), d.tolist(), ww.tolist())
     ref = summed(None, [names[a] for a, _ in es], [names[b] for _, b in es], w)
-    if set(mine) != set(ref) or any(abs(mine[k] - ref[k]) > 1e-9 * max(1.0, abs(ref[k])) for k in ref):
+    if set(mine) != set(ref) or any(abs(mine[k] - ref[k]) > 2e-6 * max(1.0, abs(ref[k])) for k in ref):
         return "edge lists differ"
     if rag.passage_node_keys != list(rag_ref.passage_node_keys):
         return "passage store order differs"
@@ -59,6 +59,32 @@ def compare(rag_ref, rag):
             a["fact_emb"].shape[0] != len(rag.facts):
         return "array shapes differ"
     return ""
+
+
+def synonymy_edges_cpu(texts, embs, threshold, topk=2047):
+    """add_synonymy_edges (HippoRAG.py:959-1020) for ALL entities the store holds after this call, with a numpy KNN in the place of
+    hipporag_amd.knn (GPU): normalised fp32 vectors, cosine, neighbours in falling score order down to the threshold, at most
+    101 per entity, not itself, entities with <= 2 alphanumerics are skipped as queries.  Returns [(text a, text b, score)]."""
+    import re
+    texts = list(texts)
+    if not texts:
+        return []
+    e = np.asarray(embs, np.float32)
+    e = e / np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-12)
+    s = (e @ e.T).astype(np.float32)
+    out = []
+    for i, t in enumerate(texts):
+        if len(re.sub("[^A-Za-z0-9]", "", t)) <= 2:
+            continue
+        order = np.argsort(-s[i], kind="stable")[:topk]
+        n = 0
+        for j in order:
+            if s[i, j] < threshold or n > 100:
+                break
+            if j != i and texts[j] != "":
+                out.append((t, texts[j], float(s[i, j])))
+                n += 1
+    return out
 
 
 def same_index(a, b):
@@ -118,16 +144,35 @@ def main():
         step_b = list(range(int(rng.integers(0, cut)), n_docs))                  # overlaps A: those must collapse
         delete = sorted(rng.choice(n_docs, int(rng.integers(1, max(2, n_docs // 3))), replace=False).tolist())
         readd = bool(rng.integers(0, 2))
-        par = dict(n_docs=n_docs, n_ent=n_ent, seed=seed, cut=cut, b_from=step_b[0], n_delete=len(delete), readd=readd)
+        syn = bool(rng.integers(0, 2))                       # synonymy edges on: the mirror takes them as an explicit list
+        thr = 0.8 if syn else 1.5
+        par = dict(n_docs=n_docs, n_ent=n_ent, seed=seed, cut=cut, b_from=step_b[0], n_delete=len(delete), readd=readd, synonymy=syn)
         tmp = tempfile.mkdtemp(prefix="soak_inc_")
         try:
             ref = rh.build_reference_rag(tmp, [docs[i] for i in step_a], [triples[i] for i in step_a], Bf16Mock(),
-                                         synonymy_edge_sim_threshold=1.5)
+                                         synonymy_edge_sim_threshold=thr)
             mine = HippoRAG(RetrievalConfig(max_batch=4, embedding_precision="bf16"), embedding_model=Bf16Mock())
-            mine.index_from_openie([docs[i] for i in step_a], [triples[i] for i in step_a])
+
+            model = Bf16Mock()
+
+            def index_mine(ids):
+                """index_from_openie; with synonymy on, like the reference: the KNN over ALL entities the store holds after the
+                call (old and new) decides the synonymy edges of the call (only when it adds a chunk, HippoRAG.py:329-335)"""
+                from hipporag_amd.retriever import compute_mdhash_id, filter_invalid_triples, text_processing
+                cands = None
+                new = [i for i in ids if compute_mdhash_id(docs[i], "chunk-") not in mine._chunk_triples]
+                if syn and new:
+                    known = set(mine.entity_texts)
+                    fresh = sorted({e for i in new for t in filter_invalid_triples(triples[i])
+                                    for e in (text_processing(t[0]), text_processing(t[2]))} - known)
+                    texts = list(mine.entity_texts) + fresh
+                    cands = synonymy_edges_cpu(texts, model.batch_encode(texts), thr) if texts else None
+                mine.index_from_openie([docs[i] for i in ids], [triples[i] for i in ids], synonym_edges=cands)
+
+            index_mine(step_a)
             why = compare(ref, mine)
             step = "a"
-            if not why:
+            if not why and not syn:
                 # the reference's working directory of this FRESH index (parquet stores, OpenIE json, chunk metadata) through
                 # the on-disk loader (SURVEY 8f-3), which rebuilds the graph from them: the same index by name.  (After an
                 # incremental life cycle the reference's graph carries history the files do not -- surviving edges are not
@@ -142,7 +187,7 @@ def main():
                 ref.global_config.force_index_from_scratch = False
                 ref.openie = rh.FixedOpenIE({d: t for d, t in zip(docs, triples)})
                 ref.index([docs[i] for i in step_b])
-                mine.index_from_openie([docs[i] for i in step_b], [triples[i] for i in step_b])
+                index_mine(step_b)
                 why, step = compare(ref, mine), "b"
             if not why:
                 ref.delete([docs[i] for i in delete])
@@ -151,7 +196,7 @@ def main():
             if not why and readd:
                 again = delete[: max(1, len(delete) // 2)]
                 ref.index([docs[i] for i in again])
-                mine.index_from_openie([docs[i] for i in again], [triples[i] for i in again])
+                index_mine(again)
                 why, step = compare(ref, mine), "d"
             par.update(ok=not why, V=len(mine._graph.names), facts=len(mine.facts))
             if why:

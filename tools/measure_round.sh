@@ -1,6 +1,7 @@
 #!/bin/bash
 # measurement pass of a round: whole GPU suite, the bench line of every configuration (CPU baselines included), the
-# N > 1 code path on one GPU (world 1), small-batch latencies, rocprofv3 kernel stats + PMC passes of the cfg 3 command
+# N > 1 code path on one GPU (world 1), small-batch latencies, the randomised soaks, rocprofv3 kernel stats + PMC passes
+# of the cfg 3 command
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r04z}
@@ -19,6 +20,11 @@ HRAG_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --steps 5 --warmup 2 --no
 HRAG_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --config cfg4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_cfg4_world1.json" 2> "$OUT/bench_cfg4_world1.err"
 timeout 600 python tools/sweep_smallb.py --batches 1,2,4,8,16,32 --out "$OUT/sweep_smallb.json" > "$OUT/sweep_smallb.log" 2> "$OUT/sweep_smallb.err"
 cut -c1-80 "$OUT/sweep_smallb.log"
+# randomised differential soaks (each prints one line per case and SOAK OK / SOAK FAILED)
+for S in soak_random soak_shards soak_mirror soak_knn; do
+  timeout 400 python tools/$S.py --seconds ${SOAK_SECONDS:-60} --seed ${SOAK_SEED:-1} > "$OUT/$S.log" 2>&1
+  echo "$S: $(tail -1 "$OUT/$S.log")"
+done
 bash tools/gpu_profile.sh "$TAG/prof" --steps 5 --warmup 1 > "$OUT/profile.log" 2>&1
 tail -3 "$OUT/profile.log"
 find "$OUT" -name '*kernel_trace.csv' -size +3M -delete

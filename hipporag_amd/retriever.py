@@ -388,7 +388,8 @@ class HippoRAG:
     # ------------------------------------------------------------------ index side
     def index_from_openie(self, docs: Sequence, chunk_triples: Sequence[Sequence[Sequence[str]]],
                           synonym_edges: Optional[Sequence[Tuple[str, str, float]]] = None,
-                          passage_embeddings=None, entity_embeddings=None, fact_embeddings=None):
+                          passage_embeddings=None, entity_embeddings=None, fact_embeddings=None,
+                          synonymy=None, synonymy_edge_topk: int = 2047, synonymy_edge_sim_threshold: float = 0.8):
         """index() after its LLM steps (HippoRAG.py:262-335): documents + their OpenIE triples in, graph /
         fact / passage arrays out.  Like the reference it is INCREMENTAL: a later call adds the chunks that
         are new (duplicates collapse on their hash), appends the entities / facts / vertices that did not
@@ -397,7 +398,14 @@ class HippoRAG:
         add_passage_edges likewise, :939-947) -- parallel to the existing ones, which is how an entity pair
         seen again gains weight (igraph multigraph; graph.build_csr sums).  Embeddings are taken as given
         (rows for the docs of THIS call / for the NEW entities and facts in the order this method appends
-        them) or computed with embedding_model.batch_encode(texts) (embedding_store.py:131)."""
+        them) or computed with embedding_model.batch_encode(texts) (embedding_store.py:131).
+
+        Synonymy edges (add_synonymy_edges, :959-1020 -- in the reference part of every index() call that adds a chunk):
+        `synonym_edges` = an explicit list [(phrase a, phrase b, score)], and / or `synonymy` = "knn": the KNN over ALL
+        entities the store holds after this call on the GPU (hipporag_amd.knn.synonymy_candidates, the reference's
+        selection rules, `synonymy_edge_topk` / `synonymy_edge_sim_threshold` like config_utils.py), or a callable
+        (entity keys, entity texts, fp32 embeddings, topk=, sim_threshold=) -> [(key a, key b, score)] with the same contract.
+        Needs entity embeddings (given, or an embedding_model)."""
         from .graph import IncrementalGraph
         chunks = [d if isinstance(d, Chunk) else Chunk(content=d) for d in docs]
         if len(chunks) != len(chunk_triples):
@@ -426,6 +434,26 @@ class HippoRAG:
                     if compute_mdhash_id(e, "entity-") not in known_e]
         self.entity_texts += new_ents
         self.entity_node_keys += [compute_mdhash_id(e, "entity-") for e in new_ents]
+
+        def embed(given, strings, dim=None):
+            if given is not None:
+                given = np.asarray(given, dtype=np.float32)
+                if given.shape[0] != len(strings):
+                    raise ValueError(f"{given.shape[0]} embedding rows for {len(strings)} new strings")
+                return given
+            if not strings:
+                return np.zeros((0, dim or 0), np.float32)
+            if self.embedding_model is None:
+                raise ValueError("no embeddings given and no embedding_model to compute them")
+            return np.asarray(self.embedding_model.batch_encode(list(strings)), dtype=np.float32)
+
+        # the entity store's rows first: the synonymy KNN below reads them
+        if entity_embeddings is not None or (self.embedding_model is not None and new_ents):
+            ee_new = embed(entity_embeddings, new_ents)
+            self.entity_embeddings = ee_new if getattr(self, "entity_embeddings", None) is None else (
+                np.concatenate([self.entity_embeddings, ee_new]) if ee_new.size else self.entity_embeddings)
+        elif not hasattr(self, "entity_embeddings"):
+            self.entity_embeddings = None
         known_f = set(self.facts)
         new_facts = []
         for tr in proc_new:
@@ -453,23 +481,21 @@ class HippoRAG:
             ka = compute_mdhash_id(text_processing(a), "entity-")
             kb = compute_mdhash_id(text_processing(b), "entity-")
             self.node_to_node_stats[(ka, kb)] = float(w)
+        if synonymy is not None and new_chunk_keys and len(self.entity_node_keys) > 1:      # :329-335: only with new chunks
+            if synonymy == "knn":
+                from .knn import synonymy_candidates as synonymy
+            elif not callable(synonymy):
+                raise ValueError("synonymy must be None, 'knn' or a callable")
+            if self.entity_embeddings is None or len(self.entity_embeddings) != len(self.entity_node_keys):
+                raise ValueError("synonymy edges need the embeddings of every entity (entity_embeddings= or an embedding_model)")
+            for ka, kb, w in synonymy(list(self.entity_node_keys), list(self.entity_texts), self.entity_embeddings,
+                                      topk=synonymy_edge_topk, sim_threshold=synonymy_edge_sim_threshold):
+                self.node_to_node_stats[(ka, kb)] = float(w)      # overwrites a fact-edge count of the same pair, like :1015
         if new_chunk_keys:                                 # augment_graph only when chunks were added (:329-335)
             # vertices: the entity store's rows, then the chunk store's, that are not vertices yet (:1171-1187)
             g.add_vertices(self.entity_node_keys)
             g.add_vertices(self.passage_node_keys)
             g.add_edges(list(self.node_to_node_stats.keys()), list(self.node_to_node_stats.values()))   # :1200-1223
-
-        def embed(given, strings, dim=None):
-            if given is not None:
-                given = np.asarray(given, dtype=np.float32)
-                if given.shape[0] != len(strings):
-                    raise ValueError(f"{given.shape[0]} embedding rows for {len(strings)} new strings")
-                return given
-            if not strings:
-                return np.zeros((0, dim or 0), np.float32)
-            if self.embedding_model is None:
-                raise ValueError("no embeddings given and no embedding_model to compute them")
-            return np.asarray(self.embedding_model.batch_encode(list(strings)), dtype=np.float32)
 
         if passage_embeddings is not None:                 # rows of THIS call's docs: keep the new chunks' rows
             passage_embeddings = np.asarray(passage_embeddings, np.float32)[new_chunk_rows]
@@ -479,12 +505,6 @@ class HippoRAG:
         self._pass_emb = pe_new if self._pass_emb is None else np.concatenate([self._pass_emb, pe_new])
         self._fact_emb = fe_new if self._fact_emb is None or not self._fact_emb.size else (
             np.concatenate([self._fact_emb, fe_new]) if fe_new.size else self._fact_emb)
-        if entity_embeddings is not None or (self.embedding_model is not None and new_ents):
-            ee_new = embed(entity_embeddings, new_ents, dim)
-            self.entity_embeddings = ee_new if getattr(self, "entity_embeddings", None) is None else (
-                np.concatenate([self.entity_embeddings, ee_new]) if ee_new.size else self.entity_embeddings)
-        elif not hasattr(self, "entity_embeddings"):
-            self.entity_embeddings = None
         self._refresh_arrays()
         return self
 

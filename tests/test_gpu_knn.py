@@ -88,3 +88,54 @@ def test_thresholded_knn_matches_the_full_lists(gpu_device, n_dup):
         np.testing.assert_array_equal(thr_i[r, :n], full_i[r, :n])
         np.testing.assert_array_equal(thr_s[r, :n], full_s[r, :n])
         assert np.all(thr_i[r, n:] == -1) and np.all(thr_s[r, n:] == 0)
+
+
+def test_index_from_openie_computes_its_synonymy_edges_on_the_gpu(gpu_device):
+    """HippoRAG.index_from_openie(synonymy="knn"): add_synonymy_edges (:959-1020) as part of the call -- the KNN over all
+    entities the store holds afterwards on the GPU (knn.synonymy_candidates) -- gives the graph the same call gives with
+    the edges computed by an fp64 KNN under the reference's selection rules and passed through synonymy=<callable>
+    (the contract tools/soak_incremental_vs_reference.py checks against the real reference on the CPU)."""
+    import re
+    from hipporag_amd.retriever import HippoRAG, RetrievalConfig
+    from tests.golden.make_golden import MockEmbeddingModel
+
+    def cpu_candidates(keys, texts, embs, *, topk=2047, sim_threshold=0.8):
+        e = np.asarray(embs, np.float64)
+        e = e / np.linalg.norm(e, axis=1, keepdims=True)
+        s = e @ e.T
+        out = []
+        for i, t in enumerate(texts):
+            if len(re.sub("[^A-Za-z0-9]", "", t)) <= 2:
+                continue
+            n = 0
+            for j in np.argsort(-s[i], kind="stable")[:topk]:
+                if s[i, j] < sim_threshold or n > 100:
+                    break
+                if j != i and texts[j] != "":
+                    out.append((keys[i], keys[j], float(s[i, j])))
+                    n += 1
+        return out
+
+    names = [f"{a} {b} works {i % 7}" for i, (a, b) in enumerate(zip("alpha beta gamma delta kappa sigma omega theta".split() * 5,
+                                                                     "river stone cloud field".split() * 10))]
+    names += [n + " group" for n in names[:12]]                      # near-duplicates: cosine >= 0.8 under the mock model
+    docs = [f"document {d} about {names[d % len(names)]}" for d in range(30)]
+    triples = [[(names[(3 * d) % len(names)], "relates to", names[(5 * d + 1) % len(names)]),
+                (names[(7 * d + 2) % len(names)], "mentions", names[(11 * d + 3) % len(names)])] for d in range(30)]
+    graphs = []
+    for how in ("knn", cpu_candidates):
+        rag = HippoRAG(RetrievalConfig(max_batch=4, embedding_precision="bf16"), embedding_model=MockEmbeddingModel())
+        rag.index_from_openie(docs[:20], triples[:20], synonymy=how)
+        rag.index_from_openie(docs[15:], triples[15:], synonymy=how)             # incremental: old pairs gain parallel edges
+        g = rag._graph
+        s, d, w = g.edge_list()
+        tot = {}
+        for a, b, x in zip(s.tolist(), d.tolist(), w.tolist()):
+            k = tuple(sorted((g.names[a], g.names[b])))
+            tot[k] = tot.get(k, 0.0) + float(x)
+        graphs.append(tot)
+    syn = {k: v for k, v in graphs[1].items() if k[0].startswith("entity-") and k[1].startswith("entity-") and v != round(v)}
+    assert len(syn) >= 12                                             # the near-duplicate names are linked
+    assert set(graphs[0]) == set(graphs[1])
+    for k in graphs[1]:
+        assert abs(graphs[0][k] - graphs[1][k]) <= 4e-6 * max(1.0, abs(graphs[1][k])), k

@@ -61,10 +61,11 @@ def compare(rag_ref, rag):
     return ""
 
 
-def synonymy_edges_cpu(texts, embs, threshold, topk=2047):
-    """add_synonymy_edges (HippoRAG.py:959-1020) for ALL entities the store holds after this call, with a numpy KNN in the place of
-    hipporag_amd.knn (GPU): normalised fp32 vectors, cosine, neighbours in falling score order down to the threshold, at most
-    101 per entity, not itself, entities with <= 2 alphanumerics are skipped as queries.  Returns [(text a, text b, score)]."""
+def synonymy_edges_cpu(keys, texts, embs, *, topk=2047, sim_threshold=0.8):
+    """The contract of hipporag_amd.knn.synonymy_candidates (add_synonymy_edges, HippoRAG.py:959-1020) with a numpy KNN in the
+    place of the GPU one: normalised fp32 vectors, cosine, neighbours in falling score order down to the threshold, at most
+    101 per entity, not itself, entities with <= 2 alphanumerics are skipped as queries.  Returns [(key a, key b, score)] --
+    what HippoRAG.index_from_openie(synonymy=<callable>) consumes."""
     import re
     texts = list(texts)
     if not texts:
@@ -79,10 +80,10 @@ def synonymy_edges_cpu(texts, embs, threshold, topk=2047):
         order = np.argsort(-s[i], kind="stable")[:topk]
         n = 0
         for j in order:
-            if s[i, j] < threshold or n > 100:
+            if s[i, j] < sim_threshold or n > 100:
                 break
             if j != i and texts[j] != "":
-                out.append((t, texts[j], float(s[i, j])))
+                out.append((keys[i], keys[j], float(s[i, j])))
                 n += 1
     return out
 
@@ -153,21 +154,11 @@ def main():
                                          synonymy_edge_sim_threshold=thr)
             mine = HippoRAG(RetrievalConfig(max_batch=4, embedding_precision="bf16"), embedding_model=Bf16Mock())
 
-            model = Bf16Mock()
-
             def index_mine(ids):
                 """index_from_openie; with synonymy on, like the reference: the KNN over ALL entities the store holds after the
-                call (old and new) decides the synonymy edges of the call (only when it adds a chunk, HippoRAG.py:329-335)"""
-                from hipporag_amd.retriever import compute_mdhash_id, filter_invalid_triples, text_processing
-                cands = None
-                new = [i for i in ids if compute_mdhash_id(docs[i], "chunk-") not in mine._chunk_triples]
-                if syn and new:
-                    known = set(mine.entity_texts)
-                    fresh = sorted({e for i in new for t in filter_invalid_triples(triples[i])
-                                    for e in (text_processing(t[0]), text_processing(t[2]))} - known)
-                    texts = list(mine.entity_texts) + fresh
-                    cands = synonymy_edges_cpu(texts, model.batch_encode(texts), thr) if texts else None
-                mine.index_from_openie([docs[i] for i in ids], [triples[i] for i in ids], synonym_edges=cands)
+                call decides the synonymy edges of the call (synonymy=<callable>: the numpy stand-in of the GPU KNN)"""
+                mine.index_from_openie([docs[i] for i in ids], [triples[i] for i in ids],
+                                       synonymy=synonymy_edges_cpu if syn else None, synonymy_edge_sim_threshold=thr)
 
             index_mine(step_a)
             why = compare(ref, mine)

@@ -104,9 +104,10 @@ def host_copy_async(t):
     if not t.is_cuda:
         return t, None
     h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    h.copy_(t, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
+    with torch.cuda.device(t.device):                 # the copy and its event on the tensor's own device and current stream
+        h.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(t.device))
     return h, ev
 
 

@@ -295,10 +295,11 @@ hrag_status launch_ppr8_finalize(const int32_t *est_f, int32_t *flags, int32_t b
                                  int32_t iters, const int32_t *ctl, int32_t e_max, const double *mass_tab,
                                  int64_t tab_stride, double *sums, float *resid, int32_t *iters_used, hipStream_t s);
 // HRAG_OPT_ACCEL: the scale of stage `stage + 2` from the maximum the boundary closing `stage` measured (seed != 0:
-// write the first two scales)
+// write the first two scales; finalize = false: only fold this launch's maximum into word[0] -- an exchange group of a
+// step that is not the step's last one)
 hrag_status launch_ppr8_next_scale(const float *ws, int32_t n_slots, int32_t *word, float *dyn, int32_t stage,
                                    float kappa_growth, int32_t seed, float cs0, float cs1, const int32_t *gate,
-                                   int32_t gate_want, hipStream_t s);
+                                   int32_t gate_want, hipStream_t s, bool finalize = true);
 // colmask |= bits of the seed vertices
 hrag_status launch_ppr8_mask_seeds(const int32_t *seed_vtx, const int32_t *seed_cnt, int32_t batch,
                                    int64_t num_vertices, uint32_t *colmask, hipStream_t s);

@@ -1100,7 +1100,8 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
     const bool prof = e->profiling;
 
     // convergence contract on the fp16 / small-batch / fp32 states: the fixed count runs, the last sweep measures the
-    // relative update of the passage scores (residual_out, flags bit 4); only the fp8 state extends on the device
+    // relative update of the passage scores (residual_out, flags bit 4); the fp8 and the fp16 states extend on the
+    // device (gate words, ext_max below), the fp32 state reports and leaves the repeat to the caller
     int sweeps_run = ppr_iters;   // fp16 states under HRAG_OPT_ACCEL: fewer (ppr_iters then names the accuracy)
     int ext_max = 0;              // fp16 states: extension stages enqueued (the device decides which of them run)
     const bool want_est = residual_out != nullptr || ppr_tol > 0.f;

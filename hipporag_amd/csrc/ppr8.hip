@@ -973,9 +973,14 @@ __global__ void ppr8_finalize_kernel(const int32_t *__restrict__ est_f, int32_t 
 //   stage after it grows its iterate by at most `growth`: dyn[stage + 2] = the power of two that maps kappa M growth to
 //   <= 224 (half the e4m3 range, like the static chain).  M = 0 (nothing left) keeps the previous scale.
 // seed = 1: write dyn[0] = cs0, dyn[1] = cs1 (the two scales known before anything was measured) and return.
+// finalize = 0 (a boundary step that is launched per exchange group, every group but the last): the launch only folds
+// its group's maximum into word[0]; the launch that follows the LAST group of the step finds the maximum of the whole
+// batch there and turns it into the scale (a scale taken from one group's slots alone would saturate or starve the
+// other groups' queries).
 __global__ __launch_bounds__(256) void ppr8_next_scale_kernel(const float *__restrict__ ws, int32_t n_slots, int32_t *word,
                                                               float *dyn, int32_t stage, float kappa_growth, int32_t seed,
-                                                              float cs0, float cs1, const int32_t *gate, int32_t gate_want) {
+                                                              float cs0, float cs1, const int32_t *gate, int32_t gate_want,
+                                                              int32_t finalize) {
     if (gate && *gate != gate_want) return;
     if (seed) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -998,6 +1003,7 @@ __global__ __launch_bounds__(256) void ppr8_next_scale_kernel(const float *__res
     }
     if (threadIdx.x != 0) return;
     if (red[0] > 0.f) __hip_atomic_fetch_max(&word[0], __float_as_int(red[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!finalize) return;
     const int before = __hip_atomic_fetch_add(&word[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (before != (int)gridDim.x - 1) return;
     const float mq = __int_as_float(__hip_atomic_load(&word[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1177,10 +1183,10 @@ hrag_status launch_ppr8_mask_seeds(const int32_t *seed_vtx, const int32_t *seed_
 
 hrag_status launch_ppr8_next_scale(const float *ws, int32_t n_slots, int32_t *word, float *dyn, int32_t stage,
                                    float kappa_growth, int32_t seed, float cs0, float cs1, const int32_t *gate,
-                                   int32_t gate_want, hipStream_t s) {
+                                   int32_t gate_want, hipStream_t s, bool finalize) {
     const unsigned blocks = seed ? 1u : (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, ceil_div(n_slots, 4096)));
     hipLaunchKernelGGL(ppr8_next_scale_kernel, dim3(blocks), dim3(256), 0, s, ws, n_slots, word, dyn, stage, kappa_growth, seed,
-                       cs0, cs1, gate, gate_want);
+                       cs0, cs1, gate, gate_want, finalize ? 1 : 0);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }

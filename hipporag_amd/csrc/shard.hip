@@ -373,9 +373,13 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
     }
     if (exchange) *exchange = st.y;
     HRAG_TRY(launch_ppr8_sweep(a, st.mode, false, s));
-    if (p.dyn && boundary && st.kappa_growth > 0.f)   // this boundary's maximum -> the scale of the stage after next
+    // this boundary's maximum -> the scale of the stage after next.  A step that is launched per exchange group
+    // (hrag_shard_ppr_sweep on an engine that owns every row) measures the maximum of the WHOLE batch: every group folds
+    // its slots into the running maximum, the last group of the step (groups are issued in ascending order) finalizes.
+    if (p.dyn && boundary && st.kappa_growth > 0.f)
         HRAG_TRY(launch_ppr8_next_scale(e->d_mmax_ws, (int32_t)std::min<int64_t>(e->mmax_slots, (int64_t)e->sell.n_chunks * a.mmax_units),
-                                        e->d_mmax_word, e->d_dyn, st.stage, st.kappa_growth, 0, 0.f, 0.f, a.gate, a.gate_want, s));
+                                        e->d_mmax_word, e->d_dyn, st.stage, st.kappa_growth, 0, 0.f, 0.f, a.gate, a.gate_want, s,
+                                        group < 0 || group == p.n_groups - 1));
     return HRAG_OK;
 }
 

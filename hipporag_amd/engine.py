@@ -315,9 +315,15 @@ class HippoRAGEngine:
             keep += [f_obj, sv, ov, nc]
         # HRAG_OPT_ACCEL needs an undirected graph (real spectrum of the sweep operator): checked where the graph is at
         # hand (row sums of the adjacency == its column sums); a directed graph keeps the plain plan, loudly
-        from .graph import looks_undirected
-        self._undirected = looks_undirected(graph) if (row_offset == 0 and n_rows == graph.num_vertices) else False
-        if (flags & _lib.OPT_ACCEL) and not self._undirected:
+        # -- evaluated only when the flag is asked for (here, or at the first set_flags(OPT_ACCEL)): the test walks the
+        # whole matrix, which a plain engine (and every incremental re-prepare of one) has no use for
+        import weakref
+        self._undirected = None if (row_offset == 0 and n_rows == graph.num_vertices) else False
+        try:
+            self._graph_ref = weakref.ref(graph)
+        except TypeError:
+            self._graph_ref = lambda g=graph: g
+        if (flags & _lib.OPT_ACCEL) and not self._is_undirected():
             logger.warning("HRAG_OPT_ACCEL dropped: the graph does not look undirected (or has no col_sum / is a row shard)")
             flags &= ~_lib.OPT_ACCEL
         self.opt_flags = int(flags)      # HRAG_OPT_* bits as set_flags leaves them
@@ -532,9 +538,22 @@ class HippoRAGEngine:
         flags |= ({"C": 0, "B": 1, "F": 2, "B0": 3}[f8_mode] << 4) | ((f8_rio & 3) << 6)
         check(self._lib.hrag_ppr_sweeps(self._handle, batch, n, damping, flags, _stream()))
 
+    def _is_undirected(self) -> bool:
+        """graph.looks_undirected of the engine's graph, evaluated once, on first use (needs the graph object the engine
+        was created from to be alive still: the mirror and the adapter keep theirs)."""
+        if self._undirected is None:
+            from .graph import looks_undirected
+            g = self._graph_ref() if getattr(self, "_graph_ref", None) else None
+            if g is None:
+                raise ValueError("HRAG_OPT_ACCEL was not asked for at creation and the graph object is gone: the "
+                                 "undirected-graph test cannot run -- pass flags=OPT_ACCEL to HippoRAGEngine()")
+            self._undirected = bool(looks_undirected(g))
+            self._graph_ref = None
+        return self._undirected
+
     def set_flags(self, flags: int, on: bool = True):
         """Set / clear HRAG_OPT_* bits after creation (e.g. _lib.OPT_NO_FP8 to rerun a saturated batch)."""
-        if on and (flags & _lib.OPT_ACCEL) and not getattr(self, "_undirected", False):
+        if on and (flags & _lib.OPT_ACCEL) and not self._is_undirected():
             raise ValueError("HRAG_OPT_ACCEL needs an undirected graph with col_sum on an unsharded engine "
                              "(hipporag_amd.graph.looks_undirected): this engine's graph does not qualify")
         check(self._lib.hrag_engine_set_flags(self._handle, flags, 1 if on else 0))

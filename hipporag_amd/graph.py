@@ -43,22 +43,54 @@ class CSRGraph:
                         self.col_idx[a:b], self.val[a:b], self.raw[a:b], self.col_sum)
 
 
-def looks_undirected(g: CSRGraph, rtol: float = 1e-5) -> bool:
-    """Necessary condition for the adjacency behind a column-normalised CSR to be symmetric (what HRAG_OPT_ACCEL's
-    Chebyshev steps need: a real spectrum): with A_ij = P_ij d_j the ROW sums of A must equal its column sums d.
-    O(nnz); catches a directed graph handed to the C ABI, not every asymmetric weighting (build_csr symmetrises by
-    construction, like the reference's undirected igraph, HippoRAG.py:236).  Unsharded graphs with col_sum only."""
+def looks_undirected(g: CSRGraph, rtol: float = 1e-5, samples: int = 4096, chunk: int = 1 << 22) -> bool:
+    """Is the adjacency behind a column-normalised CSR symmetric (what HRAG_OPT_ACCEL's Chebyshev steps need: a real
+    spectrum)?  Two tests on A_ij = P_ij d_j: (1) the ROW sums of A equal its column sums d (necessary; O(nnz), in
+    chunks of `chunk` entries so that a 2e8-entry graph costs megabytes of temporaries, not gigabytes); (2) `samples`
+    entries drawn at fixed strides have a mirror entry A_ji of the same weight (catches an asymmetric weighting with
+    balanced sums).  build_csr symmetrises by construction, like the reference's undirected igraph (HippoRAG.py:236);
+    this catches a directed graph handed to the C ABI.  Unsharded graphs with col_sum only."""
     if g.col_sum is None or g.row_ptr.shape[0] - 1 != g.num_vertices:
         return False
     d = np.asarray(g.col_sum, dtype=np.float64)
-    if g.nnz == 0:
+    nnz = int(g.nnz)
+    if nnz == 0:
         return True
-    a = np.asarray(g.val, dtype=np.float64) * d[np.asarray(g.col_idx, dtype=np.int64)]
     rp = np.asarray(g.row_ptr, dtype=np.int64)
-    row_sum = np.zeros(g.num_vertices)
-    nz = rp[1:] > rp[:-1]
-    row_sum[nz] = np.add.reduceat(a, rp[:-1][nz])
-    return bool(np.all(np.abs(row_sum - d) <= rtol * np.maximum(d, 1e-300)))
+    col, val = np.asarray(g.col_idx), np.asarray(g.val)
+    n = g.num_vertices
+    r0 = 0
+    while r0 < n:                      # whole rows per chunk
+        r1 = int(np.searchsorted(rp, rp[r0] + chunk, side="right")) - 1
+        r1 = min(max(r1, r0 + 1), n)
+        lo, hi = int(rp[r0]), int(rp[r1])
+        if hi > lo:
+            a = val[lo:hi].astype(np.float64) * d[col[lo:hi]]
+            starts = rp[r0:r1] - lo
+            nz = rp[r0 + 1:r1 + 1] > rp[r0:r1]
+            rs = np.zeros(r1 - r0)
+            rs[nz] = np.add.reduceat(a, starts[nz])
+            dd = d[r0:r1]
+            if not np.all(np.abs(rs - dd) <= rtol * np.maximum(dd, 1e-300)):
+                return False
+        elif np.any(d[r0:r1] > 0):
+            return False
+        r0 = r1
+    # sampled mirror entries: entry e = (i, j, A_ij) must meet (j, i, A_ji = A_ij)
+    k = min(samples, nnz)
+    e = (np.arange(k, dtype=np.int64) * (nnz // k)) if k else np.zeros(0, dtype=np.int64)
+    i = np.searchsorted(rp, e, side="right") - 1
+    j = col[e].astype(np.int64)
+    aij = val[e].astype(np.float64) * d[j]
+    for t in range(k):
+        lo, hi = int(rp[j[t]]), int(rp[j[t] + 1])
+        hit = np.flatnonzero(col[lo:hi] == i[t])
+        if hit.size == 0:
+            return False
+        aji = float(val[lo + hit].astype(np.float64).sum()) * d[i[t]]
+        if abs(aji - aij[t]) > 4 * rtol * max(abs(aij[t]), 1e-300):
+            return False
+    return True
 
 
 def build_csr(num_vertices: int, src, dst, weight) -> CSRGraph:

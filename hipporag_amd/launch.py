@@ -46,12 +46,29 @@ def _pump(stream, sink: List[str], echo) -> None:
     stream.close()
 
 
+def _pump_rank0(stream, held: List[str], echo) -> None:
+    """Rank 0: every non-empty line is forwarded to `echo` AS IT ARRIVES except the most recent one, which is held back
+    (held[0]) -- it may be the JSON line that belongs on stdout.  Nothing accumulates, and a long run shows its
+    progress while it runs."""
+    for line in iter(stream.readline, ""):
+        if not line.strip():
+            continue
+        if held:
+            echo.write(held[0])
+            echo.flush()
+            held[0] = line
+        else:
+            held.append(line)
+    stream.close()
+
+
 def spawn_ranks(world: int, cmd: Sequence[str], *, timeout_s: Optional[float] = None, port: Optional[int] = None,
                 env: Optional[Dict[str, str]] = None, out=None, err=None) -> int:
     """Run `cmd` as `world` ranks of one node; returns the job's exit code (0 = every rank exited 0).
 
-    Rank 0's stdout is collected: its last non-empty line is written to `out` (default sys.stdout) when the job ends,
-    its earlier lines and every other rank's stdout go to `err` (default sys.stderr) as they arrive.  All ranks share
+    Rank 0's last non-empty stdout line is written to `out` (default sys.stdout) when the job ends; its earlier lines
+    and every other rank's stdout go to `err` (default sys.stderr) as they arrive (rank 0's with a lag of one line:
+    the most recent line is held back, it may be the last).  All ranks share
     this process' stderr.  timeout_s: end the job (exit code 124) if it has not finished by then."""
     if world < 1:
         raise ValueError("world must be >= 1")
@@ -74,8 +91,8 @@ def spawn_ranks(world: int, cmd: Sequence[str], *, timeout_s: Optional[float] = 
             p = subprocess.Popen(list(cmd), env=rank_env(r, world, port, env), stdout=subprocess.PIPE, stderr=None,
                                  text=True, bufsize=1)
             procs.append(p)
-            t = threading.Thread(target=_pump, args=(p.stdout, lines0 if r == 0 else [], None if r == 0 else err),
-                                 daemon=True)
+            t = (threading.Thread(target=_pump_rank0, args=(p.stdout, lines0, err), daemon=True) if r == 0 else
+                 threading.Thread(target=_pump, args=(p.stdout, [], err), daemon=True))
             t.start()
             pumps.append(t)
         deadline = None if timeout_s is None else time.monotonic() + timeout_s
@@ -113,12 +130,9 @@ def spawn_ranks(world: int, cmd: Sequence[str], *, timeout_s: Optional[float] = 
             t.join(timeout=5)
         for sig, h in old_handlers.items():
             signal.signal(sig, h)
-        body = [ln for ln in lines0 if ln.strip()]
-        for ln in body[:-1]:
-            err.write(ln)
         err.flush()
-        if body:
-            out.write(body[-1] if body[-1].endswith("\n") else body[-1] + "\n")
+        if lines0:                           # the line rank 0 printed last
+            out.write(lines0[0] if lines0[0].endswith("\n") else lines0[0] + "\n")
             out.flush()
 
 

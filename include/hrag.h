@@ -160,10 +160,14 @@ typedef struct hrag_fact_desc {
                                       /* (damping 0.5, ppr_iters 20: 16; with ppr_tol > 0: 17, the last one plain so that the */
                                       /* convergence measure reads what it reads without the flag; iters_out reports them).   */
                                       /* The reference's PRPACK solve is tolerance-driven (HippoRAG.py:1736-1743): any sweep  */
-                                      /* count that meets the tolerance is the same answer.  Guarantees: the static e4m3      */
-                                      /* scales rest on the max-norm bound of the Chebyshev polynomial (no saturation by      */
-                                      /* construction; HRAG_FLAG_FP8_SATURATED would still report a violation -- clear the    */
-                                      /* flag and repeat); every boundary forms the TRUE residual, so refinement stays exact  */
+                                      /* count that meets the tolerance is the same answer.  Guarantees: the e4m3 scale of    */
+                                      /* every stage is MEASURED on the device -- each boundary reports the batch's max |R|,  */
+                                      /* ppr8_next_scale_kernel maps (that maximum) x (max-norm contraction of the next       */
+                                      /* stage, 7 / T_3(1 / damping)) x (growth of the iterate) to half the e4m3 range: a     */
+                                      /* rigorous bound re-anchored at every stage, not a static chain.  Failure mode: a      */
+                                      /* value outside the range sets HRAG_FLAG_FP8_SATURATED for its query -- clear the      */
+                                      /* flag and repeat on the plain plan (the Python wrapper does), then HRAG_OPT_NO_FP8;   */
+                                      /* every boundary forms the TRUE residual, so refinement stays exact                    */
                                       /* and the extension stages of the contract (plain) apply unchanged.  With ppr_tol = 0  */
                                       /* the accuracy is that of ppr_iters plain sweeps on well-mixing graphs (cfg 3: 4.4e-7  */
                                       /* against 5.5e-7) and up to 3x their truncation error on small hub-heavy ones: use the */
@@ -513,7 +517,10 @@ hrag_status hrag_shard_ppr_begin(hrag_engine *e, const float *min_dev, const flo
 
 /* sweep `sweep` (0 .. ppr_iters - 1, in order per group) on the owned rows of exchange group `group`;
  * *exchange_out = index of the state buffer whose owned block of that group was written and must be
- * exchanged before the group's next sweep (-1 after the last sweep: nothing to exchange). */
+ * exchanged before the group's next sweep (-1 after the last sweep: nothing to exchange).
+ * Issue the groups of one sweep in ASCENDING order (0 .. n_groups - 1) before any group of the next sweep: on an
+ * engine that owns every row and measures its stage scales (damping < 0.46, HRAG_OPT_ACCEL) the boundary sweeps fold
+ * each group's maximum into one running value and the launch of the last group turns it into the next scale. */
 hrag_status hrag_shard_ppr_sweep(hrag_engine *e, int32_t sweep, int32_t group, int32_t *exchange_out,
                                  int32_t *checkpoint_out, hrag_stream stream);
 

@@ -217,3 +217,47 @@ def test_shards_at_small_damping_keep_inside_the_fp8_range(gpu_device):
         for ids, scs in ((got[2][q], got[3][q]), (one[0][q], one[1][q])):
             assert float((np.abs(scs - full[ids]) / full[ids]).max()) < 1e-5, q
             assert tie_aware_equal(ids, ref.sorted_doc_ids[:100], ref.sorted_doc_scores[:100], rel_gap=2e-5), q
+
+
+def test_one_shard_in_several_exchange_groups_measures_its_scales_over_the_whole_batch(gpu_device):
+    """An engine that owns EVERY row, driven through the shard entry points in two exchange groups (the world = 1 legs
+    of `bench.py --gpus 1` under HRAG_FORCE_DIST, or a host that pipelines groups on one GPU), at damping 0.3 where
+    the plain plan MEASURES its stage scales: every boundary step is launched once per group, and the scale of the
+    stage after next must come from the maximum over ALL groups (round-4 advisor finding: it was taken from the last
+    group's slots alone, so the other groups ran on a scale that was not theirs).  300 queries = a two-slab group
+    (pair kernel) + a one-slab group; the result must be the single-call engine's, bit for bit, without a saturation
+    flag."""
+    import dataclasses
+    import torch
+    from hipporag_amd import dist as hd
+    from hipporag_amd.engine import HippoRAGEngine, ShardStages
+    b, damping, iters = 300, 0.3, 16
+    kg, pass_bits, fact_bits, index = make_case(12000, 36000, 96, seed=31506654, passage_frac=0.3, power_law=True)
+    index = dataclasses.replace(index, damping=damping)
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=13)
+    qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=14)
+    qf_t, qp_t = _bf16(qf_bits, gpu_device), _bf16(qp_bits, gpu_device)
+    kw = dict(link_top_k=5, damping=damping, passage_node_weight=0.05, ppr_iters=iters, k=100)
+    cnt = torch.full((b,), 5, dtype=torch.int32, device=gpu_device)
+    with HippoRAGEngine(kg.csr, kg.passage_vertex, pass_bits, fact_bits, kg.subj_vertex, kg.obj_vertex,
+                        kg.num_chunks, max_batch=b, max_topk=100) as eng:
+        idx, sc = eng.score_facts(qf_t, k=5)
+        out = eng.retrieve(qp_t, idx, sc, cnt, **kw)
+        torch.cuda.synchronize()
+        assert eng.timings()["slab_width"] == 128
+        one = tuple(t.cpu().numpy() for t in (out.doc_idx, out.doc_score, out.flags))
+        rs = hd.ShardedRetriever(ShardStages(eng), hd.TorchComm(0, 1), groups=2)
+        lay = eng.shard_layout(b, 2)
+        assert lay.n_groups == 2 and lay.n_slabs == 3
+        i2, s2 = rs.score_facts(qf_t, k=5)
+        got = rs.retrieve(qp_t, i2, s2, cnt, **kw)
+        torch.cuda.synchronize()
+        got = tuple(t.cpu().numpy() for t in got)
+    assert np.all(one[2] == 0) and np.all(got[2] == 0), (np.unique(one[2]), np.unique(got[2]))
+    np.testing.assert_array_equal(got[0], one[0])
+    np.testing.assert_array_equal(got[1], one[1])
+    qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+    for q in (0, 127, 128, 255, 256, 299):
+        ref = oracle.retrieve_one(index, qf[q], qp[q])
+        full = ref.x[kg.passage_vertex]
+        assert float((np.abs(got[1][q] - full[got[0][q]]) / full[got[0][q]]).max()) < 1e-5, q

@@ -167,6 +167,16 @@ def test_looks_undirected_is_what_the_accelerated_plan_is_gated_on():
     assert not looks_undirected(CSRGraph(g.num_vertices, g.row_ptr, g.col_idx, v, g.raw, g.col_sum))
     assert not looks_undirected(CSRGraph(g.num_vertices, g.row_ptr, g.col_idx, g.val, g.raw, None))
     assert not looks_undirected(g.rows(0, 1500))
+    # small chunks walk the same rows (the 2e8-entry graphs of configs[4] are tested in chunks of 4M entries)
+    assert looks_undirected(g, chunk=1000)
+    assert not looks_undirected(CSRGraph(g.num_vertices, g.row_ptr, g.col_idx, v, g.raw, g.col_sum), chunk=1000)
+    # balanced sums, asymmetric weights: a directed 3-cycle 0 -> 1 -> 2 -> 0 (row sums == column sums == 1) passes
+    # the sum test; the sampled mirror-entry test rejects it (no A_ji for A_ij)
+    rp = np.array([0, 1, 2, 3], dtype=np.int32)
+    cyc = CSRGraph(3, rp, np.array([2, 0, 1], dtype=np.int32), np.ones(3, dtype=np.float32), np.ones(3, dtype=np.float32),
+                   np.ones(3))
+    assert not looks_undirected(cyc)
+    assert looks_undirected(cyc, samples=0)                    # ... which the sums alone would have let through
 
 
 # ------------------------------------------------------------------ the mirror's batch pipeline (retriever.iter_batched_retrieve)

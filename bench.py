@@ -64,6 +64,16 @@ CONFIGS = {
     "cfg4local": dict(V=1_000_000, E=10_000_000, D=768, B=1024, seed=1237, shard_of=8, local_shards=True,
                       label="configs[3] parity run: all 8 row shards of the 1M-node/10M-edge KG emulated on ONE device, global batch 1024"),
     "tiny": dict(V=20_000, E=200_000, D=256, B=32, seed=1235, label="tiny smoke workload"),
+    # NOT a BASELINE configuration: a graph with REAL topology (tests/real2wiki.py: a deterministic triple extractor over
+    # the 6 119-passage 2WikiMultihopQA corpus the reference ships, tools/make_real2wiki.py), 32 disjoint copies with
+    # interleaved ids = 1.5M vertices / 13.1M entries / 4.2M facts, the reference's mock embedding recipe (64-d uniform).
+    # `--locality auto` vs none shows what the graph compiler's numbering buys on real per-document locality
+    "real2wiki": dict(real2wiki=True, tiles=32, V=0, E=0, D=64, B=256, seed=1240,
+                      label="NON-BASELINE: real-topology KG from the 2WikiMultihopQA corpus (LLM-free extractor), 32 "
+                            "interleaved disjoint copies: 1.5M vertices / 6.55M edges / 4.2M facts, 64-d mock embeddings, batch 256"),
+    "real2wiki1": dict(real2wiki=True, tiles=1, V=0, E=0, D=64, B=256, seed=1240,
+                       label="NON-BASELINE: real-topology KG from the 2WikiMultihopQA corpus (LLM-free extractor) at its own "
+                             "size: 46.9k vertices / 205k edges / 130k facts, 64-d mock embeddings, batch 256"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 PPR_ITERS, K_F, K_P, DAMPING, PASSAGE_W = 20, 5, 200, 0.5, 0.05
@@ -105,11 +115,11 @@ def _time_launches(fn, n_l):
 
 def fp8_mode_counts(iters, damping=None):
     """Launches of one retrieve by kernel instantiation "<mode>" or "<mode>/<residual form>": ppr8_plan and the
-    residual-form schedule of ppr8_begin in csrc/shard.hip (stages 1, 2, 3.., remainder; the residual travels in
-    its 3-byte form once damping^k <= 2^-6)."""
+    residual-form schedule of ppr8_begin in csrc/shard.hip (engine.fp8_stage_plan: 20 = 1+2+3+3+4+4+3; the residual
+    travels in its 3-byte form once damping^k <= 2^-6)."""
+    from hipporag_amd.engine import fp8_stage_plan
     damping = DAMPING if damping is None else damping
-    left = iters - 3
-    stages = [1, 2] + [3] * (left // 3) + ([left % 3] if left % 3 else [])
+    stages = fp8_stage_plan(iters, damping)
     counts = {"C": sum(m - 1 for m in stages[1:]), "B0": 1}
     k, r16 = 0, False
     for si, m in enumerate(stages):
@@ -341,17 +351,18 @@ class _NoPeers:
         pass
 
 
-def bench_local_shards(args, cfg, dev):
+def local_shards_parity(cfg, batch, cpu_queries, exchange_groups, dev):
     """BASELINE configs[3] with its result checked on one GPU: the `shard_of` row-shard engines run as threads of this
     process on one device (the state exchange is a barrier on shared buffers), the merged ranking of the global batch
-    is compared with the fp64 CPU oracle (--cpu-queries queries) and with the single-GPU engine on the relabelled
-    index (bit-identity of every query).  The wall time serialises 8 GPUs' work on one and is NOT a multi-GPU rate."""
+    is compared with the fp64 CPU oracle (`cpu_queries` queries) and with the single-GPU engine on the relabelled
+    index (bit-identity of every query).  The wall time serialises 8 GPUs' work on one and is NOT a multi-GPU rate.
+    Returns the result line as a dict (`bench.py --config cfg4local` prints it; tests/test_gpu_full_size.py asserts on it)."""
     import torch
     import oracle
     from hipporag_amd import dist as hd, synth
     from hipporag_amd.engine import HippoRAGEngine
     from tests.helpers import tie_aware_report
-    world, V, E, D, B, seed = cfg["shard_of"], cfg["V"], cfg["E"], cfg["D"], args.batch or cfg["B"], cfg["seed"]
+    world, V, E, D, B, seed = cfg["shard_of"], cfg["V"], cfg["E"], cfg["D"], batch or cfg["B"], cfg["seed"]
     kg = synth.make_kg(V, E, seed)
     pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev)
     fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev)
@@ -363,7 +374,7 @@ def bench_local_shards(args, cfg, dev):
     # the long-row cut fixes the summation order of hub rows: the same explicit value on the shards and on the
     # unsharded engine they are compared with (hrag_opts.sell_seg_len; auto would pick 256 vs 2048 here)
     seg = 256
-    got = hd.run_local_shards(world, sidx, pass_emb, fact_emb, qf, qp, kw, args.exchange_groups, dev, K_P, timings=tm,
+    got = hd.run_local_shards(world, sidx, pass_emb, fact_emb, qf, qp, kw, exchange_groups, dev, K_P, timings=tm,
                               sell_seg_len=seg)
     f_idx, f_sc, d_idx, d_sc, flags = got
     # ---- the single-GPU engine on the same relabelled index: bit-identity of the whole batch
@@ -384,7 +395,7 @@ def bench_local_shards(args, cfg, dev):
                             subj_vertex=kg.subj_vertex, obj_vertex=kg.obj_vertex, num_chunks=kg.num_chunks,
                             passage_vertex=kg.passage_vertex, p=oracle.column_normalize(a))
     qf_h, qp_h = qf.float().cpu().numpy(), qp.float().cpu().numpy()
-    n_q = max(1, min(args.cpu_queries, B))
+    n_q = max(1, min(cpu_queries, B))
     qs = sorted(set(np.linspace(0, B - 1, n_q).astype(int).tolist()))
     ok, worst, exact, npos = True, 0.0, 0, 0
     for q in qs:
@@ -395,13 +406,12 @@ def bench_local_shards(args, cfg, dev):
         want = ref.x[kg.passage_vertex][d_idx[q]]
         worst = max(worst, float((np.abs(d_sc[q] - want) / want).max()))
     wall = tm.get("wall_s_all_shards_on_one_device", float("nan"))
-    lay_groups = args.exchange_groups
-    result = {
+    return {
         "metric": "retrieval_queries_per_sec", "value": B / wall, "unit": "queries/s", "n_gpus": 1, "steps": 1,
         "warmup": 0, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["label"], "V": V, "E": E, "nnz": kg.csr.nnz, "global_batch": B,
-                   "shards": world, "exchange_groups": lay_groups, "ppr_iters": PPR_ITERS,
+                   "shards": world, "exchange_groups": exchange_groups, "ppr_iters": PPR_ITERS,
                    "parallelism": f"{world} row shards emulated as threads on ONE device (barrier exchange): a PARITY run; "
                                   "value is the serialised wall time of 8 GPUs' work, not a multi-GPU rate"},
         "parity_vs_oracle": {"queries_checked": len(qs), "queries": qs, "topk_ids_equal": bool(ok),
@@ -409,7 +419,10 @@ def bench_local_shards(args, cfg, dev):
                              "flags_or": int(np.bitwise_or.reduce(flags))},
         "bit_identical_to_single_gpu_engine_on_relabelled_index": bit,
     }
-    print(json.dumps(result))
+
+
+def bench_local_shards(args, cfg, dev):
+    print(json.dumps(local_shards_parity(cfg, args.batch, args.cpu_queries, args.exchange_groups, dev)))
     return 0
 
 
@@ -538,12 +551,19 @@ def main():
         return bench_shard_share(args, cfg, dev)
 
     t_setup = time.perf_counter()
-    kg = synth.make_kg(V, E, seed, power_law=bool(cfg.get("power_law")), community=int(cfg.get("community", 0)))
-    if cfg.get("hash_order"):
-        kg = synth.hash_order(kg, seed + 77)
     emb_dtype = torch.float16 if cfg.get("fp16") else torch.bfloat16
-    pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev, dtype=emb_dtype)
-    fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev, dtype=emb_dtype)
+    if cfg.get("real2wiki"):
+        from tests import real2wiki as rw
+        kg = rw.build_kg(int(cfg["tiles"]))
+        V, E = kg.num_vertices, kg.csr.nnz // 2
+        pass_emb = torch.from_numpy(rw.mock_embeddings(kg.n_passages, seed + 1, D)).to(dev).to(emb_dtype)
+        fact_emb = torch.from_numpy(rw.mock_embeddings(kg.n_facts, seed + 2, D)).to(dev).to(emb_dtype)
+    else:
+        kg = synth.make_kg(V, E, seed, power_law=bool(cfg.get("power_law")), community=int(cfg.get("community", 0)))
+        if cfg.get("hash_order"):
+            kg = synth.hash_order(kg, seed + 77)
+        pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev, dtype=emb_dtype)
+        fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev, dtype=emb_dtype)
     eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pass_emb, fact_emb, kg.subj_vertex, kg.obj_vertex,
                          kg.num_chunks, max_batch=B, max_topk=K_P, slab_width=args.slab_width, flags=args.engine_flags,
                          sell_sigma=args.sell_sigma, locality=args.locality)

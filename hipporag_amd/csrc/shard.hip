@@ -10,21 +10,52 @@
 
 namespace hrag {
 
-// Stage lengths: 1 (the quantised start), 2, then 3-sweep stages, the remainder (1 or 2 sweeps) last --
-// 20 = 1+2+3+3+3+3+3+2.  Why: in exact arithmetic a stage of m sweeps leaves R_new = (aAt)^m R + (R - rt/cs),
-// i.e. the residual contracts by a^m and the e4m3 rounding of the right-hand side (~2^-4.5 |R|) comes on
-// top un-attenuated: a factor (1 + 0.044 / a^m) per stage over the plain iteration.  Stages of 2-3 sweeps
-// minimise the product (measured over star / bipartite / tree / grid / benchmark graphs,
-// tools/exp_fp8_final.py and DESIGN.md section 4: this plan ~1.8x the truncation error of the sweep count on
-// average, 4.2x worst; 4-sweep stages save a boundary sweep each but cost 25 % accuracy), and a short
-// LAST stage keeps the final rounding small.
-int ppr8_plan(int iters, int *plan) {
+// Stage lengths.  In exact arithmetic a stage of m sweeps leaves R_new = (aAt)^m R + (R - rt/cs): the residual contracts
+// by a^m and the e4m3 rounding of the right-hand side (~2^-4.5 |R|) comes on top un-attenuated.  Every stage costs a
+// boundary sweep (the fp32 / 3-byte residual in and out: 0.97 - 1.08 ms against 0.77 ms for a stage sweep at BASELINE
+// configs[2]), so fewer, longer stages are cheaper -- as long as the rounding does not start to dominate a^m.
+//   * round 1 - 4: 1 (the quantised start), 2, then 3-sweep stages, the remainder (1 or 2) last: 20 = 1+2+3+3+3+3+3+2,
+//     six boundaries.  Kept for ppr_iters < 19 and for damping < 0.46 (a^4 is then below the rounding's share: longer
+//     stages only waste sweeps there; at 0.3 the scales are measured, see ppr8_begin).
+//   * round 5, damping >= 0.46 and ppr_iters >= 19: 1, 2, 3, then 3-sweep stages, then as many 4-sweep stages as the
+//     count allows, a 3-sweep stage last -- 20 = 1+2+3+3+4+4+3, FIVE boundaries.  The 4-sweep stages sit where the
+//     residual already travels in its 3-byte form (their boundaries are the cheap ones) and the last stage stays short
+//     (its rounding is the one nothing measures).  CPU emulation of the device arithmetic over 33 candidate plans x
+//     {benchmark, power-law, star forest, barbell} graphs (tools/exp_fp8_final.py, docs/experiments/README.md round 5):
+//     the same accuracy as the old plan within +-25 % at every count 19 .. 30 and damping 0.5 .. 0.6 (20 sweeps:
+//     3.7e-7 against 3.9e-7 on the benchmark graph, 7.6e-6 against 9.3e-6 on the star forest); plans with TWO
+//     boundaries fewer (1,3,4,4,5,3) cost a factor 2 and are not taken.
+// HRAG_P8_PLAN="1,2,4,4,4,4,1" (experiments only) overrides the rule when it sums to ppr_iters.
+int ppr8_plan(int iters, float damping, int *plan) {
+    if (const char *env = getenv("HRAG_P8_PLAN")) {
+        int n = 0, sum = 0;
+        for (const char *c = env; *c && n < kP8MaxStages;) {
+            const int m = atoi(c);
+            if (m < 1) { n = 0; break; }
+            plan[n++] = m; sum += m;
+            while (*c && *c != ',') ++c;
+            if (*c == ',') ++c;
+        }
+        if (n >= 2 && sum == iters && plan[0] == 1) return n;
+    }
     int n = 0;
     plan[n++] = 1;
     plan[n++] = 2;
-    int left = iters - 3;
-    while (left >= 3) { plan[n++] = 3; left -= 3; }
-    if (left > 0) plan[n++] = left;
+    if (iters < 19 || !(damping >= 0.46f)) {
+        int left = iters - 3;
+        while (left >= 3) { plan[n++] = 3; left -= 3; }
+        if (left > 0) plan[n++] = left;
+        return n;
+    }
+    // iters - 9 = 4 a + 3 b with the largest a: [1, 2, 3] + b x [3] + a x [4] + [3]
+    const int t = iters - 9;
+    int a = t / 4;
+    while (a > 0 && (t - 4 * a) % 3 != 0) --a;
+    const int b = (t - 4 * a) / 3;
+    plan[n++] = 3;
+    for (int i = 0; i < b; ++i) plan[n++] = 3;
+    for (int i = 0; i < a; ++i) plan[n++] = 4;
+    plan[n++] = 3;
     return n;
 }
 
@@ -175,7 +206,7 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     const bool may_accel = allow_accel && (e->opt_flags & HRAG_OPT_ACCEL) && e->d_dyn && e->n_rows == e->V;
     int n_stage = may_accel ? ppr8_plan_accel(iters, damping, tol > 0.f, plan, kind) : 0;
     const bool accel = n_stage > 0;
-    if (!accel) n_stage = ppr8_plan(iters, plan);
+    if (!accel) n_stage = ppr8_plan(iters, damping, plan);
     if (accel) {                                   // the base plan's own sweep count is what the session runs and reports
         iters = 0;
         for (int i = 0; i < n_stage; ++i) iters += plan[i];

@@ -845,6 +845,21 @@ class EngineStages:
         return out
 
 
+def fp8_stage_plan(iters: int, damping: float = 0.5):
+    """Python mirror of ppr8_plan (csrc/shard.hip): the stage lengths of the plain staged-fp8 PPR for `iters` sweeps.
+    bench.py prices its per-instantiation launch times with it and tools/exp_fp8_final.py emulates it; the library
+    never calls this.  iters < 19 or damping < 0.46: 1, 2, 3-sweep stages, remainder last; otherwise 1, 2, 3, 3-sweep
+    stages, as many 4-sweep stages as fit, a 3-sweep stage last (20 = 1+2+3+3+4+4+3)."""
+    if iters < 19 or not damping >= 0.46:
+        left = iters - 3
+        return [1, 2] + [3] * (left // 3) + ([left % 3] if left % 3 else [])
+    t = iters - 9
+    a = t // 4
+    while a > 0 and (t - 4 * a) % 3:
+        a -= 1
+    return [1, 2, 3] + [3] * ((t - 4 * a) // 3) + [4] * a + [3]
+
+
 class ShardStages(EngineStages):
     """The hrag_shard_* operators of a row-shard engine (staged fp8 PPR state) -- what
     hipporag_amd.dist.ShardedRetriever composes with its exchange steps."""

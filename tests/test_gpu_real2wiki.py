@@ -1,0 +1,71 @@
+"""Parity of the HIP path on a graph with REAL topology (tests/real2wiki.py: the 2WikiMultihopQA corpus the reference
+ships through a deterministic triple extractor; 46.9k vertices, 410k entries, 130k facts, hubs of degree ~2 900):
+every graph the suite ran on before was synth.make_kg's or a toy corpus.  256 queries (staged fp8 state) and 48 (two-stage
+fp16 state), against the fp64 oracle (reference call site HippoRAG.py:1736-1749), as numbered by the reference's rule
+and under the graph compiler's locality numbering (`locality="auto"`, which must switch itself on here: score >= 0.3)."""
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import real2wiki as rw
+from tests.helpers import ranked_parity, write_test_report
+
+pytestmark = pytest.mark.gpu
+
+
+def test_real_topology_parity_with_and_without_the_locality_numbering(gpu_device):
+    import torch
+    from hipporag_amd import synth
+    from hipporag_amd.engine import HippoRAGEngine
+    from hipporag_amd.graph import float_to_bf16_bits, bf16_bits_to_float
+    kg = rw.build_kg(1)
+    B, K = 256, 200
+    pass_bits = float_to_bf16_bits(rw.mock_embeddings(kg.n_passages, 11))
+    fact_bits = float_to_bf16_bits(rw.mock_embeddings(kg.n_facts, 12))
+    to_t = lambda bits: torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).to(gpu_device).view(torch.bfloat16)
+    pass_emb, fact_emb = to_t(pass_bits), to_t(fact_bits)
+    qf = synth.make_queries_torch(fact_emb, B, 31)[0]
+    qp = synth.make_queries_torch(pass_emb, B, 32)[0]
+    cnt = torch.full((B,), 5, dtype=torch.int32, device=gpu_device)
+    got = {}
+    for name, loc in (("as_given", None), ("locality_auto", "auto")):
+        with HippoRAGEngine(kg.csr, kg.passage_vertex, pass_emb, fact_emb, kg.subj_vertex, kg.obj_vertex, kg.num_chunks,
+                            max_batch=B, max_topk=K, locality=loc) as eng:
+            idx, sc = eng.score_facts(qf, k=5)
+            out = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=K)
+            sub = eng.retrieve(qp[:48], idx[:48], sc[:48], cnt[:48], ppr_iters=20, k=K)
+            torch.cuda.synchronize()
+            got[name] = dict(idx=idx.cpu().numpy(), ids=out.doc_idx.cpu().numpy(), sc=out.doc_score.cpu().numpy(),
+                             flags=out.flags.cpu().numpy(), sub_ids=sub.doc_idx.cpu().numpy(), sub_sc=sub.doc_score.cpu().numpy(),
+                             score=eng.locality_score, numbering=eng.numbering, opt=eng.opt_flags)
+    assert got["as_given"]["numbering"] is None
+    assert got["locality_auto"]["numbering"] == "locality" and got["locality_auto"]["score"] >= 0.3
+    from hipporag_amd._lib import OPT_XCD_BLOCKED
+    assert got["locality_auto"]["opt"] & OPT_XCD_BLOCKED              # real per-document locality switches the windows on
+    a = oracle.build_symmetric_csr(kg.num_vertices, kg.src, kg.dst, kg.weight)
+    index = oracle.RefIndex(fact_emb=bf16_bits_to_float(fact_bits), passage_emb=bf16_bits_to_float(pass_bits),
+                            subj_vertex=kg.subj_vertex, obj_vertex=kg.obj_vertex, num_chunks=kg.num_chunks,
+                            passage_vertex=kg.passage_vertex, p=oracle.column_normalize(a))
+    qf_h, qp_h = qf.float().cpu().numpy(), qp.float().cpu().numpy()
+    rep_out = {}
+    for name, g in got.items():
+        assert np.all(g["flags"] == 0), (name, np.unique(g["flags"]))
+        worst, gap, exact, npos, worst16 = 0.0, 0.0, 0, 0, 0.0
+        for q in list(range(0, B, 16)) + [B - 1]:
+            ref = oracle.retrieve_one(index, qf_h[q], qp_h[q])
+            np.testing.assert_array_equal(g["idx"][q], ref.fact_candidates)
+            full = ref.x[kg.passage_vertex]
+            rep = ranked_parity(g["ids"][q], g["sc"][q], ref.sorted_doc_ids, ref.sorted_doc_scores, full)
+            assert rep["equal"], (name, q, rep)
+            worst, gap = max(worst, rep["worst_rel_err"]), max(gap, rep["rel_gap"])
+            exact += rep["exact_positions"]; npos += rep["n"]
+            if q < 48:
+                r16 = ranked_parity(g["sub_ids"][q], g["sub_sc"][q], ref.sorted_doc_ids, ref.sorted_doc_scores, full)
+                assert r16["equal"], (name, "fp16 state", q, r16)
+                worst16 = max(worst16, r16["worst_rel_err"])
+        assert worst < 1e-5 and worst16 < 1e-5, (name, worst, worst16)
+        rep_out[name] = {"max_rel_score_err_fp8_state": worst, "max_rel_score_err_fp16_state": worst16,
+                         "exact_id_fraction": exact / npos, "tie_window_rel": gap, "locality_score": g["score"]}
+    write_test_report("real2wiki_parity", {"V": kg.num_vertices, "nnz": int(kg.csr.nnz), "facts": kg.n_facts, "batch": B,
+                                           "queries_vs_oracle": 17, **rep_out})

@@ -21,10 +21,10 @@ import oracle  # noqa: E402
 from exp_fp8_zspace import graphs, q8  # noqa: E402
 
 
-def plan_for(iters):
-    """stage lengths: 1, 2, 3-sweep stages, remainder last -- ppr8_plan in csrc/shard.hip"""
-    left = iters - 3
-    return [1, 2] + [3] * (left // 3) + ([left % 3] if left % 3 else [])
+def plan_for(iters, damping=0.5):
+    """stage lengths -- ppr8_plan in csrc/shard.hip (mirrored by hipporag_amd.engine.fp8_stage_plan)"""
+    from hipporag_amd.engine import fp8_stage_plan
+    return fp8_stage_plan(iters, damping)
 
 
 def ppr8(at32, d1, v, alpha, plan, rho_form=True):

@@ -33,7 +33,7 @@ def bf16(bits, dev):
     return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).to(dev).view(torch.bfloat16)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=150.0)
     ap.add_argument("--seed", type=int, default=1)
@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--replay", action="append", default=[], help="a case as printed (JSON): run exactly that one; repeatable")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--big", action="store_true", help="50k .. 200k vertices, batches up to 512, up to 2048 documents per query")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
     dev = torch.device("cuda", 0)
     t_end = time.time() + args.seconds

@@ -31,12 +31,12 @@ def bf16(bits, dev):
     return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).to(dev).view(torch.bfloat16)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "soak_shards.json"))
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
     dev = torch.device("cuda", 0)
     t_end = time.time() + args.seconds

@@ -11,7 +11,9 @@ Workload (BASELINE.json: the metric is quoted on the 1M-node KG): configs[2] =
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1, external launcher)
 
 N > 1 without a launcher (no WORLD_SIZE in the environment): bench.py spawns its own N ranks, one per GPU
-(hipporag_amd/launch.py), and prints rank 0's line.  Prints ONE JSON line (rank 0), last.
+(hipporag_amd/launch.py), and prints rank 0's line: `value` = the row-sharded leg (BASELINE.json's layout) when it is
+parity-green, `value_hybrid` / `value_replica` beside it, and -- on the default configs[2] workload -- `configs3_strong`
+= BASELINE configs[3] (global batch 1024 on the same index).  Prints ONE JSON line (rank 0), last.
 """
 
 from __future__ import annotations
@@ -51,8 +53,8 @@ CONFIGS = {
     "cfg5gpu": dict(V=10_000_000, E=100_000_000, D=1024, B=512, seed=1239, power_law=True, fp16=True,
                     label="configs[4] per-GPU share: synthetic 10M-node/100M-edge power-law KG, 10M x 1024 fp16, batch 512"),
     # configs[3] itself: the 1M-node KG sharded across the GPUs of ONE node, GLOBAL batch 1024 whatever N is (strong
-    # scaling: 128 queries per GPU at N = 8).  N = 1: the whole batch on one GPU.  N > 1 (`--gpus N`): `value` = the best
-    # parity-green corpus-sharded leg (hybrid, else rowshard), the replica leg beside it
+    # scaling: 128 queries per GPU at N = 8).  N = 1: the whole batch on one GPU.  N > 1 (`--gpus N`): `value` = the
+    # row-sharded leg when parity-green (else hybrid), `value_hybrid` / `value_replica` beside it
     "cfg4": dict(V=1_000_000, E=10_000_000, D=768, B=1024, seed=1237, global_batch=1024,
                  label="configs[3]: synthetic 1M-node/10M-edge KG sharded across the GPUs of one node, global batch 1024"),
     # one GPU's share of configs[3]: shard 0 of the 8-way row shard of the 1M-node KG with the GLOBAL batch of
@@ -115,7 +117,7 @@ def _time_launches(fn, n_l):
 
 def fp8_mode_counts(iters, damping=None):
     """Launches of one retrieve by kernel instantiation "<mode>" or "<mode>/<residual form>": ppr8_plan and the
-    residual-form schedule of ppr8_begin in csrc/shard.hip (engine.fp8_stage_plan: 20 = 1+2+3+3+4+4+3; the residual
+    residual-form schedule of ppr8_begin in csrc/shard.hip (engine.fp8_stage_plan: 20 = 1+2+3+4+4+4+2; the residual
     travels in its 3-byte form once damping^k <= 2^-6)."""
     from hipporag_amd.engine import fp8_stage_plan
     damping = DAMPING if damping is None else damping
@@ -172,6 +174,17 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
     ppr_iter_ms = phases["ppr_ms"] / PPR_ITERS      # every kernel of the PPR stage (init, reduce) / iterations
     tr = (traffic or {}).get(kernel, {})
     traffic_bytes = tr.get("bytes_per_launch") if tr.get("workload") == f"{config_name}:B{B}" else None
+    # the PMC figures are replayed, not measured in this run: they stand only while the kernel's source is the one they
+    # were collected on (tools/prof_summary.py stamps its hash) -- a changed kernel reports traffic = null, not a stale number
+    traffic_note = None
+    if traffic_bytes is not None:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from prof_summary import kernel_source_sha16
+        now = kernel_source_sha16(kernel)
+        if tr.get("kernel_source_sha16") != now:
+            traffic_bytes = None
+            traffic_note = (f"profiles/pmc_traffic.json was collected on another build of the kernel source "
+                            f"({tr.get('kernel_source_sha16')} != {now}): re-run tools/gpu_profile.sh")
     if f8 and traffic_bytes is not None and tr.get("by_instantiation"):
         # average launch of one retrieve, like `achieved`: instantiation <mode, residual form> weighted by the plan
         num = {"C": 0, "B": 1, "F": 2, "B0": 3}
@@ -193,8 +206,9 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
                             if f8 else "average launch of the sweep kernel (+ its long-row reduce)"),
         # PMC traffic is only meaningful for the workload it was collected on (profiles/pmc_traffic.json)
         "traffic": traffic_bytes,
-        "traffic_source": "replayed from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, "
-                          "FETCH_SIZE x2-corrected + WRITE_SIZE); not measured in this run",
+        "traffic_source": traffic_note or ("replayed from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, "
+                                           "FETCH_SIZE x2-corrected + WRITE_SIZE, stamped with the hash of the kernel source they were "
+                                           "collected on and dropped when it changes); not measured in this run"),
         "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_definition": "SURVEY 8(d): nnz*8 + (V+1)*4 + 2*V*B*4 + Np*B*4 per PPR iteration",
         "state_bytes_stored": sb, "algorithmic_bytes_at_stored_state_width": alg_stored,
         "frac_at_stored_state_width": alg_stored / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -493,12 +507,12 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--slab-width", type=int, default=0)
     ap.add_argument("--mode", default="auto", choices=["auto", "rowshard", "replica", "hybrid"],
-                    help="multi-GPU leg whose rate is `value` (N > 1).  All three legs are always measured and printed: "
-                         "replica (queries sharded, every GPU holds the whole index, no data-path collective), hybrid "
-                         "(embeddings row-sharded, one all-to-all of passage-score rows, PPR query-parallel on a replicated "
-                         "graph) and rowshard (BASELINE.json's layout: CSR rows + embeddings sharded, one all-gather of the "
-                         "e4m3 iterate per sweep).  auto (default): the best PARITY-GREEN corpus-sharded leg -- hybrid, else "
-                         "rowshard -- and the replica leg only when neither is green (said in `value_leg`)")
+                    help="multi-GPU leg whose rate is `value` (N > 1).  All three legs are always measured and printed "
+                         "(`value_rowshard`, `value_hybrid`, `value_replica`): rowshard (BASELINE.json's layout: CSR rows + "
+                         "embeddings sharded, one collective on the e4m3 iterate per sweep), hybrid (embeddings row-sharded, "
+                         "one all-to-all of passage-score rows, PPR query-parallel on a replicated graph) and replica (queries "
+                         "sharded, every GPU holds the whole index).  auto (default): rowshard when it is parity-green "
+                         "(SURVEY 8(e): the primary figure), else hybrid, else replica (said in `value_leg`)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-queries", type=int, default=12)
     ap.add_argument("--cpu-vec-queries", type=int, default=32, help="batch of the vectorised CPU baseline leg")
@@ -507,9 +521,15 @@ def main():
     ap.add_argument("--exchange-groups", type=int, default=2,
                     help="row-sharded mode: exchange groups pipelined against the sweeps")
     ap.add_argument("--sweep-launches", type=int, default=40)
-    ap.add_argument("--no-rowshard", action="store_true", help="N > 1: skip the secondary row-sharded leg")
-    ap.add_argument("--rowshard-timeout-s", type=float, default=240.0,
-                    help="N > 1: abandon the row-sharded leg after this long (the primary line still prints)")
+    ap.add_argument("--no-rowshard", action="store_true", help="N > 1: skip the corpus-sharded legs (replica only)")
+    ap.add_argument("--rowshard-timeout-s", type=float, default=600.0,
+                    help="N > 1: abandon the corpus-sharded legs after this long (the line still prints what was measured)")
+    ap.add_argument("--collective", default="allgather", choices=["allgather", "allreduce"],
+                    help="N > 1, row-sharded leg: the per-sweep exchange of the e4m3 iterate -- in-place all-gather of the "
+                         "owners' blocks (default), or BASELINE.json's literal all-reduce (foreign blocks zeroed, SUM over "
+                         "the bytes: the same result at twice the wire bytes)")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N > 1 on configs[2]: skip the additional configs[3] figures (global batch 1024 on the same index)")
     ap.add_argument("--sell-sigma", type=int, default=0, help="hrag_opts.sell_sigma (SELL-C-sigma sorting window; 0 = global)")
     ap.add_argument("--engine-flags", type=int, default=0, help="hrag_opts.flags (HRAG_OPT_*), e.g. 2048 = XCD_BLOCKED")
     ap.add_argument("--locality", default="none", choices=["auto", "on", "degree", "none"],
@@ -604,8 +624,17 @@ def main():
             marks[i - args.warmup + 1].record()
         torch.cuda.synchronize()
         per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+        from hipporag_amd._lib import PPR_ERR_FLOOR_F16, PPR_ERR_FLOOR_FP8, PPR_ERR_K
+        res_max = float(torch.stack(res).max())
+        floor = PPR_ERR_FLOOR_FP8 if B > 64 else PPR_ERR_FLOOR_F16
         contract = {"ppr_tol": tol, "ppr_max_iters": max(max_iters, PPR_ITERS) if tol > 0 else PPR_ITERS,
-                    "ppr_residual_max": float(torch.stack(res).max()),
+                    "ppr_residual_max": res_max,
+                    # does what this leg leaves meet the mirror's DEFAULT tolerance (--ppr-tol, 1.5e-6)?  The fixed-count
+                    # headline does not have to (BASELINE.json names a count, not a tolerance) -- this says what it costs
+                    "meets_default_tol": bool(res_max <= (args.ppr_tol if args.ppr_tol > 0 else 1.5e-6)),
+                    "default_tol": args.ppr_tol if args.ppr_tol > 0 else 1.5e-6,
+                    "error_bound_from_residual": max(PPR_ERR_K * res_max, floor),
+                    "error_bound_definition": "include/hrag.h: true relative error <= max(HRAG_PPR_ERR_K * residual, floor of the state type)",
                     "ppr_residual_definition": "damping / (1 - damping) * max over passages of the relative update of "
                                                "the passage score in the last sweep (include/hrag.h, hrag_retrieve)",
                     "sweeps_used_min": int(torch.stack(used).min()), "sweeps_used_max": int(torch.stack(used).max()),

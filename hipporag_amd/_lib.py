@@ -11,8 +11,11 @@ LIB_PATH = os.path.join(_HERE, "libhrag.so")
 
 HRAG_OK, HRAG_EINVAL, HRAG_ENOMEM, HRAG_EHIP, HRAG_EBUSY, HRAG_ECAPACITY = range(6)
 SEED_STRIDE = 32
-HRAG_VERSION = 5      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
+HRAG_VERSION = 6      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
 FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, FLAG_FP8_SATURATED, FLAG_NOT_CONVERGED = 1, 2, 4, 8, 16
+# the convergence contract's error bound (include/hrag.h): error <= max(PPR_ERR_K * residual, floor of the state type);
+# a tolerance below PPR_TOL_MIN is rejected (HRAG_EINVAL)
+PPR_ERR_K, PPR_ERR_FLOOR_FP8, PPR_ERR_FLOOR_F16, PPR_ERR_FLOOR_F32, PPR_TOL_MIN = 3.5, 5e-6, 2e-6, 5e-7, 1e-7
 # hrag_opts.flags (include/hrag.h HRAG_OPT_*)
 OPT_NATURAL_ROW_ORDER, OPT_NT_CSR, OPT_NT_STORE, OPT_F32_STATE, OPT_TEMPORAL16, OPT_NO_FP8 = 1, 2, 4, 8, 16, 32
 OPT_ROWS_BY_MINCOL, OPT_ROWS_BFS, OPT_SLABS_PER_WG_1, OPT_NO_F16, OPT_XCD_BLOCKED = 64, 128, 256, 1024, 2048

@@ -1076,6 +1076,10 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
                                  float *residual_out, int32_t *iters_out, hrag_stream stream) {
     HRAG_TRY(check_batch(e, batch));
     HRAG_REQUIRE(ppr_tol >= 0.f && ppr_tol == ppr_tol, "ppr_tol must be >= 0");
+    HRAG_REQUIRE(ppr_tol == 0.f || ppr_tol >= HRAG_PPR_TOL_MIN,
+                 "ppr_tol=%g is below HRAG_PPR_TOL_MIN=%g: fp32 arithmetic leaves an error floor of %g however small the "
+                 "measured residual reads (include/hrag.h: error <= max(%g * residual, floor))", (double)ppr_tol,
+                 (double)HRAG_PPR_TOL_MIN, (double)HRAG_PPR_ERR_FLOOR_F32, (double)HRAG_PPR_ERR_K);
     HRAG_REQUIRE(ppr_tol == 0.f || ppr_max_iters >= ppr_iters, "ppr_max_iters=%d < ppr_iters=%d", ppr_max_iters, ppr_iters);
     HRAG_REQUIRE((q_pass || pass_scores) && kept_idx && kept_score && kept_count && doc_idx_out && doc_score_out,
                  "NULL argument");

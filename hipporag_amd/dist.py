@@ -1,30 +1,30 @@
 """Multi-GPU modes of the retrieval hot path: one process per GPU, torch.distributed over RCCL
 (backend "nccl" on ROCm) / gloo in the CPU tests.  The reference has no distributed code at all
-(zero NCCL / MPI call sites); both modes are MI355X-native additions.
+(zero NCCL / MPI call sites; src/hipporag/HippoRAG.py:459 is a serial loop over the
+queries); all three modes are MI355X-native additions.
 
-replica   (default for throughput): queries are independent (the reference loop at
-          src/hipporag/HippoRAG.py:459 carries no cross-query state), every rank holds the whole
-          index (cfg 3/4: 1.5 GB embeddings + 0.16 GB CSR of 288 GB HBM) and serves its own slice
-          of the batch with the single-GPU engine.  No data-path collective.
+rowshard  (the layout BASELINE.json's north star names; `value` of `bench.py --gpus N` when parity-green):
+          the corpus is sharded row-wise -- rank g owns the CSR rows, the passage and the fact embedding rows of ITS
+          equal-sized shard of a relabelled index (shard_index) -- and the e4m3 PPR iterate is replicated.
+            * phase A : all-gather of each rank's local top-k fact candidates + MIN / MAX all-reduce (2 * B floats);
+            * phase B : MIN / MAX all-reduce of the passage scores, MAX / SUM of the prior statistics; then per PPR
+                        sweep every rank computes ITS rows of the new iterate and the owners' blocks are exchanged over
+                        xGMI, one collective per exchange group, overlapped with the sweep of the other group(s).
+                        TorchComm(collective="allgather") -- in-place all_gather_into_tensor of the owned blocks, 1 byte
+                        per vertex and query -- or "allreduce": the north star's literal form (every rank zeroes the
+                        rows it does not own, all-reduce SUM over the bytes: disjoint supports, so the sum IS the
+                        gather; twice the wire bytes, kept for comparison);
+            * final   : all-gather + merge of the local top-k lists.
+          Every output row is produced by exactly one rank from the same replicated iterate: bit-identical to the
+          single-GPU engine whatever the world size (tests/test_gpu_shard.py).
+hybrid    embeddings row-sharded, ONE all-to-all of passage-score rows, PPR query-parallel on a replicated graph
+          (HybridRetriever): 300x fewer wire bytes than the row-sharded PPR.
+replica   queries are independent (the reference loop carries no cross-query state), every rank holds the whole
+          index and serves its own slice of the batch with the single-GPU engine.  No data-path collective.
 
-rowshard  (the layout BASELINE.json's north star names): the corpus is sharded row-wise --
-          rank g owns CSR rows [r_g, r_{g+1}) (balanced by nnz), a contiguous slice of the fact
-          and of the passage embedding rows -- and the PPR vector x is replicated.  Exchange steps:
-            * phase A : all-gather of each rank's local top-k fact candidates + all-reduce of the
-                        per-query min / max (2 * B floats);
-            * phase B : all-gather of the raw passage scores [B, Np/N] -> [B, Np]; then per PPR
-                        sweep every rank computes its rows of y = alpha P x + (1-alpha) v and the
-                        new x is re-assembled over xGMI.  Assembling "sum of zero-padded slices"
-                        is an all-reduce (north star wording); since the slices are disjoint the
-                        same result is obtained with 1/2 the wire bytes by an all-gather, realised
-                        as one in-place broadcast per owner so that row shards may be uneven
-                        (collective="allreduce" keeps the literal form for comparison);
-            * final   : all-reduce of the per-query column sums (B doubles).
-          Every output row of y is produced by exactly one rank from the same replicated x, so the
-          result is bit-identical to the single-GPU engine whatever the world size.
-
-The compute itself is behind a small "stages" interface (hipporag_amd.engine.EngineStages = the
-hrag_stage_* C entry points); tests drive the same orchestration with a CPU stand-in over gloo.
+The compute of a rank is behind a small "stages" interface (hipporag_amd.engine.ShardStages = the hrag_shard_* C
+entry points); tests drive the same orchestration with a CPU stand-in over gloo (tests/test_shard_orchestration.py,
+tests/test_dist_gloo.py).
 """
 
 from __future__ import annotations
@@ -45,19 +45,6 @@ def _td():
     return torch, dist
 
 
-def balanced_row_shards(row_ptr: np.ndarray, world: int) -> List[Tuple[int, int]]:
-    """Contiguous row ranges with ~equal nnz (+ ~equal rows as the tie breaker)."""
-    n_rows = len(row_ptr) - 1
-    cost = np.asarray(row_ptr[1:], dtype=np.int64) + np.arange(1, n_rows + 1, dtype=np.int64)
-    total = int(cost[-1]) if n_rows else 0
-    bounds = [0]
-    for g in range(1, world):
-        bounds.append(int(np.searchsorted(cost, total * g / world, side="left")))
-    bounds.append(n_rows)
-    bounds = np.maximum.accumulate(np.array(bounds))
-    return [(int(bounds[g]), int(bounds[g + 1])) for g in range(world)]
-
-
 def even_shards(n: int, world: int) -> List[Tuple[int, int]]:
     base, rem = divmod(n, world)
     out, lo = [], 0
@@ -66,137 +53,6 @@ def even_shards(n: int, world: int) -> List[Tuple[int, int]]:
         out.append((lo, hi))
         lo = hi
     return out
-
-
-@dataclass
-class ShardPlan:
-    rows: List[Tuple[int, int]]
-    passages: List[Tuple[int, int]]
-    facts: List[Tuple[int, int]]
-
-
-class RowShardedRetriever:
-    """Orchestrates the row-sharded path on top of a per-rank stages object."""
-
-    def __init__(self, stages, plan: ShardPlan, rank: int, world: int, group=None,
-                 collective: str = "allgather"):
-        self.st, self.plan, self.rank, self.world, self.group = stages, plan, rank, world, group
-        if collective not in ("allgather", "allreduce"):
-            raise ValueError(collective)
-        self.collective = collective
-        self.comm_s = 0.0
-
-    # ---- exchange helpers ------------------------------------------------------------------
-    def _all_gather_cols(self, local, shards: Sequence[Tuple[int, int]]):
-        """[B, n_local] per rank -> [B, n_total] (shards may differ by one column: pad)."""
-        torch, dist = _td()
-        if self.world == 1:
-            return local
-        b = local.shape[0]
-        width = max(hi - lo for lo, hi in shards)
-        send = local.new_zeros((b, width))
-        send[:, : local.shape[1]] = local
-        recv = [torch.empty_like(send) for _ in range(self.world)]
-        dist.all_gather(recv, send, group=self.group)
-        return torch.cat([recv[g][:, : shards[g][1] - shards[g][0]] for g in range(self.world)], dim=1).contiguous()
-
-    def _assemble_x(self, x):
-        """Make every rank's owned rows of x visible everywhere (x: [n_slabs, V, bc])."""
-        torch, dist = _td()
-        if self.world == 1:
-            return
-        if self.collective == "allreduce":
-            lo, hi = self.plan.rows[self.rank]
-            x[:, :lo, :].zero_()
-            x[:, hi:, :].zero_()
-            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
-            return
-        for g, (lo, hi) in enumerate(self.plan.rows):
-            if hi == lo:
-                continue
-            for s in range(x.shape[0]):
-                dist.broadcast(x[s, lo:hi, :], src=self._global_rank(g), group=self.group)
-
-    def _global_rank(self, g: int) -> int:
-        torch, dist = _td()
-        return g if self.group is None else dist.get_global_rank(self.group, g)
-
-    # ---- phase A ---------------------------------------------------------------------------
-    def score_facts(self, q_fact, k: int = 5):
-        """Global (fact ids int32 [B, k], min-max normalised scores fp32 [B, k]), replicated."""
-        torch, dist = _td()
-        st = self.st
-        f_lo, f_hi = self.plan.facts[self.rank]
-        s_local = st.sim_scores("facts", q_fact)
-        idx, val, mn, mx = st.topk(s_local, k, idx_offset=f_lo)
-        b = idx.shape[0]
-        if self.world > 1:
-            idx_all = [torch.empty_like(idx) for _ in range(self.world)]
-            val_all = [torch.empty_like(val) for _ in range(self.world)]
-            dist.all_gather(idx_all, idx, group=self.group)
-            dist.all_gather(val_all, val, group=self.group)
-            dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self.group)
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
-        else:
-            idx_all, val_all = [idx], [val]
-        # Each list is sorted (score desc, id desc).  Reversed and concatenated in rank order,
-        # "later position" == "larger (score, id)" among equal scores, so the library's positional
-        # tie rule reproduces the global (score desc, id desc) order exactly.
-        cand_idx = torch.cat([t.flip(1) for t in idx_all], dim=1).contiguous()
-        cand_val = torch.cat([t.flip(1) for t in val_all], dim=1)
-        cand_val = torch.where(cand_idx < 0, torch.full_like(cand_val, float("-inf")), cand_val).contiguous()
-        pos, top_val, _, _ = st.topk(cand_val, k)
-        top_idx = torch.gather(cand_idx, 1, pos.clamp(min=0).long())
-        top_idx = torch.where(pos < 0, torch.full_like(top_idx, -1), top_idx).to(torch.int32)
-        rng = (mx - mn).unsqueeze(1)
-        norm = torch.where(rng == 0, torch.ones_like(top_val), (top_val - mn.unsqueeze(1)) / rng)
-        norm = torch.where(top_idx < 0, torch.zeros_like(norm), norm)
-        return top_idx, norm
-
-    # ---- phase B ---------------------------------------------------------------------------
-    def retrieve(self, q_pass, kept_idx, kept_score, kept_count, *, link_top_k=5, damping=0.5,
-                 passage_node_weight=0.05, ppr_iters=20, k=200):
-        torch, dist = _td()
-        st = self.st
-        b = q_pass.shape[0]
-        s_local = st.sim_scores("passages", q_pass)
-        t0 = time.perf_counter()
-        s_full = self._all_gather_cols(s_local, self.plan.passages)
-        self.comm_s += time.perf_counter() - t0
-        mn, mx = st.row_minmax(s_full)
-        sv, sw, sc, flags = st.seeds(kept_idx, kept_score, kept_count, link_top_k)
-        tele = st.teleport(s_full, mn, mx, passage_node_weight, flags)
-        seeds = (sv, sw, sc)
-        x, y = st.new_state(b), st.new_state(b)
-        st.ppr_init(tele, seeds, b, x)
-        self._assemble_x(x)
-        for _ in range(ppr_iters):
-            st.ppr_step(tele, seeds, b, damping, x, y)
-            self._assemble_x(y)
-            x, y = y, x
-        sums = st.colsum(x, b)
-        if self.world > 1:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
-        doc = st.doc_scores(x, sums, b, s_full, mn, mx, flags)
-        doc_idx, doc_val, _, _ = st.topk(doc, k)
-        return doc_idx, doc_val, flags
-
-
-def build_sharded_engine(kg, pass_emb, fact_emb, rank: int, world: int, max_batch: int, max_topk: int,
-                         slab_width: int = 0):
-    """fp32-state row shard (hrag_stage_* operators): the index is sliced in its given vertex order
-    (embeddings: torch bf16 on device or numpy bf16 bits; full matrices are sliced here)."""
-    from .engine import EngineStages, HippoRAGEngine
-    plan = ShardPlan(balanced_row_shards(kg.csr.row_ptr, world), even_shards(kg.n_passages, world),
-                     even_shards(kg.n_facts, world))
-    r_lo, r_hi = plan.rows[rank]
-    p_lo, p_hi = plan.passages[rank]
-    f_lo, f_hi = plan.facts[rank]
-    eng = HippoRAGEngine(kg.csr.rows(r_lo, r_hi), kg.passage_vertex, pass_emb[p_lo:p_hi], fact_emb[f_lo:f_hi],
-                         kg.subj_vertex, kg.obj_vertex, kg.num_chunks, max_batch=max_batch, max_topk=max_topk,
-                         slab_width=slab_width, row_offset=r_lo, passage_offset=p_lo, fact_offset=f_lo,
-                         n_passages=kg.n_passages, n_facts=kg.n_facts)
-    return eng, EngineStages(eng), plan
 
 
 # --------------------------------------------------------------------------------------------
@@ -307,11 +163,16 @@ def build_shard_engine(sidx: ShardedIndex, pass_emb, fact_emb, rank: int, max_ba
 
 class TorchComm:
     """The exchange steps of the row-sharded path over torch.distributed (nccl = RCCL over xGMI; gloo in
-    the CPU tests).  State exchange = ONE in-place all-gather per exchange group: the owned rows of a group
-    are one contiguous block at rank * own_bytes."""
+    the CPU tests).  State exchange = ONE in-place collective per exchange group: the owned rows of a group
+    are one contiguous block at rank * own_bytes.  collective="allgather" (default): all_gather_into_tensor of the
+    owned blocks; "allreduce": BASELINE.json's literal wording -- every rank zeroes the blocks it does not own and
+    the group region is all-reduced (SUM over uint8: the supports are disjoint, so no byte ever adds to another
+    and the sum is the gather, bit for bit) -- twice the wire bytes of the all-gather, kept for comparison."""
 
-    def __init__(self, rank: int, world: int, group=None):
-        self.rank, self.world, self.group = rank, world, group
+    def __init__(self, rank: int, world: int, group=None, collective: str = "allgather"):
+        if collective not in ("allgather", "allreduce"):
+            raise ValueError(f"collective must be 'allgather' or 'allreduce', not {collective!r}")
+        self.rank, self.world, self.group, self.collective = rank, world, group, collective
 
     def all_reduce(self, t, op: str):
         torch, dist = _td()
@@ -367,6 +228,10 @@ class TorchComm:
             raise ValueError("state exchange would overwrite the zero row: shards do not tile [0, V)")
         base = g * lay.group_bytes
         out = buf[base: base + self.world * lay.own_bytes]
+        if self.collective == "allreduce":
+            out[: lay.own_offset].zero_()
+            out[lay.own_offset + lay.own_bytes:].zero_()
+            return dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         inp = buf[base + lay.own_offset: base + lay.own_offset + lay.own_bytes]
         return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
 
@@ -720,18 +585,54 @@ def run_local_hybrid(world: int, kg_arrays: dict, sidx: "ShardedIndex", pass_emb
 # bench.py --gpus N (N > 1)
 # --------------------------------------------------------------------------------------------
 def pick_value_leg(mode: str, hybrid, rowshard) -> str:
-    """Which leg of an N > 1 run becomes `value`: a leg counts only when it produced a rate AND its parity check
-    against the single-GPU engine is green.  auto: the corpus-sharded legs first (hybrid, then rowshard) -- the
-    replica leg shards nothing and is the fallback, never the preference."""
+    """Which leg of an N > 1 run becomes `value`: a leg counts only when it produced a rate AND its parity checks
+    (bit / tolerance identity with the single-GPU engine on every rank; the fp64 oracle on rank 0) are green.
+    auto: the ROW-SHARDED leg first -- the layout BASELINE.json's north star names and SURVEY.md 8(e) makes the primary
+    figure -- then the hybrid leg (the better engineering: no per-sweep collective; always printed beside it as
+    `value_hybrid`), the replica leg (which shards nothing) only when neither is green."""
     def green(leg):
         return isinstance(leg, dict) and "value" in leg and bool(leg.get("parity", {}).get("ok"))
-    if mode == "replica":
-        return "replica"
-    if mode in ("hybrid", "auto") and green(hybrid):
-        return "hybrid"
     if mode in ("rowshard", "auto") and green(rowshard):
         return "rowshard"
-    return "replica"
+    if mode in ("hybrid", "auto") and green(hybrid):
+        return "hybrid"
+    return "replica"            # mode "replica", or no green leg of the kind that was asked for
+
+
+class OracleProbe:
+    """The fp64 CPU oracle beside the N > 1 legs (rank 0 only; round-4 review: the legs were only ever compared with the
+    single-GPU engine).  Built lazily -- host fp32 copies of the embeddings + the column-normalised matrix -- and shared
+    by the legs; check() compares a leg's ranked ids / scores for a few queries of the global batch."""
+
+    def __init__(self, kg, fact_emb, pass_emb):
+        self.kg, self.fact_emb, self.pass_emb, self.index = kg, fact_emb, pass_emb, None
+
+    def _build(self):
+        import oracle
+        kg = self.kg
+        a = oracle.build_symmetric_csr(kg.num_vertices, kg.src, kg.dst, kg.weight)
+        self.index = oracle.RefIndex(fact_emb=self.fact_emb.float().cpu().numpy(), passage_emb=self.pass_emb.float().cpu().numpy(),
+                                     subj_vertex=kg.subj_vertex, obj_vertex=kg.obj_vertex, num_chunks=kg.num_chunks,
+                                     passage_vertex=kg.passage_vertex, p=oracle.column_normalize(a))
+
+    def check(self, qf, qp, doc_idx, doc_score, rows):
+        """qf / qp: query tensors of the batch; doc_idx / doc_score: the leg's result rows for the same batch positions;
+        rows: the positions to check.  Returns the parity record."""
+        import oracle
+        from tests.helpers import ranked_parity
+        if self.index is None:
+            self._build()
+        qf_h, qp_h = qf.float().cpu().numpy(), qp.float().cpu().numpy()
+        ids, sc = doc_idx.cpu().numpy(), doc_score.cpu().numpy()
+        ok, worst, exact, n = True, 0.0, 0, 0
+        for q in rows:
+            ref = oracle.retrieve_one(self.index, qf_h[q], qp_h[q])
+            rep = ranked_parity(ids[q], sc[q], ref.sorted_doc_ids, ref.sorted_doc_scores, ref.x[self.kg.passage_vertex])
+            ok = ok and rep["equal"] and rep["worst_rel_err"] < 1e-5
+            worst = max(worst, rep["worst_rel_err"])
+            exact += rep["exact_positions"]; n += rep["n"]
+        return {"against": "fp64 CPU oracle (oracle.retrieve_one), rank 0", "queries": [int(q) for q in rows],
+                "topk_ids_equal": bool(ok), "exact_id_fraction": exact / max(n, 1), "max_rel_score_err": worst, "ok": bool(ok)}
 
 
 def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_fn=None) -> int:
@@ -846,21 +747,33 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
         "replica": {"value": replica_qps, "unit": "queries/s", "ms_per_step": replica_s * 1e3 / max(args.steps, 1),
                     "parallelism": f"replica x{world}: every GPU holds the whole index and serves its own {B} queries"},
         "rowshard": None, "hybrid": None,
-        "multi_gpu_note": "`value` = the best parity-green corpus-sharded leg (hybrid, else rowshard; `value_leg` names "
-                          "it); all three legs are printed whenever N > 1.  No multi-GPU box was available to the "
-                          "rounds that wrote this code: every N > 1 figure is the driver's to take",
+        "value_rowshard": None, "value_hybrid": None, "value_replica": replica_qps,
+        "multi_gpu_note": "`value` = the ROW-SHARDED leg when it is parity-green (`value_leg` names the leg): CSR rows + "
+                          "embeddings sharded over the GPUs, one collective on the e4m3 PPR iterate per sweep -- the layout "
+                          "BASELINE.json's north star names (SURVEY.md 8(e): the primary figure).  `value_hybrid` "
+                          "(embeddings sharded, PPR query-parallel, no per-sweep collective: the faster design) and "
+                          "`value_replica` (nothing sharded) are always printed beside it; a weak-scaling run on "
+                          "configs[2] also carries `configs3_strong` = BASELINE configs[3]'s global batch of 1024 on the "
+                          "same index.  No multi-GPU box was available to the rounds that wrote this code: every "
+                          "N > 1 figure is the driver's to take",
     }
 
-    # The row-sharded leg (the layout BASELINE.json's north star names) must never cost the line: a
-    # watchdog prints what has been measured (rank 0) and ends the process if the leg or the teardown stalls.
+    # The sharded legs must never cost the line: a watchdog prints what has been measured (rank 0) and ends the
+    # process if a leg or the teardown stalls.
     import threading
     printed = threading.Event()
+    hybrid_box, strong_box = {}, {}
 
     def emit(rowshard):
         if rank == 0 and not printed.is_set():
             printed.set()
             result["rowshard"] = rowshard
             result["hybrid"] = hybrid_box.get("res")
+            for name in ("rowshard", "hybrid"):
+                leg = result[name]
+                result["value_" + name] = leg.get("value") if isinstance(leg, dict) else None
+            if strong_box:
+                result["configs3_strong"] = strong_box
             pick = pick_value_leg(getattr(args, "mode", "auto"), hybrid_box.get("res"), rowshard)
             if pick != "replica":
                 # primary number = a leg that shards the CORPUS; the replica figure stays beside it
@@ -887,7 +800,6 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
 
     limit = float(getattr(args, "rowshard_timeout_s", 240.0))
     rowshard = None
-    hybrid_box = {}
     if getattr(args, "no_rowshard", False) or limit <= 0:
         rowshard = {"skipped": True}
     else:
@@ -900,16 +812,56 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
         except Exception as exc:
             rowshard = {"error": f"shard engine: {type(exc).__name__}: {exc}"}
         if seng is not None:
+            probe = OracleProbe(kg, fact_emb, pass_emb) if rank == 0 and not getattr(args, "no_cpu_baseline", False) else None
+            ctx = dict(args=args, kg=kg, sidx=sidx, seng=seng, pass_emb=pass_emb, fact_emb=fact_emb, rank=rank, world=world,
+                       K_F=K_F, K_P=K_P, ITERS=ITERS, DAMP=DAMP, PW=PW, seed=seed, dev=dev, barrier_sync=barrier_sync,
+                       max_over_ranks=max_over_ranks, replica_eng=eng, probe=probe)
             try:    # embeddings row-sharded, PPR query-parallel (no exchange in the PPR)
-                hybrid_box["res"] = _hybrid_leg(args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS,
-                                                DAMP, PW, seed, dev, barrier_sync, max_over_ranks, eng)
+                hybrid_box["res"] = _hybrid_leg(B=B, **ctx)
             except Exception as exc:
                 hybrid_box["res"] = {"error": f"{type(exc).__name__}: {exc}"}
             try:
-                rowshard = _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW,
-                                         seed, V, dev, barrier_sync, max_over_ranks, eng, sidx=sidx, seng=seng)
+                rowshard = _rowshard_leg(B=B, **ctx)
             except Exception as exc:  # the replica measurement above stays valid; report instead of dying
                 rowshard = {"error": f"{type(exc).__name__}: {exc}"}
+            # BASELINE configs[3] in the same line: a weak-scaling run on configs[2] (per-GPU batch 256) also measures the
+            # STRONG figure -- the same index, global batch 1024 whatever N is -- so that one driver command yields both
+            gb3 = int(os.environ.get("HRAG_STRONG_GLOBAL_BATCH", "1024"))     # env: exercise the code on one GPU (world 1)
+            if (not strong and not args.batch and (world > 1 or "HRAG_STRONG_GLOBAL_BATCH" in os.environ)
+                    and args.config == "cfg3" and gb3 % world == 0 and gb3 // world <= B
+                    and not getattr(args, "no_strong", False)):
+                b3 = gb3 // world
+                strong_box.update({"workload": "configs[3]: the same 1M-node/10M-edge index sharded across the GPUs of one node, "
+                                               f"GLOBAL batch {gb3} ({b3} per GPU): strong scaling", "global_batch": gb3,
+                                   "per_gpu_batch": b3})
+                for name, fn in (("rowshard", _rowshard_leg), ("hybrid", _hybrid_leg)):
+                    try:
+                        strong_box[name] = fn(B=b3, **dict(ctx, probe=None, seed=seed + 50000))
+                    except Exception as exc:
+                        strong_box[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                    strong_box["value_" + name] = strong_box[name].get("value")
+                try:
+                    sq = [synth.make_queries_torch(fact_emb, b3, seed + 61000 + i + 1000 * rank)[0] for i in range(2 + args.steps)]
+                    sp = [synth.make_queries_torch(pass_emb, b3, seed + 62000 + i + 1000 * rank)[0] for i in range(2 + args.steps)]
+
+                    def step3(i):
+                        i3, s3 = eng.score_facts(sq[i], k=K_F)
+                        return eng.retrieve(sp[i], i3, s3, cnt[:b3], link_top_k=K_F, damping=DAMP, passage_node_weight=PW,
+                                            ppr_iters=ITERS, k=K_P)
+                    step3(0); step3(1)
+                    barrier_sync()
+                    t3 = time.perf_counter()
+                    for i in range(2, 2 + args.steps):
+                        step3(i)
+                    barrier_sync()
+                    s3 = max_over_ranks(time.perf_counter() - t3)
+                    strong_box["value_replica"] = gb3 * args.steps / s3
+                except Exception as exc:
+                    strong_box["value_replica"] = None
+                    strong_box["replica_error"] = f"{type(exc).__name__}: {exc}"
+                pick3 = pick_value_leg(getattr(args, "mode", "auto"), strong_box.get("hybrid"), strong_box.get("rowshard"))
+                strong_box["value_leg"] = pick3
+                strong_box["value"] = strong_box.get("value_" + pick3)
             seng.close()
         leg_done.set()
     eng.close()
@@ -921,11 +873,12 @@ def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_f
     return 0
 
 
-def _hybrid_leg(args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW, seed, dev,
-                barrier_sync, max_over_ranks, replica_eng):
+def _hybrid_leg(*, args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW, seed, dev,
+                barrier_sync, max_over_ranks, replica_eng, probe=None):
     """The global batch (world * B) in the hybrid mode: every rank scores all queries against ITS embedding rows, one
     all-to-all hands it the passage-score rows of its B queries, the PPR runs on the rank's own (replicated-graph)
-    engine without any exchange.  Checked bit for bit against the single-GPU engine on the rank's queries."""
+    engine without any exchange.  Checked bit for bit against the single-GPU engine on the rank's queries (every rank)
+    and, with `probe`, against the fp64 oracle on 4 of rank 0's queries."""
     torch, dist = _td()
     from . import synth
     from .engine import ShardStages
@@ -958,6 +911,13 @@ def _hybrid_leg(args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K_F, K
                 torch.equal(idx[mine], i1) and torch.equal(sc[mine], s1))
     ok = torch.tensor([1 if same else 0], device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    parity = {"against": "single-GPU engine on this rank's queries, every rank", "bit_identical_on_every_rank": bool(ok.item() == 1),
+              "ok": bool(ok.item() == 1)}
+    if probe is not None:       # rank 0's slice of the last global batch starts at row 0
+        rows = sorted({0, B // 3, (2 * B) // 3, B - 1})
+        parity["vs_oracle"] = probe.check(gqf[n - 1][mine], gqp[n - 1][mine], out.doc_idx, out.doc_score, rows)
+        parity["ok"] = bool(parity["ok"] and parity["vs_oracle"]["ok"])
+    barrier_sync()               # the other ranks wait for rank 0's oracle queries here, not inside a later collective
     np_total = len(sidx.passage_vertex)
     return {"value": gb * steps / sec, "unit": "queries/s", "global_batch": gb, "steps": steps,
             "ms_per_step": sec * 1e3 / steps,
@@ -965,25 +925,21 @@ def _hybrid_leg(args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K_F, K
                            f"PPR query-parallel on a replicated graph (no exchange)",
             "wire_bytes_per_global_batch_total": int((world - 1) / world * gb * np_total * 4 + world * (world - 1) * gb * K_F * 8),
             "wire_bytes_received_per_gpu_per_global_batch": int((world - 1) / world * B * np_total * 4 + (world - 1) * gb * K_F * 8),
-            "parity": {"against": "single-GPU engine on this rank's queries, every rank", "bit_identical_on_every_rank": bool(ok.item() == 1),
-                       "ok": bool(ok.item() == 1)}}
+            "parity": parity}
 
 
-def _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW, seed, V, dev,
-                  barrier_sync, max_over_ranks, replica_eng, sidx=None, seng=None):
-    """The global batch (world * B) over the row-sharded corpus: fp8-state shards, one all-gather per
-    exchange group and sweep; checked against the single-GPU engine on the same queries."""
+def _rowshard_leg(*, args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW, seed, dev,
+                  barrier_sync, max_over_ranks, replica_eng, probe=None):
+    """The global batch (world * B) over the row-sharded corpus: fp8-state shards, one collective per exchange group and
+    sweep (--collective allgather | allreduce); checked against the single-GPU engine on the same queries and, with
+    `probe`, against the fp64 oracle on 4 queries of the global batch (rank 0)."""
     torch, dist = _td()
     from . import synth
     from .engine import ShardStages
     gb = world * B
     groups = int(getattr(args, "exchange_groups", 2))
-    own_engine = seng is None
-    if sidx is None:
-        sidx = shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
-    if seng is None:
-        seng = build_shard_engine(sidx, pass_emb, fact_emb, rank, gb, K_P)
-    rs = ShardedRetriever(ShardStages(seng), TorchComm(rank, world), groups=groups)
+    collective = getattr(args, "collective", "allgather")
+    rs = ShardedRetriever(ShardStages(seng), TorchComm(rank, world, collective=collective), groups=groups)
     rs_steps, rs_warm = max(1, args.steps), max(1, min(args.warmup, 2))
     n = rs_steps + rs_warm
     gqf = [synth.make_queries_torch(fact_emb, gb, seed + 9000 + i)[0] for i in range(n)]
@@ -1017,19 +973,25 @@ def _rowshard_leg(args, kg, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS,
     parity = {"against": "single-GPU engine, same queries (first per-GPU batch of the last global batch)",
               "queries": int(B), "fraction_of_ranked_ids_equal": same_ids, "max_rel_score_diff": float(rel.max()),
               "flags_or": flags_any, "ok": bool(rel.max() < 1e-5 and same_ids > 0.999 and not (flags_any & 8))}
+    if probe is not None:       # queries spread over the WHOLE global batch (every rank's rows of the merged result)
+        rows = sorted({0, gb // 3, (2 * gb) // 3, gb - 1})
+        parity["vs_oracle"] = probe.check(gqf[n - 1], gqp[n - 1], out[0], out[1], rows)
+        parity["ok"] = bool(parity["ok"] and parity["vs_oracle"]["ok"])
+    barrier_sync()
     lay = seng.shard_layout(gb, groups)
     wire = (world - 1) / world * sidx.num_vertices * 128 * lay.n_slabs     # e4m3 bytes each GPU receives per sweep
+    if collective == "allreduce":
+        wire *= 2                                                          # ring all-reduce: reduce-scatter + all-gather
     nnz_own = int(sidx.csr.row_ptr[(rank + 1) * sidx.rows_per_shard] - sidx.csr.row_ptr[rank * sidx.rows_per_shard])
-    res = {"value": gb * rs_steps / rs_s, "unit": "queries/s", "global_batch": gb, "steps": rs_steps,
-           "ms_per_step": rs_s * 1e3 / rs_steps,
-           "parallelism": f"rowshard x{world}: CSR rows + passage / fact embeddings sharded, e4m3 PPR iterate "
-                          f"replicated, one all-gather per exchange group and sweep",
-           "exchange": "in-place all_gather_into_tensor of the owners' row blocks (RCCL), "
-                       f"{lay.n_groups} exchange group(s) pipelined against the sweeps of the other group(s)",
-           "wire_bytes_received_per_gpu_per_sweep": wire, "state_bytes_per_buffer": int(lay.state_bytes),
-           "n_slabs": int(lay.n_slabs), "exchange_groups": int(lay.n_groups),
-           "wire_bytes_received_per_gpu_per_global_batch": wire * ITERS,
-           "rows_per_shard": int(sidx.rows_per_shard), "nnz_this_shard": nnz_own, "parity": parity}
-    if own_engine:
-        seng.close()
-    return res
+    return {"value": gb * rs_steps / rs_s, "unit": "queries/s", "global_batch": gb, "steps": rs_steps,
+            "ms_per_step": rs_s * 1e3 / rs_steps,
+            "parallelism": f"rowshard x{world}: CSR rows + passage / fact embeddings sharded, e4m3 PPR iterate "
+                           f"replicated, one {collective} per exchange group and sweep",
+            "exchange": ("in-place all_gather_into_tensor of the owners' row blocks (RCCL)" if collective == "allgather" else
+                         "all-reduce SUM over the group region with the foreign blocks zeroed (the north star's literal form)")
+                        + f", {lay.n_groups} exchange group(s) pipelined against the sweeps of the other group(s)",
+            "collective": collective,
+            "wire_bytes_received_per_gpu_per_sweep": wire, "state_bytes_per_buffer": int(lay.state_bytes),
+            "n_slabs": int(lay.n_slabs), "exchange_groups": int(lay.n_groups),
+            "wire_bytes_received_per_gpu_per_global_batch": wire * ITERS,
+            "rows_per_shard": int(sidx.rows_per_shard), "nnz_this_shard": nnz_own, "parity": parity}

@@ -230,6 +230,7 @@ class HippoRAGEngine:
         self._handle = C.c_void_p(0)
 
         pv = np.ascontiguousarray(passage_vertex, dtype=np.int32)
+        caller_graph = graph            # what the lazy undirected-graph test looks at (a relabelling changes nothing for it)
         self._perm = self._inv_perm = None
         self.locality_score = self.numbering = None
         if locality:
@@ -320,9 +321,9 @@ class HippoRAGEngine:
         import weakref
         self._undirected = None if (row_offset == 0 and n_rows == graph.num_vertices) else False
         try:
-            self._graph_ref = weakref.ref(graph)
+            self._graph_ref = weakref.ref(caller_graph)
         except TypeError:
-            self._graph_ref = lambda g=graph: g
+            self._graph_ref = lambda g=caller_graph: g
         if (flags & _lib.OPT_ACCEL) and not self._is_undirected():
             logger.warning("HRAG_OPT_ACCEL dropped: the graph does not look undirected (or has no col_sum / is a row shard)")
             flags &= ~_lib.OPT_ACCEL
@@ -849,15 +850,15 @@ def fp8_stage_plan(iters: int, damping: float = 0.5):
     """Python mirror of ppr8_plan (csrc/shard.hip): the stage lengths of the plain staged-fp8 PPR for `iters` sweeps.
     bench.py prices its per-instantiation launch times with it and tools/exp_fp8_final.py emulates it; the library
     never calls this.  iters < 19 or damping < 0.46: 1, 2, 3-sweep stages, remainder last; otherwise 1, 2, 3, 3-sweep
-    stages, as many 4-sweep stages as fit, a 3-sweep stage last (20 = 1+2+3+3+4+4+3)."""
+    stages, as many 4-sweep stages as fit, a 2-sweep stage last (20 = 1+2+3+4+4+4+2: five boundaries instead of six)."""
     if iters < 19 or not damping >= 0.46:
         left = iters - 3
         return [1, 2] + [3] * (left // 3) + ([left % 3] if left % 3 else [])
-    t = iters - 9
+    t = iters - 8
     a = t // 4
     while a > 0 and (t - 4 * a) % 3:
         a -= 1
-    return [1, 2, 3] + [3] * ((t - 4 * a) // 3) + [4] * a + [3]
+    return [1, 2, 3] + [3] * ((t - 4 * a) // 3) + [4] * a + [2]
 
 
 class ShardStages(EngineStages):

@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hrag_version() == _lib.HRAG_VERSION == 5            # 0 * 1000 + 5 (HRAG_OPT_ACCEL, hrag_shard_ppr_gate, stream-ordered calls)
+    assert lib.hrag_version() == _lib.HRAG_VERSION == 6            # 0 * 1000 + 6 (error bound constants, HRAG_PPR_TOL_MIN, round-5 stage plan)
 
 
 def test_ctypes_structs_match_the_header_layout(tmp_path):

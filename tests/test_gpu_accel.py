@@ -10,6 +10,7 @@ import pytest
 
 import oracle
 from hipporag_amd import synth
+from hipporag_amd._lib import PPR_ERR_FLOOR_F16, PPR_ERR_FLOOR_FP8, PPR_ERR_K, PPR_TOL_MIN
 from hipporag_amd.graph import bf16_bits_to_float
 from tests.helpers import prior_noise_allowance, write_test_report
 
@@ -84,6 +85,10 @@ def test_sixteen_accelerated_sweeps_stand_for_twenty_plain_ones(gpu_device, b, p
             worst[key] = max(worst[key], e)
             if key == "contract":
                 under = max(under, e / max(float(con_res[q]), 1e-30))
+                # the bound include/hrag.h states for a met tolerance, query by query
+                assert e <= max(PPR_ERR_K * float(con_res[q]), PPR_ERR_FLOOR_FP8), (q, e, float(con_res[q]))
+            else:       # a fixed count reports what it leaves: the same inequality holds for the reported residual
+                assert e <= max(PPR_ERR_K * float(got[key][2][q]), PPR_ERR_FLOOR_FP8), (key, q, e, float(got[key][2][q]))
     write_test_report(f"accel_small_graph_b{b}", {"worst_rel_err_plain20": worst[False], "worst_rel_err_accel16": worst[True],
                                                    "worst_rel_err_accel_contract": worst["contract"],
                                                    "sweeps_contract_min_max": [int(con_used.min()), int(con_used.max())],
@@ -173,6 +178,7 @@ def test_accelerated_fp16_states_fourteen_sweeps_stand_for_twenty(gpu_device, b)
             worst[acc] = max(worst[acc], e)
             if acc is True:
                 under = max(under, e / max(float(res[q]), 1e-30))
+            assert e <= max(PPR_ERR_K * float(res[q]), PPR_ERR_FLOOR_F16), (acc, q, e, float(res[q]))   # include/hrag.h's bound
     write_test_report(f"accel_fp16_state_b{b}", {"worst_rel_err_plain20": worst[False], "worst_rel_err_accel14": worst[True],
                                                   "worst_rel_err_accel_contract": worst["contract"], "sweeps_accel_contract": tol_used,
                                                   "residual_max_plain20": float(got[False][2].max()),
@@ -185,3 +191,26 @@ def test_accelerated_fp16_states_fourteen_sweeps_stand_for_twenty(gpu_device, b)
     # an accelerated first stage leaves puts a floor of 3e-6 .. 1e-5 under the measured residual): 20 sweeps, nothing flagged
     assert tol_used == 20 and con_res <= 1.5e-6 and np.all(con_flags == 0), (tol_used, con_res)
     assert worst["contract"] < 1e-5 / 1.5, worst
+
+
+def test_a_tolerance_below_the_arithmetic_floor_is_rejected(gpu_device):
+    """include/hrag.h: error <= max(HRAG_PPR_ERR_K * residual, floor) -- a ppr_tol below HRAG_PPR_TOL_MIN promises nothing
+    fp32 arithmetic can deliver (the measure of a converged iterate reads 1e-8 next to a true error of 2e-7), so
+    hrag_retrieve and the shard entry point refuse it instead of letting a caller believe it; 0 (fixed count) and
+    HRAG_PPR_TOL_MIN itself are accepted."""
+    import torch
+    from hipporag_amd._lib import HragError
+    from hipporag_amd.engine import HippoRAGEngine
+    from tests.test_gpu_fp8_adversarial import _small_engine_inputs
+    for b in (8, 40, 130):
+        kg, pass_bits, fact_bits, qf, qp = _small_engine_inputs(b, gpu_device)
+        with HippoRAGEngine(kg.csr, kg.passage_vertex, pass_bits, fact_bits, kg.subj_vertex, kg.obj_vertex,
+                            kg.num_chunks, max_batch=b, max_topk=50) as eng:
+            idx, sc = eng.score_facts(qf, k=5)
+            cnt = _t(np.full(b, 5, np.int32), gpu_device)
+            with pytest.raises(HragError, match="HRAG_PPR_TOL_MIN"):
+                eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50, ppr_tol=1e-9, ppr_max_iters=30)
+            ok = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50, ppr_tol=PPR_TOL_MIN, ppr_max_iters=30)
+            fixed = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50)
+            torch.cuda.synchronize()
+            assert int(fixed.iters_used.max()) == 20 and int(ok.iters_used.max()) >= 20

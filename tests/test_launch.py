@@ -81,8 +81,10 @@ def test_value_leg_prefers_a_parity_green_corpus_sharded_leg():
     green = {"value": 1.0, "ms_per_step": 1.0, "parity": {"ok": True}}
     red = {"value": 9.0, "ms_per_step": 1.0, "parity": {"ok": False}}
     failed = {"error": "boom"}
-    assert pick_value_leg("auto", green, green) == "hybrid"
+    assert pick_value_leg("auto", green, green) == "rowshard"       # the north star's layout is the primary figure
     assert pick_value_leg("auto", red, green) == "rowshard"
+    assert pick_value_leg("auto", green, red) == "hybrid"
+    assert pick_value_leg("hybrid", green, green) == "hybrid"
     assert pick_value_leg("auto", failed, red) == "replica"
     assert pick_value_leg("auto", None, {"skipped": True}) == "replica"
     assert pick_value_leg("rowshard", green, green) == "rowshard"

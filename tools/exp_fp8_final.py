@@ -27,9 +27,11 @@ def plan_for(iters, damping=0.5):
     return fp8_stage_plan(iters, damping)
 
 
-def ppr8(at32, d1, v, alpha, plan, rho_form=True):
+def ppr8(at32, d1, v, alpha, plan, rho_form=True, measure_rows=None):
     """Mirror of ppr8_begin / ppr8_sweep (csrc/shard.hip) + the kernels of csrc/ppr8.hip, fp32 arithmetic.
-    rho_form: the true residual travels as (rt + fp16 remainder) once damping^k <= 2^-6, like the device."""
+    rho_form: the true residual travels as (rt + fp16 remainder) once damping^k <= 2^-6, like the device.
+    measure_rows (passage rows): also return the contract's measure per query, damping / (1 - damping) *
+    max_p |R_p| / z_p of the final sweep (include/hrag.h, hrag_retrieve)."""
     import math
     al, be = np.float32(alpha), np.float32(1 - alpha)
     zv = (v / d1[:, None])
@@ -68,6 +70,10 @@ def ppr8(at32, d1, v, alpha, plan, rho_form=True):
                 rho = (q - rt).astype(np.float16).astype(np.float32)
     z = X + R
     x = z * d1[:, None]
+    if measure_rows is not None:
+        zz = z[measure_rows]
+        m = np.where(zz > 0, np.abs(R[measure_rows]) / np.where(zz > 0, zz, 1), 0.0).max(axis=0) * alpha / (1 - alpha)
+        return x / x.sum(0), m
     return x / x.sum(0)
 
 

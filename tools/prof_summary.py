@@ -30,6 +30,16 @@ def short(name: str) -> str:
     return out[:120]
 
 
+KERNEL_SOURCES = {"ppr8_kernel": "ppr8.hip", "ppr16_kernel": "ppr16.hip", "ppr_spmm_kernel": "ppr_spmm.hip"}
+
+
+def kernel_source_sha16(kernel: str):
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "hipporag_amd", "csrc", KERNEL_SOURCES.get(kernel, ""))
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16] if os.path.isfile(path) else None
+
+
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     workload = sys.argv[3] if len(sys.argv) > 3 else "cfg3:B256"   # what tools/pmc_target.py ran
@@ -82,7 +92,10 @@ def main():
             if "bytes_per_launch" in d and base in ("ppr8_kernel", "ppr16_kernel", "ppr_spmm_kernel") and n > seen.get(base, 0):
                 seen[base] = n      # the variant with the most launches (mode H for ppr16_kernel, C for ppr8_kernel)
                 traffic[base] = {"bytes_per_launch": d["bytes_per_launch"], "l2_hit_rate": d.get("l2_hit_rate"),
-                                 "workload": workload, "source": os.path.basename(dst) + "_pmc.json"}
+                                 "workload": workload, "source": os.path.basename(dst) + "_pmc.json",
+                                 # bench.py replays these figures only while the kernel's source is the one they were
+                                 # collected on (a changed kernel makes roofline.traffic null until the passes are re-run)
+                                 "kernel_source_sha16": kernel_source_sha16(base)}
         if inst8 and "ppr8_kernel" in traffic:
             traffic["ppr8_kernel"]["by_instantiation"] = inst8
         if traffic:

@@ -147,6 +147,7 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
     f8 = phases["slab_width"] == 128                # hrag_retrieve took the staged fp8-state path
     f16 = phases["slab_width"] == 64 and B > 32     # ... the two-stage fp16-state path
     per_mode = None
+    harness_ms = None
     if f8:
         counts = fp8_mode_counts(PPR_ITERS)
         per_mode = {}
@@ -154,8 +155,14 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
             mode, _, rio = key.partition("/")
             per_mode[key] = _time_launches(lambda n, mode=mode, rio=int(rio or 0): eng.ppr_sweeps(
                 B, n, DAMPING, f8=True, f8_mode=mode, f8_rio=rio), n_l)
-        spmm_ms = sum(counts[m] * per_mode[m] for m in counts) / PPR_ITERS
+        harness_ms = sum(counts[m] * per_mode[m] for m in counts) / PPR_ITERS
         main_ms = _time_launches(lambda n: eng.ppr_sweeps(B, n, DAMPING, main_only=True, f8=True), n_l)
+        # The average launch of a retrieve, measured IN SITU: HIP events (inside the library, on the launch stream) around
+        # the PPR_ITERS sweep launches of real retrieves on fresh queries (median of the profiled steps).  The per-
+        # instantiation figures above come from a harness that re-launches ONE instantiation on whatever the state holds;
+        # they are a breakdown, not the measurement: on hub-heavy graphs the harness's boundary launches drift into the
+        # e4m3 saturation path (atomics) and read up to 2x slow (real2wiki, round 5), which the in-situ figure cannot
+        spmm_ms = phases["ppr_ms"] / PPR_ITERS
     else:
         main_ms = _time_launches(lambda n: eng.ppr_sweeps(B, n, DAMPING, main_only=True, f16=f16), n_l)
         spmm_ms = _time_launches(lambda n: eng.ppr_sweeps(B, n, DAMPING, main_only=False, f16=f16), n_l)
@@ -202,8 +209,11 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
     roofline = {
         "bound": "hbm", "kernel": kernel_launched, "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "frac_definition": ("average launch of one retrieve over the kernel's instantiations (stage plan counts)"
+        "frac_definition": ("algorithmic bytes of one PPR iteration / average sweep launch of a real retrieve: HIP events around "
+                            "its 20 sweep launches (all instantiations of the stage plan), median of the profiled steps"
                             if f8 else "average launch of the sweep kernel (+ its long-row reduce)"),
+        "launch_ms_from_instantiation_harness": harness_ms,
+        "instantiation_harness_agrees": (bool(abs(harness_ms / spmm_ms - 1) < 0.05) if harness_ms else None),
         # PMC traffic is only meaningful for the workload it was collected on (profiles/pmc_traffic.json)
         "traffic": traffic_bytes,
         "traffic_source": traffic_note or ("replayed from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, "
@@ -675,11 +685,15 @@ def main():
             accel["with_convergence_contract"] = ac
         eng.set_flags(OPT_ACCEL, False)
 
-    # phase breakdown of one more step (HIP events inside the library, same stream)
+    # phase breakdown (HIP events inside the library, same stream): five more steps on fresh queries, the one with the
+    # median PPR time is reported (the last batch last: its results are what the oracle spot check reads)
     eng.set_profiling(True)
-    out = step(n_batches - 1)
-    torch.cuda.synchronize()
-    phases = eng.timings()
+    runs = []
+    for i in list(range(max(args.warmup, n_batches - 5), n_batches - 1)) + [n_batches - 1]:
+        out = step(i)
+        torch.cuda.synchronize()
+        runs.append(eng.timings())
+    phases = sorted(runs, key=lambda t: t["ppr_ms"])[len(runs) // 2]
     eng.set_profiling(False)
 
     roofline, f8, f16 = measure_roofline(eng, kg, V, B, phases, args.config, args.sweep_launches)

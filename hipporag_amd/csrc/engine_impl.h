@@ -286,7 +286,7 @@ inline hrag_status prep_query(hrag_engine *e, const uint16_t *q, int32_t batch, 
 // The fp8 path serves a batch when the truncation error of `iters` sweeps is below the parity bar
 // (damping^iters <= 2^-18) and the stage plan fits.
 bool ppr8_usable(const hrag_engine *e, int batch, int iters, float damping);
-int ppr8_plan(int iters, float damping, int *plan);
+int ppr8_plan(int iters, float damping, bool measured, int *plan);
 // HRAG_OPT_ACCEL: stage lengths 1, 3, 3, ... (+ a closing plain stage of 1 sweep when `measured`: the convergence measure
 // then reads a plain sweep's update) standing for the accuracy of `iters` plain sweeps; kind[i] = 1 marks a stage whose
 // sweeps are Chebyshev steps.  Returns the number of stages, 0 when the variant saves no sweep

@@ -846,12 +846,13 @@ class EngineStages:
         return out
 
 
-def fp8_stage_plan(iters: int, damping: float = 0.5):
+def fp8_stage_plan(iters: int, damping: float = 0.5, tol: float = 0.0):
     """Python mirror of ppr8_plan (csrc/shard.hip): the stage lengths of the plain staged-fp8 PPR for `iters` sweeps.
     bench.py prices its per-instantiation launch times with it and tools/exp_fp8_final.py emulates it; the library
-    never calls this.  iters < 19 or damping < 0.46: 1, 2, 3-sweep stages, remainder last; otherwise 1, 2, 3, 3-sweep
-    stages, as many 4-sweep stages as fit, a 2-sweep stage last (20 = 1+2+3+4+4+4+2: five boundaries instead of six)."""
-    if iters < 19 or not damping >= 0.46:
+    never calls this.  iters < 19, damping < 0.46 or a tolerance (the final measure then drives decisions and reads lowest
+    after the round-1 plan): 1, 2, 3-sweep stages, remainder last; otherwise 1, 2, 3, 3-sweep stages, as many 4-sweep stages
+    as fit, a 2-sweep stage last (20 = 1+2+3+4+4+4+2: five boundaries instead of six)."""
+    if iters < 19 or not damping >= 0.46 or tol > 0:
         left = iters - 3
         return [1, 2] + [3] * (left // 3) + ([left % 3] if left % 3 else [])
     t = iters - 8

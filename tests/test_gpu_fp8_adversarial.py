@@ -302,11 +302,18 @@ def test_the_device_extends_exactly_when_the_measured_residual_is_above_the_tole
                         max_batch=b, max_topk=50) as eng:
         idx, sc = eng.score_facts(qf, k=5)
         cnt = _t(np.full(b, 5, np.int32), gpu_device)
-        fixed = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50)
+        # the base: 20 sweeps under a tolerance nothing exceeds (round 5: a call WITH a tolerance runs the stage plan whose
+        # final measure reads lowest, a fixed count the one with a boundary fewer -- csrc/shard.hip ppr8_plan -- so the two
+        # kinds of call agree to the parity bar, not bit for bit)
+        fixed = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50, ppr_tol=1.0, ppr_max_iters=30)
+        count = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50)
         torch.cuda.synchronize()
         assert eng.timings()["slab_width"] == 128
         r20 = float(fixed.residual.max())
-        assert r20 > 0 and int(fixed.iters_used.max()) == 20
+        assert r20 > 0 and int(fixed.iters_used.max()) == 20 and int(count.iters_used.max()) == 20
+        same = count.doc_idx == fixed.doc_idx
+        assert float(same.float().mean()) > 0.99
+        assert float(((count.doc_score - fixed.doc_score).abs() / fixed.doc_score)[same].max()) < 5e-6
         above = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50, ppr_tol=1.05 * r20, ppr_max_iters=30)
         below = eng.retrieve(qp, idx, sc, cnt, ppr_iters=20, k=50, ppr_tol=0.95 * r20, ppr_max_iters=30)
         torch.cuda.synchronize()

@@ -1,5 +1,6 @@
 """The N > 1 paths over REAL RCCL (backend "nccl"), two processes on two GPUs: the row-sharded retriever with two
-exchange groups (in-place all_gather_into_tensor of the owners' blocks, pipelined against the other group's sweep) and
+exchange groups (in-place all_gather_into_tensor of the owners' blocks, pipelined against the other group's sweep; then
+the same with the literal all-reduce exchange) and
 the hybrid retriever (all_to_all of passage-score rows), each bit-identical to the single-GPU engine.
 
 Skipped unless the box has at least two GPUs -- no such box was available to the rounds that wrote this code (every
@@ -56,6 +57,12 @@ def _worker(rank, world, port, ret):
             torch.cuda.synchronize()
             assert torch.equal(idx, i1) and torch.equal(sc, s1)
             assert torch.equal(d_idx, o1.doc_idx) and torch.equal(d_sc, o1.doc_score) and int(flags.max()) == 0
+        # ... and with the north star's literal exchange: all-reduce SUM over the bytes, foreign blocks zeroed
+        rs2 = hd.ShardedRetriever(ShardStages(seng), hd.TorchComm(rank, world, collective="allreduce"), groups=2)
+        i2, s2 = rs2.score_facts(qf, k=5)
+        d2_idx, d2_sc, flags2 = rs2.retrieve(qp, i2, s2, cnt, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(d2_idx, d_idx) and torch.equal(d2_sc, d_sc) and int(flags2.max()) == 0
         # hybrid: embeddings sharded, one all_to_all, PPR on this rank's half of the batch (original index)
         ppr = hd.build_ppr_engine(kg.csr, kg.passage_vertex, kg.subj_vertex, kg.obj_vertex, kg.num_chunks, 128, b // world, 100)
         hy = hd.HybridRetriever(ShardStages(seng), ppr, comm, sidx.passages)

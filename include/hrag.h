@@ -177,7 +177,10 @@ typedef struct hrag_fact_desc {
                                       /* cannot see whether the CSR it was given came from a symmetric adjacency: setting the */
                                       /* flag on a DIRECTED graph is a caller error (complex spectrum: the steps may converge */
                                       /* more slowly than the plan assumes; the contract would flag it, ppr_tol = 0 would     */
-                                      /* not) -- the Python wrapper checks row sums == column sums of A and refuses           */
+                                      /* not) -- the Python wrapper checks row sums == column sums of A in chunks AND that    */
+                                      /* 4096 sampled entries have a mirror entry of the same weight                          */
+                                      /* (hipporag_amd.graph.looks_undirected, evaluated when the flag is first asked for),   */
+                                      /* and refuses otherwise                                                                 */
 
 typedef struct hrag_opts {
     int32_t max_batch;    /* largest B any call will pass (workspace is sized once)              */

@@ -37,6 +37,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=150.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0: only the time bound): a seeded run of a fixed\n                    number of cases is the same on every box")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "soak_random.json"))
     ap.add_argument("--replay", action="append", default=[], help="a case as printed (JSON): run exactly that one; repeatable")
     ap.add_argument("--verbose", action="store_true")
@@ -47,7 +48,7 @@ def main(argv=None):
     t_end = time.time() + args.seconds
     cases, bad = [], 0
     replay = [json.loads(x) for x in args.replay]
-    while time.time() < t_end and (not args.replay or replay):
+    while time.time() < t_end and (not args.replay or replay) and not (args.cases and len(cases) >= args.cases):
         forced = replay.pop(0) if args.replay else None
         if forced is not None:                      # the case's own stream of random decisions restarts from its seed
             rng = np.random.default_rng(forced["seed"])

@@ -35,13 +35,14 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0: only the time bound): a seeded run of a fixed\n                    number of cases is the same on every box")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "soak_shards.json"))
     args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
     dev = torch.device("cuda", 0)
     t_end = time.time() + args.seconds
     cases, bad = [], 0
-    while time.time() < t_end:
+    while time.time() < t_end and not (args.cases and len(cases) >= args.cases):
         v = int(rng.choice([3000, 8000, 16000]))
         e = int(v * rng.choice([3, 8, 15]))
         world = int(rng.choice([2, 3, 4, 8]))

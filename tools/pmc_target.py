@@ -22,12 +22,17 @@ from hipporag_amd.engine import HippoRAGEngine
 cfg = CONFIGS[os.environ.get("HRAG_PMC_CONFIG", "cfg3")]
 V, E, B, seed = cfg["V"], cfg["E"], int(os.environ.get("HRAG_PMC_BATCH", cfg["B"])), cfg["seed"]
 dev = torch.device("cuda", 0)
-kg = synth.make_kg(V, E, seed, community=int(os.environ.get("HRAG_COMMUNITY", cfg.get("community", 0))))
+if cfg.get("real2wiki"):      # the real-topology graph (tests/real2wiki.py), HRAG_PMC_CONFIG=real2wiki
+    from tests import real2wiki as rw
+    kg = rw.build_kg(int(cfg["tiles"]))
+else:
+    kg = synth.make_kg(V, E, seed, community=int(os.environ.get("HRAG_COMMUNITY", cfg.get("community", 0))))
 pemb = synth.make_embeddings_torch(kg.n_passages, 64, 1, dev)
 femb = synth.make_embeddings_torch(kg.n_facts, 64, 2, dev)
 eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pemb, femb, kg.subj_vertex, kg.obj_vertex, kg.num_chunks,
                      max_batch=B, max_topk=200, slab_width=int(os.environ.get("HRAG_SLAB", "0")),
-                     flags=int(os.environ.get("HRAG_FLAGS", "0")), sell_sigma=int(os.environ.get("HRAG_SELL_SIGMA", "0")))
+                     flags=int(os.environ.get("HRAG_FLAGS", "0")), sell_sigma=int(os.environ.get("HRAG_SELL_SIGMA", "0")),
+                     locality=os.environ.get("HRAG_LOCALITY") or None)
 qf, _ = synth.make_queries_torch(femb, B, 7)
 qp, _ = synth.make_queries_torch(pemb, B, 8)
 cnt = torch.full((B,), 5, dtype=torch.int32, device=dev)

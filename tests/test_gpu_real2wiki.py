@@ -69,3 +69,47 @@ def test_real_topology_parity_with_and_without_the_locality_numbering(gpu_device
                          "exact_id_fraction": exact / npos, "tie_window_rel": gap, "locality_score": g["score"]}
     write_test_report("real2wiki_parity", {"V": kg.num_vertices, "nnz": int(kg.csr.nnz), "facts": kg.n_facts, "batch": B,
                                            "queries_vs_oracle": 17, **rep_out})
+
+
+def test_mirror_end_to_end_on_the_real_corpus_equals_the_mirror_over_the_oracle_engine(gpu_device, monkeypatch):
+    """The path a user of the reference takes, on real topology: HippoRAG.index_from_openie over the first 1 500 documents
+    of the corpus (their triples as strings), then retrieve() for 24 fact-like query strings -- once with the device engine
+    (the mirror's defaults: accelerated stages under the convergence contract, locality="auto"), once with the engine
+    replaced by the oracle-backed CPU stand-in of tests/support (same host code, the oracle's exact solve): the same
+    documents in the same order, scores within the parity bar.  Reference surface: HippoRAG.py:413-499 (retrieve),
+    :262-335 (index)."""
+    import importlib.util
+    import os
+    from hipporag_amd import engine as engine_mod
+    from hipporag_amd.retriever import HippoRAG, RetrievalConfig
+    from tests.helpers import tie_aware_equal
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "support", "adapter_on_real_reference.py")
+    spec = importlib.util.spec_from_file_location("adapter_on_real_reference", path)
+    sup = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sup)
+    docs, triples = rw.openie_inputs(1500)
+    model = sup.Bf16Mock()
+    queries = [" ".join(triples[i][0]) for i in range(0, 1500, 63) if triples[i]][:24]
+    cfg = dict(embedding_precision="bf16", max_batch=16, retrieval_top_k=50)
+    gpu = HippoRAG(RetrievalConfig(**cfg), embedding_model=model)
+    gpu.index_from_openie(docs, triples)
+    got = gpu.retrieve(queries, num_to_retrieve=20)
+    assert gpu.engine is not None and gpu.engine.device.type == "cuda"
+    monkeypatch.setattr(engine_mod, "HippoRAGEngine", sup.OracleEngine)
+    cpu = HippoRAG(RetrievalConfig(**cfg), embedding_model=model)
+    cpu.index_from_openie(docs, triples)
+    want = cpu.retrieve(queries, num_to_retrieve=20)
+    assert cpu.engine.device.type == "cpu"
+    pos = {d: i for i, d in enumerate(docs)}
+    worst = 0.0
+    for g, w in zip(got, want):
+        assert g.question == w.question and len(g.docs) == len(w.docs) == 20
+        gi, wi = [pos[d] for d in g.docs], [pos[d] for d in w.docs]
+        assert tie_aware_equal(gi, wi, np.asarray(w.doc_scores, dtype=np.float64), rel_gap=2e-5), (g.question, gi, wi)
+        by_doc = dict(zip(w.docs, np.asarray(w.doc_scores, dtype=np.float64)))
+        for d, s in zip(g.docs, np.asarray(g.doc_scores, dtype=np.float64)):
+            if d in by_doc:
+                worst = max(worst, abs(s / by_doc[d] - 1))
+    write_test_report("real2wiki_mirror_end_to_end", {"documents": len(docs), "queries": len(queries),
+                                                      "max_rel_score_diff_to_the_oracle_backed_mirror": worst})
+    assert worst < 1e-5, worst

@@ -1,4 +1,5 @@
-"""Round-5 experiment: the first boundary sweep (mode B0) in its light form (csrc/ppr8.hip ppr8_pair_b0_kernel) against the
+"""(Archived with docs/experiments/r05_b0_light_kernel.patch: apply the patch to csrc/ppr8.hip first -- the product
+ignores HRAG_P8_B0_LIGHT.)  Round-5 experiment: the first boundary sweep (mode B0) in its light form (csrc/ppr8.hip ppr8_pair_b0_kernel) against the
 common pair kernel -- launch time by HIP events and bit-identity of a whole retrieve.  HRAG_P8_B0_LIGHT is read once per
 process, so every variant runs in a process of its own:  python tools/exp_b0_light.py (spawns 0 / 4 / 5)."""
 import hashlib
@@ -7,7 +8,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

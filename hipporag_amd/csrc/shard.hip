@@ -94,9 +94,9 @@ int ppr8_plan(int iters, float damping, bool measured, int *plan) {
 //   * Convergence measure.  The contract's measure is the size of the update a PLAIN sweep applies: after Chebyshev
 //     stages the true residual is spread over the whole spectrum (equi-oscillation) and its mid-spectrum part, which the
 //     next plain sweep annihilates, makes the measure read 60x the true error (cfg 3, round 3).  With `measured` the plan
-//     therefore ends on a plain stage of ONE sweep (its boundary + the passage-row final sweep: the measure then reads
-//     what is left after a plain sweep, the quantity the a-posteriori bound a / (1 - a) |update| is about), and the
-//     extension stages are plain.
+//     therefore ends on a PLAIN stage (round 4: one sweep; round 5: two, see below -- the measure then reads what is
+//     left after a plain sweep that follows a plain sweep, the quantity the a-posteriori bound a / (1 - a) |update| is
+//     about), and the extension stages are plain.
 double cheb_T(int m, double x) {                 // Chebyshev polynomial T_m(x), x >= 1
     double t0 = 1.0, t1 = x;
     if (m == 0) return 1.0;
@@ -116,6 +116,21 @@ int ppr8_plan_accel(int iters, float damping, bool measured, int *plan, int *kin
     if (n3 < 2 || total >= iters || n3 + 1 + (measured ? 1 : 0) > kP8MaxStages) return 0;
     int n = 0;
     plan[n] = 1; kind[n++] = 0;
+    // Under a tolerance (round 5): the same 3 n3 + 2 sweeps and the same number of boundaries, arranged as 1, 2 (plain),
+    // 3-sweep Chebyshev stages x (n3 - 1), 2 (plain) instead of 1, 3 x n3, 1 (plain).  What the final sweep REPORTS depends
+    // on the last stages (ppr8_plan): a plain 2-sweep stage right after the quantised start takes the large first residual
+    // down before the Chebyshev stages see it, and two plain sweeps at the end leave less mid-spectrum residue for the
+    // measure to read than one.  CPU emulation (benchmark / power-law / barbell graphs): the measure reads 2 - 5x lower at
+    // the same true error (8e-8 against 4e-7, 3e-7 against 6e-7, 5e-7 against 1.4e-6); on the device at BASELINE configs[2]
+    // the residual after 17 sweeps sat just above the default tolerance for most batches (18 sweeps), see profiles/r05*.
+    // HRAG_P8_ACCEL_CLOSE=1 keeps the round-4 arrangement (A/B measurements).
+    static const bool old_close = [] { const char *e = getenv("HRAG_P8_ACCEL_CLOSE"); return e && e[0] == '1'; }();
+    if (measured && !old_close && n3 >= 3) {
+        plan[n] = 2; kind[n++] = 0;
+        for (int i = 0; i < n3 - 1; ++i) { plan[n] = 3; kind[n++] = 1; }
+        plan[n] = 2; kind[n++] = 0;
+        return n;
+    }
     for (int i = 0; i < n3; ++i) { plan[n] = 3; kind[n++] = 1; }
     if (measured) { plan[n] = 1; kind[n++] = 0; }
     return n;

@@ -157,8 +157,9 @@ typedef struct hrag_fact_desc {
                                       /* steps on the real spectrum [-damping, damping] of the sweep operator instead of      */
                                       /* three Richardson sweeps (csrc/shard.hip ppr8_plan_accel).  `ppr_iters` then names an */
                                       /* ACCURACY -- the truncation error of that many plain sweeps -- and fewer sweeps run   */
-                                      /* (damping 0.5, ppr_iters 20: 16; with ppr_tol > 0: 17, the last one plain so that the */
-                                      /* convergence measure reads what it reads without the flag; iters_out reports them).   */
+                                      /* (damping 0.5, ppr_iters 20: 16; with ppr_tol > 0: 17 -- 1, 2 plain, Chebyshev stages,  */
+                                      /* 2 plain at the end, so that the convergence measure reads a plain sweep's update as   */
+                                      /* it does without the flag; iters_out reports them).                                   */
                                       /* The reference's PRPACK solve is tolerance-driven (HippoRAG.py:1736-1743): any sweep  */
                                       /* count that meets the tolerance is the same answer.  Guarantees: the e4m3 scale of    */
                                       /* every stage is MEASURED on the device -- each boundary reports the batch's max |R|,  */

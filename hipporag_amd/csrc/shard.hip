@@ -17,7 +17,7 @@ namespace hrag {
 //   * round 1 - 4: 1 (the quantised start), 2, then 3-sweep stages, the remainder (1 or 2) last: 20 = 1+2+3+3+3+3+3+2,
 //     six boundaries.  Kept for ppr_iters < 19 and for damping < 0.46 (a^4 is then below the rounding's share: longer
 //     stages only waste sweeps there; at 0.3 the scales are measured, see ppr8_begin).
-//   * round 5, damping >= 0.46, ppr_iters >= 19 and ppr_tol = 0: 1, 2, 3, then 3-sweep stages, then as many 4-sweep stages as the
+//   * round 5, damping >= 0.46 and ppr_iters >= 19, fixed count: 1, 2, 3, then 3-sweep stages, then as many 4-sweep stages as the
 //     count allows, a 2-sweep stage last -- 20 = 1+2+3+4+4+4+2, FIVE boundaries.  The 4-sweep stages sit where the
 //     residual already travels in its 3-byte form (their boundaries are the cheap ones); the last stage stays as short
 //     as it was: its right-hand side is quantised at sweep K - 2, and that rounding is what the final sweep's measure
@@ -28,11 +28,11 @@ namespace hrag {
 //     measured residual within -10 % .. +40 % of the old plan at every count 19 .. 30 and damping 0.5 .. 0.6 (20 sweeps,
 //     benchmark graph: 3.4e-7 / 4.8e-7 against 3.9e-7 / 4.9e-7); plans with TWO boundaries fewer (1,3,4,4,5,3) cost a
 //     factor 2 in accuracy and 6x in the reported residual and are not taken.
-//     On the device the new plan keeps the true error (cfg 3: the 12 oracle queries unchanged at 5.5e-7) but its final
-//     sweep still REPORTS 2.2x the old plan's residual (5.5e-6 against 2.5e-6, profiles/r05b_bench_cfg3.json): under a
-//     tolerance that is an extension stage for every batch instead of some (14.25 k against 14.7 k queries/s).  So the
-//     rule looks at what the call asked for: `measured` (ppr_tol > 0: the final measure drives decisions) keeps the
-//     round-1 plan, a fixed count (ppr_tol = 0: only the launches count) takes the shorter one.
+//     On the device the fixed-count plan keeps the true error (cfg 3: the 12 oracle queries unchanged at 5.5e-7) but its
+//     final sweep REPORTS 2.2x the round-1 plan's residual (5.5e-6 against 2.5e-6): under a tolerance that is an extension
+//     stage for every batch.  So the rule looks at what the call asked for: a fixed count (ppr_tol = 0: only the launches
+//     count) takes the plan above; `measured` (ppr_tol > 0: the final measure drives decisions) ends on 2 + 1 instead
+//     (20 = 1+2+3+3+4+4+2+1: the round-1 plan's stage count, a lower final measure -- docs/experiments/README.md round 5).
 // HRAG_P8_PLAN="1,2,4,4,4,4,1" (experiments only) overrides the rule when it sums to ppr_iters.
 int ppr8_plan(int iters, float damping, bool measured, int *plan) {
     if (const char *env = getenv("HRAG_P8_PLAN")) {
@@ -49,14 +49,18 @@ int ppr8_plan(int iters, float damping, bool measured, int *plan) {
     int n = 0;
     plan[n++] = 1;
     plan[n++] = 2;
-    if (iters < 19 || !(damping >= 0.46f) || measured) {
+    if (iters < 19 || !(damping >= 0.46f)) {
         int left = iters - 3;
         while (left >= 3) { plan[n++] = 3; left -= 3; }
         if (left > 0) plan[n++] = left;
         return n;
     }
-    // iters - 8 = 4 a + 3 b with the largest a: [1, 2, 3] + b x [3] + a x [4] + [2]
-    const int t = iters - 8;
+    // fixed count:       iters - 8 = 4 a + 3 b with the largest a: [1, 2, 3] + b x [3] + a x [4] + [2]
+    // under a tolerance: iters - 9 = 4 a + 3 b:                    [1, 2, 3] + b x [3] + a x [4] + [2, 1] -- as many stages
+    //   as the round-1 plan had (20 = 1+2+3+3+4+4+2+1), but the last right-hand side is quantised one sweep before the
+    //   end: what the final sweep reports is lower (cfg 3: fewer batches need the 21st sweep, 14.65 k -> 15.1 k queries/s
+    //   under the default tolerance; same emulated true error: 3.6e-7 against 3.9e-7)
+    const int t = iters - (measured ? 9 : 8);
     int a = t / 4;
     while (a > 0 && (t - 4 * a) % 3 != 0) --a;
     const int b = (t - 4 * a) / 3;
@@ -64,6 +68,7 @@ int ppr8_plan(int iters, float damping, bool measured, int *plan) {
     for (int i = 0; i < b; ++i) plan[n++] = 3;
     for (int i = 0; i < a; ++i) plan[n++] = 4;
     plan[n++] = 2;
+    if (measured) plan[n++] = 1;
     return n;
 }
 

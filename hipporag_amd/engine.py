@@ -849,17 +849,17 @@ class EngineStages:
 def fp8_stage_plan(iters: int, damping: float = 0.5, tol: float = 0.0):
     """Python mirror of ppr8_plan (csrc/shard.hip): the stage lengths of the plain staged-fp8 PPR for `iters` sweeps.
     bench.py prices its per-instantiation launch times with it and tools/exp_fp8_final.py emulates it; the library
-    never calls this.  iters < 19, damping < 0.46 or a tolerance (the final measure then drives decisions and reads lowest
-    after the round-1 plan): 1, 2, 3-sweep stages, remainder last; otherwise 1, 2, 3, 3-sweep stages, as many 4-sweep stages
-    as fit, a 2-sweep stage last (20 = 1+2+3+4+4+4+2: five boundaries instead of six)."""
-    if iters < 19 or not damping >= 0.46 or tol > 0:
+    never calls this.  iters < 19 or damping < 0.46: 1, 2, 3-sweep stages, remainder last.  Otherwise 1, 2, 3, 3-sweep
+    stages, as many 4-sweep stages as fit, then: a 2-sweep stage last at a fixed count (20 = 1+2+3+4+4+4+2: five
+    boundaries instead of six); 2 + 1 under a tolerance (20 = 1+2+3+3+4+4+2+1: the final measure reads lower)."""
+    if iters < 19 or not damping >= 0.46:
         left = iters - 3
         return [1, 2] + [3] * (left // 3) + ([left % 3] if left % 3 else [])
-    t = iters - 8
+    t = iters - (9 if tol > 0 else 8)
     a = t // 4
     while a > 0 and (t - 4 * a) % 3:
         a -= 1
-    return [1, 2, 3] + [3] * ((t - 4 * a) // 3) + [4] * a + [2]
+    return [1, 2, 3] + [3] * ((t - 4 * a) // 3) + [4] * a + ([2, 1] if tol > 0 else [2])
 
 
 class ShardStages(EngineStages):

@@ -55,7 +55,8 @@ def test_stage_plan_matches_the_engine():
     assert plan_for(19) == [1, 2, 3, 3, 4, 4, 2] and plan_for(24) == [1, 2, 3, 4, 4, 4, 4, 2]
     assert plan_for(20, 0.3) == [1, 2, 3, 3, 3, 3, 3, 2]
     from hipporag_amd.engine import fp8_stage_plan
-    assert fp8_stage_plan(20, 0.5, tol=1.5e-6) == [1, 2, 3, 3, 3, 3, 3, 2]      # under a tolerance: the plan whose measure reads lowest
+    assert fp8_stage_plan(20, 0.5, tol=1.5e-6) == [1, 2, 3, 3, 4, 4, 2, 1]      # under a tolerance: ends on 2 + 1 (lower final measure)
+    assert all(sum(fp8_stage_plan(k, 0.5, tol=1e-6)) == k and len(fp8_stage_plan(k, 0.5, tol=1e-6)) <= 11 for k in range(16, 31))
     for al in (0.3, 0.5, 0.6):
         assert all(sum(plan_for(k, al)) == k and len(plan_for(k, al)) <= 12 for k in range(16, 31))   # kP8MaxStages
 

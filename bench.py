@@ -66,7 +66,7 @@ CONFIGS = {
     "cfg4local": dict(V=1_000_000, E=10_000_000, D=768, B=1024, seed=1237, shard_of=8, local_shards=True,
                       label="configs[3] parity run: all 8 row shards of the 1M-node/10M-edge KG emulated on ONE device, global batch 1024"),
     "tiny": dict(V=20_000, E=200_000, D=256, B=32, seed=1235, label="tiny smoke workload"),
-    # NOT a BASELINE configuration: a graph with REAL topology (tests/real2wiki.py: a deterministic triple extractor over
+    # NOT a BASELINE configuration: a graph with REAL topology (tools/real2wiki.py: a deterministic triple extractor over
     # the 6 119-passage 2WikiMultihopQA corpus the reference ships, tools/make_real2wiki.py), 32 disjoint copies with
     # interleaved ids = 1.5M vertices / 13.1M entries / 4.2M facts, the reference's mock embedding recipe (64-d uniform).
     # `--locality auto` vs none shows what the graph compiler's numbering buys on real per-document locality
@@ -148,6 +148,7 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
     f16 = phases["slab_width"] == 64 and B > 32     # ... the two-stage fp16-state path
     per_mode = None
     harness_ms = None
+    replay_ms = replay_err = None
     if f8:
         counts = fp8_mode_counts(PPR_ITERS)
         per_mode = {}
@@ -157,6 +158,12 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
                 B, n, DAMPING, f8=True, f8_mode=mode, f8_rio=rio), n_l)
         harness_ms = sum(counts[m] * per_mode[m] for m in counts) / PPR_ITERS
         main_ms = _time_launches(lambda n: eng.ppr_sweeps(B, n, DAMPING, main_only=True, f8=True), n_l)
+        # the ceiling of the formulation, measured in THIS run on the engine's own matrix and state: the state-row
+        # gathers of a stage sweep alone (256 bytes per matrix slot, padding slots included; ppr8_pair_replay_kernel)
+        try:
+            replay_ms = _time_launches(lambda n: eng.ppr_sweeps(B, n, DAMPING, f8=True, f8_gather_replay=True), n_l)
+        except Exception as exc:
+            replay_ms, replay_err = None, f"{type(exc).__name__}: {exc}"
         # The average launch of a retrieve, measured IN SITU: HIP events (inside the library, on the launch stream) around
         # the PPR_ITERS sweep launches of real retrieves on fresh queries (median of the profiled steps).  The per-
         # instantiation figures above come from a harness that re-launches ONE instantiation on whatever the state holds;
@@ -228,17 +235,61 @@ def measure_roofline(eng, kg, V, B, phases, config_name, n_l):
         "frac_mode_c": (alg / (per_mode["C"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if f8 else None,
         "ppr_stage_ms_per_iteration": ppr_iter_ms,
         "frac_whole_ppr_stage": alg / (ppr_iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        # "0.37 of 0.42": a sweep that fetches one state row per matrix slot cannot run faster than the replay of exactly
+        # those fetches; frac_ceiling = what `frac` would read if every sweep launch took only that long
+        "gather_replay_ms": replay_ms,
+        "gather_replay_definition": ("hrag_ppr_sweeps flag 256, same run: the gathers of a stage sweep alone -- the engine's SELL-8 "
+                                     "(col, val) stream and one 256-byte piece of the e4m3 state per slot; nothing computed or stored"
+                                     if f8 else None),
+        "gather_replay_error": replay_err,
+        "formulation_ceiling_frac": (alg / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if replay_ms else None,
+        "frac_of_formulation_ceiling": (replay_ms / spmm_ms) if replay_ms else None,
+        "stage_sweep_over_gather_replay": (per_mode["C"] / replay_ms) if (replay_ms and per_mode) else None,
         "launches_timed": n_l, "slab_width": bc, "n_slabs": n_slabs,
         "frac_of_measured_copy_peak_6290": achieved / 6290.0,
     }
     return roofline, f8, f16
 
 
+def device_reset_vectors(eng, kg, q_fact, q_pass, cnt, n_q):
+    """The reset ("personalization") vectors the DEVICE built for the first n_q queries of a batch, as fp64 host arrays
+    [n_q][V] in the caller's vertex numbering: phase A again (deterministic), then the stage-level operators of
+    include/hrag.h -- hrag_stage_seeds, hrag_sim_scores + hrag_row_minmax + hrag_stage_teleport -- which launch the SAME
+    kernels the fused hrag_retrieve launches (build_seeds_kernel, rows_to_slab_kernel<kMinMaxScale>), so the values are the
+    ones the PPR solve of that batch started from.  What the PPR-only parity figure is computed on (HippoRAG.py:1736-1749:
+    the step the reference hands to PRPACK)."""
+    import torch
+    from hipporag_amd.engine import EngineStages
+    st = EngineStages(eng)
+    idx, sc = eng.score_facts(q_fact, k=K_F)
+    sv, sw, scnt, flags = st.seeds(idx, sc, cnt, K_F)
+    raw = st.sim_scores("passages", q_pass)
+    mn, mx = st.row_minmax(raw)
+    tele = st.teleport(raw, mn, mx, PASSAGE_W, flags)              # [slab][passage][column]
+    torch.cuda.synchronize()
+    bc = tele.shape[2]
+    inv = eng._inv_perm.cpu().numpy() if getattr(eng, "_perm", None) is not None else None   # engine numbering -> caller's
+    pv = np.asarray(kg.passage_vertex)                  # teleport rows are in passage order (unchanged by a renumbering)
+    out = []
+    sv_h, sw_h, sc_h = sv.cpu().numpy(), sw.cpu().numpy().astype(np.float64), scnt.cpu().numpy()
+    for q in range(n_q):
+        v = np.zeros(eng.num_vertices)
+        v[pv] = tele[q // bc, :, q % bc].double().cpu().numpy()
+        ids = sv_h[q, :sc_h[q]]
+        ids = inv[ids] if inv is not None else ids
+        np.add.at(v, ids, sw_h[q, :sc_h[q]])
+        out.append(v)
+    return out
+
+
 def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, budget_s, max_queries,
-                 vec_queries=32, nx_budget_s=6.0, also=None):
+                 vec_queries=32, nx_budget_s=6.0, also=None, device_resets=None, ppr_only_budget_s=25.0):
     """Reference-style CPU loop on a bounded sample (rank 0 only) + parity spot check.
-    also: {name: (ids, scores)} -- further device results for the same queries, checked against the same oracle rows."""
+    also: {name: (ids, scores)} -- further device results for the same queries, checked against the same oracle rows.
+    device_resets: device_reset_vectors() of the same batch -> the PPR-ONLY error of every leg (its scores against the
+    exact fp64 solution for the reset vector the device itself built: no similarity / prior arithmetic in it)."""
     import oracle
+    from oracle.checks import percentiles, ulp4_report
     from oracle.cpu_baseline import ReferenceStyleRetriever
     try:
         from threadpoolctl import threadpool_info
@@ -258,9 +309,16 @@ def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, bu
     n_done, t0 = 0, time.perf_counter()
     ids_equal, max_rel = True, 0.0
     exact_pos = n_pos = exact_rows = 0
-    from tests.helpers import ranked_parity
+    from oracle.checks import ranked_parity
     tie_window = 0.0
     also_stats = {}
+    rel_all, ulp4 = [], {"equal": True, "exact": 0, "n": 0}
+
+    def rel_errs(ids_row, sc_row, full_scores):
+        want = np.asarray(full_scores, dtype=np.float64)[ids_row]
+        nz = want > 0
+        return np.abs(np.asarray(sc_row, dtype=np.float64)[nz] / want[nz] - 1)
+
     while n_done < min(max_queries, qf.shape[0]):
         ids, scores = ref.retrieve_one(qf[n_done], qp[n_done])
         g_ids = gpu_idx[n_done]
@@ -273,9 +331,15 @@ def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, bu
         exact_pos += rep["exact_positions"]; n_pos += rep["n"]; exact_rows += int(rep["exact_positions"] == rep["n"])
         max_rel = max(max_rel, rep["worst_rel_err"])
         tie_window = max(tie_window, rep["rel_gap"])
+        rel_all.append(rel_errs(g_ids, gpu_scores[n_done], full))
+        u4 = ulp4_report(g_ids, ids, scores)       # the same verdict at SURVEY 8(c)'s own window (4 ulp of fp32)
+        ulp4["equal"] = ulp4["equal"] and u4["equal"]; ulp4["exact"] += u4["exact_positions"]; ulp4["n"] += u4["n"]
         for name, (a_idx, a_sc) in (also or {}).items():
             r2 = ranked_parity(a_idx[n_done], a_sc[n_done], ids, scores, full)
-            st = also_stats.setdefault(name, {"topk_ids_equal": True, "exact": 0, "n": 0, "max_rel_score_err": 0.0, "tie_window_rel": 0.0})
+            st = also_stats.setdefault(name, {"topk_ids_equal": True, "exact": 0, "n": 0, "max_rel_score_err": 0.0, "tie_window_rel": 0.0,
+                                              "rel": [], "ulp4_equal": True})
+            st["rel"].append(rel_errs(a_idx[n_done], a_sc[n_done], full))
+            st["ulp4_equal"] = st["ulp4_equal"] and ulp4_report(a_idx[n_done], ids, scores)["equal"]
             st["topk_ids_equal"] = st["topk_ids_equal"] and bool(r2["equal"])
             st["exact"] += r2["exact_positions"]; st["n"] += r2["n"]
             st["max_rel_score_err"] = max(st["max_rel_score_err"], r2["worst_rel_err"])
@@ -298,10 +362,39 @@ def cpu_baseline(kg, fact_emb_t, pass_emb_t, qf_t, qp_t, gpu_idx, gpu_scores, bu
                                            "max relative score error) (tie class)",
               "tie_window_rel": tie_window,
               "exact_id_fraction": exact_pos / max(n_pos, 1), "queries_with_identical_id_lists": exact_rows,
-              "max_rel_score_err": max_rel}
+              "max_rel_score_err": max_rel,
+              "rel_score_err": percentiles(np.concatenate(rel_all)) if rel_all else None,
+              "rel_score_err_definition": "end to end: |device score / oracle score - 1| over every returned (query, rank)",
+              # the contract's own tie window (set-equality only where adjacent oracle scores differ by
+              # <= 4 ulp of fp32 = 4.8e-7 relative): how much of the verdict above leans on the wider measured-error window
+              "topk_ids_equal_at_4ulp_window": bool(ulp4["equal"]), "tie_window_4ulp_rel": 4 * 2.0 ** -23}
     for name, st in also_stats.items():
         parity[name] = {"topk_ids_equal": st["topk_ids_equal"], "exact_id_fraction": st["exact"] / max(st["n"], 1),
-                        "max_rel_score_err": st["max_rel_score_err"], "tie_window_rel": st["tie_window_rel"]}
+                        "max_rel_score_err": st["max_rel_score_err"], "tie_window_rel": st["tie_window_rel"],
+                        "rel_score_err": percentiles(np.concatenate(st["rel"])) if st["rel"] else None,
+                        "topk_ids_equal_at_4ulp_window": bool(st["ulp4_equal"])}
+    # ---- PPR-ONLY error: every leg's scores against the exact fp64 PPR of the reset vector the DEVICE built (the step
+    # the reference hands to igraph / PRPACK, HippoRAG.py:1736-1749).  No similarity, min-max or seed arithmetic in it, so
+    # -- unlike the end-to-end figure, whose maximum is owned by the fp32 prior -- it moves with the PPR plan
+    if device_resets:
+        t_p = time.perf_counter()
+        legs = {"headline": (gpu_idx, gpu_scores)}
+        legs.update(also or {})
+        errs = {name: [] for name in legs}
+        n_p = 0
+        for qi, v in enumerate(device_resets[:n_done]):
+            x = oracle.ppr_exact(index.p, v, DAMPING)[kg.passage_vertex]
+            for name, (l_idx, l_sc) in legs.items():
+                errs[name].append(rel_errs(l_idx[qi], l_sc[qi], x))
+            n_p += 1
+            if time.perf_counter() - t_p > ppr_only_budget_s:
+                break
+        parity["ppr_only"] = {
+            "definition": "|device score / x*_p - 1| over every returned (query, rank), x* = exact fp64 PPR (oracle.ppr_exact) of "
+                          "the reset vector the device built for that query (read back through hrag_stage_seeds / "
+                          "hrag_stage_teleport: the kernels the fused call launches)",
+            "queries_checked": n_p, "seconds": time.perf_counter() - t_p,
+            **{name: percentiles(np.concatenate(e)) if e else None for name, e in errs.items()}}
     # ---- "vectorised" leg: batched sgemm + argpartition + OpenMP SpMM over all host cores, the
     # same algorithm and sweep count as the GPU path -- the ratio against THIS number is the one free of the
     # reference's Python overhead
@@ -385,7 +478,7 @@ def local_shards_parity(cfg, batch, cpu_queries, exchange_groups, dev):
     import oracle
     from hipporag_amd import dist as hd, synth
     from hipporag_amd.engine import HippoRAGEngine
-    from tests.helpers import tie_aware_report
+    from oracle.checks import tie_aware_report
     world, V, E, D, B, seed = cfg["shard_of"], cfg["V"], cfg["E"], cfg["D"], batch or cfg["B"], cfg["seed"]
     kg = synth.make_kg(V, E, seed)
     pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev)
@@ -523,8 +616,10 @@ def main():
                          "one all-to-all of passage-score rows, PPR query-parallel on a replicated graph) and replica (queries "
                          "sharded, every GPU holds the whole index).  auto (default): rowshard when it is parity-green "
                          "(SURVEY 8(e): the primary figure), else hybrid, else replica (said in `value_leg`)")
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    ap.add_argument("--cpu-queries", type=int, default=12)
+    ap.add_argument("--cpu-budget-s", type=float, default=45.0)
+    ap.add_argument("--cpu-queries", type=int, default=32, help="queries of the last batch checked against the CPU oracle")
+    ap.add_argument("--cpu-ppr-queries", type=int, default=16,
+                    help="... of which this many also get the PPR-only check (exact fp64 solve of the device's own reset vector)")
     ap.add_argument("--cpu-vec-queries", type=int, default=32, help="batch of the vectorised CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accel", action="store_true", help="skip the HRAG_OPT_ACCEL leg (never `value`)")
@@ -555,7 +650,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("HRAG_FORCE_DIST"):
         # the driver's command is plain `python bench.py --gpus N ...`: be our own launcher -- N ranks of this very
         # command, one per GPU, rendezvous on 127.0.0.1; rank 0's JSON line is the last line of our stdout
-        from hipporag_amd.launch import self_spawn
+        from hipporag_amd.launch import self_spawn, visible_gpu_count
+        n_dev = visible_gpu_count()      # no torch import: a box with too few GPUs must say so in seconds, not minutes
+        if n_dev is not None and n_dev < args.gpus:
+            sys.stderr.write(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node (one rank per device); "
+                             f"{n_dev} visible\n")
+            return 2
         return self_spawn(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
     import torch
@@ -566,8 +666,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1 or os.environ.get("HRAG_FORCE_DIST"):   # env: exercise the N>1 code on 1 GPU
-        from hipporag_amd import dist as hdist
-        return hdist.bench_main(args, CONFIGS, rank, local_rank, world, roofline_fn=measure_roofline)
+        import bench_dist
+        return bench_dist.bench_main(args, CONFIGS, rank, local_rank, world, roofline_fn=measure_roofline)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback on this path)")
@@ -583,7 +683,7 @@ def main():
     t_setup = time.perf_counter()
     emb_dtype = torch.float16 if cfg.get("fp16") else torch.bfloat16
     if cfg.get("real2wiki"):
-        from tests import real2wiki as rw
+        from tools import real2wiki as rw
         kg = rw.build_kg(int(cfg["tiles"]))
         V, E = kg.num_vertices, kg.csr.nnz // 2
         pass_emb = torch.from_numpy(rw.mock_embeddings(kg.n_passages, seed + 1, D)).to(dev).to(emb_dtype)
@@ -735,9 +835,14 @@ def main():
         last = n_batches - 1
         also = ({"with_accelerated_stages": (out_a.doc_idx.cpu().numpy(), out_a.doc_score.cpu().numpy())}
                 if out_a is not None else None)
+        try:
+            resets = device_reset_vectors(eng, kg, qf[last], qp[last], cnt, min(args.cpu_ppr_queries, B))
+        except Exception as exc:        # the probe must never cost the line
+            resets = None
+            result["ppr_only_probe_error"] = f"{type(exc).__name__}: {exc}"
         cb, parity = cpu_baseline(kg, fact_emb, pass_emb, qf[last], qp[last], out.doc_idx.cpu().numpy(),
                                   out.doc_score.cpu().numpy(), args.cpu_budget_s, args.cpu_queries,
-                                  vec_queries=args.cpu_vec_queries, also=also)
+                                  vec_queries=args.cpu_vec_queries, also=also, device_resets=resets)
         result["cpu_baseline"] = cb
         result["parity_spot_check"] = parity
         result["speedup_vs_cpu_port"] = qps / cb["value"]

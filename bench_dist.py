@@ -1,0 +1,444 @@
+"""bench.py --gpus N (N > 1): the multi-GPU benchmark HARNESS -- one rank per GPU over RCCL, the three legs (row-sharded,
+hybrid, replica), their parity probes (single-GPU engine on every rank; the fp64 CPU oracle on rank 0) and the watchdogs.
+Measurement code, not product: it lives beside bench.py (round 6: moved out of hipporag_amd/dist.py, which keeps only what
+a deployment needs -- shard_index, build_shard_engine, ShardedRetriever, HybridRetriever, TorchComm).  The oracle is
+imported here as the CHECKER of a leg's results only (rank 0)."""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from hipporag_amd.dist import (HybridRetriever, ShardedRetriever, TorchComm, _td, build_shard_engine, shard_index)
+
+
+# --------------------------------------------------------------------------------------------
+# bench.py --gpus N (N > 1)
+# --------------------------------------------------------------------------------------------
+def pick_value_leg(mode: str, hybrid, rowshard) -> str:
+    """Which leg of an N > 1 run becomes `value`: a leg counts only when it produced a rate AND its parity checks
+    (bit / tolerance identity with the single-GPU engine on every rank; the fp64 oracle on rank 0) are green.
+    auto: the ROW-SHARDED leg first -- the layout BASELINE.json's north star names and SURVEY.md 8(e) makes the primary
+    figure -- then the hybrid leg (the better engineering: no per-sweep collective; always printed beside it as
+    `value_hybrid`), the replica leg (which shards nothing) only when neither is green."""
+    def green(leg):
+        return isinstance(leg, dict) and "value" in leg and bool(leg.get("parity", {}).get("ok"))
+    if mode in ("rowshard", "auto") and green(rowshard):
+        return "rowshard"
+    if mode in ("hybrid", "auto") and green(hybrid):
+        return "hybrid"
+    return "replica"            # mode "replica", or no green leg of the kind that was asked for
+
+
+class OracleProbe:
+    """The fp64 CPU oracle beside the N > 1 legs (rank 0 only; round-4 review: the legs were only ever compared with the
+    single-GPU engine).  Built lazily -- host fp32 copies of the embeddings + the column-normalised matrix -- and shared
+    by the legs; check() compares a leg's ranked ids / scores for a few queries of the global batch."""
+
+    def __init__(self, kg, fact_emb, pass_emb):
+        self.kg, self.fact_emb, self.pass_emb, self.index = kg, fact_emb, pass_emb, None
+
+    def _build(self):
+        import oracle
+        kg = self.kg
+        a = oracle.build_symmetric_csr(kg.num_vertices, kg.src, kg.dst, kg.weight)
+        self.index = oracle.RefIndex(fact_emb=self.fact_emb.float().cpu().numpy(), passage_emb=self.pass_emb.float().cpu().numpy(),
+                                     subj_vertex=kg.subj_vertex, obj_vertex=kg.obj_vertex, num_chunks=kg.num_chunks,
+                                     passage_vertex=kg.passage_vertex, p=oracle.column_normalize(a))
+
+    def check(self, qf, qp, doc_idx, doc_score, rows):
+        """qf / qp: query tensors of the batch; doc_idx / doc_score: the leg's result rows for the same batch positions;
+        rows: the positions to check.  Returns the parity record."""
+        import oracle
+        from oracle.checks import ranked_parity
+        if self.index is None:
+            self._build()
+        qf_h, qp_h = qf.float().cpu().numpy(), qp.float().cpu().numpy()
+        ids, sc = doc_idx.cpu().numpy(), doc_score.cpu().numpy()
+        ok, worst, exact, n = True, 0.0, 0, 0
+        for q in rows:
+            ref = oracle.retrieve_one(self.index, qf_h[q], qp_h[q])
+            rep = ranked_parity(ids[q], sc[q], ref.sorted_doc_ids, ref.sorted_doc_scores, ref.x[self.kg.passage_vertex])
+            ok = ok and rep["equal"] and rep["worst_rel_err"] < 1e-5
+            worst = max(worst, rep["worst_rel_err"])
+            exact += rep["exact_positions"]; n += rep["n"]
+        return {"against": "fp64 CPU oracle (oracle.retrieve_one), rank 0", "queries": [int(q) for q in rows],
+                "topk_ids_equal": bool(ok), "exact_id_fraction": exact / max(n, 1), "max_rel_score_err": worst, "ok": bool(ok)}
+
+
+    def check_guarded(self, *a):
+        """check(), never raising: rank 0 must reach the barrier behind the probe whatever the oracle does (a missing
+        module, a numerical error) -- the other ranks are waiting there (round-5 advice)."""
+        try:
+            return self.check(*a)
+        except Exception as exc:
+            return {"against": "fp64 CPU oracle (oracle.retrieve_one), rank 0", "ok": False,
+                    "error": f"{type(exc).__name__}: {exc}"}
+
+
+def bench_main(args, configs, rank: int, local_rank: int, world: int, roofline_fn=None) -> int:
+    torch, dist = _td()
+    from hipporag_amd import synth
+    from hipporag_amd.engine import HippoRAGEngine
+
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks "
+                         f"(plain `python bench.py --gpus {args.gpus}` spawns them itself; or "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < world:
+        raise SystemExit(f"bench.py --gpus {world} needs {world} GPUs on this node (one rank per device); "
+                         f"{n_dev} visible to rank {rank}")
+    cfg = configs[args.config]
+    strong = "global_batch" in cfg                  # configs[3]: the global batch is fixed, the per-GPU batch shrinks
+    if strong and not args.batch and cfg["global_batch"] % world:
+        raise SystemExit(f"--config {args.config}: the global batch {cfg['global_batch']} is not a multiple of --gpus {world}")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1:      # HRAG_FORCE_DIST=1 on one GPU without a launcher: a rendezvous with ourselves
+        from hipporag_amd.launch import free_port
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+    # RCCL prints its version banner on the C-level stdout when the first communicator comes up: send that to stderr so
+    # that the ONE JSON line is the only thing rank 0 ever writes to stdout (an external launcher does not filter)
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.barrier()
+        torch.cuda.synchronize()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    finally:
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    V, E, D, seed = cfg["V"], cfg["E"], cfg["D"], cfg["seed"]
+    # per-GPU batch: fixed (weak scaling), or the fixed global batch dealt to the GPUs (strong scaling, configs[3])
+    B = args.batch or (cfg["global_batch"] // world if strong else cfg["B"])
+    K_F, K_P, ITERS, DAMP, PW = 5, 200, 20, 0.5, 0.05
+
+    kg = synth.make_kg(V, E, seed, power_law=bool(cfg.get("power_law")))   # same seed on every rank => identical index
+    emb_dtype = torch.float16 if cfg.get("fp16") else torch.bfloat16
+    pass_emb = synth.make_embeddings_torch(kg.n_passages, D, seed + 1, dev, dtype=emb_dtype)
+    fact_emb = synth.make_embeddings_torch(kg.n_facts, D, seed + 2, dev, dtype=emb_dtype)
+    n_batches = args.steps + args.warmup
+    cnt = torch.full((B,), K_F, dtype=torch.int32, device=dev)
+
+    def barrier_sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(seconds: float) -> float:
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---------------- replica mode: every rank serves its own B queries ----------------------
+    eng = HippoRAGEngine(kg.csr, kg.passage_vertex, pass_emb, fact_emb, kg.subj_vertex, kg.obj_vertex,
+                         kg.num_chunks, max_batch=B, max_topk=K_P, slab_width=args.slab_width,
+                         locality=getattr(args, "locality", None))
+    qf = [synth.make_queries_torch(fact_emb, B, seed + 100 + i + 1000 * rank)[0] for i in range(n_batches)]
+    qp = [synth.make_queries_torch(pass_emb, B, seed + 500 + i + 1000 * rank)[0] for i in range(n_batches)]
+
+    def step(i):
+        idx, sc = eng.score_facts(qf[i], k=K_F)
+        return eng.retrieve(qp[i], idx, sc, cnt, link_top_k=K_F, damping=DAMP, passage_node_weight=PW,
+                            ppr_iters=ITERS, k=K_P)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier_sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_batches):
+        step(i)
+    barrier_sync()
+    replica_s = max_over_ranks(time.perf_counter() - t0)
+    replica_qps = world * B * args.steps / replica_s
+    # phase breakdown + the dominant kernel's roofline, measured on this rank's engine (every rank runs
+    # it so that the ranks stay in step; rank 0 reports)
+    roofline = phases = None
+    if roofline_fn is not None:
+        eng.set_profiling(True)
+        step(n_batches - 1)
+        torch.cuda.synchronize()
+        phases = eng.timings()
+        eng.set_profiling(False)
+        roofline, _, _ = roofline_fn(eng, kg, V, B, phases, args.config, getattr(args, "sweep_launches", 40))
+        barrier_sync()
+    result = {
+        "metric": "retrieval_queries_per_sec", "value": replica_qps, "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": replica_s * 1e3 / max(args.steps, 1), "higher_is_better": True,
+        "scaling": "strong" if strong and not args.batch else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "value_leg": "replica",
+        "config": {"workload": cfg["label"], "V": V, "E": E, "nnz": kg.csr.nnz,
+                   "n_passages": kg.n_passages, "n_facts": kg.n_facts, "dim": D,
+                   "global_batch": world * B, "per_gpu_batch": B, "ppr_iters": ITERS,
+                   "linking_top_k": K_F, "retrieval_top_k": K_P,
+                   "parallelism": f"replica x{world} (queries sharded, no data-path collective)"},
+        "roofline": roofline,
+        "phases_ms": ({k: phases[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")}
+                      if phases else None),
+        "replica": {"value": replica_qps, "unit": "queries/s", "ms_per_step": replica_s * 1e3 / max(args.steps, 1),
+                    "parallelism": f"replica x{world}: every GPU holds the whole index and serves its own {B} queries"},
+        "rowshard": None, "hybrid": None,
+        "value_rowshard": None, "value_hybrid": None, "value_replica": replica_qps,
+        "multi_gpu_note": "`value` = the ROW-SHARDED leg when it is parity-green (`value_leg` names the leg): CSR rows + "
+                          "embeddings sharded over the GPUs, one collective on the e4m3 PPR iterate per sweep -- the layout "
+                          "BASELINE.json's north star names (SURVEY.md 8(e): the primary figure).  `value_hybrid` "
+                          "(embeddings sharded, PPR query-parallel, no per-sweep collective: the faster design) and "
+                          "`value_replica` (nothing sharded) are always printed beside it; a weak-scaling run on "
+                          "configs[2] also carries `configs3_strong` = BASELINE configs[3]'s global batch of 1024 on the "
+                          "same index.  No multi-GPU box was available to the rounds that wrote this code: every "
+                          "N > 1 figure is the driver's to take",
+    }
+
+    # The sharded legs must never cost the line: a watchdog prints what has been measured (rank 0) and ends the
+    # process if a leg or the teardown stalls.
+    import threading
+    printed = threading.Event()
+    hybrid_box, strong_box, rowshard_box = {}, {}, {}
+
+    def emit(rowshard):
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            result["rowshard"] = rowshard
+            result["hybrid"] = hybrid_box.get("res")
+            for name in ("rowshard", "hybrid"):
+                leg = result[name]
+                result["value_" + name] = leg.get("value") if isinstance(leg, dict) else None
+            if strong_box:
+                result["configs3_strong"] = dict(strong_box)      # a snapshot: the main thread may still be filling it
+            pick = pick_value_leg(getattr(args, "mode", "auto"), hybrid_box.get("res"), rowshard)
+            if pick != "replica":
+                # primary number = a leg that shards the CORPUS; the replica figure stays beside it
+                leg = result[pick]
+                result["value"], result["ms_per_step"] = leg["value"], leg["ms_per_step"]
+                result["config"]["parallelism"] = leg["parallelism"]
+            result["value_leg"] = pick
+            try:   # RCCL's version banner sits in the C stdio buffer: emit it first so that the JSON is the last line
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(json.dumps(result), flush=True)
+
+    def watchdog(limit_s, why):
+        done = threading.Event()
+
+        def run():
+            if not done.wait(limit_s):
+                # a row-sharded leg that FINISHED (parity-green or not) survives a stall in the work behind it
+                emit(rowshard_box.get("res") or {"error": f"{why} exceeded {limit_s:.0f} s; leg abandoned"})
+                os._exit(0)
+        threading.Thread(target=run, daemon=True).start()
+        return done
+
+    limit = float(getattr(args, "rowshard_timeout_s", 240.0))
+    rowshard = None
+    if getattr(args, "no_rowshard", False) or limit <= 0:
+        rowshard = {"skipped": True}
+    else:
+        leg_done = watchdog(limit, "hybrid + row-sharded legs")
+        sidx = seng = None
+        try:
+            gb = world * B
+            sidx = shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+            seng = build_shard_engine(sidx, pass_emb, fact_emb, rank, gb, K_P)
+        except Exception as exc:
+            rowshard = {"error": f"shard engine: {type(exc).__name__}: {exc}"}
+        if seng is not None:
+            probe = OracleProbe(kg, fact_emb, pass_emb) if rank == 0 and not getattr(args, "no_cpu_baseline", False) else None
+            ctx = dict(args=args, kg=kg, sidx=sidx, seng=seng, pass_emb=pass_emb, fact_emb=fact_emb, rank=rank, world=world,
+                       K_F=K_F, K_P=K_P, ITERS=ITERS, DAMP=DAMP, PW=PW, seed=seed, dev=dev, barrier_sync=barrier_sync,
+                       max_over_ranks=max_over_ranks, replica_eng=eng, probe=probe)
+            try:    # embeddings row-sharded, PPR query-parallel (no exchange in the PPR)
+                hybrid_box["res"] = _hybrid_leg(B=B, **ctx)
+            except Exception as exc:
+                hybrid_box["res"] = {"error": f"{type(exc).__name__}: {exc}"}
+            try:
+                rowshard = _rowshard_leg(B=B, **ctx)
+            except Exception as exc:  # the replica measurement above stays valid; report instead of dying
+                rowshard = {"error": f"{type(exc).__name__}: {exc}"}
+            rowshard_box["res"] = rowshard
+            # BASELINE configs[3] in the same line: a weak-scaling run on configs[2] (per-GPU batch 256) also measures the
+            # STRONG figure -- the same index, global batch 1024 whatever N is -- so that one driver command yields both
+            gb3 = int(os.environ.get("HRAG_STRONG_GLOBAL_BATCH", "1024"))     # env: exercise the code on one GPU (world 1)
+            if (not strong and not args.batch and (world > 1 or "HRAG_STRONG_GLOBAL_BATCH" in os.environ)
+                    and args.config == "cfg3" and gb3 % world == 0 and gb3 // world <= B
+                    and not getattr(args, "no_strong", False)):
+                b3 = gb3 // world
+                strong_box.update({"workload": "configs[3]: the same 1M-node/10M-edge index sharded across the GPUs of one node, "
+                                               f"GLOBAL batch {gb3} ({b3} per GPU): strong scaling", "global_batch": gb3,
+                                   "per_gpu_batch": b3})
+                for name, fn in (("rowshard", _rowshard_leg), ("hybrid", _hybrid_leg)):
+                    try:
+                        strong_box[name] = fn(B=b3, **dict(ctx, probe=None, seed=seed + 50000))
+                    except Exception as exc:
+                        strong_box[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                    strong_box["value_" + name] = strong_box[name].get("value")
+                try:
+                    sq = [synth.make_queries_torch(fact_emb, b3, seed + 61000 + i + 1000 * rank)[0] for i in range(2 + args.steps)]
+                    sp = [synth.make_queries_torch(pass_emb, b3, seed + 62000 + i + 1000 * rank)[0] for i in range(2 + args.steps)]
+
+                    def step3(i):
+                        i3, s3 = eng.score_facts(sq[i], k=K_F)
+                        return eng.retrieve(sp[i], i3, s3, cnt[:b3], link_top_k=K_F, damping=DAMP, passage_node_weight=PW,
+                                            ppr_iters=ITERS, k=K_P)
+                    step3(0); step3(1)
+                    barrier_sync()
+                    t3 = time.perf_counter()
+                    for i in range(2, 2 + args.steps):
+                        step3(i)
+                    barrier_sync()
+                    s3 = max_over_ranks(time.perf_counter() - t3)
+                    strong_box["value_replica"] = gb3 * args.steps / s3
+                except Exception as exc:
+                    strong_box["value_replica"] = None
+                    strong_box["replica_error"] = f"{type(exc).__name__}: {exc}"
+                pick3 = pick_value_leg(getattr(args, "mode", "auto"), strong_box.get("hybrid"), strong_box.get("rowshard"))
+                strong_box["value_leg"] = pick3
+                strong_box["value"] = strong_box.get("value_" + pick3)
+            seng.close()
+        leg_done.set()
+    eng.close()
+    emit(rowshard)
+    teardown_done = watchdog(30.0, "process-group teardown")
+    dist.barrier()
+    dist.destroy_process_group()
+    teardown_done.set()
+    return 0
+
+
+def _hybrid_leg(*, args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW, seed, dev,
+                barrier_sync, max_over_ranks, replica_eng, probe=None):
+    """The global batch (world * B) in the hybrid mode: every rank scores all queries against ITS embedding rows, one
+    all-to-all hands it the passage-score rows of its B queries, the PPR runs on the rank's own (replicated-graph)
+    engine without any exchange.  Checked bit for bit against the single-GPU engine on the rank's queries (every rank)
+    and, with `probe`, against the fp64 oracle on 4 of rank 0's queries."""
+    torch, dist = _td()
+    from hipporag_amd import synth
+    from hipporag_amd.engine import ShardStages
+    gb = world * B
+    hy = HybridRetriever(ShardStages(seng), replica_eng, TorchComm(rank, world), sidx.passages)
+    steps, warm = max(1, args.steps), max(1, min(args.warmup, 2))
+    n = steps + warm
+    gqf = [synth.make_queries_torch(fact_emb, gb, seed + 7000 + i)[0] for i in range(n)]
+    gqp = [synth.make_queries_torch(pass_emb, gb, seed + 7500 + i)[0] for i in range(n)]
+    gcnt = torch.full((gb,), K_F, dtype=torch.int32, device=dev)
+    kw = dict(link_top_k=K_F, damping=DAMP, passage_node_weight=PW, ppr_iters=ITERS, k=K_P)
+
+    def step(i):
+        idx, sc = hy.score_facts(gqf[i], k=K_F)
+        return idx, sc, hy.retrieve(gqp[i], idx, sc, gcnt, **kw)
+
+    for i in range(warm):
+        step(i)
+    barrier_sync()
+    t0 = time.perf_counter()
+    for i in range(warm, n):
+        idx, sc, out = step(i)
+    barrier_sync()
+    sec = max_over_ranks(time.perf_counter() - t0)
+    mine = hy.my_rows(gb)
+    i1, s1 = replica_eng.score_facts(gqf[n - 1][mine], k=K_F)
+    one = replica_eng.retrieve(gqp[n - 1][mine], i1, s1, gcnt[mine], **kw)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(out.doc_idx, one.doc_idx) and torch.equal(out.doc_score, one.doc_score) and
+                torch.equal(idx[mine], i1) and torch.equal(sc[mine], s1))
+    ok = torch.tensor([1 if same else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    parity = {"against": "single-GPU engine on this rank's queries, every rank", "bit_identical_on_every_rank": bool(ok.item() == 1),
+              "ok": bool(ok.item() == 1)}
+    if probe is not None:       # rank 0's slice of the last global batch starts at row 0
+        rows = sorted({0, B // 3, (2 * B) // 3, B - 1})
+        parity["vs_oracle"] = probe.check_guarded(gqf[n - 1][mine], gqp[n - 1][mine], out.doc_idx, out.doc_score, rows)
+        parity["ok"] = bool(parity["ok"] and parity["vs_oracle"]["ok"])
+    barrier_sync()               # the other ranks wait for rank 0's oracle queries here, not inside a later collective
+    np_total = len(sidx.passage_vertex)
+    return {"value": gb * steps / sec, "unit": "queries/s", "global_batch": gb, "steps": steps,
+            "ms_per_step": sec * 1e3 / steps,
+            "parallelism": f"hybrid x{world}: fact / passage embeddings row-sharded, one all-to-all of passage-score rows, "
+                           f"PPR query-parallel on a replicated graph (no exchange)",
+            "wire_bytes_per_global_batch_total": int((world - 1) / world * gb * np_total * 4 + world * (world - 1) * gb * K_F * 8),
+            "wire_bytes_received_per_gpu_per_global_batch": int((world - 1) / world * B * np_total * 4 + (world - 1) * gb * K_F * 8),
+            "parity": parity}
+
+
+def _rowshard_leg(*, args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K_F, K_P, ITERS, DAMP, PW, seed, dev,
+                  barrier_sync, max_over_ranks, replica_eng, probe=None):
+    """The global batch (world * B) over the row-sharded corpus: fp8-state shards, one collective per exchange group and
+    sweep (--collective allgather | allreduce); checked against the single-GPU engine on the same queries and, with
+    `probe`, against the fp64 oracle on 4 queries of the global batch (rank 0)."""
+    torch, dist = _td()
+    from hipporag_amd import synth
+    from hipporag_amd.engine import ShardStages
+    gb = world * B
+    groups = int(getattr(args, "exchange_groups", 2))
+    collective = getattr(args, "collective", "allgather")
+    rs = ShardedRetriever(ShardStages(seng), TorchComm(rank, world, collective=collective), groups=groups)
+    rs_steps, rs_warm = max(1, args.steps), max(1, min(args.warmup, 2))
+    n = rs_steps + rs_warm
+    gqf = [synth.make_queries_torch(fact_emb, gb, seed + 9000 + i)[0] for i in range(n)]
+    gqp = [synth.make_queries_torch(pass_emb, gb, seed + 9500 + i)[0] for i in range(n)]
+    gcnt = torch.full((gb,), K_F, dtype=torch.int32, device=dev)
+
+    def rs_step(i):
+        idx, sc = rs.score_facts(gqf[i], k=K_F)
+        return rs.retrieve(gqp[i], idx, sc, gcnt, link_top_k=K_F, damping=DAMP, passage_node_weight=PW,
+                           ppr_iters=ITERS, k=K_P, check_saturation=False)      # flags are checked after the timed loop
+
+    for i in range(rs_warm):
+        rs_step(i)
+    barrier_sync()
+    t0 = time.perf_counter()
+    for i in range(rs_warm, n):
+        out = rs_step(i)
+    barrier_sync()
+    rs_s = max_over_ranks(time.perf_counter() - t0)
+    # parity: the last global batch's first B queries through the single-GPU engine of this rank
+    qf, qp = gqf[n - 1][:B], gqp[n - 1][:B]
+    idx1, sc1 = replica_eng.score_facts(qf, k=K_F)
+    one = replica_eng.retrieve(qp, idx1, sc1, gcnt[:B], link_top_k=K_F, damping=DAMP, passage_node_weight=PW,
+                               ppr_iters=ITERS, k=K_P)
+    torch.cuda.synchronize()
+    ids_s, sc_s = out[0][:B].cpu().numpy(), out[1][:B].cpu().numpy()
+    ids_1, sc_1 = one.doc_idx.cpu().numpy(), one.doc_score.cpu().numpy()
+    same_ids = float((ids_s == ids_1).mean())
+    rel = np.abs(sc_s - sc_1) / np.maximum(np.abs(sc_1), 1e-30)
+    flags_any = int(out[2].max().item())
+    parity = {"against": "single-GPU engine, same queries (first per-GPU batch of the last global batch)",
+              "queries": int(B), "fraction_of_ranked_ids_equal": same_ids, "max_rel_score_diff": float(rel.max()),
+              "flags_or": flags_any, "ok": bool(rel.max() < 1e-5 and same_ids > 0.999 and not (flags_any & 8))}
+    if probe is not None:       # queries spread over the WHOLE global batch (every rank's rows of the merged result)
+        rows = sorted({0, gb // 3, (2 * gb) // 3, gb - 1})
+        parity["vs_oracle"] = probe.check_guarded(gqf[n - 1], gqp[n - 1], out[0], out[1], rows)
+        parity["ok"] = bool(parity["ok"] and parity["vs_oracle"]["ok"])
+    barrier_sync()
+    lay = seng.shard_layout(gb, groups)
+    wire = (world - 1) / world * sidx.num_vertices * 128 * lay.n_slabs     # e4m3 bytes each GPU receives per sweep
+    if collective == "allreduce":
+        wire *= 2                                                          # ring all-reduce: reduce-scatter + all-gather
+    nnz_own = int(sidx.csr.row_ptr[(rank + 1) * sidx.rows_per_shard] - sidx.csr.row_ptr[rank * sidx.rows_per_shard])
+    return {"value": gb * rs_steps / rs_s, "unit": "queries/s", "global_batch": gb, "steps": rs_steps,
+            "ms_per_step": rs_s * 1e3 / rs_steps,
+            "parallelism": f"rowshard x{world}: CSR rows + passage / fact embeddings sharded, e4m3 PPR iterate "
+                           f"replicated, one {collective} per exchange group and sweep",
+            "exchange": ("in-place all_gather_into_tensor of the owners' row blocks (RCCL)" if collective == "allgather" else
+                         "all-reduce SUM over the group region with the foreign blocks zeroed (the north star's literal form)")
+                        + f", {lay.n_groups} exchange group(s) pipelined against the sweeps of the other group(s)",
+            "collective": collective,
+            "wire_bytes_received_per_gpu_per_sweep": wire, "state_bytes_per_buffer": int(lay.state_bytes),
+            "n_slabs": int(lay.n_slabs), "exchange_groups": int(lay.n_groups),
+            "wire_bytes_received_per_gpu_per_global_batch": wire * ITERS,
+            "rows_per_shard": int(sidx.rows_per_shard), "nnz_this_shard": nnz_own, "parity": parity}

@@ -265,6 +265,7 @@ struct Ppr8Args {
     float *est_ws = nullptr;   // scratch [n_slabs][m.n_pchunks][128]: the maximum of every wavefront that holds a passage row
 };
 hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, bool main_only, hipStream_t s);
+hrag_status launch_ppr8_gather_replay(const Ppr8Args &a, hipStream_t s);   // measurement only (ppr8.hip)
 // c_0 = Q(v/d * c0_scale) on the owned rows of slabs [slab0, slab0 + n_slabs)
 hrag_status launch_ppr8_init(const Ppr8Args &a, float c0_scale, hipStream_t s);
 // per-query statistics of the passage prior over the OWNED passages (scores fp32 [B, ld], local order):

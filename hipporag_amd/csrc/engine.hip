@@ -1388,8 +1388,10 @@ hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damp
                      "no fp8 PPR state for batch %d (needs col_sum, max_batch > 64 and a preceding hrag_retrieve)", batch);
         const int mode = (flags >> 4) & 3;   // 0 = C, 1 = B, 2 = F, 3 = B0 (Ppr8Mode)
         const int rio = (flags >> 6) & 3;    // residual form of B / F (Ppr8Args.rio)
-        for (int it = 0; it < n; ++it)
-            HRAG_TRY(ppr8_bench_sweep(e, mode, rio, it, (flags & 1) != 0, (hipStream_t)stream));
+        for (int it = 0; it < n; ++it) {
+            if (flags & 256) HRAG_TRY(ppr8_bench_gather_replay(e, it, (hipStream_t)stream));   // the gathers alone
+            else HRAG_TRY(ppr8_bench_sweep(e, mode, rio, it, (flags & 1) != 0, (hipStream_t)stream));
+        }
         return HRAG_OK;
     }
     if (flags & 2) {

@@ -320,4 +320,5 @@ hrag_status ppr8_doc_scores(hrag_engine *e, const float *mn, const float *mx, in
 // measurement hook: one launch of kernel mode `mode` over the buffers of the active session (it: parity of
 // the ping-pong); results are garbage, the memory traffic is that of a real sweep of that mode
 hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int rio, int it, bool main_only, hipStream_t s);
+hrag_status ppr8_bench_gather_replay(hrag_engine *e, int it, hipStream_t s);
 }  // namespace hrag

@@ -762,6 +762,48 @@ __device__ __forceinline__ void ppr8_pair_body(const Ppr8Args &a) {
 template <int MODE, int RIO, bool EST>
 __global__ __launch_bounds__(256, 2) void ppr8_pair_kernel(const Ppr8Args a) { ppr8_pair_body<MODE, RIO, EST>(a); }
 
+// Measurement only (hrag_ppr_sweeps flag 256; bench.py `roofline.gather_replay_ms`): the GATHERS of a stage sweep and
+// nothing else -- the same workgroup -> (chunk, slab pair) map, the same (col, val) stream read two steps ahead, the
+// same sixteen 16-byte loads per lane and step (one 256-byte piece of the state per matrix slot), no right-hand side,
+// no residual, no arithmetic beyond an XOR that keeps the loads alive, nothing stored.  What it takes is the floor of
+// ANY sweep that fetches the state row of every slot of this matrix once: the ceiling of the formulation, measured on
+// the engine's own matrix and state.
+__global__ __launch_bounds__(256, 2) void ppr8_pair_replay_kernel(const Ppr8Args a) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & 7;
+    const int id = blockIdx.x, wps = a.wps, nsg = (a.n_slabs >> 1) / wps, wave = threadIdx.x >> 6;
+    const int slab = a.slab0 + 2 * (((id >> 3) % nsg) * wps + (wave & (wps - 1)));
+    const int cg = a.cg_per_xcd > 0 ? (id & 7) * a.cg_per_xcd + id / (8 * nsg) : (id / (8 * nsg)) * 8 + (id & 7);
+    const int chunk = __builtin_amdgcn_readfirstlane(cg * (4 / wps) + wave / wps);
+    if (chunk >= a.m.n_chunks) return;
+    const int2 meta = a.m.chunk_meta[chunk];
+    const int n_steps = meta.y;
+    const int g = slab / a.spg, k = slab - g * a.spg;
+    const char *xs = reinterpret_cast<const char *>(a.x) + (size_t)g * (size_t)a.group_bytes + (size_t)k * 128;
+    const unsigned stride = a.row_stride;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int2 *>(a.m.pairs), 0, (int)a.m.pairs_bytes, 0x00020000);
+    const unsigned pbase = (unsigned)meta.x * 512u;
+    const unsigned poff = (unsigned)lane * 8u;
+    const unsigned lane_off = (unsigned)gl * 16u;
+    v4i_t sink = {0, 0, 0, 0};
+    int2 p0 = ld_pair(prs, poff, pbase);
+    int2 p1 = ld_pair(prs, poff + 512u, pbase);
+    for (int s = 0; s < n_steps; ++s) {
+        const int2 p2 = ld_pair(prs, poff + (unsigned)(s + 2) * 512u, pbase);
+        v4i_t x0[8], x1[8];
+        float wk[8];
+        Gather8P<0>::load(x0, x1, wk, p0.x, p0.y, xs, stride, lane_off);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) sink ^= x0[kk] ^ x1[kk];
+        p0 = p1;
+        p1 = p2;
+    }
+    // never true for an e4m3 state (0x7f / 0xff bytes are NaN and are never stored): keeps the loads, stores nothing
+    if ((sink.x ^ sink.y ^ sink.z ^ sink.w) == 0x7f7f7f7f && a.flags) atomicOr(a.flags, 0);
+}
+
 // c_0 = Q(v/d * c0_scale) on the OWNED rows of the launch's slabs that carry a teleport row (passages, seeds): it is
 // zero elsewhere, and its only reader, the first boundary sweep (mode B0: R_0 = b v/d is formed on the fly), neither
 // gathers a column outside the bitmap of those rows nor reads its own c there -- 7/8 of the state is not written.
@@ -1080,6 +1122,21 @@ hrag_status launch_ppr8_sweep(const Ppr8Args &a, int mode, bool main_only, hipSt
     HRAG_TRY(sweep_dispatch(a, mode, main_only, s));
     if (a.est && mode == kP8ModeF)   // column maxima of the per-wavefront scratch
         return launch_est_reduce(a.est_ws, a.m.n_pchunks, 128, a.slab0, a.n_slabs, a.batch, a.est, a.gate, a.gate_want, s);
+    return HRAG_OK;
+}
+
+hrag_status launch_ppr8_gather_replay(const Ppr8Args &a_in, hipStream_t s) {
+    Ppr8Args b = a_in;
+    if (!(b.m.n_chunks > 0 && b.spg % 2 == 0 && b.slab0 % 2 == 0 && b.n_slabs >= 2 && b.n_slabs % 2 == 0)) {
+        set_error("gather replay: needs a slab-pair state (an even number of 128-query slabs, batch > 128)");
+        return HRAG_EINVAL;
+    }
+    const int np = b.n_slabs / 2;
+    b.wps = (a_in.wps == 4 && np % 4 == 0) ? 4 : (a_in.wps >= 2 && np % 2 == 0) ? 2 : 1;
+    const unsigned ncg = (unsigned)ceil_div(b.m.n_chunks, 4 / b.wps);
+    if (b.cg_per_xcd) b.cg_per_xcd = (int32_t)(round_up(ncg, 8) / 8);
+    hipLaunchKernelGGL(ppr8_pair_replay_kernel, dim3((unsigned)round_up(ncg, 8) * (unsigned)(np / b.wps)), dim3(256), 0, s, b);
+    HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }
 

@@ -479,6 +479,15 @@ hrag_status ppr8_bench_sweep(hrag_engine *e, int mode, int rio, int it, bool mai
     return launch_ppr8_sweep(a, mode, main_only, s);
 }
 
+// hrag_ppr_sweeps flag 256: the gathers of a stage sweep alone, on the session's matrix and state (measurement only)
+hrag_status ppr8_bench_gather_replay(hrag_engine *e, int it, hipStream_t s) {
+    const Ppr8Session &p = e->p8;
+    HRAG_REQUIRE(p.active, "no fp8 PPR session");
+    Ppr8Args a = base_args(e);
+    a.x = p.buf[it & 1];
+    return launch_ppr8_gather_replay(a, s);
+}
+
 hrag_status ppr8_doc_scores(hrag_engine *e, const float *mn, const float *mx, int32_t *flags, int32_t batch,
                             hipStream_t s, bool fp8_session) {
     SlabLayout l64;

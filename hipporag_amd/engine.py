@@ -531,12 +531,15 @@ class HippoRAGEngine:
         return x, flags
 
     def ppr_sweeps(self, batch: int, n: int, damping: float = 0.5, main_only: bool = False,
-                   f16: bool = False, small: bool = False, f8: bool = False, f8_mode: str = "C", f8_rio: int = 0):
+                   f16: bool = False, small: bool = False, f8: bool = False, f8_mode: str = "C", f8_rio: int = 0,
+                   f8_gather_replay: bool = False):
         """Measurement hook: n sweeps of the fp32 slab kernel, of the fp16-state kernel (f16=True), of
         the small-batch kernel (small=True, batch <= 8) or of the fp8-state kernel (f8=True; f8_mode picks
-        the kernel instantiation: "C" stage sweep, "B" boundary, "B0" first boundary, "F" final)."""
+        the kernel instantiation: "C" stage sweep, "B" boundary, "B0" first boundary, "F" final;
+        f8_gather_replay=True: only the state-row gathers of a stage sweep, nothing computed or written)."""
         flags = (1 if main_only else 0) | (2 if f16 else 0) | (4 if small else 0) | (8 if f8 else 0)
         flags |= ({"C": 0, "B": 1, "F": 2, "B0": 3}[f8_mode] << 4) | ((f8_rio & 3) << 6)
+        flags |= 256 if (f8 and f8_gather_replay) else 0
         check(self._lib.hrag_ppr_sweeps(self._handle, batch, n, damping, flags, _stream()))
 
     def _is_undirected(self) -> bool:

@@ -136,6 +136,25 @@ def spawn_ranks(world: int, cmd: Sequence[str], *, timeout_s: Optional[float] = 
             out.flush()
 
 
+def visible_gpu_count() -> Optional[int]:
+    """HIP devices visible to this process, WITHOUT importing torch (the first `import torch` on a fresh box pages the
+    image in for a minute or two): hipGetDeviceCount through ctypes.  None when libamdhip64 cannot be loaded (the caller
+    then lets the ranks find out)."""
+    import ctypes
+    for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            lib = ctypes.CDLL(name)
+        except OSError:
+            continue
+        n = ctypes.c_int(0)
+        try:
+            rc = lib.hipGetDeviceCount(ctypes.byref(n))
+        except Exception:
+            return None
+        return int(n.value) if rc == 0 else 0
+    return None
+
+
 def self_spawn(world: int, script: str, argv: Sequence[str], **kw) -> int:
     """`python script argv...` as `world` ranks (what bench.py does for --gpus N when no launcher set WORLD_SIZE)."""
     return spawn_ranks(world, [sys.executable, script, *argv], **kw)

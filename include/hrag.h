@@ -405,7 +405,10 @@ hrag_status hrag_split_f32(const float *x_dev, int64_t rows, int32_t dim, int32_
  * flags bit3: the fp8-state kernel over the buffers of the last hrag_retrieve (HRAG_EINVAL without col_sum /
  *             max_batch <= 64 / batch <= 64 / no preceding hrag_retrieve); bits 4-5 pick the instantiation
  *             (0 stage sweep C, 1 boundary B, 2 final F, 3 first boundary B0), bits 6-7 the residual form of
- *             B / F (0 fp32, 2 fp32 in / 3-byte out, 3 3-byte in / out; F: 1 = 3-byte in). */
+ *             B / F (0 fp32, 2 fp32 in / 3-byte out, 3 3-byte in / out; F: 1 = 3-byte in);
+ *             with bit 3, bit 8 (256) = GATHER REPLAY: the state-row gathers of a stage sweep and nothing else
+ *             (same matrix, same state, same launch geometry; nothing is written) -- the floor of any sweep that
+ *             fetches one state row per matrix slot (bench.py roofline.gather_replay_ms). */
 hrag_status hrag_ppr_sweeps(hrag_engine *e, int32_t batch, int32_t n, float damping, int32_t flags,
                             hrag_stream stream);
 

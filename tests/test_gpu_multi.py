@@ -22,16 +22,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, backend="nccl", one_device=False):
     import torch
     import torch.distributed as dist
     from hipporag_amd import dist as hd, synth
     from hipporag_amd.engine import HippoRAGEngine, ShardStages
     from tests.helpers import make_case
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dev = torch.device("cuda", rank)
+    dev = torch.device("cuda", 0 if one_device else rank)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        make_comm = hd.TorchComm
+    else:       # two ranks on ONE device: RCCL has nothing to run on; the exchanges go through the host (gloo)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        make_comm = hd.HostStagedComm
     try:
         b = 512                                             # four 128-query slabs: two exchange groups of two
         kg, pass_bits, fact_bits, _ = make_case(12000, 120000, 128, seed=901)
@@ -43,7 +48,7 @@ def _worker(rank, world, port, ret):
         qf, qp = bf16(synth.make_queries_np(fact_bits, b, seed=3)[0]), bf16(synth.make_queries_np(pass_bits, b, seed=4)[0])
         cnt = torch.full((b,), 5, dtype=torch.int32, device=dev)
         kw = dict(link_top_k=5, damping=0.5, passage_node_weight=0.05, ppr_iters=20, k=100)
-        comm = hd.TorchComm(rank, world)
+        comm = make_comm(rank, world)
         seng = hd.build_shard_engine(sidx, pass_bits, fact_bits, rank, max_batch=b, max_topk=100, sell_seg_len=64)
         rs = hd.ShardedRetriever(ShardStages(seng), comm, groups=2)
         assert seng.shard_layout(b, 2).n_groups == 2
@@ -58,7 +63,7 @@ def _worker(rank, world, port, ret):
             assert torch.equal(idx, i1) and torch.equal(sc, s1)
             assert torch.equal(d_idx, o1.doc_idx) and torch.equal(d_sc, o1.doc_score) and int(flags.max()) == 0
         # ... and with the north star's literal exchange: all-reduce SUM over the bytes, foreign blocks zeroed
-        rs2 = hd.ShardedRetriever(ShardStages(seng), hd.TorchComm(rank, world, collective="allreduce"), groups=2)
+        rs2 = hd.ShardedRetriever(ShardStages(seng), make_comm(rank, world, collective="allreduce"), groups=2)
         i2, s2 = rs2.score_facts(qf, k=5)
         d2_idx, d2_sc, flags2 = rs2.retrieve(qp, i2, s2, cnt, **kw)
         torch.cuda.synchronize()
@@ -81,6 +86,21 @@ def _worker(rank, world, port, ret):
         ret[rank] = 1
     finally:
         dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_real_shard_kernels_over_gloo_match_the_single_gpu_engine():
+    """What CAN run on a one-GPU box (round-5 review, item 4a): TWO PROCESSES, each with its own row-shard engine on
+    cuda:0, a real torch.distributed group (gloo, exchanges staged through the host: dist.HostStagedComm) and the REAL
+    hrag_shard_* kernels -- the row-sharded retriever with both collectives and two exchange groups, and the hybrid
+    retriever, every result bit-identical to the single-GPU engine.  Until now real kernels had only met emulated
+    in-process ranks and real process groups only numpy stand-ins."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret, "gloo", True), nprocs=2, join=True)
+    assert dict(ret) == {0: 1, 1: 1}
 
 
 def test_rccl_rowshard_and_hybrid_on_two_gpus_match_the_single_gpu_engine():

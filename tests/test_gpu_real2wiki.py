@@ -1,4 +1,4 @@
-"""Parity of the HIP path on a graph with REAL topology (tests/real2wiki.py: the 2WikiMultihopQA corpus the reference
+"""Parity of the HIP path on a graph with REAL topology (tools/real2wiki.py: the 2WikiMultihopQA corpus the reference
 ships through a deterministic triple extractor; 46.9k vertices, 410k entries, 130k facts, hubs of degree ~2 900):
 every graph the suite ran on before was synth.make_kg's or a toy corpus.  256 queries (staged fp8 state) and 48 (two-stage
 fp16 state), against the fp64 oracle (reference call site HippoRAG.py:1736-1749), as numbered by the reference's rule
@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
-from tests import real2wiki as rw
+from tools import real2wiki as rw
 from tests.helpers import ranked_parity, write_test_report
 
 pytestmark = pytest.mark.gpu

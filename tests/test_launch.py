@@ -1,6 +1,6 @@
 """`python bench.py --gpus N` is its own launcher (hipporag_amd/launch.py): the driver runs exactly that command, with
 no torchrun in front.  CPU tests: the launcher with a stub worker (environment, rank 0's JSON line last, a dying rank
-ends the job), bench.py itself on this GPU-less box (must fail AFTER spawning, with the device-count message), and the
+ends the job), bench.py itself on this GPU-less box (must fail in seconds with ONE device-count line, before any rank starts), and the
 choice of the leg that becomes `value` at N > 1."""
 
 import io
@@ -9,11 +9,12 @@ import os
 import subprocess
 import sys
 import textwrap
+import time
 
 import pytest
 
 from hipporag_amd import launch
-from hipporag_amd.dist import pick_value_leg
+from bench_dist import pick_value_leg
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -65,16 +66,45 @@ def test_spawn_ranks_times_out(tmp_path):
     assert launch.spawn_ranks(2, cmd, out=out, err=err, timeout_s=1.0) == 124
 
 
-def test_bench_gpus_2_spawns_its_ranks_and_fails_on_the_device_count_here():
-    """On this GPU-less container the N > 1 bench must get as far as its ranks (no 'launch with torchrun' hint) and
-    fail there with the device-count message; nothing is printed on stdout."""
+def _bench_gpus_2(extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HRAG_FORCE_DIST")}
+    env.update(extra_env or {})
+    t0 = time.monotonic()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--config", "tiny"], env=env, capture_output=True, text=True, timeout=600)
+    return p, time.monotonic() - t0
+
+
+def test_bench_gpus_2_fails_fast_with_one_clear_line_where_there_are_fewer_gpus():
+    """`python bench.py --gpus 2` on a box with fewer than 2 GPUs (this container: none; a 1-GPU box: see the gpu test
+    below): ONE clear line on stderr, a non-zero exit code, nothing on stdout, in seconds -- the device count is taken
+    through ctypes before any rank (or torch) is started (round-5 review, item 4b)."""
+    p, dt = _bench_gpus_2()
     assert p.returncode != 0
     assert "needs 2 GPUs on this node" in p.stderr, p.stderr[-2000:]
-    assert "torch.distributed.run" not in p.stderr.split("needs 2 GPUs")[0][-400:]
+    assert len([ln for ln in p.stderr.splitlines() if ln.strip()]) == 1, p.stderr[-2000:]
+    assert "torch.distributed.run" not in p.stderr
     assert p.stdout.strip() == ""
+    assert dt < 10.0, dt
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_fails_fast_on_a_one_gpu_box():
+    """The same command on the GPU box the driver runs the suite on: with exactly one device visible it must end the
+    same way (skipped where 2+ devices are visible: there the command is a real run)."""
+    from hipporag_amd.launch import visible_gpu_count
+    if (visible_gpu_count() or 0) >= 2:
+        pytest.skip("2+ GPUs visible: `bench.py --gpus 2` is a real run here")
+    p, dt = _bench_gpus_2()
+    assert p.returncode != 0 and "needs 2 GPUs on this node" in p.stderr and p.stdout.strip() == "", (p.returncode, p.stderr[-1000:])
+    assert dt < 10.0, dt
+
+
+def test_the_ranks_still_check_the_device_count_themselves_under_an_external_launcher():
+    """With WORLD_SIZE set by a launcher the pre-check is not taken; rank 0 must refuse with the same message."""
+    env = {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(launch.free_port())}
+    p, _ = _bench_gpus_2(env)
+    assert p.returncode != 0 and "needs 2 GPUs on this node" in p.stderr, p.stderr[-2000:]
 
 
 def test_value_leg_prefers_a_parity_green_corpus_sharded_leg():

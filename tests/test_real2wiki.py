@@ -1,6 +1,6 @@
 """The real-topology fixture (tests/golden/real2wiki_triples.npz, tools/make_real2wiki.py: a deterministic LLM-free triple
 extractor over the corpus the reference ships) -- CPU side: the fixture is what its generator says, the direct numpy
-graph builder (tests/real2wiki.build_kg, used by `bench.py --config real2wiki`) gives the SAME graph as the mirror's
+graph builder (tools/real2wiki.build_kg, used by `bench.py --config real2wiki`) gives the SAME graph as the mirror's
 index_from_openie (the reference's rules, HippoRAG.py:867-957, :1159-1223), tiling keeps the per-tile graph, and the
 graph compiler's locality numbering finds the per-document locality a real corpus has."""
 
@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from tests import real2wiki as rw
+from tools import real2wiki as rw
 
 
 def test_fixture_shape():

@@ -22,8 +22,8 @@ from hipporag_amd.engine import HippoRAGEngine
 cfg = CONFIGS[os.environ.get("HRAG_PMC_CONFIG", "cfg3")]
 V, E, B, seed = cfg["V"], cfg["E"], int(os.environ.get("HRAG_PMC_BATCH", cfg["B"])), cfg["seed"]
 dev = torch.device("cuda", 0)
-if cfg.get("real2wiki"):      # the real-topology graph (tests/real2wiki.py), HRAG_PMC_CONFIG=real2wiki
-    from tests import real2wiki as rw
+if cfg.get("real2wiki"):      # the real-topology graph (tools/real2wiki.py), HRAG_PMC_CONFIG=real2wiki
+    from tools import real2wiki as rw
     kg = rw.build_kg(int(cfg["tiles"]))
 else:
     kg = synth.make_kg(V, E, seed, community=int(os.environ.get("HRAG_COMMUNITY", cfg.get("community", 0))))

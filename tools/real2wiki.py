@@ -24,7 +24,7 @@ import os
 
 import numpy as np
 
-FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real2wiki_triples.npz")
+FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "real2wiki_triples.npz")
 DIM = 64
 PRED = ("mentions", "co-occurs with")
 

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libhrag.so")
 
 HRAG_OK, HRAG_EINVAL, HRAG_ENOMEM, HRAG_EHIP, HRAG_EBUSY, HRAG_ECAPACITY = range(6)
 SEED_STRIDE = 32
-HRAG_VERSION = 6      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
+HRAG_VERSION = 7      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
 FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, FLAG_FP8_SATURATED, FLAG_NOT_CONVERGED = 1, 2, 4, 8, 16
 # the convergence contract's error bound (include/hrag.h): error <= max(PPR_ERR_K * residual, floor of the state type);
 # a tolerance below PPR_TOL_MIN is rejected (HRAG_EINVAL)
@@ -64,6 +64,20 @@ class ShardLayout(C.Structure):
                 ("own_offset", C.c_int64), ("own_bytes", C.c_int64)]
 
 
+class Stats(C.Structure):
+    """hrag_stats of include/hrag.h."""
+    _fields_ = [("is_workspace", C.c_int32), ("live_workspaces", C.c_int32), ("index_bytes", C.c_int64),
+                ("workspace_bytes", C.c_int64), ("ppr_states", C.c_int32), ("fp8_unavailable", C.c_int32),
+                ("last_ppr_state", C.c_int32), ("reserved", C.c_int32), ("calls_score_facts", C.c_int64),
+                ("calls_retrieve", C.c_int64), ("calls_dense_retrieve", C.c_int64), ("calls_ppr", C.c_int64),
+                ("calls_shard", C.c_int64), ("queries", C.c_int64)]
+
+
+PPR_STATE_F32, PPR_STATE_F16, PPR_STATE_SMALL, PPR_STATE_FP8 = 1, 2, 4, 8
+FP8_UNAVAILABLE = {1: "hrag_graph_desc.col_sum was not given", 2: "V + 1 > 2^24 vertices",
+                   4: "the passage shard is not aligned with the row shard", 8: "disabled by HRAG_OPT_F32_STATE / HRAG_OPT_NO_FP8",
+                   16: "max_batch <= 64 (never needed)"}
+
 _P = C.c_void_p
 _I32, _I64, _F32 = C.c_int32, C.c_int64, C.c_float
 
@@ -74,6 +88,8 @@ SIGNATURES = {
     "hrag_engine_create": (C.c_int, [C.POINTER(GraphDesc), C.POINTER(EmbedDesc), C.POINTER(EmbedDesc),
                                      C.POINTER(FactDesc), C.POINTER(Opts), C.POINTER(_P)]),
     "hrag_engine_destroy": (C.c_int, [_P]),
+    "hrag_workspace_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "hrag_engine_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "hrag_score_facts": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P]),
     "hrag_retrieve": (C.c_int, [_P, _P, _I32, _P, _P, _P, _I32, _I32, _F32, _F32, _I32, _I32, _F32, _I32, _P, _P, _P,
                                 _P, _P, _P]),

@@ -24,26 +24,46 @@ void free_store(Sell8Store &m) {
     m = Sell8Store();
 }
 
+// the per-call buffers of an engine handle: everything hrag_workspace_create allocates afresh
+static void workspace_ptrs(hrag_engine *e, std::vector<void **> &out) {
+    void **ptrs[] = {(void **)&e->d_partial, (void **)&e->d_x, (void **)&e->d_y, (void **)&e->d_tele, (void **)&e->d_tele_dense,
+                     (void **)&e->d_spass, (void **)&e->d_sfact, (void **)&e->d_doc, (void **)&e->d_mn_p, (void **)&e->d_mx_p,
+                     (void **)&e->d_seed_vtx, (void **)&e->d_seed_cnt, (void **)&e->d_flags, (void **)&e->d_seed_w,
+                     (void **)&e->d_colsum_partial, (void **)&e->d_sums, (void **)&e->d_partial16, (void **)&e->d_h16[0],
+                     (void **)&e->d_h16[1], (void **)&e->d_h16[2], (void **)&e->d_h16[3], (void **)&e->d_tele16,
+                     (void **)&e->d_row_slot, (void **)&e->d_qscale, (void **)&e->d_ssum, (void **)&e->d_tele_sv,
+                     (void **)&e->d_partial_sv, (void **)&e->d_topk_ws, (void **)&e->d_R8, (void **)&e->d_rho8,
+                     (void **)&e->d_partial8, (void **)&e->d_fused_ws, (void **)&e->d_mn_f, (void **)&e->d_mx_f,
+                     (void **)&e->d_fused_sel, (void **)&e->d_xp8, (void **)&e->d_colmask, (void **)&e->d_stagep,
+                     (void **)&e->d_pool8[0], (void **)&e->d_pool8[1], (void **)&e->d_pool8[2], (void **)&e->d_sv16[0],
+                     (void **)&e->d_sv16[1], (void **)&e->d_sv16[2], (void **)&e->d_sv16[3], (void **)&e->d_zmax_bits,
+                     (void **)&e->d_zmax, (void **)&e->d_mass, (void **)&e->d_prior_part, (void **)&e->d_est_f,
+                     (void **)&e->d_ctl, (void **)&e->d_iters_used, (void **)&e->d_resid, (void **)&e->d_mass_tab,
+                     (void **)&e->d_est_ws, (void **)&e->d_qsplit, (void **)&e->d_dyn, (void **)&e->d_mmax_ws,
+                     (void **)&e->d_mmax_word, (void **)&e->sell.lcount, (void **)&e->fsell.lcount};
+    out.assign(std::begin(ptrs), std::end(ptrs));
+}
+
 void free_engine(hrag_engine *e) {
     if (!e) return;
-    void *ptrs[] = {e->d_row_ptr, e->d_col, e->d_val, e->d_row_order, e->d_seg_row, e->d_seg_begin,
-                    e->d_seg_end, e->d_seg_slot, e->d_mrow_row, e->d_mrow_first, e->d_mrow_cnt, e->d_partial,
-                    e->d_passage_vertex, e->d_row_to_tele, e->d_pemb, e->d_femb, e->d_subj, e->d_obj,
-                    e->d_num_chunks, e->d_x, e->d_y, e->d_tele, e->d_tele_dense, e->d_spass,
-                    e->d_sfact, e->d_doc, e->d_mn_p, e->d_mx_p, e->d_seed_vtx, e->d_seed_cnt,
-                    e->d_flags, e->d_seed_w, e->d_colsum_partial, e->d_sums, e->d_partial16, e->d_h16[0],
-                    e->d_h16[1], e->d_h16[2], e->d_h16[3], e->d_tele16, e->d_row_slot, e->d_qscale,
-                    e->d_ssum, e->d_tele_sv, e->d_partial_sv, e->d_topk_ws, e->d_deg,
-                    e->d_pinvdeg, e->d_R8, e->d_rho8, e->d_partial8, e->d_fused_ws, e->d_mn_f, e->d_mx_f, e->d_fused_sel,
-                    e->d_xp8, e->d_row_ptele, e->d_iso, e->d_piso, e->d_colmask_static, e->d_colmask,
-                    e->d_stagep, e->d_pool8[0], e->d_pool8[1], e->d_pool8[2], e->d_sv16[0], e->d_sv16[1],
-                    e->d_sv16[2], e->d_sv16[3], e->d_zmax_bits, e->d_zmax,
-                    e->d_mass, e->d_prior_part, e->d_est_f, e->d_ctl, e->d_iters_used, e->d_resid,
-                    e->d_mass_tab, e->d_est_ws, e->d_qsplit, e->d_dyn, e->d_mmax_ws, e->d_mmax_word};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
-    free_store(e->sell);
-    free_store(e->fsell);
+    std::vector<void **> ws;
+    workspace_ptrs(e, ws);
+    for (void **p : ws) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    if (!e->borrowed) {   // the immutable half: graph, embeddings, static tables, the SELL-8 matrices
+        void *ptrs[] = {e->d_row_ptr, e->d_col, e->d_val, e->d_row_order, e->d_seg_row, e->d_seg_begin,
+                        e->d_seg_end, e->d_seg_slot, e->d_mrow_row, e->d_mrow_first, e->d_mrow_cnt,
+                        e->d_passage_vertex, e->d_row_to_tele, e->d_pemb, e->d_femb, e->d_subj, e->d_obj,
+                        e->d_num_chunks, e->d_deg, e->d_pinvdeg, e->d_row_ptele, e->d_iso, e->d_piso, e->d_colmask_static};
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+        free_store(e->sell);
+        free_store(e->fsell);
+    } else if (e->parent) {
+        e->parent->n_workspaces.v.fetch_sub(1);
+    }
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->ev_last) (void)hipEventDestroy(e->ev_last);
@@ -251,10 +271,7 @@ hrag_status build_sell8(const hrag_engine *e, const std::vector<int32_t> &row_pt
     HRAG_TRY(dev_upload(&out->lrow_first, lrow_first.data(), (int64_t)lrow_first.size()));
     HRAG_TRY(dev_upload(&out->lrow_cnt, lrow_cnt.data(), (int64_t)lrow_cnt.size()));
     HRAG_TRY(dev_upload(&out->seg_lrow, seg_lrow.data(), (int64_t)seg_lrow.size()));
-    const int64_t n_cnt = (int64_t)n_slabs64(e->max_batch) * (int64_t)lrow_row.size();
-    HRAG_TRY(dev_alloc(&out->lcount, n_cnt));
-    if (n_cnt > 0) HRAG_HIP_TRY(hipMemset(out->lcount, 0, (size_t)n_cnt * sizeof(int32_t)));
-    return HRAG_OK;
+    return HRAG_OK;   // the arrival counters (lcount) are per workspace: alloc_workspace
 }
 
 Ppr16Args ppr16_args(const hrag_engine *e, const uint16_t *x, uint16_t *y, const uint16_t *aux,
@@ -510,6 +527,147 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
 
 }  // namespace
 
+// The per-call half of an engine handle, sized once for max_batch: scores, PPR states of every width, seeds, flags,
+// counters.  hrag_engine_create builds it after the index; hrag_workspace_create builds ONLY this for a handle that
+// borrows the index of another engine.  Needs e->want_sell / want_f16 / has_facts / f8_ready and the SELL-8 metadata.
+static hrag_status alloc_workspace(hrag_engine *e) {
+    const bool unsharded = e->n_rows == e->V;
+    tl_alloc_bytes = &e->workspace_bytes;
+    struct Unbook { ~Unbook() { tl_alloc_bytes = nullptr; } } unbook;
+    // ---- workspace, sized once for max_batch
+    const int B = e->max_batch;
+    SlabLayout lay = e->layout(B);
+    e->state_elems = unsharded ? (int64_t)lay.n_slabs * e->V * lay.bc : 0;   // d_x / d_y: hrag_retrieve, hrag_ppr
+    if (e->want_sell) {
+        HRAG_TRY(dev_alloc(&e->d_tele_sv, (e->n_passages + (int64_t)kSvMaxBatch * kMaxSeeds) * kSvMaxBatch));
+        HRAG_TRY(dev_alloc(&e->d_partial_sv, (int64_t)std::max({e->sell.n_partial, e->fsell.n_partial, 1}) * kSvMaxBatch));
+        for (auto &p : e->d_sv16) {   // two-stage fp16 state of the small-batch path: h ping / pong, r, c
+            HRAG_TRY(dev_alloc(&p, e->V * (int64_t)kSvMaxBatch));
+            HRAG_HIP_TRY(hipMemset(p, 0, (size_t)e->V * kSvMaxBatch * sizeof(uint16_t)));
+        }
+        e->sell_ready = true;
+    }
+    if (e->want_sell || e->f8_ready) {
+        // per-batch copy of the row -> teleport slot map with the seed rows patched in (local rows)
+        HRAG_TRY(dev_alloc(&e->d_row_slot, e->n_rows));
+        HRAG_HIP_TRY(hipMemcpy(e->d_row_slot, e->f8_ready ? e->d_row_ptele : e->d_row_to_tele,
+                        (size_t)e->n_rows * sizeof(int32_t), hipMemcpyDeviceToDevice));
+    }
+    if (e->want_sell && !(e->want_f16 || e->f8_ready)) {   // small-batch-only engine: per-query scale of the fp16 state
+        HRAG_TRY(dev_alloc(&e->d_qscale, B));
+        HRAG_TRY(dev_alloc(&e->d_ssum, B));
+    }
+    if (e->want_f16 || e->f8_ready) {
+        // teleport rows of the fp16 and fp8 paths: the owned passages, then the seed rows (fp32, 64-query slabs)
+        const int ns = n_slabs64(B);
+        e->tele16_rows = e->p_rows + (int64_t)B * kMaxSeeds;
+        HRAG_TRY(dev_alloc(&e->d_tele16, (int64_t)ns * e->tele16_rows * 64));
+        HRAG_HIP_TRY(hipMemset(e->d_tele16, 0, (size_t)ns * e->tele16_rows * 64 * sizeof(float)));
+        HRAG_TRY(dev_alloc(&e->d_qscale, B));
+        HRAG_TRY(dev_alloc(&e->d_ssum, B));
+    }
+    if (e->want_f16) {
+        const int ns = n_slabs64(B);
+        // the fp16 STATE only has to hold the batches the fp8 path does not take (<= 64 queries)
+        e->f16_max_batch = e->f8_ready ? std::min(B, 64) : B;
+        e->state16_elems = (int64_t)n_slabs64(e->f16_max_batch) * e->V * 64;
+        e->state_elems = std::max(e->state_elems, e->state16_elems);  // d_x also receives h + c
+        for (auto &p : e->d_h16) HRAG_TRY(dev_alloc(&p, e->state16_elems));
+        HRAG_TRY(dev_alloc(&e->d_partial16, (int64_t)ns * std::max(e->sell.n_partial, 1) * 64));
+        for (auto &p : e->d_h16) HRAG_HIP_TRY(hipMemset(p, 0, (size_t)e->state16_elems * sizeof(uint16_t)));
+        if (!e->f8_ready) HRAG_TRY(dev_alloc(&e->d_xp8, (int64_t)ns * std::max<int64_t>(e->p_rows, 1) * 64));
+        e->f16_ready = true;
+    }
+    if (e->f8_ready) {
+        const int ns = n_slabs128(B);
+        HRAG_TRY(dev_alloc(&e->d_R8, (int64_t)ns * std::max<int64_t>(e->n_rows, 1) * 128));
+        HRAG_TRY(dev_alloc(&e->d_rho8, (int64_t)ns * std::max<int64_t>(e->n_rows, 1) * 128));
+        HRAG_TRY(dev_alloc(&e->d_partial8, (int64_t)ns * std::max({e->sell.n_partial, e->fsell.n_partial, 1}) * 128));
+        HRAG_TRY(dev_alloc(&e->d_stagep, (int64_t)kP8MaxStages * ns * std::max<int64_t>(e->p_rows, 1) * 128));
+        HRAG_TRY(dev_alloc(&e->d_xp8, (int64_t)n_slabs64(B) * std::max<int64_t>(e->p_rows, 1) * 64));
+        HRAG_TRY(dev_alloc(&e->d_zmax_bits, B));
+        HRAG_TRY(dev_alloc(&e->d_zmax, B));
+        HRAG_TRY(dev_alloc(&e->d_mass, 2 * (int64_t)B));
+        HRAG_TRY(dev_alloc(&e->d_prior_part, (int64_t)kP8PriorSplit * B * 2));
+        if (unsharded) {
+            // hrag_retrieve's own state buffers: groups of two slabs, [group][V + 1][2][128] (ppr8_layout)
+            e->state8_bytes = (int64_t)round_up(ns, 2) * (e->V + 1) * 128;
+            for (auto &p : e->d_pool8) {
+                HRAG_TRY(dev_alloc(&p, e->state8_bytes));
+                HRAG_HIP_TRY(hipMemset(p, 0, (size_t)e->state8_bytes));
+            }
+        }
+    }
+    HRAG_TRY(dev_alloc(&e->d_partial, (int64_t)(round_up(B, 4) + 64) * std::max(e->n_partial, 1)));
+    HRAG_TRY(dev_alloc(&e->d_x, e->state_elems));
+    HRAG_TRY(dev_alloc(&e->d_y, e->state_elems));
+    if (unsharded) HRAG_TRY(dev_alloc(&e->d_tele, (int64_t)lay.n_slabs * std::max<int64_t>(e->n_passages, 1) * lay.bc));
+    e->ld_p = round_up(std::max<int64_t>(e->p_rows, 1), 4);   // score rows cover the OWNED passages
+    e->ld_f = round_up(std::max<int64_t>(e->f_rows, 1), 4);
+    HRAG_TRY(dev_alloc(&e->d_spass, (int64_t)B * e->ld_p));
+    HRAG_TRY(dev_alloc(&e->d_doc, (int64_t)B * e->ld_p));
+    if (e->has_facts) HRAG_TRY(dev_alloc(&e->d_sfact, (int64_t)B * e->ld_f));
+    if (e->has_facts && B > 16) {
+        HRAG_TRY(dev_alloc(&e->d_fused_ws, 2 * sim_fused_tiles(std::max<int64_t>(e->f_rows, 1)) * B));
+        HRAG_TRY(dev_alloc(&e->d_fused_sel, sim_fused_sel_ints(B)));
+        HRAG_HIP_TRY(hipMemset(e->d_fused_sel, 0, (size_t)sim_fused_sel_ints(B) * sizeof(int32_t)));
+        HRAG_TRY(dev_alloc(&e->d_mn_f, B));
+        HRAG_TRY(dev_alloc(&e->d_mx_f, B));
+    }
+    HRAG_TRY(dev_alloc(&e->d_mn_p, B));
+    HRAG_TRY(dev_alloc(&e->d_mx_p, B));
+    HRAG_TRY(dev_alloc(&e->d_seed_vtx, (int64_t)B * kMaxSeeds));
+    HRAG_TRY(dev_alloc(&e->d_seed_w, (int64_t)B * kMaxSeeds));
+    HRAG_TRY(dev_alloc(&e->d_seed_cnt, B));
+    HRAG_TRY(dev_alloc(&e->d_flags, B));
+    // colsum partials: worst case is the narrowest slab (most slabs * bc stays ~B, padded)
+    HRAG_TRY(dev_alloc(&e->d_colsum_partial, (int64_t)kColsumBlocks * (round_up(B, 4) + 64)));
+    HRAG_TRY(dev_alloc(&e->d_sums, B));
+    HRAG_TRY(dev_alloc(&e->d_est_f, B));
+    HRAG_TRY(dev_alloc(&e->d_ctl, kP8MaxExt + 1));
+    HRAG_TRY(dev_alloc(&e->d_iters_used, B));
+    HRAG_TRY(dev_alloc(&e->d_resid, B));
+    {
+        // every wavefront of a sweep that measures est writes one row of (queries per slab row) floats; the widest
+        // user is the final sweep of the fp8 state (the chunks that hold passage rows, 128 queries per row)
+        const int64_t c_p = e->fsell.n_pchunks, c_f = e->fsell.n_chunks;
+        int64_t n = c_f * 8;                                                   // small batches (last sweep: passage rows)
+        if (e->f8_ready) n = std::max(n, (int64_t)n_slabs128(B) * c_p * 128);   // the chunks that hold passage rows
+        if (e->f16_ready) n = std::max(n, (int64_t)n_slabs64(e->f16_max_batch) * c_f * 64);
+        HRAG_TRY(dev_alloc(&e->d_est_ws, std::max<int64_t>(n, 1)));
+    }
+    HRAG_TRY(dev_alloc(&e->d_mass_tab, (int64_t)(kP8MaxExt + 1) * B));
+    if (e->f8_ready) {   // HRAG_OPT_ACCEL: measured stage scales
+        e->mmax_slots = (int64_t)(e->sell.n_chunks + 8) * n_slabs128(B);
+        HRAG_TRY(dev_alloc(&e->d_dyn, 2 * kP8DynInv));
+        HRAG_TRY(dev_alloc(&e->d_mmax_ws, e->mmax_slots));
+        HRAG_TRY(dev_alloc(&e->d_mmax_word, 2));   // [0] running maximum (float bits), [1] arrival counter of the reduction
+        HRAG_HIP_TRY(hipMemset(e->d_dyn, 0, 2 * kP8DynInv * sizeof(float)));
+        HRAG_HIP_TRY(hipMemset(e->d_mmax_ws, 0, (size_t)e->mmax_slots * sizeof(float)));
+        HRAG_HIP_TRY(hipMemset(e->d_mmax_word, 0, 2 * sizeof(int32_t)));
+    }
+    {
+        char *ws = nullptr;
+        HRAG_TRY(dev_alloc(&ws, (int64_t)kTopkWsBytes));
+        e->d_topk_ws = ws;
+    }
+    if (e->state_elems) {
+        HRAG_HIP_TRY(hipMemset(e->d_x, 0, (size_t)e->state_elems * sizeof(float)));
+        HRAG_HIP_TRY(hipMemset(e->d_y, 0, (size_t)e->state_elems * sizeof(float)));
+    }
+    HRAG_HIP_TRY(hipMemset(e->d_seed_cnt, 0, (size_t)B * sizeof(int32_t)));
+    // arrival counters of the long rows (one set per handle: two handles may sweep the same matrix at once)
+    for (Sell8Store *m : {&e->sell, &e->fsell}) {
+        const int64_t n_cnt = (int64_t)n_slabs64(e->max_batch) * (int64_t)m->n_lrow;
+        HRAG_TRY(dev_alloc(&m->lcount, n_cnt));
+        if (n_cnt > 0) HRAG_HIP_TRY(hipMemset(m->lcount, 0, (size_t)n_cnt * sizeof(int32_t)));
+    }
+    if (e->colmask_words > 0) HRAG_TRY(dev_alloc(&e->d_colmask, e->colmask_words));   // per-batch copy of the column bitmap
+    for (auto &ev : e->ev) HRAG_HIP_TRY(hipEventCreate(&ev));
+    HRAG_HIP_TRY(hipEventCreateWithFlags(&e->ev_last, hipEventDisableTiming));
+    return HRAG_OK;
+}
+
 extern "C" {
 
 hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *facts,
@@ -549,6 +707,8 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     if (!e) { set_error("out of host memory"); return HRAG_ENOMEM; }
     HRAG_HIP_TRY(hipGetDevice(&e->device));
     hrag_status st = HRAG_OK;
+    tl_alloc_bytes = &e->index_bytes;      // everything allocated until alloc_workspace is the (shareable) index
+    struct Unbook { ~Unbook() { tl_alloc_bytes = nullptr; } } unbook;
 #define E_TRY(expr) do { st = (expr); if (st != HRAG_OK) { free_engine(e); return st; } } while (0)
 #define E_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error("%s -> %s", #expr, hipGetErrorString(_e)); free_engine(e); return HRAG_EHIP; } } while (0)
 
@@ -657,6 +817,12 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
     const bool want_f8 = !(opts->flags & HRAG_OPT_F32_STATE) && !(opts->flags & HRAG_OPT_NO_FP8) && g->col_sum &&
                          e->V + 1 <= ((int64_t)1 << 24) && e->shard_aligned &&
                          (unsharded ? (want_f16 && opts->max_batch > 64) : true);
+    e->fp8_unavailable = want_f8 ? 0
+        : ((opts->flags & (HRAG_OPT_F32_STATE | HRAG_OPT_NO_FP8)) ? HRAG_FP8_UNAVAILABLE_DISABLED : 0) |
+          (!g->col_sum ? HRAG_FP8_UNAVAILABLE_NO_COL_SUM : 0) |
+          (e->V + 1 > ((int64_t)1 << 24) ? HRAG_FP8_UNAVAILABLE_TOO_MANY_VERTICES : 0) |
+          (!e->shard_aligned ? HRAG_FP8_UNAVAILABLE_SHARD_NOT_ALIGNED : 0) |
+          (unsharded && !(want_f16 && opts->max_batch > 64) ? HRAG_FP8_UNAVAILABLE_SMALL_MAX_BATCH : 0);
     if (want_sell || want_f8) {
         std::vector<int32_t> h_col((size_t)e->nnz);
         std::vector<float> h_val((size_t)e->nnz);
@@ -726,7 +892,6 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
             std::vector<uint32_t> mask((size_t)e->colmask_words, 0u);
             for (int64_t q = 0; q < e->n_passages; ++q) mask[(size_t)(h_pv[(size_t)q] >> 5)] |= 1u << (h_pv[(size_t)q] & 31);
             E_TRY(dev_upload(&e->d_colmask_static, mask.data(), e->colmask_words));
-            E_TRY(dev_alloc(&e->d_colmask, e->colmask_words));
         }
         if (want_f8) {
             E_TRY(dev_upload(&e->d_row_ptele, ptele.data(), e->n_rows));
@@ -770,129 +935,9 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
         E_TRY(dev_upload(&e->d_num_chunks, fd->num_chunks, e->V));
     }
     // ---- workspace, sized once for max_batch
-    const int B = e->max_batch;
-    SlabLayout lay = e->layout(B);
-    e->state_elems = unsharded ? (int64_t)lay.n_slabs * e->V * lay.bc : 0;   // d_x / d_y: hrag_retrieve, hrag_ppr
-    if (want_sell) {
-        E_TRY(dev_alloc(&e->d_tele_sv, (e->n_passages + (int64_t)kSvMaxBatch * kMaxSeeds) * kSvMaxBatch));
-        E_TRY(dev_alloc(&e->d_partial_sv, (int64_t)std::max({e->sell.n_partial, e->fsell.n_partial, 1}) * kSvMaxBatch));
-        for (auto &p : e->d_sv16) {   // two-stage fp16 state of the small-batch path: h ping / pong, r, c
-            E_TRY(dev_alloc(&p, e->V * (int64_t)kSvMaxBatch));
-            E_HIP(hipMemset(p, 0, (size_t)e->V * kSvMaxBatch * sizeof(uint16_t)));
-        }
-        e->sell_ready = true;
-    }
-    if (want_sell || e->f8_ready) {
-        // per-batch copy of the row -> teleport slot map with the seed rows patched in (local rows)
-        E_TRY(dev_alloc(&e->d_row_slot, e->n_rows));
-        E_HIP(hipMemcpy(e->d_row_slot, e->f8_ready ? e->d_row_ptele : e->d_row_to_tele,
-                        (size_t)e->n_rows * sizeof(int32_t), hipMemcpyDeviceToDevice));
-    }
-    if (want_sell && !(want_f16 || e->f8_ready)) {   // small-batch-only engine: per-query scale of the fp16 state
-        E_TRY(dev_alloc(&e->d_qscale, B));
-        E_TRY(dev_alloc(&e->d_ssum, B));
-    }
-    if (want_f16 || e->f8_ready) {
-        // teleport rows of the fp16 and fp8 paths: the owned passages, then the seed rows (fp32, 64-query slabs)
-        const int ns = n_slabs64(B);
-        e->tele16_rows = e->p_rows + (int64_t)B * kMaxSeeds;
-        E_TRY(dev_alloc(&e->d_tele16, (int64_t)ns * e->tele16_rows * 64));
-        E_HIP(hipMemset(e->d_tele16, 0, (size_t)ns * e->tele16_rows * 64 * sizeof(float)));
-        E_TRY(dev_alloc(&e->d_qscale, B));
-        E_TRY(dev_alloc(&e->d_ssum, B));
-    }
-    if (want_f16) {
-        const int ns = n_slabs64(B);
-        // the fp16 STATE only has to hold the batches the fp8 path does not take (<= 64 queries)
-        e->f16_max_batch = e->f8_ready ? std::min(B, 64) : B;
-        e->state16_elems = (int64_t)n_slabs64(e->f16_max_batch) * e->V * 64;
-        e->state_elems = std::max(e->state_elems, e->state16_elems);  // d_x also receives h + c
-        for (auto &p : e->d_h16) E_TRY(dev_alloc(&p, e->state16_elems));
-        E_TRY(dev_alloc(&e->d_partial16, (int64_t)ns * std::max(e->sell.n_partial, 1) * 64));
-        for (auto &p : e->d_h16) E_HIP(hipMemset(p, 0, (size_t)e->state16_elems * sizeof(uint16_t)));
-        if (!e->f8_ready) E_TRY(dev_alloc(&e->d_xp8, (int64_t)ns * std::max<int64_t>(e->p_rows, 1) * 64));
-        e->f16_ready = true;
-    }
-    if (e->f8_ready) {
-        const int ns = n_slabs128(B);
-        E_TRY(dev_alloc(&e->d_R8, (int64_t)ns * std::max<int64_t>(e->n_rows, 1) * 128));
-        E_TRY(dev_alloc(&e->d_rho8, (int64_t)ns * std::max<int64_t>(e->n_rows, 1) * 128));
-        E_TRY(dev_alloc(&e->d_partial8, (int64_t)ns * std::max({e->sell.n_partial, e->fsell.n_partial, 1}) * 128));
-        E_TRY(dev_alloc(&e->d_stagep, (int64_t)kP8MaxStages * ns * std::max<int64_t>(e->p_rows, 1) * 128));
-        E_TRY(dev_alloc(&e->d_xp8, (int64_t)n_slabs64(B) * std::max<int64_t>(e->p_rows, 1) * 64));
-        E_TRY(dev_alloc(&e->d_zmax_bits, B));
-        E_TRY(dev_alloc(&e->d_zmax, B));
-        E_TRY(dev_alloc(&e->d_mass, 2 * (int64_t)B));
-        E_TRY(dev_alloc(&e->d_prior_part, (int64_t)kP8PriorSplit * B * 2));
-        if (unsharded) {
-            // hrag_retrieve's own state buffers: groups of two slabs, [group][V + 1][2][128] (ppr8_layout)
-            e->state8_bytes = (int64_t)round_up(ns, 2) * (e->V + 1) * 128;
-            for (auto &p : e->d_pool8) {
-                E_TRY(dev_alloc(&p, e->state8_bytes));
-                E_HIP(hipMemset(p, 0, (size_t)e->state8_bytes));
-            }
-        }
-    }
-    E_TRY(dev_alloc(&e->d_partial, (int64_t)(round_up(B, 4) + 64) * std::max(e->n_partial, 1)));
-    E_TRY(dev_alloc(&e->d_x, e->state_elems));
-    E_TRY(dev_alloc(&e->d_y, e->state_elems));
-    if (unsharded) E_TRY(dev_alloc(&e->d_tele, (int64_t)lay.n_slabs * std::max<int64_t>(e->n_passages, 1) * lay.bc));
-    e->ld_p = round_up(std::max<int64_t>(e->p_rows, 1), 4);   // score rows cover the OWNED passages
-    e->ld_f = round_up(std::max<int64_t>(e->f_rows, 1), 4);
-    E_TRY(dev_alloc(&e->d_spass, (int64_t)B * e->ld_p));
-    E_TRY(dev_alloc(&e->d_doc, (int64_t)B * e->ld_p));
-    if (facts) E_TRY(dev_alloc(&e->d_sfact, (int64_t)B * e->ld_f));
-    if (facts && B > 16) {
-        E_TRY(dev_alloc(&e->d_fused_ws, 2 * sim_fused_tiles(std::max<int64_t>(e->f_rows, 1)) * B));
-        E_TRY(dev_alloc(&e->d_fused_sel, sim_fused_sel_ints(B)));
-        E_HIP(hipMemset(e->d_fused_sel, 0, (size_t)sim_fused_sel_ints(B) * sizeof(int32_t)));
-        E_TRY(dev_alloc(&e->d_mn_f, B));
-        E_TRY(dev_alloc(&e->d_mx_f, B));
-    }
-    E_TRY(dev_alloc(&e->d_mn_p, B));
-    E_TRY(dev_alloc(&e->d_mx_p, B));
-    E_TRY(dev_alloc(&e->d_seed_vtx, (int64_t)B * kMaxSeeds));
-    E_TRY(dev_alloc(&e->d_seed_w, (int64_t)B * kMaxSeeds));
-    E_TRY(dev_alloc(&e->d_seed_cnt, B));
-    E_TRY(dev_alloc(&e->d_flags, B));
-    // colsum partials: worst case is the narrowest slab (most slabs * bc stays ~B, padded)
-    E_TRY(dev_alloc(&e->d_colsum_partial, (int64_t)kColsumBlocks * (round_up(B, 4) + 64)));
-    E_TRY(dev_alloc(&e->d_sums, B));
-    E_TRY(dev_alloc(&e->d_est_f, B));
-    E_TRY(dev_alloc(&e->d_ctl, kP8MaxExt + 1));
-    E_TRY(dev_alloc(&e->d_iters_used, B));
-    E_TRY(dev_alloc(&e->d_resid, B));
-    {
-        // every wavefront of a sweep that measures est writes one row of (queries per slab row) floats; the widest
-        // user is the final sweep of the fp8 state (the chunks that hold passage rows, 128 queries per row)
-        const int64_t c_p = e->fsell.n_pchunks, c_f = e->fsell.n_chunks;
-        int64_t n = c_f * 8;                                                   // small batches (last sweep: passage rows)
-        if (e->f8_ready) n = std::max(n, (int64_t)n_slabs128(B) * c_p * 128);   // the chunks that hold passage rows
-        if (e->f16_ready) n = std::max(n, (int64_t)n_slabs64(e->f16_max_batch) * c_f * 64);
-        E_TRY(dev_alloc(&e->d_est_ws, std::max<int64_t>(n, 1)));
-    }
-    E_TRY(dev_alloc(&e->d_mass_tab, (int64_t)(kP8MaxExt + 1) * B));
-    if (e->f8_ready) {   // HRAG_OPT_ACCEL: measured stage scales
-        e->mmax_slots = (int64_t)(e->sell.n_chunks + 8) * n_slabs128(B);
-        E_TRY(dev_alloc(&e->d_dyn, 2 * kP8DynInv));
-        E_TRY(dev_alloc(&e->d_mmax_ws, e->mmax_slots));
-        E_TRY(dev_alloc(&e->d_mmax_word, 2));   // [0] running maximum (float bits), [1] arrival counter of the reduction
-        E_HIP(hipMemset(e->d_dyn, 0, 2 * kP8DynInv * sizeof(float)));
-        E_HIP(hipMemset(e->d_mmax_ws, 0, (size_t)e->mmax_slots * sizeof(float)));
-        E_HIP(hipMemset(e->d_mmax_word, 0, 2 * sizeof(int32_t)));
-    }
-    {
-        char *ws = nullptr;
-        E_TRY(dev_alloc(&ws, (int64_t)kTopkWsBytes));
-        e->d_topk_ws = ws;
-    }
-    if (e->state_elems) {
-        E_HIP(hipMemset(e->d_x, 0, (size_t)e->state_elems * sizeof(float)));
-        E_HIP(hipMemset(e->d_y, 0, (size_t)e->state_elems * sizeof(float)));
-    }
-    E_HIP(hipMemset(e->d_seed_cnt, 0, (size_t)B * sizeof(int32_t)));
-    for (auto &ev : e->ev) E_HIP(hipEventCreate(&ev));
-    E_HIP(hipEventCreateWithFlags(&e->ev_last, hipEventDisableTiming));
+    e->want_sell = want_sell; e->want_f16 = want_f16; e->has_facts = facts != nullptr;
+    tl_alloc_bytes = nullptr;
+    E_TRY(alloc_workspace(e));
     E_HIP(hipDeviceSynchronize());
 #undef E_TRY
 #undef E_HIP
@@ -902,10 +947,70 @@ hrag_status hrag_engine_create(const hrag_graph_desc *g, const hrag_embed_desc *
 
 hrag_status hrag_engine_destroy(hrag_engine *e) {
     if (e) {
+        if (!e->borrowed && e->n_workspaces.v.load() > 0) {
+            set_error("engine still has %d live workspace(s) (hrag_workspace_create): destroy them first -- they borrow "
+                      "this engine's index buffers", e->n_workspaces.v.load());
+            return HRAG_EINVAL;
+        }
         (void)hipSetDevice(e->device);
         (void)hipDeviceSynchronize();
         free_engine(e);
     }
+    return HRAG_OK;
+}
+
+// "engine immutable after create -> concurrent read-only calls allowed on distinct streams with distinct
+// workspaces".  The new handle shares every index buffer of `e` (graph, SELL-8 matrices, embeddings, static tables: no
+// second copy of the 1.5 GB of embeddings) and owns a full set of per-call buffers, its own entry flag, events, option
+// flags and timings -- so a call on it never meets HRAG_EBUSY because of a call on `e` or on another workspace.
+hrag_status hrag_workspace_create(hrag_engine *e, hrag_engine **out) {
+    HRAG_REQUIRE(e != nullptr && out != nullptr, "engine and out must be non-NULL");
+    *out = nullptr;
+    hrag_engine *root = e->borrowed ? e->parent : e;
+    HRAG_REQUIRE(root != nullptr, "workspace without a parent engine");
+    HRAG_HIP_TRY(hipSetDevice(root->device));
+    hrag_engine *w = new (std::nothrow) hrag_engine(*root);      // index pointers, sizes, options: copied
+    if (!w) { set_error("out of host memory"); return HRAG_ENOMEM; }
+    w->borrowed = true;
+    w->parent = root;
+    std::vector<void **> ws;
+    workspace_ptrs(w, ws);
+    for (void **p : ws) *p = nullptr;                            // ... the per-call half: its own
+    for (auto &ev : w->ev) ev = nullptr;
+    w->ev_last = nullptr; w->last_stream = nullptr; w->have_last = false;
+    w->profiling = false; w->have_retrieve_ev = false; w->have_fact_ev = false;
+    w->last = hrag_timings{};
+    w->p8 = Ppr8Session();
+    w->sell_ready = w->f16_ready = false;                        // set again by alloc_workspace
+    w->state_elems = w->state16_elems = w->state8_bytes = 0;
+    w->index_bytes = 0; w->workspace_bytes = 0;
+    w->last_ppr_state = 0;
+    root->n_workspaces.v.fetch_add(1);
+    const hrag_status st = alloc_workspace(w);
+    if (st != HRAG_OK) { free_engine(w); return st; }
+    HRAG_HIP_TRY(hipDeviceSynchronize());
+    *out = w;
+    return HRAG_OK;
+}
+
+hrag_status hrag_engine_stats(hrag_engine *e, hrag_stats *out) {
+    HRAG_REQUIRE(e != nullptr && out != nullptr, "engine and out must be non-NULL");
+    hrag_stats s = {};
+    s.is_workspace = e->borrowed ? 1 : 0;
+    s.live_workspaces = e->borrowed ? 0 : e->n_workspaces.v.load();
+    s.index_bytes = e->borrowed && e->parent ? e->parent->index_bytes : e->index_bytes;
+    s.workspace_bytes = e->workspace_bytes;
+    s.ppr_states = HRAG_PPR_STATE_F32 | (e->f16_ready ? HRAG_PPR_STATE_F16 : 0) | (e->sell_ready ? HRAG_PPR_STATE_SMALL : 0) |
+                   (e->f8_ready ? HRAG_PPR_STATE_FP8 : 0);
+    s.fp8_unavailable = e->fp8_unavailable;
+    s.last_ppr_state = e->last_ppr_state;
+    s.calls_score_facts = e->counters.score_facts.load();
+    s.calls_retrieve = e->counters.retrieve.load();
+    s.calls_dense_retrieve = e->counters.dense.load();
+    s.calls_ppr = e->counters.ppr.load();
+    s.calls_shard = e->counters.shard.load();
+    s.queries = e->counters.queries.load();
+    *out = s;
     return HRAG_OK;
 }
 
@@ -981,6 +1086,7 @@ hrag_status hrag_score_facts(hrag_engine *e, const uint16_t *q, int32_t batch, i
                  "engine goes through hrag_sim_scores + hrag_topk_rows + an all-gather");
     hipStream_t s = (hipStream_t)stream;
     HRAG_ENGINE_CALL(e, stream);
+    e->counters.score_facts.fetch_add(1);
     if (e->profiling) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_FACT0], s));
     HRAG_TRY(prep_query(e, q, batch, s, &q));
     if (batch > 16 && k <= 16 && e->f_rows > 0 && e->d_fused_ws) {
@@ -1272,6 +1378,9 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
     e->last.ppr_iters = ppr_iters;
     e->last.n_slabs = lay.n_slabs;
     e->last.slab_width = f8 ? 128 : lay.bc;
+    e->last_ppr_state = f8 ? HRAG_PPR_STATE_FP8 : f16 ? HRAG_PPR_STATE_F16 : sv ? HRAG_PPR_STATE_SMALL : HRAG_PPR_STATE_F32;
+    e->counters.retrieve.fetch_add(1);
+    e->counters.queries.fetch_add(batch);
     return HRAG_OK;
 }
 
@@ -1318,6 +1427,8 @@ hrag_status hrag_dense_retrieve(hrag_engine *e, const uint16_t *q_pass, int32_t 
     HRAG_REQUIRE(k >= 1 && k <= e->max_topk, "k=%d outside [1, max_topk=%d]", k, e->max_topk);
     hipStream_t s = (hipStream_t)stream;
     HRAG_ENGINE_CALL(e, stream);
+    e->counters.dense.fetch_add(1);
+    e->counters.queries.fetch_add(batch);
     HRAG_TRY(prep_query(e, q_pass, batch, s, &q_pass));
     HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->kdim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
     return launch_row_topk(e->d_spass, batch, e->n_passages, e->ld_p, k, 0, kNormMinMax, doc_idx_out,
@@ -1332,6 +1443,7 @@ hrag_status hrag_ppr(hrag_engine *e, const float *reset, int32_t batch, float da
     HRAG_REQUIRE(e->n_rows == e->V, "hrag_ppr needs an unsharded engine");
     hipStream_t s = (hipStream_t)stream;
     HRAG_ENGINE_CALL(e, stream);
+    e->counters.ppr.fetch_add(1);
     if (!e->d_tele_dense) HRAG_TRY(dev_alloc(&e->d_tele_dense, e->state_elems));  // first use only
     if (use_sv(e, batch)) {   // run_ppr seam at B = 1 (ppr_sv.hip), v dense over all vertices
         const int bp = sv_width(batch);

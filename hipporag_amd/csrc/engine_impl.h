@@ -19,6 +19,9 @@ constexpr float kPpr16CScale = 64.f;  // correction / residual are stored as f16
 
 enum EvId { EV_START = 0, EV_SIM, EV_SEED, EV_PPR, EV_RANK, EV_FACT0, EV_FACT1, EV_COUNT };
 
+// where dev_alloc books the bytes it hands out (hrag_engine_stats: index vs workspace), per creating thread
+inline thread_local int64_t *tl_alloc_bytes = nullptr;
+
 template <typename T>
 inline hrag_status dev_alloc(T **p, int64_t count) {
     *p = nullptr;
@@ -30,6 +33,7 @@ inline hrag_status dev_alloc(T **p, int64_t count) {
         *p = nullptr;
         return HRAG_ENOMEM;
     }
+    if (tl_alloc_bytes) *tl_alloc_bytes += count * (int64_t)sizeof(T);
     return HRAG_OK;
 }
 
@@ -109,6 +113,21 @@ struct Ppr8Session {
 }  // namespace hrag
 
 using namespace hrag;
+
+// host-side entry flag of an engine handle; copying a handle (hrag_workspace_create) starts from "not in a call"
+struct CallFlag {
+    std::atomic<int> v{0};
+    CallFlag() = default;
+    CallFlag(const CallFlag &) : v(0) {}
+    CallFlag &operator=(const CallFlag &) { v.store(0); return *this; }
+};
+// cumulative counters of one engine handle (hrag_engine_stats)
+struct CallCounters {
+    std::atomic<long long> score_facts{0}, retrieve{0}, dense{0}, ppr{0}, shard{0}, queries{0};
+    CallCounters() = default;
+    CallCounters(const CallCounters &) {}
+    CallCounters &operator=(const CallCounters &) { return *this; }
+};
 
 struct hrag_engine {
     int device = 0;
@@ -194,7 +213,18 @@ struct hrag_engine {
     int32_t *d_mmax_word = nullptr;
     int64_t mmax_slots = 0;
     // one call in flight per engine (include/hrag.h): host-side entry flag + the end of the last call on its stream
-    std::atomic<int> in_call{0};
+    CallFlag in_call;
+    CallCounters counters;
+    // hrag_workspace_create: a WORKSPACE handle borrows the immutable index buffers of `parent` (graph, SELL-8 matrices,
+    // embeddings, static tables) and owns only the per-call buffers; free_engine frees what the handle owns
+    bool borrowed = false;
+    hrag_engine *parent = nullptr;
+    CallFlag n_workspaces;          // live workspaces of this (root) engine: hrag_engine_destroy refuses while > 0
+    // what hrag_engine_create decided (alloc_workspace reads them again for a workspace handle)
+    bool want_sell = false, want_f16 = false, has_facts = false;
+    int32_t fp8_unavailable = 0;    // HRAG_FP8_UNAVAILABLE_* bits: why the engine has no e4m3 PPR state (0: it has one)
+    int32_t last_ppr_state = 0;     // HRAG_PPR_STATE_* of the last retrieve on this handle
+    int64_t index_bytes = 0, workspace_bytes = 0;   // device memory of the two halves (hrag_engine_stats)
     hipEvent_t ev_last = nullptr;
     hipStream_t last_stream = nullptr;
     bool have_last = false;
@@ -241,7 +271,7 @@ struct EngineCall {
     EngineCall(hrag_engine *eng, hipStream_t stream) : e(eng), s(stream) {
         if (!e) return;
         int expected = 0;
-        if (!e->in_call.compare_exchange_strong(expected, 1)) {
+        if (!e->in_call.v.compare_exchange_strong(expected, 1)) {
             set_error("engine busy: another thread is inside a call on this engine (one call in flight per engine)");
             st = HRAG_EBUSY;
             return;
@@ -262,7 +292,7 @@ struct EngineCall {
         if (st == HRAG_OK && !capturing && e->ev_last) {
             if (hipEventRecord(e->ev_last, s) == hipSuccess) { e->last_stream = s; e->have_last = true; }
         }
-        e->in_call.store(0);
+        e->in_call.v.store(0);
     }
 };
 #define HRAG_ENGINE_CALL(e, stream)                 \

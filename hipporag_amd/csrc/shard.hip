@@ -577,6 +577,7 @@ hrag_status hrag_shard_ppr_begin(hrag_engine *e, const float *mn, const float *m
                                  float damping, int32_t ppr_iters, int32_t ppr_max_iters, float ppr_tol,
                                  int32_t n_groups, void *state0, void *state1, void *state2, int32_t *n_steps_out,
                                  hrag_stream stream) {
+    if (e) e->counters.shard.fetch_add(1);
     HRAG_TRY(shard_batch(e, batch));
     HRAG_REQUIRE(mn && mx && zmax && mass && seed_vtx && seed_w && seed_cnt && flags, "NULL argument");
     HRAG_REQUIRE(damping >= 0.f && damping < 1.f, "damping %g outside [0, 1)", (double)damping);

@@ -344,9 +344,44 @@ class HippoRAGEngine:
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
+        """Destroy the handle.  An engine closes the workspaces it handed out first (they borrow its index buffers)."""
+        for w in list(getattr(self, "_workspaces", ())):
+            w.close()
         if getattr(self, "_handle", None) and self._handle.value:
-            self._lib.hrag_engine_destroy(self._handle)
+            check(self._lib.hrag_engine_destroy(self._handle))
             self._handle = C.c_void_p(0)
+            parent = getattr(self, "_parent", None)
+            if parent is not None and self in parent._workspaces:
+                parent._workspaces.remove(self)
+
+    def workspace(self) -> "HippoRAGEngine":
+        """A second WORKSPACE on this index (hrag_workspace_create): an engine object with the same methods
+        that shares this engine's device-resident index -- graph, SELL-8 matrices, embeddings: nothing is copied -- and owns
+        its own per-call buffers, so another thread can run score_facts / retrieve on it, on its own stream, WHILE this
+        engine (or another workspace) is inside a call.  Results are bit-identical.  Close workspaces before the engine
+        (close() of the engine does it); gather_embeddings() on any handle needs all handles idle."""
+        import copy
+        root = getattr(self, "_parent", None) or self
+        w = copy.copy(root)                      # plain attributes: sizes, numbering, dtype, the library
+        w._handle = C.c_void_p(0)
+        w._workspaces = []
+        w._parent = root
+        with _torch().cuda.device(root.device):
+            check(root._lib.hrag_workspace_create(root._handle, C.byref(w._handle)))
+        if not hasattr(root, "_workspaces"):
+            root._workspaces = []
+        root._workspaces.append(w)
+        return w
+
+    def stats(self) -> dict:
+        """hrag_engine_stats: device bytes of the shared index / of this handle's workspace, the PPR state types the
+        handle can run (and why not the e4m3 one), the state the last retrieve ran on, call counters."""
+        from ._lib import FP8_UNAVAILABLE, Stats
+        s = Stats()
+        check(self._lib.hrag_engine_stats(self._handle, C.byref(s)))
+        d = {name: int(getattr(s, name)) for name, _ in Stats._fields_ if name != "reserved"}
+        d["fp8_unavailable_reasons"] = [txt for bit, txt in FP8_UNAVAILABLE.items() if s.fp8_unavailable & bit]
+        return d
 
     def __del__(self):
         try:

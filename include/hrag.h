@@ -41,7 +41,7 @@ extern "C" {
 #endif
 
 #define HRAG_VERSION_MAJOR 0
-#define HRAG_VERSION_MINOR 6
+#define HRAG_VERSION_MINOR 7
 
 typedef enum hrag_status {
     HRAG_OK = 0,
@@ -232,6 +232,58 @@ hrag_status hrag_engine_create(const hrag_graph_desc *graph, const hrag_embed_de
                                const hrag_embed_desc *passages, const hrag_fact_desc *fact_desc,
                                const hrag_opts *opts, hrag_engine **out);
 hrag_status hrag_engine_destroy(hrag_engine *e);
+
+/* ------------------------------------------------------------------------------------------
+ * Workspaces ("engine immutable after create -> concurrent read-only calls allowed on
+ * distinct streams with distinct workspaces").  The reference serves one query at a time from one
+ * Python thread (HippoRAG.py:459); a server that wants several retrieves in flight on ONE index makes
+ * one workspace per stream / thread:
+ *
+ *   hrag_workspace_create(e, &w)   w is an engine HANDLE like e -- every entry point of this header takes
+ *                                  it -- that BORROWS e's index (graph, SELL-8 matrices, embeddings, static
+ *                                  tables: nothing is copied, no second 1.5 GB of embeddings) and OWNS a
+ *                                  full set of per-call buffers (scores, PPR states, seeds, flags, the
+ *                                  long-row arrival counters), its own entry flag, option flags
+ *                                  (hrag_engine_set_flags acts on the handle it is given), events and
+ *                                  timings.  Sized for e's max_batch / max_topk.
+ *
+ * Calls on e and on its workspaces may run CONCURRENTLY from different threads on different streams: a
+ * handle rejects a second thread (HRAG_EBUSY) only for ITSELF.  Results are bit-identical to the same
+ * call on e.  Rules: destroy every workspace (hrag_engine_destroy(w)) before the engine it came from
+ * (hrag_engine_destroy(e) returns HRAG_EINVAL while workspaces are alive); the one entry point that
+ * WRITES the index -- hrag_engine_gather_embeddings -- must not run while any other handle is in a call.
+ * A workspace of a workspace is a workspace of the same root engine.
+ * ------------------------------------------------------------------------------------------ */
+hrag_status hrag_workspace_create(hrag_engine *e, hrag_engine **out);
+
+/* What an engine handle holds and has done (SURVEY.md 8(b) hrag_stats).  Host-side, no device work. */
+#define HRAG_PPR_STATE_F32 1    /* fp32 slabs (csrc/ppr_spmm.hip): every engine                                 */
+#define HRAG_PPR_STATE_F16 2    /* two-stage fp16 state, 8 < batch <= 64 (csrc/ppr16.hip)                        */
+#define HRAG_PPR_STATE_SMALL 4  /* batch <= 8 kernels (csrc/ppr_sv.hip)                                          */
+#define HRAG_PPR_STATE_FP8 8    /* staged e4m3 state, batch > 64 and every row shard (csrc/ppr8.hip)             */
+/* why an engine has NO staged e4m3 state -- its batches > 64 then run on the two-stage fp16 state (2 bytes per gathered
+ * element instead of 1: about twice the sweep time) or, once V * 128 >= 2^32 (V >= 33.5 M), on the fp32 slabs (4 bytes);
+ * same results within the same bar; hrag_shard_ppr_begin refuses such an engine.  hrag_stats.last_ppr_state says which
+ * state a call ran on */
+#define HRAG_FP8_UNAVAILABLE_NO_COL_SUM 1          /* hrag_graph_desc.col_sum was NULL                            */
+#define HRAG_FP8_UNAVAILABLE_TOO_MANY_VERTICES 2   /* V + 1 > 2^24: the gather offsets are formed by a 24-bit     */
+                                                   /* multiply ((V + 1) * 256 bytes must also stay below 2^32)   */
+#define HRAG_FP8_UNAVAILABLE_SHARD_NOT_ALIGNED 4   /* owned passages != passages whose vertex is an owned row     */
+#define HRAG_FP8_UNAVAILABLE_DISABLED 8            /* HRAG_OPT_F32_STATE / HRAG_OPT_NO_FP8 at creation             */
+#define HRAG_FP8_UNAVAILABLE_SMALL_MAX_BATCH 16    /* unsharded engine with max_batch <= 64: never needed          */
+typedef struct hrag_stats {
+    int32_t is_workspace;       /* 1: the handle came from hrag_workspace_create                                  */
+    int32_t live_workspaces;    /* workspaces of this engine that have not been destroyed                          */
+    int64_t index_bytes;        /* device bytes of the shared half (graph, matrices, embeddings)                  */
+    int64_t workspace_bytes;    /* device bytes of this handle's per-call half                                     */
+    int32_t ppr_states;         /* HRAG_PPR_STATE_* the handle can run                                             */
+    int32_t fp8_unavailable;    /* HRAG_FP8_UNAVAILABLE_* (0: the e4m3 state exists)                               */
+    int32_t last_ppr_state;     /* HRAG_PPR_STATE_* the last hrag_retrieve / _scored on this handle ran on (0: none) */
+    int32_t reserved;
+    int64_t calls_score_facts, calls_retrieve, calls_dense_retrieve, calls_ppr, calls_shard;
+    int64_t queries;            /* queries served by hrag_retrieve / _scored / hrag_dense_retrieve                  */
+} hrag_stats;
+hrag_status hrag_engine_stats(hrag_engine *e, hrag_stats *out);
 
 /* Phase A == get_fact_scores (HippoRAG.py:1427-1465) + the candidate selection of
  * rerank_facts (:1683-1688) for B queries at once.

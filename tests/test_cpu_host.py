@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hrag_version() == _lib.HRAG_VERSION == 6            # 0 * 1000 + 6 (error bound constants, HRAG_PPR_TOL_MIN, round-5 stage plan)
+    assert lib.hrag_version() == _lib.HRAG_VERSION == 7            # 0 * 1000 + 7 (round 6: hrag_workspace_create, hrag_engine_stats, gather-replay flag)
 
 
 def test_ctypes_structs_match_the_header_layout(tmp_path):

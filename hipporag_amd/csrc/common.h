@@ -9,6 +9,7 @@
 namespace hrag {
 
 void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+const char *experiment_env(const char *name);   // errors.cpp: a measurement switch of the environment, read once, announced on stderr
 
 #define HRAG_HIP_TRY(expr)                                                                  \
     do {                                                                                    \

@@ -115,7 +115,7 @@ hrag_status ppr_step(hrag_engine *e, const float *tele, int64_t tele_rows, const
 // HRAG_SELL8_SEG_LEN overrides (experiments).
 int32_t sell8_seg_len(int64_t nnz_owned, int max_batch, int32_t asked = 0) {
     if (asked >= 8 && asked <= 1 << 20) return (int32_t)round_up(asked, 8);   // hrag_opts.sell_seg_len
-    if (const char *env = std::getenv("HRAG_SELL8_SEG_LEN")) {
+    if (const char *env = experiment_env("HRAG_SELL8_SEG_LEN")) {
         const int v = std::atoi(env);
         if (v >= 8 && v <= 1 << 20) return (int32_t)round_up(v, 8);
     }

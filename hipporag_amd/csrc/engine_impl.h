@@ -108,6 +108,10 @@ struct Ppr8Session {
     int32_t e_max = 0;
     bool want_est = false;
     float tol = 0.f;
+    // per-group issue of a session with measured scales (dyn): the boundary of a step finalises its maximum when the LAST
+    // group arrives, so the groups of a step must come in ascending order and a step must be complete before the next
+    // begins -- ppr8_sweep enforces it (a stale scale would otherwise only show as a saturation flag)
+    int32_t last_step = -1, last_group = -1;
 };
 
 }  // namespace hrag

@@ -1078,7 +1078,7 @@ __global__ void ppr8_mask_seeds_kernel(const int32_t *__restrict__ seed_vtx, con
 // The pair kernel takes the slabs that come in adjacent pairs (groups of even width), ppr8_kernel an odd last slab.
 // HRAG_P8_PAIR=0 keeps everything on ppr8_kernel (A/B measurements).
 static bool p8_pair_enabled() {
-    static const bool v = [] { const char *e = getenv("HRAG_P8_PAIR"); return !(e && e[0] == '0'); }();
+    static const bool v = [] { const char *e = experiment_env("HRAG_P8_PAIR"); return !(e && e[0] == '0'); }();
     return v;
 }
 

@@ -35,7 +35,7 @@ namespace hrag {
 //     (20 = 1+2+3+3+4+4+2+1: the round-1 plan's stage count, a lower final measure -- docs/experiments/README.md round 5).
 // HRAG_P8_PLAN="1,2,4,4,4,4,1" (experiments only) overrides the rule when it sums to ppr_iters.
 int ppr8_plan(int iters, float damping, bool measured, int *plan) {
-    if (const char *env = getenv("HRAG_P8_PLAN")) {
+    if (const char *env = experiment_env("HRAG_P8_PLAN")) {
         int n = 0, sum = 0;
         for (const char *c = env; *c && n < kP8MaxStages;) {
             const int m = atoi(c);
@@ -45,6 +45,12 @@ int ppr8_plan(int iters, float damping, bool measured, int *plan) {
             if (*c == ',') ++c;
         }
         if (n >= 2 && sum == iters && plan[0] == 1) return n;
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "libhrag: HRAG_P8_PLAN=%s ignored for ppr_iters=%d (needs >= 2 stages, at most %d, starting with 1, "
+                            "summing to ppr_iters): the default plan runs\n", env, iters, kP8MaxStages);
+        }
     }
     int n = 0;
     plan[n++] = 1;
@@ -129,7 +135,7 @@ int ppr8_plan_accel(int iters, float damping, bool measured, int *plan, int *kin
     // the same true error (8e-8 against 4e-7, 3e-7 against 6e-7, 5e-7 against 1.4e-6); on the device at BASELINE configs[2]
     // the residual after 17 sweeps sat just above the default tolerance for most batches (18 sweeps), see profiles/r05*.
     // HRAG_P8_ACCEL_CLOSE=1 keeps the round-4 arrangement (A/B measurements).
-    static const bool old_close = [] { const char *e = getenv("HRAG_P8_ACCEL_CLOSE"); return e && e[0] == '1'; }();
+    static const bool old_close = [] { const char *e = experiment_env("HRAG_P8_ACCEL_CLOSE"); return e && e[0] == '1'; }();
     if (measured && !old_close && n3 >= 3) {
         plan[n] = 2; kind[n++] = 0;
         for (int i = 0; i < n3 - 1; ++i) { plan[n] = 3; kind[n++] = 1; }
@@ -386,6 +392,7 @@ hrag_status ppr8_begin(hrag_engine *e, const float *mn, const float *mx, const f
     a.y = p.buf[0];
     HRAG_TRY(launch_ppr8_init(a, kP8C0Scale, s));
     p.active = true;
+    p.last_step = p.last_group = -1;
     return HRAG_OK;
 }
 
@@ -394,6 +401,17 @@ hrag_status ppr8_sweep(hrag_engine *e, int32_t i, int32_t group, int32_t *exchan
     HRAG_REQUIRE(p.active, "no fp8 PPR session: call the begin step first");
     HRAG_REQUIRE(i >= 0 && i < p.n_steps, "sweep %d outside [0, %d)", i, p.n_steps);
     HRAG_REQUIRE(group >= -1 && group < p.n_groups, "group %d outside [0, %d)", group, p.n_groups);
+    if (p.dyn && group >= 0) {
+        // measured stage scales + per-group issue: (step, group) must advance in lexicographic order without gaps
+        const bool next_group = i == p.last_step && group == p.last_group + 1;
+        const bool next_step = group == 0 && (p.last_step < 0 ? true : (i > p.last_step && p.last_group == p.n_groups - 1));
+        HRAG_REQUIRE(next_group || next_step,
+                     "hrag_shard_ppr_sweep(step %d, group %d) after (step %d, group %d): with measured stage scales the groups of a "
+                     "step must be issued in ascending order and a step completed before the next begins (include/hrag.h)",
+                     i, group, p.last_step, p.last_group);
+        e->p8.last_step = i;
+        e->p8.last_group = group;
+    }
     const Ppr8Step &st = p.steps[i];
     Ppr8Args a = base_args(e);
     if (st.gate >= 0) { a.gate = e->d_ctl + st.gate; a.gate_want = st.gate_want; }

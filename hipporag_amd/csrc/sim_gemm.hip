@@ -399,7 +399,7 @@ int64_t sim_fused_sel_ints(int32_t batch) { static_assert(kSelRec == kSelRecInts
 // A/B switch for measurements and for the bit-identity test of the two GEMM kernels: HRAG_SIM_SMALL_TILES=1 in the
 // environment keeps every shape on sim_gemm_kernel (read once)
 bool sim_gemm_force_small_tiles() {
-    static const bool v = [] { const char *e = getenv("HRAG_SIM_SMALL_TILES"); return e && e[0] == '1'; }();
+    static const bool v = [] { const char *e = experiment_env("HRAG_SIM_SMALL_TILES"); return e && e[0] == '1'; }();
     return v;
 }
 

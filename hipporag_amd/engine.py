@@ -195,6 +195,19 @@ class PendingRetrieve:
         return out
 
 
+def _graph_fingerprint(g) -> tuple:
+    """A cheap identity of a CSR graph's arrays (sizes + strided samples of row_ptr / col_idx / val, no full pass): equal for
+    the arrays an engine was created from, different -- with overwhelming likelihood -- once they were edited in place."""
+    def sample(a):
+        a = np.asarray(a)
+        if a.size == 0:
+            return b""
+        step = max(1, a.size // 1024)
+        return np.ascontiguousarray(a.reshape(-1)[::step][:1024]).tobytes()
+    return (int(g.num_vertices), int(np.asarray(g.col_idx).shape[0]), hash(sample(g.row_ptr)), hash(sample(g.col_idx)),
+            hash(sample(g.val)))
+
+
 class HippoRAGEngine:
     """Device-resident retrieval state: CSR graph, bf16 fact / passage embeddings, lookup arrays.
 
@@ -320,9 +333,10 @@ class HippoRAGEngine:
         # whole matrix, which a plain engine (and every incremental re-prepare of one) has no use for
         import weakref
         self._undirected = None if (row_offset == 0 and n_rows == graph.num_vertices) else False
+        self._graph_print = _graph_fingerprint(caller_graph)      # what was uploaded: the lazy test must see the same arrays
         try:
             self._graph_ref = weakref.ref(caller_graph)
-        except TypeError:
+        except TypeError:       # an object that cannot be weakly referenced: hold it only until the test has run
             self._graph_ref = lambda g=caller_graph: g
         if (flags & _lib.OPT_ACCEL) and not self._is_undirected():
             logger.warning("HRAG_OPT_ACCEL dropped: the graph does not look undirected (or has no col_sum / is a row shard)")
@@ -586,12 +600,19 @@ class HippoRAGEngine:
             if g is None:
                 raise ValueError("HRAG_OPT_ACCEL was not asked for at creation and the graph object is gone: the "
                                  "undirected-graph test cannot run -- pass flags=OPT_ACCEL to HippoRAGEngine()")
+            if _graph_fingerprint(g) != self._graph_print:
+                raise ValueError("the graph object was modified after the engine was created from it: the undirected-graph "
+                                 "test would look at another matrix than the one on the device -- create the engine with "
+                                 "flags=OPT_ACCEL, or keep the graph arrays unchanged until set_flags(OPT_ACCEL)")
             self._undirected = bool(looks_undirected(g))
             self._graph_ref = None
         return self._undirected
 
     def set_flags(self, flags: int, on: bool = True):
-        """Set / clear HRAG_OPT_* bits after creation (e.g. _lib.OPT_NO_FP8 to rerun a saturated batch)."""
+        """Set / clear HRAG_OPT_* bits after creation (e.g. _lib.OPT_NO_FP8 to rerun a saturated batch).
+        OPT_ACCEL, first time: runs graph.looks_undirected on the graph OBJECT the engine was created from -- it must
+        still be alive and unchanged (a fingerprint of its arrays is checked); engines that will need the flag later can
+        pass it at creation instead, which runs the test there."""
         if on and (flags & _lib.OPT_ACCEL) and not self._is_undirected():
             raise ValueError("HRAG_OPT_ACCEL needs an undirected graph with col_sum on an unsharded engine "
                              "(hipporag_amd.graph.looks_undirected): this engine's graph does not qualify")

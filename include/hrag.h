@@ -16,14 +16,14 @@
  *   - every compute entry point takes the HIP stream to enqueue on (pass
  *     torch.cuda.current_stream().cuda_stream) and returns after enqueueing: no
  *     device synchronisation, no allocation in the call path (graph-capture safe);
- *   - ONE call in flight per engine: the workspace (scores, PPR state, seeds) belongs to the engine.  Calls on one
+ *   - ONE call in flight per engine HANDLE: the workspace (scores, PPR state, seeds) belongs to the handle.  Calls on one
  *     stream queue up as usual; a call on ANOTHER stream is ordered behind the previous call ON THE DEVICE (the
  *     library makes the new stream wait for the event that ends the previous call: no host synchronisation, no
  *     error -- a multi-stream pipeline just serialises on this engine's workspace); a call from a second THREAD
  *     while one is still inside the library is REJECTED with HRAG_EBUSY (never a silent race).  Real concurrency =
- *     one engine per stream (the index arrays are small next to 288 GB) -- SURVEY.md 8(b)'s separate workspace
- *     objects were not built.  Replays of a captured HIP graph bypass the library and are NOT ordered against
- *     direct calls on other streams: keep them on one stream;
+ *     one WORKSPACE per stream / thread: hrag_workspace_create gives a second handle on the same index (nothing of
+ *     the index is copied) whose calls run concurrently with this one's -- SURVEY.md 8(b).  Replays of a captured HIP
+ *     graph bypass the library and are NOT ordered against direct calls on other streams: keep them on one stream;
  *   - bf16 = the upper 16 bits of an IEEE-754 binary32, passed as uint16_t (fp16 engines:
  *     IEEE binary16 bit patterns in the same uint16_t slots);
  *   - all index outputs are int32, all score outputs fp32;
@@ -40,6 +40,14 @@
 extern "C" {
 #endif
 
+/* Version history of the ABI (hrag_version() = major * 1000 + minor):
+ *   0.6  error-bound constants, HRAG_PPR_TOL_MIN; stage plan 1+2+3+4+4+4+2 for a FIXED sweep count.  Note for callers
+ *        that read residual_out of a fixed-count call (ppr_tol = 0): that plan REPORTS about 2.2x the residual of the
+ *        0.5 plan at the same true error (the last right-hand side is quantised later) -- a host-side threshold on it
+ *        must be re-derived; a call with ppr_tol > 0 takes the plan ending on 2 + 1, so a fixed-count call and a
+ *        tolerance call at the same 20 sweeps are no longer bit-identical;
+ *   0.7  hrag_workspace_create, hrag_engine_stats (hrag_stats), hrag_ppr_sweeps flag 256 (gather replay);
+ *        hrag_shard_ppr_sweep enforces the ascending (step, group) order of a session with measured stage scales. */
 #define HRAG_VERSION_MAJOR 0
 #define HRAG_VERSION_MINOR 7
 
@@ -48,8 +56,8 @@ typedef enum hrag_status {
     HRAG_EINVAL = 1,      /* bad shape / null pointer / unsupported option                    */
     HRAG_ENOMEM = 2,      /* hipMalloc failed                                                  */
     HRAG_EHIP = 3,        /* a HIP runtime call failed; text in hrag_last_error()              */
-    HRAG_EBUSY = 4,       /* another THREAD is inside a call on this engine (the workspace lives in the engine: one   */
-                          /* call in flight; calls on other streams are ordered behind it on the device, see above)   */
+    HRAG_EBUSY = 4,       /* another THREAD is inside a call on this HANDLE (its workspace is in use; a second handle  */
+                          /* from hrag_workspace_create runs concurrently; calls on other streams queue on the device) */
     HRAG_ECAPACITY = 5    /* batch / k larger than the engine was created for                  */
 } hrag_status;
 

@@ -113,3 +113,62 @@ def test_mirror_end_to_end_on_the_real_corpus_equals_the_mirror_over_the_oracle_
     write_test_report("real2wiki_mirror_end_to_end", {"documents": len(docs), "queries": len(queries),
                                                       "max_rel_score_diff_to_the_oracle_backed_mirror": worst})
     assert worst < 1e-5, worst
+
+
+def test_retrieve_ircot_on_the_real_corpus_equals_the_mirror_over_the_oracle_engine(gpu_device, monkeypatch):
+    """retrieve_ircot (HippoRAG.py:509-558) against the ORACLE, not against the HIP path itself (round-5 review, weak
+    item 4): the same multi-step run -- 12 questions, up to 3 steps, a deterministic "reasoner" whose thoughts are
+    fact-like strings of the corpus chosen by (question, step), two questions stopping early on 'So the answer is:' --
+    once on the device engine (steps of 12, then 10 active queries: the small-batch and fp16-state kernels), once with
+    the engine replaced by the oracle-backed CPU stand-in of tests/support: the same merged document lists in the same
+    order (tie-class aware) and max-merged scores within the parity bar."""
+    import importlib.util
+    import os
+    from hipporag_amd import engine as engine_mod
+    from hipporag_amd.retriever import HippoRAG, RetrievalConfig
+    from tests.helpers import tie_aware_equal
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "support", "adapter_on_real_reference.py")
+    spec = importlib.util.spec_from_file_location("adapter_on_real_reference", path)
+    sup = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sup)
+    docs, triples = rw.openie_inputs(800)
+    model = sup.Bf16Mock()
+    with_facts = [i for i in range(len(docs)) if triples[i]]
+    questions = [" ".join(triples[i][0]) for i in with_facts[::61]][:12]
+    assert len(questions) == 12
+
+    def reason(query, retrieved, thoughts):
+        qi, step = questions.index(query), len(thoughts)
+        if qi in (3, 7) and step == 1:
+            return "So the answer is: enough"
+        t = triples[with_facts[(qi * 37 + step * 101 + 5) % len(with_facts)]]
+        return " ".join(t[(qi + step) % len(t)])
+
+    cfg = dict(embedding_precision="bf16", max_batch=16, retrieval_top_k=40)
+    gpu = HippoRAG(RetrievalConfig(**cfg), embedding_model=model)
+    gpu.index_from_openie(docs, triples)
+    got = gpu.retrieve_ircot(questions, max_qa_steps=3, num_to_retrieve=15, reason_fn=reason)
+    assert gpu.engine.device.type == "cuda"
+    monkeypatch.setattr(engine_mod, "HippoRAGEngine", sup.OracleEngine)
+    cpu = HippoRAG(RetrievalConfig(**cfg), embedding_model=model)
+    cpu.index_from_openie(docs, triples)
+    want = cpu.retrieve_ircot(questions, max_qa_steps=3, num_to_retrieve=15, reason_fn=reason)
+    assert cpu.engine.device.type == "cpu"
+    pos = {d: i for i, d in enumerate(docs)}
+    worst, n_docs = 0.0, 0
+    for g, w in zip(got, want):
+        assert g.question == w.question and g.thoughts == w.thoughts
+        n = min(len(g.docs), len(w.docs), 15)
+        gi, wi = [pos[d] for d in g.docs[:n]], [pos[d] for d in w.docs[:n]]
+        assert tie_aware_equal(gi, wi, np.asarray(w.doc_scores[:n], dtype=np.float64), rel_gap=2e-5), (g.question, gi, wi)
+        by_doc = dict(zip(w.docs, np.asarray(w.doc_scores, dtype=np.float64)))
+        for d, s in zip(g.docs[:n], np.asarray(g.doc_scores[:n], dtype=np.float64)):
+            if d in by_doc:
+                worst = max(worst, abs(s / by_doc[d] - 1))
+                n_docs += 1
+    assert [len(s.thoughts) for s in got] == [2 if i not in (3, 7) else 2 for i in range(12)]
+    assert got[3].thoughts[-1].startswith("So the answer is:") and got[7].thoughts[-1].startswith("So the answer is:")
+    write_test_report("real2wiki_ircot_vs_oracle_backed_mirror", {"documents": len(docs), "questions": len(questions),
+                                                                  "documents_compared": n_docs,
+                                                                  "max_rel_score_diff_to_the_oracle_backed_mirror": worst})
+    assert worst < 1e-5 and n_docs >= 12 * 10, (worst, n_docs)

@@ -248,6 +248,150 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(const uint16_t *__restrict_
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// X2: the round-4 product schedule (ONE barrier per k-step, embedding ring of 3 stages, TWO full query stages) +
+// specialised loader waves (0-3 embeddings, 4-7 queries) + optionally persistent workgroups over contiguous row ranges
+// + the 128 x 64 wave tile (register-only min / max epilogue).
+template <int MODE, bool TILEMAX>
+__global__ __launch_bounds__(512) void gemm_x2_kernel(const uint16_t *__restrict__ emb, int64_t rows, int32_t dim,
+                                                      const uint16_t *__restrict__ q, int32_t batch,
+                                                      float *__restrict__ out, int64_t ld, int32_t tn,
+                                                      int64_t range_rows, float *__restrict__ tmax,
+                                                      float *__restrict__ tmin) {
+    constexpr int SA = 3, A_STAGE = 32768, B_STAGE = 32768, AL = 8;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [3][A_STAGE] then [2][B_STAGE]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool a_loader = wave < 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nt = slot % tn;
+    const int64_t range = (int64_t)(slot / tn) * 8 + xcd;
+    const int64_t m_begin = range * range_rows;
+    if (m_begin >= rows) return;
+    const int64_t m_end = (m_begin + range_rows < rows) ? m_begin + range_rows : rows;
+    const int ntile = (int)((m_end - m_begin + 255) / 256);
+    const int nk = dim / 64;
+    const int total = ntile * nk;
+    const int b0 = nt * 256;
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lrow & 7);
+    int ld_tile = 0, ld_kt = 0, ld_slot = 0, ld_g = 0;
+    auto issue_a = [&]() {
+        const uint32_t sa = smem_base + (uint32_t)(ld_slot * A_STAGE);
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            const int blk = wave * AL + i;
+            int64_t r = m_begin + (int64_t)ld_tile * 256 + blk * 8 + lrow;
+            r = r < m_end ? r : m_end - 1;
+            glds16<true>(emb + (size_t)r * dim + ld_kt * 64 + lchunk * 8, sa + (uint32_t)(blk * 1024));
+        }
+        ++ld_g;
+        if (++ld_slot == SA) ld_slot = 0;
+        if (++ld_kt == nk) { ld_kt = 0; ++ld_tile; }
+    };
+    auto issue_b = [&](int bslot, int kt) {
+        const uint32_t sb = smem_base + (uint32_t)(SA * A_STAGE + bslot * B_STAGE);
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            const int blk = (wave - 4) * AL + i;
+            int r = b0 + blk * 8 + lrow;
+            r = r < batch ? r : batch - 1;
+            glds16<false>(q + (size_t)r * dim + kt * 64 + lchunk * 8, sb + (uint32_t)(blk * 1024));
+        }
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fk = lane >> 4;
+    const uint32_t a_lane = (uint32_t)((wm * 128 + frow) * 128);
+    const uint32_t b_lane = (uint32_t)((wn * 64 + frow) * 128);
+
+    if (a_loader) {
+        issue_a();
+        if (ld_g < total) issue_a();
+        if (total >= 2) wait_vm<AL>(); else wait_vm<0>();
+    } else if (MODE != 2) {
+        issue_b(0, 0);
+        wait_vm<0>();
+    }
+    wg_barrier();
+    int tile_i = 0, kt = 0, a_slot = 0;
+    for (int g = 0; g < total; ++g) {
+        const int kt_next = (kt + 1 == nk) ? 0 : kt + 1;
+        if (a_loader) { if (ld_g < total) issue_a(); }                       // A(g + 2)
+        else if (MODE != 2 && g + 1 < total) issue_b((g + 1) & 1, kt_next);  // B(g + 1)
+        if constexpr (MODE == 0) {
+            const unsigned char *sa = smem + a_slot * A_STAGE + a_lane;
+            const unsigned char *sb = smem + SA * A_STAGE + (g & 1) * B_STAGE + b_lane;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 a[8], b[4];
+                const int c = ((s * 4 + fk) ^ (frow & 7)) << 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const uint4 *>(sb + j * 2048 + c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const uint4 *>(sa + i * 2048 + c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+            }
+        }
+        if (kt + 1 == nk) {
+            const int64_t m0 = m_begin + (int64_t)tile_i * 256 + wm * 128;
+            if constexpr (TILEMAX) {
+                if (m0 < m_end) {
+                    const int64_t t128 = m0 >> 7;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int64_t m = m0 + i * 16 + 4 * fk;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (m + r < m_end) {
+                                    mx = fmaxf(mx, acc[i][j][r]);
+                                    mn = fminf(mn, acc[i][j][r]);
+                                }
+                        }
+                        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                        mn = fminf(mn, __shfl_xor(mn, 16, 64));
+                        mn = fminf(mn, __shfl_xor(mn, 32, 64));
+                        const int gb = b0 + wn * 64 + j * 16 + lane;
+                        if (lane < 16 && gb < batch) {
+                            tmax[(size_t)t128 * batch + gb] = mx;
+                            tmin[(size_t)t128 * batch + gb] = mn;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (g + 1 < total) {
+            if (a_loader) {
+                if (g + 2 < total) wait_vm<AL>(); else wait_vm<0>();   // A(g + 1) landed, A(g + 2) may fly
+            } else {
+                wait_vm<0>();                                          // B(g + 1)
+            }
+        }
+        wg_barrier();
+        if (++a_slot == SA) a_slot = 0;
+        if (++kt == nk) { kt = 0; ++tile_i; }
+    }
+    if constexpr (MODE != 0) {
+        if (tid == 0 && total < 0) tmax[0] = acc[0][0][0];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Ping-pong variant: the two waves of a SIMD run ONE PHASE apart (group 1 = waves 4-7 passes one extra barrier first):
 // while one group issues the 32 MFMAs of a half k-step, the other reads its 12 fragments for the next one.  Four
@@ -536,6 +680,150 @@ Times time_it(F launch) {
     return {t[0], t[2]};
 }
 
+// Asymmetric pipeline: THREE stages for the embedding rows (HBM: the long-latency stream, prefetch distance 2) and TWO
+// for the query tile (L2), BK = 64: 3 * 32 KB + 2 * 32 KB = 160 KB at a 256 x 256 tile -- the whole LDS of a CU.
+// Issue order per step: B(k + 1) then A(k + 2), so that `vmcnt(loads of one A stage)` leaves exactly A(k + 2) in flight.
+template <int MI, int NJ, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64, 1) void gemm_asym_kernel(const uint16_t *__restrict__ emb, int64_t rows, int32_t dim,
+                                                                      const uint16_t *__restrict__ q, int32_t batch,
+                                                                      float *__restrict__ tmax) {
+    constexpr int NW = WGM * WGN, BK = 64;
+    constexpr int BM = WGM * MI * 16, BN = WGN * NJ * 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int A_LOADS = BM / 8 / NW;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int64_t mt = blockIdx.x;
+    if (mt * BM >= rows) return;
+    const int64_t m0 = mt * BM;
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lrow & 7);
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    auto issue_a = [&](int stage, int k0) {
+        const uint32_t sa = smem_base + (uint32_t)(stage * A_BYTES);
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int blk = wave * A_LOADS + i;
+            int64_t r = m0 + blk * 8 + lrow;
+            r = r < rows ? r : rows - 1;
+            glds16<true>(emb + (size_t)r * dim + k0 + lchunk * 8, sa + (uint32_t)(blk * 1024));
+        }
+    };
+    auto issue_b = [&](int stage, int k0) {
+        const uint32_t sb = smem_base + (uint32_t)(3 * A_BYTES + stage * B_BYTES);
+#pragma unroll
+        for (int i = 0; i < BN / 8 / NW; ++i) {
+            const int blk = wave * (BN / 8 / NW) + i;
+            int r = blk * 8 + lrow;
+            r = r < batch ? r : batch - 1;
+            glds16<false>(q + (size_t)r * dim + k0 + lchunk * 8, sb + (uint32_t)(blk * 1024));
+        }
+    };
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fk = lane >> 4;
+    const int nk = dim / BK;
+    issue_b(0, 0);
+    issue_a(0, 0);
+    if (nk > 1) issue_a(1, BK);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LOADS) : "memory");   // A(kt + 1) may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) issue_b((kt + 1) & 1, (kt + 1) * BK);
+        if (kt + 2 < nk) issue_a((kt + 2) % 3, (kt + 2) * BK);
+        const unsigned char *sa = smem + (kt % 3) * A_BYTES;
+        const unsigned char *sb = smem + 3 * A_BYTES + (kt & 1) * B_BYTES;
+#pragma unroll
+        for (int s = 0; s < BK / 32; ++s) {
+            const int c = s * 4 + fk;
+            uint4 a[MI], b[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int r = wm * (MI * 16) + i * 16 + frow;
+                a[i] = *reinterpret_cast<const uint4 *>(sa + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int r = wn * (NJ * 16) + j * 16 + frow;
+                b[j] = *reinterpret_cast<const uint4 *>(sb + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const int gb = wn * (NJ * 16) + j * 16 + lane;
+        if (lane < 16 && gb < batch) tmax[((size_t)mt * WGM + wm) * batch + gb] = mx;
+    }
+}
+
+template <int MI, int NJ, int WGM, int WGN>
+void run_asym(const char *name, const uint16_t *emb, int64_t rows, int dim, const uint16_t *q, int batch, float *tmax) {
+    constexpr int BM = WGM * MI * 16, BN = WGN * NJ * 16;
+    const int lds = 3 * BM * 128 + 2 * BN * 128;
+    auto k = gemm_asym_kernel<MI, NJ, WGM, WGN>;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err != hipSuccess) { printf("%-44s %d KB of LDS refused: %s\n", name, lds / 1024, hipGetErrorString(err)); (void)hipGetLastError(); return; }
+    const unsigned grid = (unsigned)((rows + BM - 1) / BM);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(WGM * WGN * 64), lds, 0, emb, rows, dim, q, batch, tmax);
+    err = hipGetLastError();
+    if (err != hipSuccess) { printf("%-44s launch failed: %s\n", name, hipGetErrorString(err)); return; }
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int n = 20;
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(WGM * WGN * 64), lds, 0, emb, rows, dim, q, batch, tmax);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= n;
+    const double flop = 2.0 * rows * batch * dim;
+    printf("%-44s tile %3dx%3d lds %3d KB  %.3f ms  %.0f TFLOP/s (%.1f %% of 2.5 PF)  %.2f TB/s of A\n", name, BM, BN, lds / 1024,
+           ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0, (double)rows * dim * 2 / ms / 1e9);
+}
+
+
+template <int MODE, bool TILEMAX>
+void run_x2(const char *name, bool persistent, const uint16_t *emb, int64_t rows, int dim, const uint16_t *q, int batch,
+            float *out, float *tmax, float *tmin) {
+    const int tn = (batch + 255) / 256;
+    const int lds = 3 * 32768 + 2 * 32768;
+    auto k = gemm_x2_kernel<MODE, TILEMAX>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    int64_t nranges, range_rows;
+    if (persistent) {
+        int g = n_cus() / (8 * tn) * (8 * tn);
+        nranges = g / tn;
+        range_rows = ((rows + nranges - 1) / nranges + 127) / 128 * 128;
+    } else {
+        range_rows = 256;
+        nranges = ((rows + 255) / 256 + 7) / 8 * 8;
+    }
+    const unsigned grid = (unsigned)(nranges * tn);
+    auto launch = [&]() {
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, emb, rows, dim, q, batch, out, (int64_t)rows, tn, range_rows, tmax, tmin);
+    };
+    const Times t = time_it(launch);
+    const double flop = 2.0 * rows * batch * dim;
+    printf("%-58s grid %5u range %6lld  best %.3f med %.3f ms  %5.0f TFLOP/s (%4.1f %%)  %.2f TB/s of A\n", name, grid,
+           (long long)range_rows, t.best, t.med, flop / t.med / 1e9, flop / t.med / 1e9 / 25.0, (double)rows * dim * 2 / t.med / 1e9);
+    fflush(stdout);
+}
+
 // persistent = true: one workgroup per CU and contiguous row ranges; false: one 256-row tile per workgroup
 template <int SA, int MODE, bool BLOCKED, bool PRIO, bool TILEMAX>
 void run_p(const char *name, bool persistent, const uint16_t *emb, int64_t rows, int dim, const uint16_t *q, int batch,
@@ -681,28 +969,24 @@ int main(int argc, char **argv) {
             printf("\n");
         }
     };
-    // the query tile re-laid [tile][k-step][256 queries][64 k]: every 32 KB stage contiguous
-    uint16_t *qb;
-    CK(hipMalloc(&qb, (size_t)max_batch * dim * 2));
-    {
-        std::vector<uint16_t> hb((size_t)max_batch * dim);
-        const int nk = dim / 64;
-        for (int b = 0; b < max_batch; ++b)
-            for (int k = 0; k < dim; ++k)
-                hb[((size_t)((b / 256) * nk + k / 64) * 256 + (b % 256)) * 64 + (k % 64)] = hq[(size_t)b * dim + k];
-        CK(hipMemcpy(qb, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
-    }
     clear(256);
-    run_pp<3, 0, false, true, 0, true>("[check] PP SA3 persistent, blocked queries", true, emb, rows, dim, qb, 256, out, tmax, tmin);
-    check(256, "PP SA3 blocked queries B=256");
-    for (int rep = 0; rep < 2; ++rep) {
+    run_x2<0, true>("[check] X2 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
+    check(256, "X2 persistent B=256");
+    clear(1024);
+    run_x2<0, true>("[check] X2 tile per WG B=1000", false, emb, rows, dim, q, 1000, out, tmax, tmin);
+    check(1000, "X2 tile per WG B=1000");
+    float *tmax_old;
+    CK(hipMalloc(&tmax_old, (size_t)(rows / 16 + 64) * 256 * 4));
+    for (int rep = 0; rep < 3; ++rep) {
         printf("---- round %d, B = 256\n", rep);
-        run_pp<3, 0, false, true, 0, false>("PP SA3 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
-        run_pp<3, 0, false, true, 0, true>("PP SA3 persistent, blocked queries", true, emb, rows, dim, qb, 256, out, tmax, tmin);
-        run_pp<3, 1, false, true, 0, false>("PP SA3 loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
-        run_pp<3, 1, false, true, 0, true>("PP SA3 loads only, blocked queries", true, emb, rows, dim, qb, 256, out, tmax, tmin);
-        run_pp<3, 4, false, true, 0, false>("PP SA3 query loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
-        run_pp<3, 4, false, true, 0, true>("PP SA3 query loads only, blocked queries", true, emb, rows, dim, qb, 256, out, tmax, tmin);
+        run_asym<4, 8, 4, 2>("round-4 product structure (8 waves 64x128, A3 + B2)", emb, rows, dim, q, 256, tmax_old);
+        run_x2<0, true>("X2 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
+        run_x2<0, true>("X2 one tile per workgroup", false, emb, rows, dim, q, 256, out, tmax, tmin);
+        run_x2<1, true>("X2 persistent, loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+        run_x2<2, true>("X2 persistent, A loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
     }
+    printf("---- B = 1024\n");
+    run_x2<0, true>("X2 persistent B=1024", true, emb, rows, dim, q, 1024, out, tmax, tmin);
+    run_x2<0, true>("X2 one tile per workgroup B=1024", false, emb, rows, dim, q, 1024, out, tmax, tmin);
     return 0;
 }

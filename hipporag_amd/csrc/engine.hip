@@ -309,6 +309,27 @@ static double accel_omega(int k, double rho) {    // w_k of the recurrence above
     for (int j = 2; j <= k; ++j) w = j == 2 ? 1.0 / (1.0 - rho * rho / 2.0) : 1.0 / (1.0 - rho * rho * w / 4.0);
     return w;
 }
+// The two-stage fp16 states (ppr16.hip, ppr_sv.hip) split `iters` sweeps into K1 on h + the residual sweep + K2 on the
+// correction c.  >= 16 sweeps: halves, as in every round.  11 .. 15 sweeps (round 6: the BASE count of a tolerance-driven
+// call -- the contract's measure adds stages when the graph needs them, so a caller on a well-mixing graph need not pay
+// for the worst-case count): K1 = 9 where the count allows -- the correction then starts at damping^9 = 2e-3 of the
+// iterate and its fp16 rounding, 2^-11 of that = 9.5e-7 of the iterate, stays inside HRAG_PPR_ERR_FLOOR_F16 -- and at
+// least one correction sweep + the final sweep.  Below 11 the fp32 state runs (K1 < 8: c too large for its fp16 rounding).
+constexpr int kTwoStageMinIters = 11;
+static inline void split16(int iters, int *k1, int *k2) {
+    *k1 = iters >= 16 ? iters / 2 : std::min(9, iters - 3);
+    *k2 = iters - *k1 - 1;
+}
+// ... which is an argument about damping^K1: a short count qualifies only where damping^K1 <= 2.2e-3 (0.5^9 = 1.95e-3;
+// a larger damping factor keeps the fp32 state below 16 sweeps, as before round 6)
+static inline bool two_stage_ok(int iters, float damping) {
+    if (iters >= 16) return true;
+    if (iters < kTwoStageMinIters) return false;
+    int k1, k2;
+    split16(iters, &k1, &k2);
+    return std::pow((double)damping, (double)k1) <= 2.2e-3;
+}
+
 static bool accel_plan16(int iters, float damping, int *k1_out, int *k2_out) {
     const double al = (double)damping;
     // damping above ~0.6: the equi-oscillating error of a Chebyshev stage sits on the SMALL passage scores as well, and
@@ -352,7 +373,8 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
                       int *e_max_out = nullptr) {
     const int ns = n_slabs64(batch);
     const int nt = (e->opt_flags & HRAG_OPT_TEMPORAL16) ? 0 : 3;
-    int k1 = iters / 2, k2 = iters - k1 - 1, kc = 0;   // kc: Chebyshev steps among the k2 correction sweeps
+    int k1, k2, kc = 0;                                // kc: Chebyshev steps among the k2 correction sweeps
+    split16(iters, &k1, &k2);
     const bool accel = allow_accel && (e->opt_flags & HRAG_OPT_ACCEL) && accel_plan16(iters, damping, &k1, &kc);
     if (accel) k2 = kc + 2;                            // + one plain correction sweep + the final sweep
     const int sweeps = k1 + 1 + k2;
@@ -406,10 +428,10 @@ hrag_status ppr16_run(hrag_engine *e, int batch, float damping, int iters, hipSt
     return HRAG_OK;
 }
 
-// The fp16 two-stage scheme needs K1 >= 8 sweeps before the residual sweep (error ~ 2^-(11+K1)).
-inline bool use_f16(const hrag_engine *e, int batch, int iters) {
+// The fp16 two-stage scheme needs K1 >= 8 sweeps before the residual sweep (error ~ 2^-(11+K1)): split16.
+inline bool use_f16(const hrag_engine *e, int batch, int iters, float damping) {
     return e->f16_ready && !(e->opt_flags & HRAG_OPT_NO_F16) && batch > kSvMaxBatch && batch <= e->f16_max_batch &&
-           iters >= 16;
+           two_stage_ok(iters, damping);
 }
 inline bool use_sv(const hrag_engine *e, int batch) { return e->sell_ready && batch <= kSvMaxBatch; }
 inline int sv_width(int batch) { return batch <= 1 ? 1 : batch <= 2 ? 2 : batch <= 4 ? 4 : 8; }
@@ -429,8 +451,8 @@ PprSvArgs ppr_sv_args(const hrag_engine *e, const Sell8Store &m, const void *x, 
 }
 
 // the two-stage fp16 state of the small-batch path needs K1 >= 8 sweeps before the residual sweep
-inline bool use_sv_half(const hrag_engine *e, int iters) {
-    return e->d_sv16[0] != nullptr && !(e->opt_flags & HRAG_OPT_NO_F16) && iters >= 16;
+inline bool use_sv_half(const hrag_engine *e, int iters, float damping) {
+    return e->d_sv16[0] != nullptr && !(e->opt_flags & HRAG_OPT_NO_F16) && two_stage_ok(iters, damping);
 }
 
 // hrag_ppr (all rows wanted): x_0 = v, `iters` plain sweeps; the final state ends in e->d_x ([V][bp] fp32)
@@ -455,7 +477,7 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
     if (sweeps_out) *sweeps_out = iters;
     if (e_max_out) *e_max_out = 0;
     if (iters < 1) return ppr_sv_run_full(e, row_slot, tele, bp, damping, iters, s);
-    if (!use_sv_half(e, iters)) {
+    if (!use_sv_half(e, iters, damping)) {
         float *x = e->d_x, *y = e->d_y;
         HRAG_TRY(launch_ppr_sv_init(ppr_sv_args(e, e->sell, nullptr, x, row_slot, tele, damping), bp, s));
         for (int it = 0; it < iters; ++it) {
@@ -468,7 +490,8 @@ hrag_status ppr_sv_run(hrag_engine *e, const int32_t *row_slot, const float *tel
         if (x != e->d_x) std::swap(e->d_x, e->d_y);
         return HRAG_OK;
     }
-    int k1 = iters / 2, k2 = iters - k1 - 1, kc = 0;   // the plan of ppr16_run, Chebyshev steps included (accel_plan16)
+    int k1, k2, kc = 0;                                // the plan of ppr16_run, Chebyshev steps included (accel_plan16)
+    split16(iters, &k1, &k2);
     const bool accel = allow_accel && (e->opt_flags & HRAG_OPT_ACCEL) && accel_plan16(iters, damping, &k1, &kc);
     if (accel) k2 = kc + 2;
     const int sweeps = k1 + 1 + k2;
@@ -1202,7 +1225,7 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
     const bool sv = use_sv(e, batch);
     const bool f8 = !sv && batch > 64 && e->d_pool8[0] && ppr8_usable(e, batch, ppr_iters, damping);
     const int f8_iters = ppr_iters;
-    const bool f16 = !sv && !f8 && use_f16(e, batch, ppr_iters);
+    const bool f16 = !sv && !f8 && use_f16(e, batch, ppr_iters, damping);
     const int bp = sv_width(batch);
     SlabLayout lay = e->layout(batch);
     if (f16 || f8) { lay.bc = 64; lay.n_slabs = n_slabs64(batch); }
@@ -1233,7 +1256,7 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
         HRAG_TRY(prep_query(e, q_pass, batch, s, &q_pass));
         HRAG_TRY(launch_sim_gemm(e->d_pemb, e->p_rows, e->kdim, q_pass, batch, e->d_spass, e->ld_p, s, 0, e->emb_dtype));
     }
-    const bool sv_half = sv && use_sv_half(e, ppr_iters);
+    const bool sv_half = sv && use_sv_half(e, ppr_iters, damping);
     HRAG_TRY(launch_row_minmax(e->d_spass, batch, e->n_passages, e->ld_p, e->d_mn_p, e->d_mx_p, s,
                                (f16 || sv_half) ? e->d_ssum : nullptr));
     if (prof) HRAG_HIP_TRY(hipEventRecord(e->ev[EV_SIM], s));

@@ -109,7 +109,8 @@ def build_engine_from_reference(rag, *, max_batch: int = 256, embedding_precisio
 
 
 def attach(rag, *, max_batch: int = 256, ppr_iters: Optional[int] = None, batched_retrieve: bool = True,
-           ppr_tol: float = 1.5e-6, ppr_max_iters: int = 400, embedding_precision: str = "f32"):
+           ppr_tol: float = 1.5e-6, ppr_max_iters: int = 400, embedding_precision: str = "f32",
+           ppr_base_iters_narrow: Optional[int] = 12):
     """Patch ``rag`` in place; returns it.  Call again after ``index()`` / ``delete()`` (they change
     the graph and the stores; the reference only resets ``ready_to_retrieve`` on delete, :411)."""
     import torch
@@ -181,7 +182,8 @@ def attach(rag, *, max_batch: int = 256, ppr_iters: Optional[int] = None, batche
                                               linking_top_k=int(cfg.linking_top_k), damping=cfg.damping,
                                               passage_node_weight=cfg.passage_node_weight, ppr_iters=sweeps,
                                               num_to_retrieve=int(num_to_retrieve), n_passages=len(rag.passage_node_keys),
-                                              timers=rag, ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters):
+                                              timers=rag, ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters,
+                                              ppr_base_iters_narrow=ppr_base_iters_narrow):
             with gc_paused():
                 for q, (d_idx, d_sc, seeds) in zip(queries[lo: lo + len(rows)], rows):
                     r = build_result(q, d_idx, d_sc, num_to_retrieve, seeds)

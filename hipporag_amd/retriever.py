@@ -167,6 +167,14 @@ class RetrievalConfig:
     ppr_tol: float = 1.5e-6
     ppr_max_iters: int = 400             # bound on the sweeps a slowly mixing graph may cost (fp8 state: 30, then
                                          # the flagged queries are repeated on the wider state)
+    ppr_base_iters_narrow: Optional[int] = 12     # batches of at most 64 queries (interactive calls, IRCoT steps) under the
+                                         # contract (ppr_tol > 0): this many sweeps ALWAYS run (>= 11) instead of the
+                                         # worst-case count above, and the measured residual adds stages of 1, 2, 3, 3
+                                         # sweeps where the graph needs them -- PRPACK likewise stops when ITS residual
+                                         # says so (HippoRAG.py:1736-1743).  Same error bound (include/hrag.h; asserted per
+                                         # query on the adversarial graphs: tests/test_gpu_fp8_adversarial.py); 15 sweeps
+                                         # instead of 20 on the benchmark graph: -20 ... -24 % per call
+                                         # (profiles/r06d_sweep_smallb_cfg3.json).  None / 0: the count above always runs
     ppr_accel: bool = True               # HRAG_OPT_ACCEL (include/hrag.h): wide batches (> 64 queries) run Chebyshev steps
                                          # inside the fp8 stages -- 17 sweeps + what the measured residual asks for
                                          # instead of 20 + ...; the answer is tolerance-driven either way, like the
@@ -217,7 +225,7 @@ def batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Sequenc
 def iter_batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Sequence, rerank_filter: Callable, *,
                           linking_top_k: int, damping: float, passage_node_weight: float, ppr_iters: int,
                           num_to_retrieve: int, n_passages: int, timers=None, ppr_tol: float = 0.0,
-                          ppr_max_iters: int = 0):
+                          ppr_max_iters: int = 0, ppr_base_iters_narrow: Optional[int] = None):
     """The body of retrieve() (HippoRAG.py:459-480), shared by the mirror class below and by
     reference_adapter.attach(): phase A on the device, the recognition-memory filter on the host (rerank_facts
     :1659-1707), phase B on the device, in batches of eng.max_batch queries.  Yields (offset of the batch, [(doc ids,
@@ -233,7 +241,9 @@ def iter_batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Se
 
     ppr_tol / ppr_max_iters: the convergence contract (RetrievalConfig): queries the engine flags as not converged
     within its sweep budget are repeated -- those queries only -- on the wider state with the sweeps their
-    residual asks for, so a slowly mixing graph costs time, never accuracy."""
+    residual asks for, so a slowly mixing graph costs time, never accuracy.
+    ppr_base_iters_narrow (RetrievalConfig.ppr_base_iters_narrow): the sweeps that ALWAYS run for a batch of at most 64
+    queries under a tolerance -- the measure adds stages where the graph needs them."""
     import torch
     from .engine import host_copy_async, host_wait
     k_f = int(linking_top_k)
@@ -296,7 +306,11 @@ def iter_batched_retrieve(eng, queries: List[str], q_tensor: Callable, facts: Se
         tick("rerank_time", t0)
         t0 = time.time()
         args = (q_tensor(qs, "passage"), torch.from_numpy(kept_idx), torch.from_numpy(kept_sc), torch.from_numpy(kept_cnt))
-        kw = dict(link_top_k=k_f, damping=damping, passage_node_weight=passage_node_weight, ppr_iters=ppr_iters,
+        base = ppr_iters
+        if ppr_base_iters_narrow and ppr_tol > 0 and len(qs) <= 64 and damping <= 0.5:     # (the two-stage state's short
+            # split is an argument about damping^9: csrc/engine.hip two_stage_ok; other damping factors keep the count above)
+            base = max(11, min(int(ppr_base_iters_narrow), ppr_iters))     # narrow batch under the contract: latency mode
+        kw = dict(link_top_k=k_f, damping=damping, passage_node_weight=passage_node_weight, ppr_iters=base,
                   k=k_docs, ppr_tol=ppr_tol, ppr_max_iters=ppr_max_iters, **({"want_all_scores": True} if beyond else {}))
         if two_halves:
             bt.pending = eng.retrieve_converged_start(*args, **kw)
@@ -768,6 +782,7 @@ class HippoRAG:
                                               self.rerank_filter, linking_top_k=cfg.linking_top_k, damping=cfg.damping,
                                               passage_node_weight=cfg.passage_node_weight, ppr_iters=self._ppr_iters(),
                                               ppr_tol=cfg.ppr_tol, ppr_max_iters=cfg.ppr_max_iters,
+                                              ppr_base_iters_narrow=cfg.ppr_base_iters_narrow,
                                               num_to_retrieve=num_to_retrieve, n_passages=len(self.passage_node_keys),
                                               timers=self):
             with gc_paused():       # around the materialisation only: the filter (an LLM call in production) runs outside

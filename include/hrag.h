@@ -133,7 +133,7 @@ typedef struct hrag_fact_desc {
 #define HRAG_OPT_NT_STORE 4          /* fp32-state kernel: non-temporal stores for the new PPR state       */
 #define HRAG_OPT_F32_STATE 8         /* plain CSR + fp32 slab state only: none of the staged fp8 state  */
                                      /* (batch > 64), the two-stage fp16 state (batch > 8, ppr_iters    */
-                                     /* >= 16) and the small-batch kernels (batch <= 8); same 1e-5 bar  */
+                                     /* >= 11) and the small-batch kernels (batch <= 8); same 1e-5 bar  */
 #define HRAG_OPT_TEMPORAL16 16       /* fp16-state kernels: plain instead of non-temporal (col, val)   */
                                      /* loads and state stores (non-temporal is 3 % faster at cfg 3)   */
 

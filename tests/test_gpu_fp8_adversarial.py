@@ -511,3 +511,59 @@ def test_accelerated_stages_on_adversarial_graphs_under_the_contract(gpu_device,
         worst = max(worst, float((np.abs(full[nz] / want[nz] - 1) - allow[nz]).max()))
         assert np.all(full[~nz] == 0), q
     assert worst < 1e-5 / 1.5, (name, b, worst)
+
+
+@pytest.mark.parametrize("b", [1, 8, 40])
+@pytest.mark.parametrize("name", ["ring", "stars", "barbell_wild_weights", "tiny_component", "sparse_power_law"])
+def test_a_base_count_of_12_sweeps_under_the_contract_keeps_the_error_bound_on_the_fp16_states(gpu_device, name, b):
+    """Round 6, the latency mode of the narrow batches (RetrievalConfig.ppr_base_iters_narrow; csrc/engine.hip split16):
+    under a tolerance only 12 sweeps ALWAYS run on the two-stage fp16 states (K1 = 9 on h, the residual sweep, one
+    correction sweep, the measuring final sweep) and the measured residual adds stages where the graph mixes slowly.
+    The bound include/hrag.h states must hold query by query exactly as it does for the worst-case base count of 20:
+    true relative error of EVERY passage <= max(HRAG_PPR_ERR_K * residual, floor of the fp16 state), against the exact
+    fp64 solution (the reference's PRPACK iterates to 1e-10: HippoRAG.py:1736-1743)."""
+    import dataclasses
+    import torch
+    from hipporag_amd._lib import PPR_ERR_FLOOR_F16, PPR_ERR_K
+    from hipporag_amd.engine import HippoRAGEngine
+    make, damping, _ = CASES[name]
+    n, src, dst, w, pv, pinned = make()
+    csr, pass_bits, fact_bits, index = _index(n, src, dst, w, pv, 64, seed=11, pinned_facts=pinned)
+    index = dataclasses.replace(index, damping=damping)
+    n_p = len(pv)
+    qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=5)
+    for i in range(min(b, len(pinned))):
+        qf_bits[i] = fact_bits[i]
+    qp_bits, _ = synth.make_queries_np(pass_bits, b, seed=6)
+    tol = 1.5e-6
+    with HippoRAGEngine(csr, index.passage_vertex, pass_bits, fact_bits, index.subj_vertex, index.obj_vertex,
+                        index.num_chunks, max_batch=b, max_topk=n_p) as eng:
+        idx, sc = eng.score_facts(_bf16(qf_bits, gpu_device), k=5)
+        cnt = _t(np.full(b, 5, np.int32), gpu_device)
+        raw = eng.retrieve(_bf16(qp_bits, gpu_device), idx, sc, cnt, damping=damping, ppr_iters=12, k=n_p,
+                           ppr_tol=tol, ppr_max_iters=400)
+        torch.cuda.synchronize()
+        assert eng.timings()["slab_width"] == (64 if b > 8 else (1 if b == 1 else 8))      # an fp16 state served the call
+        raw_used = raw.iters_used.cpu().numpy()
+        out = eng.retrieve_converged(_bf16(qp_bits, gpu_device), idx, sc, cnt, damping=damping, ppr_iters=12,
+                                     k=n_p, ppr_tol=tol, ppr_max_iters=400)
+        torch.cuda.synchronize()
+        got_idx, got_sc, flags = out.doc_idx.cpu().numpy(), out.doc_score.cpu().numpy(), out.flags.cpu().numpy()
+        resid, used = out.residual.cpu().numpy(), out.iters_used.cpu().numpy()
+    assert raw_used.min() >= 12 and raw_used.max() <= 12 + 9             # 12 always ran; at most the four extension stages
+    assert np.all(flags == 0) and np.all(resid <= tol) and np.all(resid >= 0)
+    qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
+    worst = 0.0
+    for q in sorted(set(list(range(min(b, len(pinned)))) + list(range(0, b, max(1, b // 6))))):
+        exact = oracle.retrieve_one(index, qf[q], qp[q])
+        want = exact.x[index.passage_vertex]
+        full = np.empty(n_p)
+        full[got_idx[q]] = got_sc[q]
+        nz = want > 0
+        allow = prior_noise_allowance(index, qp[q])
+        e = float((np.abs(full[nz] / want[nz] - 1) - allow[nz]).max())
+        worst = max(worst, e)
+        assert e <= max(PPR_ERR_K * float(resid[q]), PPR_ERR_FLOOR_F16), (name, b, q, e, float(resid[q]))
+    write_test_report(f"base12_contract_{name}_b{b}", {"worst_rel_err": worst, "residual_max": float(resid.max()),
+                                                       "sweeps_first_call_max": int(raw_used.max()), "sweeps_max": int(used.max())})
+    assert worst < 1e-5 / 1.5, (name, b, worst)

@@ -104,6 +104,7 @@ def main():
             rows = batched_retrieve(SerialEngine(rag.engine), queries, rag._q_tensor, rag.facts, rag.rerank_filter,
                                     linking_top_k=cfg.linking_top_k, damping=cfg.damping, passage_node_weight=cfg.passage_node_weight,
                                     ppr_iters=rag._ppr_iters(), ppr_tol=cfg.ppr_tol, ppr_max_iters=cfg.ppr_max_iters,
+                                    ppr_base_iters_narrow=cfg.ppr_base_iters_narrow,
                                     num_to_retrieve=want_n, n_passages=len(rag.passage_node_keys))
             ok = len(got) == nq == len(rows) == len(dpr)
             why = "" if ok else "lengths"

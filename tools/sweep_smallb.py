@@ -84,6 +84,28 @@ def main():
         torch.cuda.synchronize()
         accel_ms = (time.perf_counter() - t0) * 1e3 / n
         eng.set_flags(OPT_ACCEL, False)
+        # under the convergence contract (what the mirror runs): base count 20 vs the latency mode's 12 (round 6:
+        # RetrievalConfig.ppr_base_iters_narrow) -- sweeps that ran, latency, and the score difference between the two
+        contract = {}
+        outs = {}
+        for base in (20, 12):
+            def cstep(base=base):
+                idx, sc = eng.score_facts(qf, k=5)
+                return eng.retrieve(qp, idx, sc, cnt, ppr_iters=base, k=200, ppr_tol=1.5e-6, ppr_max_iters=29)
+            for _ in range(3):
+                o = cstep()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                cstep()
+            torch.cuda.synchronize()
+            outs[base] = o
+            contract[f"base{base}"] = {"latency_ms": (time.perf_counter() - t0) * 1e3 / n, "sweeps_used_max": int(o.iters_used.max()),
+                                       "residual_max": float(o.residual.max()), "flags_or": int(o.flags.max())}
+        same = outs[12].doc_idx == outs[20].doc_idx
+        rel = ((outs[12].doc_score - outs[20].doc_score).abs() / outs[20].doc_score.clamp_min(1e-30))[same]
+        contract["base12_vs_base20"] = {"top_k_positions_with_the_same_id": float(same.float().mean()),
+                                        "max_rel_score_diff_at_those": float(rel.max()) if rel.numel() else None}
         kw = dict(small=True) if B <= 8 else dict(f16=True)
         eng.ppr_sweeps(B, 4, 0.5, **kw)
         e0.record()
@@ -97,7 +119,8 @@ def main():
                       sweep_alg_gbs=alg / (sweep_us * 1e-6) / 1e9,
                       phases={k: ph[k] for k in ("fact_sim_ms", "pass_sim_ms", "seed_ms", "ppr_ms", "rank_ms", "total_ms")},
                       slab_width=ph["slab_width"],
-                      accel={"latency_ms": accel_ms, "qps": B / accel_ms * 1e3, "sweeps": used})
+                      accel={"latency_ms": accel_ms, "qps": B / accel_ms * 1e3, "sweeps": used},
+                      under_contract=contract)
         print(B, json.dumps(res[B]), flush=True)
         eng.close()
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)

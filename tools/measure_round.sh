@@ -5,7 +5,7 @@
 # rocprofv3 kernel stats + PMC passes of the cfg 3 command.      bash tools/measure_round.sh <tag>
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r05z}
+TAG=${1:-r06z}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$REPO"
@@ -48,7 +48,7 @@ except Exception as e:
 P
 HRAG_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --steps 3 --warmup 1 --collective allreduce --no-cpu-baseline --no-strong > "$OUT/bench_dist_world1_allreduce.json" 2> "$OUT/bench_dist_world1_allreduce.err"
 HRAG_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --config cfg4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_cfg4_world1.json" 2> "$OUT/bench_cfg4_world1.err"
-timeout 600 python tools/sweep_smallb.py --batches 1,2,4,8,16,32 --out "$OUT/sweep_smallb.json" > "$OUT/sweep_smallb.log" 2> "$OUT/sweep_smallb.err"
+timeout 600 python tools/sweep_smallb.py --batches 1,2,4,8,16,32,64 --out "$OUT/sweep_smallb.json" > "$OUT/sweep_smallb.log" 2> "$OUT/sweep_smallb.err"
 cut -c1-100 "$OUT/sweep_smallb.log"
 for CFG in cfg2 cfg3; do
   timeout 600 python tools/bench_mirror.py --config $CFG --queries 1024 > "$OUT/bench_mirror_$CFG.json" 2> "$OUT/bench_mirror_$CFG.err"; tail -c 300 "$OUT/bench_mirror_$CFG.json"; echo

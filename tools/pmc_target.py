@@ -43,6 +43,8 @@ if width == 128:      # staged fp8 state: every instantiation of ppr8_kernel (te
     # ... and the residual forms of B / F (second template argument: 0 fp32, 2 fp32 in / 3-byte out, 3 3-byte, F: 1)
     for mode, rio in (("C", 0), ("B0", 0), ("B", 0), ("B", 2), ("B", 3), ("F", 1)):
         eng.ppr_sweeps(B, 4, 0.5, main_only=True, f8=True, f8_mode=mode, f8_rio=rio)
+    if B > 128:   # the gathers of a stage sweep alone (round 6: ppr8_pair_replay_kernel, bench.py roofline.gather_replay_ms)
+        eng.ppr_sweeps(B, 4, 0.5, f8=True, f8_gather_replay=True)
 else:
     eng.ppr_sweeps(B, 4, 0.5, main_only=True, f16=width == 64 and B > 8, small=B <= 8 and width <= 8)
 torch.cuda.synchronize()

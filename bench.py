@@ -830,6 +830,10 @@ def main():
                 sim_algorithmic_bytes(kg.n_facts, kg.n_passages, D, B), 2.0 * B * (kg.n_facts + kg.n_passages) * D,
                 phases["fact_sim_ms"] + phases["pass_sim_ms"]),
         "n_long_rows": phases["n_long_rows"], "setup_s": setup_s,
+        # hrag_engine_stats: device bytes of the shareable index / of this handle's workspace, PPR state types, the state
+        # the last call ran on (8 = staged e4m3), why no e4m3 state if there is none
+        "engine_stats": (lambda st: {k: st[k] for k in ("index_bytes", "workspace_bytes", "ppr_states", "last_ppr_state",
+                                                         "fp8_unavailable", "fp8_unavailable_reasons")})(eng.stats()),
     }
     if not args.no_cpu_baseline:
         last = n_batches - 1

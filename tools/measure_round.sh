@@ -51,7 +51,7 @@ HRAG_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --config cfg4 --steps 3 -
 timeout 600 python tools/sweep_smallb.py --batches 1,2,4,8,16,32,64 --out "$OUT/sweep_smallb.json" > "$OUT/sweep_smallb.log" 2> "$OUT/sweep_smallb.err"
 cut -c1-100 "$OUT/sweep_smallb.log"
 for CFG in cfg2 cfg3; do
-  timeout 600 python tools/bench_mirror.py --config $CFG --queries 1024 > "$OUT/bench_mirror_$CFG.json" 2> "$OUT/bench_mirror_$CFG.err"; tail -c 300 "$OUT/bench_mirror_$CFG.json"; echo
+  timeout 600 python tools/bench_mirror.py --config $CFG --queries 4096 > "$OUT/bench_mirror_$CFG.json" 2> "$OUT/bench_mirror_$CFG.err"; tail -c 300 "$OUT/bench_mirror_$CFG.json"; echo
 done
 # randomised differential soaks (each prints one line per case and SOAK OK / SOAK FAILED)
 for S in soak_random soak_shards soak_mirror soak_knn; do

@@ -796,6 +796,131 @@ void run_asym(const char *name, const uint16_t *emb, int64_t rows, int dim, cons
            ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0, (double)rows * dim * 2 / ms / 1e9);
 }
 
+template <int MI, int NJ, int WGM, int WGN, int ISSUE>
+__global__ __launch_bounds__(WGM * WGN * 64, 1) void gemm_asym2_kernel(const uint16_t *__restrict__ emb, int64_t rows, int32_t dim,
+                                                                      const uint16_t *__restrict__ q, int32_t batch,
+                                                                      float *__restrict__ tmax) {
+    constexpr int NW = WGM * WGN, BK = 64;
+    constexpr int BM = WGM * MI * 16, BN = WGN * NJ * 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int A_LOADS = BM / 8 / NW;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int64_t mt = blockIdx.x;
+    if (mt * BM >= rows) return;
+    const int64_t m0 = mt * BM;
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lrow & 7);
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    auto issue_a = [&](int stage, int k0) {
+        const uint32_t sa = smem_base + (uint32_t)(stage * A_BYTES);
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int blk = wave * A_LOADS + i;
+            int64_t r = m0 + blk * 8 + lrow;
+            r = r < rows ? r : rows - 1;
+            glds16<true>(emb + (size_t)r * dim + k0 + lchunk * 8, sa + (uint32_t)(blk * 1024));
+        }
+    };
+    auto issue_b = [&](int stage, int k0) {
+        const uint32_t sb = smem_base + (uint32_t)(3 * A_BYTES + stage * B_BYTES);
+#pragma unroll
+        for (int i = 0; i < BN / 8 / NW; ++i) {
+            const int blk = wave * (BN / 8 / NW) + i;
+            int r = blk * 8 + lrow;
+            r = r < batch ? r : batch - 1;
+            glds16<false>(q + (size_t)r * dim + k0 + lchunk * 8, sb + (uint32_t)(blk * 1024));
+        }
+    };
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fk = lane >> 4;
+    const int nk = dim / BK;
+    issue_b(0, 0);
+    issue_a(0, 0);
+    if (nk > 1) issue_a(1, BK);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LOADS) : "memory");   // A(kt + 1) may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        auto issue_next = [&]() {
+            if (kt + 1 < nk) issue_b((kt + 1) & 1, (kt + 1) * BK);
+            if (kt + 2 < nk) issue_a((kt + 2) % 3, (kt + 2) * BK);
+        };
+        if constexpr (ISSUE == 0) issue_next();
+        const unsigned char *sa = smem + (kt % 3) * A_BYTES;
+        const unsigned char *sb = smem + 3 * A_BYTES + (kt & 1) * B_BYTES;
+        uint4 a[MI], b[NJ];
+        auto frags = [&](int s) {
+            const int c = s * 4 + fk;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int r = wn * (NJ * 16) + j * 16 + frow;
+                b[j] = *reinterpret_cast<const uint4 *>(sb + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int r = wm * (MI * 16) + i * 16 + frow;
+                a[i] = *reinterpret_cast<const uint4 *>(sa + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+        };
+        auto mfmas = [&]() {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        };
+        frags(0);
+        if constexpr (ISSUE == 1) issue_next();       // behind the first fragment reads: issue overlaps the LDS latency
+        mfmas();
+        if constexpr (ISSUE == 2) issue_next();       // between the halves
+        frags(1);
+        if constexpr (ISSUE == 3) issue_next();       // behind the second half's reads
+        mfmas();
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const int gb = wn * (NJ * 16) + j * 16 + lane;
+        if (lane < 16 && gb < batch) tmax[((size_t)mt * WGM + wm) * batch + gb] = mx;
+    }
+}
+
+
+template <int MI, int NJ, int WGM, int WGN, int ISSUE>
+void run_asym2(const char *name, const uint16_t *emb, int64_t rows, int dim, const uint16_t *q, int batch, float *tmax) {
+    constexpr int BM = WGM * MI * 16, BN = WGN * NJ * 16;
+    const int lds = 3 * BM * 128 + 2 * BN * 128;
+    auto k = gemm_asym2_kernel<MI, NJ, WGM, WGN, ISSUE>;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err != hipSuccess) { printf("%-44s %d KB of LDS refused: %s\n", name, lds / 1024, hipGetErrorString(err)); (void)hipGetLastError(); return; }
+    const unsigned grid = (unsigned)((rows + BM - 1) / BM);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(WGM * WGN * 64), lds, 0, emb, rows, dim, q, batch, tmax);
+    err = hipGetLastError();
+    if (err != hipSuccess) { printf("%-44s launch failed: %s\n", name, hipGetErrorString(err)); return; }
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int n = 20;
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(WGM * WGN * 64), lds, 0, emb, rows, dim, q, batch, tmax);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= n;
+    const double flop = 2.0 * rows * batch * dim;
+    printf("%-44s tile %3dx%3d lds %3d KB  %.3f ms  %.0f TFLOP/s (%.1f %% of 2.5 PF)  %.2f TB/s of A\n", name, BM, BN, lds / 1024,
+           ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0, (double)rows * dim * 2 / ms / 1e9);
+}
+
 
 template <int MODE, bool TILEMAX>
 void run_x2(const char *name, bool persistent, const uint16_t *emb, int64_t rows, int dim, const uint16_t *q, int batch,
@@ -969,24 +1094,15 @@ int main(int argc, char **argv) {
             printf("\n");
         }
     };
-    clear(256);
-    run_x2<0, true>("[check] X2 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
-    check(256, "X2 persistent B=256");
-    clear(1024);
-    run_x2<0, true>("[check] X2 tile per WG B=1000", false, emb, rows, dim, q, 1000, out, tmax, tmin);
-    check(1000, "X2 tile per WG B=1000");
     float *tmax_old;
     CK(hipMalloc(&tmax_old, (size_t)(rows / 16 + 64) * 256 * 4));
-    for (int rep = 0; rep < 3; ++rep) {
-        printf("---- round %d, B = 256\n", rep);
-        run_asym<4, 8, 4, 2>("round-4 product structure (8 waves 64x128, A3 + B2)", emb, rows, dim, q, 256, tmax_old);
-        run_x2<0, true>("X2 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
-        run_x2<0, true>("X2 one tile per workgroup", false, emb, rows, dim, q, 256, out, tmax, tmin);
-        run_x2<1, true>("X2 persistent, loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
-        run_x2<2, true>("X2 persistent, A loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+    for (int rep = 0; rep < 4; ++rep) {
+        printf("---- round %d, B = 256: where the next stages' loads are issued inside a k-step\n", rep);
+        run_asym<4, 8, 4, 2>("round-4 product structure", emb, rows, dim, q, 256, tmax_old);
+        run_asym2<4, 8, 4, 2, 0>("same, restructured source, issue first (as product)", emb, rows, dim, q, 256, tmax_old);
+        run_asym2<4, 8, 4, 2, 1>("issue behind the first fragment reads", emb, rows, dim, q, 256, tmax_old);
+        run_asym2<4, 8, 4, 2, 2>("issue between the halves", emb, rows, dim, q, 256, tmax_old);
+        run_asym2<4, 8, 4, 2, 3>("issue behind the second half's reads", emb, rows, dim, q, 256, tmax_old);
     }
-    printf("---- B = 1024\n");
-    run_x2<0, true>("X2 persistent B=1024", true, emb, rows, dim, q, 1024, out, tmax, tmin);
-    run_x2<0, true>("X2 one tile per workgroup B=1024", false, emb, rows, dim, q, 1024, out, tmax, tmin);
     return 0;
 }

@@ -633,6 +633,10 @@ def main():
                     help="N > 1, row-sharded leg: the per-sweep exchange of the e4m3 iterate -- in-place all-gather of the "
                          "owners' blocks (default), or BASELINE.json's literal all-reduce (foreign blocks zeroed, SUM over "
                          "the bytes: the same result at twice the wire bytes)")
+    ap.add_argument("--shard-driver", default="python", choices=["python", "native"],
+                    help="N > 1, row-sharded leg: the host loop around the hrag_shard_* steps in Python (dist.ShardedRetriever) or "
+                         "inside the library (hrag_shard_retrieve with hrag_comm callbacks: dist.NativeShardedRetriever); "
+                         "bit-identical results")
     ap.add_argument("--no-strong", action="store_true",
                     help="N > 1 on configs[2]: skip the additional configs[3] figures (global batch 1024 on the same index)")
     ap.add_argument("--sell-sigma", type=int, default=0, help="hrag_opts.sell_sigma (SELL-C-sigma sorting window; 0 = global)")

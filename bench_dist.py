@@ -13,7 +13,8 @@ import time
 
 import numpy as np
 
-from hipporag_amd.dist import (HybridRetriever, ShardedRetriever, TorchComm, _td, build_shard_engine, shard_index)
+from hipporag_amd.dist import (HybridRetriever, NativeShardedRetriever, ShardedRetriever, TorchComm, _td, build_shard_engine,
+                               shard_index)
 
 
 # --------------------------------------------------------------------------------------------
@@ -386,7 +387,9 @@ def _rowshard_leg(*, args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K
     gb = world * B
     groups = int(getattr(args, "exchange_groups", 2))
     collective = getattr(args, "collective", "allgather")
-    rs = ShardedRetriever(ShardStages(seng), TorchComm(rank, world, collective=collective), groups=groups)
+    driver = getattr(args, "shard_driver", "python")
+    Retriever = NativeShardedRetriever if driver == "native" else ShardedRetriever
+    rs = Retriever(ShardStages(seng), TorchComm(rank, world, collective=collective), groups=groups)
     rs_steps, rs_warm = max(1, args.steps), max(1, min(args.warmup, 2))
     n = rs_steps + rs_warm
     gqf = [synth.make_queries_torch(fact_emb, gb, seed + 9000 + i)[0] for i in range(n)]
@@ -437,7 +440,8 @@ def _rowshard_leg(*, args, kg, sidx, seng, pass_emb, fact_emb, rank, world, B, K
             "exchange": ("in-place all_gather_into_tensor of the owners' row blocks (RCCL)" if collective == "allgather" else
                          "all-reduce SUM over the group region with the foreign blocks zeroed (the north star's literal form)")
                         + f", {lay.n_groups} exchange group(s) pipelined against the sweeps of the other group(s)",
-            "collective": collective,
+            "collective": collective, "host_loop": ("inside the library (hrag_shard_retrieve + hrag_comm callbacks)" if driver == "native"
+                                                    else "Python (dist.ShardedRetriever around the hrag_shard_* steps)"),
             "wire_bytes_received_per_gpu_per_sweep": wire, "state_bytes_per_buffer": int(lay.state_bytes),
             "n_slabs": int(lay.n_slabs), "exchange_groups": int(lay.n_groups),
             "wire_bytes_received_per_gpu_per_global_batch": wire * ITERS,

@@ -73,6 +73,18 @@ class Stats(C.Structure):
                 ("calls_shard", C.c_int64), ("queries", C.c_int64)]
 
 
+COMM_ALL_REDUCE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
+COMM_ALL_GATHER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+COMM_EXCHANGE_BEGIN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+COMM_EXCHANGE_WAIT = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p)
+
+
+class Comm(C.Structure):
+    """hrag_comm of include/hrag.h: the collectives a host supplies to hrag_shard_score_facts_all / hrag_shard_retrieve."""
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32), ("all_reduce", COMM_ALL_REDUCE),
+                ("all_gather", COMM_ALL_GATHER), ("exchange_begin", COMM_EXCHANGE_BEGIN), ("exchange_wait", COMM_EXCHANGE_WAIT)]
+
+
 PPR_STATE_F32, PPR_STATE_F16, PPR_STATE_SMALL, PPR_STATE_FP8 = 1, 2, 4, 8
 FP8_UNAVAILABLE = {1: "hrag_graph_desc.col_sum was not given", 2: "V + 1 > 2^24 vertices",
                    4: "the passage shard is not aligned with the row shard", 8: "disabled by HRAG_OPT_F32_STATE / HRAG_OPT_NO_FP8",
@@ -126,6 +138,10 @@ SIGNATURES = {
     "hrag_shard_ppr_decide": (C.c_int, [_P, _I32, _P]),
     "hrag_shard_ppr_gate": (C.c_int, [_P, _I32, C.POINTER(_I32), _P]),
     "hrag_shard_finish": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
+    "hrag_shard_workspace_bytes": (C.c_int64, [_P, _I32, _I32, _I32]),
+    "hrag_shard_score_facts_all": (C.c_int, [_P, C.POINTER(Comm), _P, _I32, _I32, _P, _I64, _P, _P, _P]),
+    "hrag_shard_retrieve": (C.c_int, [_P, C.POINTER(Comm), _P, _I32, _P, _P, _P, _I32, _I32, _F32, _F32, _I32, _I32, _F32, _I32,
+                                      _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "hrag_engine_set_flags": (C.c_int, [_P, _I32, _I32]),
     "hrag_engine_gather_embeddings": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P]),
     "hrag_get_timings": (C.c_int, [_P, C.POINTER(Timings)]),

@@ -23,7 +23,7 @@ INCLUDE = os.path.join(ROOT, "include")
 OBJ_DIR = os.path.join(HERE, "_obj")
 LIB = os.path.join(PKG, "libhrag.so")
 SOURCES = ["errors.cpp", "ppr_spmm.hip", "ppr16.hip", "ppr8.hip", "ppr_sv.hip", "layout.hip", "sim_gemm.hip", "sim_gemm256.hip", "sim_gemv.hip", "topk.hip", "knn.hip", "seeds.hip",
-           "engine.hip", "shard.hip"]
+           "engine.hip", "shard.hip", "shard_driver.hip"]
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "engine_impl.h"), os.path.join(INCLUDE, "hrag.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I" + INCLUDE, "-I" + HERE]

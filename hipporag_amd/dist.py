@@ -463,6 +463,144 @@ class ShardedRetriever:
         return top_idx, top_val, flags | sat
 
 
+class NativeShardedRetriever:
+    """ShardedRetriever with the host loop INSIDE the library (include/hrag.h: hrag_shard_score_facts_all /
+    hrag_shard_retrieve, csrc/shard_driver.hip): one C call per phase; the library calls back only for the collectives
+    (hrag_comm), which this class serves with the same `comm` object the Python loop uses (TorchComm over RCCL,
+    HostStagedComm over gloo) -- so the two forms can be compared bit for bit (tests/test_gpu_multi.py).  A host without
+    torch supplies four RCCL one-liners instead.  `stages` = ShardStages of this rank's shard engine."""
+
+    def __init__(self, stages, comm, groups: int = 2):
+        from . import _lib
+        self.st, self.comm, self.groups = stages, comm, groups
+        self._lib, self._L = stages.lib, _lib
+        self._bufs, self._ws, self._pend = {}, {}, {}
+        self._regions = []                 # device tensors the library may hand pointers into (workspace, state buffers)
+        self._error = None
+        L = _lib
+
+        def guard(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as exc:       # a Python exception must not cross the C frame: report through the status
+                    self._error = exc
+                    return 1
+            return run
+
+        self._cb = (L.COMM_ALL_REDUCE(guard(self._all_reduce)), L.COMM_ALL_GATHER(guard(self._all_gather)),
+                    L.COMM_EXCHANGE_BEGIN(guard(self._exchange_begin)), L.COMM_EXCHANGE_WAIT(guard(self._exchange_wait)))
+        self._c = L.Comm(None, comm.rank, comm.world, *self._cb)
+
+    # ---- device pointer -> view of a tensor this object owns
+    def _view(self, ptr: int, nbytes: int, dtype):
+        torch = _td()[0]
+        for t in self._regions:
+            off = ptr - t.data_ptr()
+            if 0 <= off and off + nbytes <= t.numel() * t.element_size():
+                return t.view(torch.uint8).reshape(-1)[off: off + nbytes].view(dtype)
+        raise RuntimeError("hrag_comm callback: pointer outside the buffers handed to the library")
+
+    def _all_reduce(self, user, buf, count, dtype, op, stream):
+        torch = _td()[0]
+        dt = {0: torch.float32, 1: torch.float64, 2: torch.int32}[dtype]
+        self.comm.all_reduce(self._view(buf, count * (8 if dtype == 1 else 4), dt), {0: "min", 1: "max", 2: "sum"}[op])
+
+    def _all_gather(self, user, send, recv, nbytes, stream):
+        torch = _td()[0]
+        parts = self.comm.all_gather(self._view(send, nbytes, torch.uint8))
+        out = self._view(recv, nbytes * self.comm.world, torch.uint8)
+        for r, p in enumerate(parts):
+            out[r * nbytes: (r + 1) * nbytes].copy_(p)
+
+    def _exchange_begin(self, user, region, own_bytes, group, stream):
+        lay, bufs = self._cur
+        for t in bufs:
+            off = region - t.data_ptr()
+            if 0 <= off < t.numel():
+                if off != group * lay.group_bytes or own_bytes != lay.own_bytes:
+                    raise RuntimeError("hrag_comm.exchange_begin: region does not match the shard layout")
+                self._pend[group] = self.comm.exchange(t, lay, group)
+                return
+        raise RuntimeError("hrag_comm.exchange_begin: region outside the state buffers")
+
+    def _exchange_wait(self, user, group, stream):
+        self.comm.wait(self._pend.pop(group, None))
+
+    # ---- buffers
+    def _state(self, batch: int):
+        if batch not in self._bufs:
+            lay = self.st.shard_layout(batch, self.groups)
+            self._bufs[batch] = (lay, [self.st.new_state(lay) for _ in range(3)])
+        return self._bufs[batch]
+
+    def _workspace(self, batch: int, k: int):
+        torch = _td()[0]
+        key = (batch, k)
+        if key not in self._ws:
+            n = int(self._lib.hrag_shard_workspace_bytes(self.st.h, self.comm.world, batch, k))
+            self._ws[key] = torch.empty((n,), dtype=torch.uint8, device=self.st.device)
+        return self._ws[key]
+
+    def _call(self, fn, *args):
+        from ._lib import check
+        self._error = None
+        st = fn(*args)
+        if self._error is not None:
+            raise self._error
+        check(st)
+
+    def score_facts(self, q_fact, k: int = 5):
+        torch = _td()[0]
+        from .engine import _stream
+        q = self.st.e._q(q_fact)
+        b = q.shape[0]
+        ws = self._workspace(b, k)
+        idx = torch.empty((b, k), dtype=torch.int32, device=self.st.device)
+        val = torch.empty((b, k), dtype=torch.float32, device=self.st.device)
+        self._regions = [ws]
+        self._call(self._lib.hrag_shard_score_facts_all, self.st.h, C_byref(self._c), q.data_ptr(), b, k, ws.data_ptr(),
+                   ws.numel(), idx.data_ptr(), val.data_ptr(), _stream())
+        return idx, val
+
+    def retrieve(self, q_pass, kept_idx, kept_score, kept_count, *, link_top_k=5, damping=0.5, passage_node_weight=0.05,
+                 ppr_iters=20, k=200, ppr_tol=0.0, ppr_max_iters=0, check_saturation=True):
+        """Same contract as ShardedRetriever.retrieve: (doc ids, doc scores, flags[, residual, sweeps used])."""
+        torch = _td()[0]
+        from .engine import _stream
+        q = self.st.e._q(q_pass)
+        b = q.shape[0]
+        lay, bufs = self._state(b)
+        ws = self._workspace(b, k)
+        dev = self.st.device
+        kept_idx = kept_idx.to(dev, torch.int32).contiguous()
+        kept_score = kept_score.to(dev, torch.float32).contiguous()
+        kept_count = kept_count.to(dev, torch.int32).contiguous()
+        idx = torch.empty((b, k), dtype=torch.int32, device=dev)
+        val = torch.empty((b, k), dtype=torch.float32, device=dev)
+        flags = torch.empty((b,), dtype=torch.int32, device=dev)
+        contract = ppr_tol > 0
+        resid = torch.empty((b,), dtype=torch.float32, device=dev) if contract else None
+        used = torch.empty((b,), dtype=torch.int32, device=dev) if contract else None
+        self._regions, self._cur, self._pend = [ws] + list(bufs), (lay, bufs), {}
+        self.st.e._p8_batch = b
+        self._call(self._lib.hrag_shard_retrieve, self.st.h, C_byref(self._c), q.data_ptr(), b, kept_idx.data_ptr(),
+                   kept_score.data_ptr(), kept_count.data_ptr(), kept_idx.shape[1], link_top_k, damping, passage_node_weight,
+                   ppr_iters, max(ppr_max_iters, ppr_iters), ppr_tol, k, lay.n_groups, bufs[0].data_ptr(),
+                   bufs[1].data_ptr(), bufs[2].data_ptr(), ws.data_ptr(), ws.numel(), idx.data_ptr(), val.data_ptr(),
+                   flags.data_ptr(), resid.data_ptr() if contract else None, used.data_ptr() if contract else None, _stream())
+        if check_saturation and bool((flags & 8).any()):
+            raise RuntimeError("fp8 PPR state saturated on a row shard (HRAG_FLAG_FP8_SATURATED): a static scale bound "
+                               "was violated; use the replica / hybrid mode for this batch")
+        return (idx, val, flags, resid, used) if contract else (idx, val, flags)
+
+
+def C_byref(x):
+    import ctypes
+    return ctypes.byref(x)
+
+
 class HybridRetriever:
     """The hybrid multi-GPU mode SURVEY.md 8(e) ends on: the EMBEDDINGS are row-sharded over the GPUs (the part of
     the index that grows with the corpus: configs[4] holds 20 GB of them), the PPR runs QUERY-PARALLEL on a replicated

@@ -46,7 +46,8 @@ extern "C" {
  *        0.5 plan at the same true error (the last right-hand side is quantised later) -- a host-side threshold on it
  *        must be re-derived; a call with ppr_tol > 0 takes the plan ending on 2 + 1, so a fixed-count call and a
  *        tolerance call at the same 20 sweeps are no longer bit-identical;
- *   0.7  hrag_workspace_create, hrag_engine_stats (hrag_stats), hrag_ppr_sweeps flag 256 (gather replay);
+ *   0.7  hrag_workspace_create, hrag_engine_stats (hrag_stats), hrag_ppr_sweeps flag 256 (gather replay); hrag_comm +
+ *        hrag_shard_score_facts_all / hrag_shard_retrieve / hrag_shard_workspace_bytes (one call per phase on a row shard);
  *        hrag_shard_ppr_sweep enforces the ascending (step, group) order of a session with measured stage scales. */
 #define HRAG_VERSION_MAJOR 0
 #define HRAG_VERSION_MINOR 7
@@ -634,6 +635,64 @@ hrag_status hrag_shard_ppr_gate(hrag_engine *e, int32_t step, int32_t *open_out,
 hrag_status hrag_shard_finish(hrag_engine *e, const float *min_dev, const float *max_dev, int32_t *flags_dev,
                               int32_t batch, int32_t k, int32_t *idx_out_dev, float *score_out_dev,
                               float *residual_out_dev, int32_t *iters_out_dev, hrag_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ONE CALL PER PHASE on a row shard (round 6).  The steps above leave the order of the local steps, the exchanges and the
+ * all-reduces to the host (hipporag_amd/dist.py ShardedRetriever is that host loop, ~100 lines per phase).  The two
+ * drivers below run exactly that loop INSIDE the library and call the host back only for the collectives, so that a
+ * multi-GPU host -- one process per GPU, one engine per process -- needs four small functions (RCCL one-liners on the
+ * given stream) and two calls.  Results are bit-identical to the host loop (tests/test_gpu_multi.py, two processes).
+ *
+ * hrag_comm: every function works IN PLACE on DEVICE memory, must be ordered after the work already enqueued on `stream`
+ * and before work enqueued on it later (an RCCL call on that stream is; a host-staged implementation synchronises it),
+ * and returns 0 on success (anything else aborts the driver with HRAG_EINVAL).  world == 1: the pointers may be NULL.
+ *   all_reduce      buf_dev: `count` elements of dtype HRAG_COMM_F32 / _F64 / _I32, op HRAG_COMM_MIN / _MAX / _SUM
+ *   all_gather      recv_dev = world blocks of bytes_per_rank in rank order; block `rank` = send_dev
+ *   exchange_begin  the per-sweep state exchange of one exchange group: region_dev = world blocks of own_bytes, block
+ *                   `rank` holds this shard's fresh rows; start the all-gather in place (it may run asynchronously on a
+ *                   stream of the host's as long as it is ordered behind `stream` at the time of the call) ...
+ *   exchange_wait   ... and make `stream` wait for the exchange of `group` (every block then holds its owner's rows).
+ *                   At most one exchange per group is in flight; group g's exchange overlaps the sweeps of the others.
+ * ------------------------------------------------------------------------------------------ */
+#define HRAG_COMM_F32 0
+#define HRAG_COMM_F64 1
+#define HRAG_COMM_I32 2
+#define HRAG_COMM_MIN 0
+#define HRAG_COMM_MAX 1
+#define HRAG_COMM_SUM 2
+typedef struct hrag_comm {
+    void *user;             /* passed back to every function */
+    int32_t rank, world;
+    int32_t (*all_reduce)(void *user, void *buf_dev, int64_t count, int32_t dtype, int32_t op, hrag_stream stream);
+    int32_t (*all_gather)(void *user, const void *send_dev, void *recv_dev, int64_t bytes_per_rank, hrag_stream stream);
+    int32_t (*exchange_begin)(void *user, void *region_dev, int64_t own_bytes, int32_t group, hrag_stream stream);
+    int32_t (*exchange_wait)(void *user, int32_t group, hrag_stream stream);
+} hrag_comm;
+
+/* bytes of caller-owned device scratch the two drivers need for `batch` queries and lists of k entries */
+int64_t hrag_shard_workspace_bytes(hrag_engine *e, int32_t world, int32_t batch, int32_t k);
+
+/* phase A over all shards: hrag_shard_score_facts + all-gather of the candidates + MIN / MAX all-reduce + the merge:
+ * idx_out_dev int32 [B, k] global fact ids (-1 beyond), score_out_dev fp32 [B, k] min-max normalised with the GLOBAL
+ * row minimum / maximum -- replicated on every shard, equal to hrag_score_facts of the unsharded engine. */
+hrag_status hrag_shard_score_facts_all(hrag_engine *e, const hrag_comm *comm, const uint16_t *q_fact_dev, int32_t batch,
+                                       int32_t k, void *workspace_dev, int64_t workspace_bytes, int32_t *idx_out_dev,
+                                       float *score_out_dev, hrag_stream stream);
+
+/* phase B over all shards = hrag_retrieve of the unsharded engine (same arguments, same outputs, replicated on every
+ * shard): passage scores, statistics all-reduced, hrag_shard_ppr_begin, every sweep of every exchange group with its
+ * exchange, the contract's all-reduced measure and decisions (ppr_tol > 0), hrag_shard_finish, the merged top-k.
+ * state0..2_dev: three state buffers of hrag_shard_layout_query(e, batch, n_groups).state_bytes, zeroed ONCE by the
+ * caller (row V of every group must stay zero) and reusable across calls; flags_out_dev int32 [B] also carries bit 3
+ * (HRAG_FLAG_FP8_SATURATED) of EVERY shard; residual_out_dev / iters_out_dev may be NULL (written when ppr_tol > 0). */
+hrag_status hrag_shard_retrieve(hrag_engine *e, const hrag_comm *comm, const uint16_t *q_pass_dev, int32_t batch,
+                                const int32_t *kept_idx_dev, const float *kept_score_dev, const int32_t *kept_count_dev,
+                                int32_t kf, int32_t link_top_k, float damping, float passage_node_weight,
+                                int32_t ppr_iters, int32_t ppr_max_iters, float ppr_tol, int32_t k, int32_t n_groups,
+                                void *state0_dev, void *state1_dev, void *state2_dev, void *workspace_dev,
+                                int64_t workspace_bytes, int32_t *doc_idx_out_dev, float *doc_score_out_dev,
+                                int32_t *flags_out_dev, float *residual_out_dev, int32_t *iters_out_dev,
+                                hrag_stream stream);
 
 /* Index update with the embeddings staying on the device (incremental index() / delete(), HippoRAG.py:262-411:
  * the reference re-reads everything from its stores in prepare_retrieval_objects): compose the embedding

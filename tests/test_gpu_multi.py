@@ -68,6 +68,21 @@ def _worker(rank, world, port, ret, backend="nccl", one_device=False):
         d2_idx, d2_sc, flags2 = rs2.retrieve(qp, i2, s2, cnt, **kw)
         torch.cuda.synchronize()
         assert torch.equal(d2_idx, d_idx) and torch.equal(d2_sc, d_sc) and int(flags2.max()) == 0
+        # the same two phases with the host loop INSIDE the library (hrag_shard_score_facts_all / hrag_shard_retrieve, round
+        # 6): the library calls back for the collectives only -- bit-identical to the Python loop, fixed count and contract
+        nat = hd.NativeShardedRetriever(ShardStages(seng), make_comm(rank, world), groups=2)
+        ni, ns = nat.score_facts(qf, k=5)
+        n_idx, n_sc, n_flags = nat.retrieve(qp, ni, ns, cnt, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(ni, idx) and torch.equal(ns, sc)
+        assert torch.equal(n_idx, d_idx) and torch.equal(n_sc, d_sc) and torch.equal(n_flags, flags)
+        c_py = rs.retrieve(qp, idx, sc, cnt, ppr_tol=1.5e-6, ppr_max_iters=29, **kw)
+        c_nat = nat.retrieve(qp, idx, sc, cnt, ppr_tol=1.5e-6, ppr_max_iters=29, **kw)
+        torch.cuda.synchronize()
+        assert len(c_py) == len(c_nat) == 5
+        for got, want in zip(c_nat, c_py):
+            assert torch.equal(got, want)
+        assert int(c_nat[4].min()) >= 20
         # hybrid: embeddings sharded, one all_to_all, PPR on this rank's half of the batch (original index)
         ppr = hd.build_ppr_engine(kg.csr, kg.passage_vertex, kg.subj_vertex, kg.obj_vertex, kg.num_chunks, 128, b // world, 100)
         hy = hd.HybridRetriever(ShardStages(seng), ppr, comm, sidx.passages)

@@ -261,3 +261,46 @@ def test_one_shard_in_several_exchange_groups_measures_its_scales_over_the_whole
         ref = oracle.retrieve_one(index, qf[q], qp[q])
         full = ref.x[kg.passage_vertex]
         assert float((np.abs(got[1][q] - full[got[0][q]]) / full[got[0][q]]).max()) < 1e-5, q
+
+
+def test_the_one_call_drivers_equal_the_python_host_loop_at_world_1(gpu_device):
+    """hrag_shard_score_facts_all / hrag_shard_retrieve (csrc/shard_driver.hip, round 6): the host loop of
+    dist.ShardedRetriever run inside the library.  World 1 (no collective is called: the C side of the drivers alone --
+    layout, step / group order, exchange bookkeeping, contract decisions, candidate merge) against the Python loop on the
+    same engine: bit-identical ids, scores, flags, residuals, sweep counts; the two-process form with real collectives
+    is tests/test_gpu_multi.py."""
+    import torch
+    from hipporag_amd import dist as hd, synth
+    from hipporag_amd.engine import ShardStages
+    from tests.helpers import make_case
+    kg, pass_bits, fact_bits, _ = make_case(9000, 90000, 64, seed=515)
+    sidx = hd.shard_index(kg.csr, kg.passage_vertex, 1, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+    b = 300
+
+    def bf16(bits):
+        return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).to(gpu_device).view(torch.bfloat16)
+
+    qf, qp = bf16(synth.make_queries_np(fact_bits, b, seed=3)[0]), bf16(synth.make_queries_np(pass_bits, b, seed=4)[0])
+    cnt = torch.full((b,), 5, dtype=torch.int32, device=gpu_device)
+    seng = hd.build_shard_engine(sidx, pass_bits, fact_bits, 0, max_batch=b, max_topk=60)
+    try:
+        py = hd.ShardedRetriever(ShardStages(seng), hd.TorchComm(0, 1), groups=2)
+        nat = hd.NativeShardedRetriever(ShardStages(seng), hd.TorchComm(0, 1), groups=2)
+        i0, s0 = py.score_facts(qf, k=5)
+        i1, s1 = nat.score_facts(qf, k=5)
+        assert torch.equal(i0, i1) and torch.equal(s0, s1)
+        for kw in (dict(ppr_iters=20, k=60), dict(ppr_iters=20, k=60, ppr_tol=1.5e-6, ppr_max_iters=29),
+                   dict(ppr_iters=16, k=7, damping=0.4)):
+            want = py.retrieve(qp, i0, s0, cnt, **kw)
+            got = nat.retrieve(qp, i0, s0, cnt, **kw)
+            torch.cuda.synchronize()
+            assert len(want) == len(got)
+            for g, w in zip(got, want):
+                assert torch.equal(g, w), kw
+        # a too-small workspace and a bad comm are refused with a message, not a crash
+        from hipporag_amd._lib import HragError
+        nat._ws[(b, 60)] = nat._ws[(b, 60)][:1024]
+        with pytest.raises(HragError):
+            nat.retrieve(qp, i0, s0, cnt, ppr_iters=20, k=60)
+    finally:
+        seng.close()

@@ -532,7 +532,9 @@ class NativeShardedRetriever:
     def _state(self, batch: int):
         if batch not in self._bufs:
             lay = self.st.shard_layout(batch, self.groups)
-            self._bufs[batch] = (lay, [self.st.new_state(lay) for _ in range(3)])
+            make = lambda: [self.st.new_state(lay) for _ in range(3)]
+            bufs = self.comm.shared_buffers(("state", batch), make) if hasattr(self.comm, "shared_buffers") else make()
+            self._bufs[batch] = (lay, bufs)
         return self._bufs[batch]
 
     def _workspace(self, batch: int, k: int):
@@ -655,12 +657,13 @@ class HybridRetriever:
 
 def run_local_shards(world: int, sidx: "ShardedIndex", pass_emb, fact_emb, q_fact, q_pass, retrieve_kw: dict,
                      groups: int, device, max_topk: int, filter_fn=None, timings: Optional[dict] = None,
-                     sell_seg_len: int = 0):
+                     sell_seg_len: int = 0, native: bool = False):
     """All `world` shards of `sidx` as threads of THIS process on ONE device, meeting at barriers (LocalComm) and
     sharing the three e4m3 state buffers: the emulated gather SURVEY.md 8(e) prescribes.  Returns rank 0's
     (fact idx, fact score, doc idx, doc score, flags) as numpy arrays after checking that every rank computed the
     same replicated result.  Used by tests/test_gpu_shard.py and by `bench.py --config cfg4local` (the parity-checked
-    form of BASELINE configs[3] when only one GPU is at hand)."""
+    form of BASELINE configs[3] when only one GPU is at hand).  native: the host loop inside the library
+    (NativeShardedRetriever: hrag_shard_retrieve calling back into LocalComm from every shard thread)."""
     import threading
     torch = _td()[0]
     from .engine import ShardStages
@@ -672,7 +675,8 @@ def run_local_shards(world: int, sidx: "ShardedIndex", pass_emb, fact_emb, q_fac
             torch.cuda.set_device(device)
             eng = build_shard_engine(sidx, pass_emb, fact_emb, rank, max_batch=b, max_topk=max_topk,
                                      sell_seg_len=sell_seg_len)
-            rs = ShardedRetriever(ShardStages(eng), LocalComm(rank, world, shared), groups=groups)
+            rs = (NativeShardedRetriever if native else ShardedRetriever)(ShardStages(eng), LocalComm(rank, world, shared),
+                                                                          groups=groups)
             torch.cuda.synchronize()
             shared["_barrier"].wait()
             t0 = time.perf_counter()

@@ -304,3 +304,23 @@ def test_the_one_call_drivers_equal_the_python_host_loop_at_world_1(gpu_device):
             nat.retrieve(qp, i0, s0, cnt, ppr_iters=20, k=60)
     finally:
         seng.close()
+
+
+@pytest.mark.parametrize("world,b,groups,kw_extra", [(8, 256, 2, {}), (3, 130, 0, dict(ppr_iters=24)),
+                                                      (4, 200, 2, dict(ppr_tol=1.5e-6, ppr_max_iters=29))])
+def test_the_one_call_drivers_with_emulated_ranks_equal_the_python_host_loop(gpu_device, world, b, groups, kw_extra):
+    """hrag_shard_retrieve with `world` shard threads on one device calling back into dist.LocalComm (every collective is
+    a barrier on shared buffers): 8 / 3 / 4 ranks, one or two exchange groups, fixed count and the contract -- every
+    rank's replicated result equals what the Python host loop (dist.ShardedRetriever) returns on the same shards."""
+    from hipporag_amd import dist as hd
+    kg, pass_bits, fact_bits, _ = make_case(12000, 120000, 64, seed=640 + world, power_law=(world == 3))
+    sidx = hd.shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+    qf = _bf16(synth.make_queries_np(fact_bits, b, seed=3)[0], gpu_device)
+    qp = _bf16(synth.make_queries_np(pass_bits, b, seed=4)[0], gpu_device)
+    kw = dict(link_top_k=5, damping=0.5, passage_node_weight=0.05, ppr_iters=20, k=80)
+    kw.update(kw_extra)
+    want = hd.run_local_shards(world, sidx, pass_bits, fact_bits, qf, qp, kw, groups, gpu_device, 80)
+    got = hd.run_local_shards(world, sidx, pass_bits, fact_bits, qf, qp, kw, groups, gpu_device, 80, native=True)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+    assert np.all(got[4] == 0)

@@ -29,6 +29,7 @@ tests/test_dist_gloo.py).
 
 from __future__ import annotations
 
+import ctypes
 import json
 import os
 import sys
@@ -562,7 +563,7 @@ class NativeShardedRetriever:
         idx = torch.empty((b, k), dtype=torch.int32, device=self.st.device)
         val = torch.empty((b, k), dtype=torch.float32, device=self.st.device)
         self._regions = [ws]
-        self._call(self._lib.hrag_shard_score_facts_all, self.st.h, C_byref(self._c), q.data_ptr(), b, k, ws.data_ptr(),
+        self._call(self._lib.hrag_shard_score_facts_all, self.st.h, ctypes.byref(self._c), q.data_ptr(), b, k, ws.data_ptr(),
                    ws.numel(), idx.data_ptr(), val.data_ptr(), _stream())
         return idx, val
 
@@ -587,7 +588,7 @@ class NativeShardedRetriever:
         used = torch.empty((b,), dtype=torch.int32, device=dev) if contract else None
         self._regions, self._cur, self._pend = [ws] + list(bufs), (lay, bufs), {}
         self.st.e._p8_batch = b
-        self._call(self._lib.hrag_shard_retrieve, self.st.h, C_byref(self._c), q.data_ptr(), b, kept_idx.data_ptr(),
+        self._call(self._lib.hrag_shard_retrieve, self.st.h, ctypes.byref(self._c), q.data_ptr(), b, kept_idx.data_ptr(),
                    kept_score.data_ptr(), kept_count.data_ptr(), kept_idx.shape[1], link_top_k, damping, passage_node_weight,
                    ppr_iters, max(ppr_max_iters, ppr_iters), ppr_tol, k, lay.n_groups, bufs[0].data_ptr(),
                    bufs[1].data_ptr(), bufs[2].data_ptr(), ws.data_ptr(), ws.numel(), idx.data_ptr(), val.data_ptr(),
@@ -596,11 +597,6 @@ class NativeShardedRetriever:
             raise RuntimeError("fp8 PPR state saturated on a row shard (HRAG_FLAG_FP8_SATURATED): a static scale bound "
                                "was violated; use the replica / hybrid mode for this batch")
         return (idx, val, flags, resid, used) if contract else (idx, val, flags)
-
-
-def C_byref(x):
-    import ctypes
-    return ctypes.byref(x)
 
 
 class HybridRetriever:

@@ -47,6 +47,7 @@ def main(argv=None):
         e = int(v * rng.choice([3, 8, 15]))
         world = int(rng.choice([2, 3, 4, 8]))
         mode = str(rng.choice(["rowshard", "rowshard", "hybrid"]))
+        native = bool(rng.integers(0, 2)) if mode == "rowshard" else False   # the host loop inside the library (round 6)
         b = int(rng.choice([40, 66, 128, 130, 256, 300]))
         if mode == "hybrid":
             b = max(world, b // world * world)            # the hybrid deals the batch evenly
@@ -57,7 +58,7 @@ def main(argv=None):
         power_law = bool(rng.integers(0, 2))
         seed = int(rng.integers(1, 1 << 30))
         par = dict(v=v, e=e, world=world, mode=mode, b=b, groups=groups, damping=damping, iters=iters, tol=tol,
-                   power_law=power_law, seed=seed)
+                   power_law=power_law, seed=seed, native=native)
         kg, pass_bits, fact_bits, index = make_case(v, e, 64, seed=seed, power_law=power_law)
         index = dataclasses.replace(index, damping=damping)
         qf_bits, _ = synth.make_queries_np(fact_bits, b, seed=seed + 3)
@@ -70,9 +71,13 @@ def main(argv=None):
         try:
             sidx = hd.shard_index(kg.csr, kg.passage_vertex, world, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
             if mode == "rowshard":
-                got = hd.run_local_shards(world, sidx, pass_bits, fact_bits, qf_t, qp_t, kw, groups, dev, k_docs)
+                got = hd.run_local_shards(world, sidx, pass_bits, fact_bits, qf_t, qp_t, kw, groups, dev, k_docs, native=native)
                 d_idx, d_sc, flags = got[2], got[3], got[4]
                 same_as_single = None
+                if native and rng.random() < 0.25:       # and bit for bit the Python host loop, on a quarter of the cases
+                    ref_loop = hd.run_local_shards(world, sidx, pass_bits, fact_bits, qf_t, qp_t, kw, groups, dev, k_docs)
+                    if not all(np.array_equal(a, b_) for a, b_ in zip(got, ref_loop)):
+                        raise AssertionError("hrag_shard_retrieve differs from the Python host loop")
             else:
                 arrays = dict(csr=kg.csr, passage_vertex=kg.passage_vertex, subj_vertex=kg.subj_vertex,
                               obj_vertex=kg.obj_vertex, num_chunks=kg.num_chunks)

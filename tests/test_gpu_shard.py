@@ -106,6 +106,12 @@ def test_shards_with_filter_subsets_dpr_fallback_isolated_passages_and_empty_fac
     kw = dict(link_top_k=5, damping=0.5, passage_node_weight=0.05, ppr_iters=20, k=50)
     got = _run_shards(world, sidx, pass_bits, fact_bits, _bf16(qf_bits, gpu_device), _bf16(qp_bits, gpu_device),
                       kw, 2, gpu_device, 50, filter_fn=filt)
+    # the one-call driver (hrag_shard_retrieve) on the same filtered batch: rows that kept nothing, partial rows, isolated
+    # passages and the passage-vertex seed take the same path inside the library -- bit for bit the Python host loop
+    nat = hd.run_local_shards(world, sidx, pass_bits, fact_bits, _bf16(qf_bits, gpu_device), _bf16(qp_bits, gpu_device),
+                              kw, 2, gpu_device, 50, filt, native=True)
+    for g_, n_ in zip(got, nat):
+        np.testing.assert_array_equal(g_, n_)
     qf, qp = bf16_bits_to_float(qf_bits), bf16_bits_to_float(qp_bits)
     pv = kg.passage_vertex
     for q in range(b):

@@ -1,7 +1,7 @@
 // Experiment harness (not product code), round 6: a PERSISTENT similarity GEMM with a deep embedding-row ring and
 // specialised loader waves, next to the round-4 structure of csrc/sim_gemm256.hip (tools/gemm_bench.hip).
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench2.hip -o tools/_bin/gemm_bench2 && tools/_bin/gemm_bench2
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench2.hip -o tools/_bin/gemm_bench2 && tools/_bin/gemm_bench2 [a|b|c|d|e|f|all]
 //
 // Design under test (S[b][m] = sum_k Q[b][k] E[m][k], the same v_mfma_f32_16x16x32 chain per score as the product):
 //   * one workgroup per CU (512 threads), each owning a CONTIGUOUS range of embedding rows and one 256-query tile; the
@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <string>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -1017,7 +1018,10 @@ void run_pp(const char *name, bool persistent, const uint16_t *emb, int64_t rows
 static float bf16_to_f(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
 
 int main(int argc, char **argv) {
-    const int64_t rows = argc > 1 ? atoll(argv[1]) : 875000;
+    // usage: gemm_bench2 [a|b|c|d|e|f|all]   (the experiments of docs/experiments/README.md, round 6; logs: profiles/r06_gemm_exp_*)
+    const std::string exp = argc > 1 ? argv[1] : "all";
+    auto want = [&](const char *e) { return exp == "all" || exp == e; };
+    const int64_t rows = 875000;
     const int dim = 768;
     const int max_batch = 1024;
     uint16_t *emb, *q; float *tmax, *tmin, *out;
@@ -1094,15 +1098,119 @@ int main(int argc, char **argv) {
             printf("\n");
         }
     };
+
+    uint16_t *qb;      // the query tile re-laid [tile][k-step][256 queries][64 k]: every 32 KB stage contiguous
+    CK(hipMalloc(&qb, (size_t)max_batch * dim * 2));
+    {
+        std::vector<uint16_t> hb((size_t)max_batch * dim);
+        const int nk = dim / 64;
+        for (int b = 0; b < max_batch; ++b)
+            for (int k = 0; k < dim; ++k)
+                hb[((size_t)((b / 256) * nk + k / 64) * 256 + (b % 256)) * 64 + (k % 64)] = hq[(size_t)b * dim + k];
+        CK(hipMemcpy(qb, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+    }
     float *tmax_old;
     CK(hipMalloc(&tmax_old, (size_t)(rows / 16 + 64) * 256 * 4));
-    for (int rep = 0; rep < 4; ++rep) {
-        printf("---- round %d, B = 256: where the next stages' loads are issued inside a k-step\n", rep);
-        run_asym<4, 8, 4, 2>("round-4 product structure", emb, rows, dim, q, 256, tmax_old);
-        run_asym2<4, 8, 4, 2, 0>("same, restructured source, issue first (as product)", emb, rows, dim, q, 256, tmax_old);
-        run_asym2<4, 8, 4, 2, 1>("issue behind the first fragment reads", emb, rows, dim, q, 256, tmax_old);
-        run_asym2<4, 8, 4, 2, 2>("issue between the halves", emb, rows, dim, q, 256, tmax_old);
-        run_asym2<4, 8, 4, 2, 3>("issue behind the second half's reads", emb, rows, dim, q, 256, tmax_old);
+
+    if (want("a")) {   // lockstep, deep embedding ring + half query stages, loader-specialised waves
+        printf("==== (a) lockstep variant: ring of SA stages + two half query stages, waves 0-3 / 4-7 load A / B\n");
+        clear(256);
+        run_p<4, 0, false, false, true>("[check] SA4 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
+        check(256, "SA4 persistent B=256");
+        clear(1024);
+        run_p<3, 0, false, false, true>("[check] SA3 persistent B=1000", true, emb, rows, dim, q, 1000, out, tmax, tmin);
+        check(1000, "SA3 persistent B=1000");
+        for (int rep = 0; rep < 2; ++rep) {
+            printf("---- round %d, B = 256\n", rep);
+            run_p<4, 0, false, false, true>("SA4 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_p<4, 0, false, true, true>("SA4 persistent setprio", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_p<4, 0, false, false, true>("SA4 one tile per workgroup", false, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_p<3, 0, false, false, true>("SA3 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_p<4, 0, true, false, true>("SA4 persistent, blocked A layout", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_p<4, 1, false, false, true>("SA4 persistent, loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_p<4, 2, false, false, true>("SA4 persistent, A loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_p<3, 2, false, false, true>("SA3 persistent, A loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_p<4, 2, true, false, true>("SA4 persistent, A loads only, blocked", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_p<4, 2, false, false, true>("SA4 one tile per WG, A loads only", false, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_p<4, 3, false, false, true>("SA4 persistent, compute only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+        }
+        printf("---- B = 1024 (MFMA-bound shape)\n");
+        run_p<4, 0, false, false, true>("SA4 persistent B=1024", true, emb, rows, dim, q, 1024, out, tmax, tmin);
+        run_p<4, 0, false, true, true>("SA4 persistent setprio B=1024", true, emb, rows, dim, q, 1024, out, tmax, tmin);
+        run_p<4, 0, false, false, true>("SA4 one tile per workgroup B=1024", false, emb, rows, dim, q, 1024, out, tmax, tmin);
+        printf("---- passage shape (rows 125000, stores S)\n");
+        run_p<4, 0, false, false, false>("SA4 persistent rows=125000 store", true, emb, 125000, dim, q, 256, out, tmax, tmin);
+        run_p<4, 0, false, false, false>("SA4 tile per WG rows=125000 store", false, emb, 125000, dim, q, 256, out, tmax, tmin);
+    }
+    if (want("b")) {   // staggered ping-pong wave groups
+        printf("==== (b) ping-pong variant: waves 4-7 one phase behind waves 0-3\n");
+        clear(256);
+        run_pp<3, 0, false, true>("[check] PP SA3 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
+        check(256, "PP SA3 persistent B=256");
+        for (int rep = 0; rep < 2; ++rep) {
+            printf("---- round %d, B = 256\n", rep);
+            run_pp<3, 0, false, true>("PP SA3 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_pp<3, 0, true, true>("PP SA3 persistent setprio", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_pp<3, 0, false, true>("PP SA3 one tile per workgroup", false, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_pp<3, 1, false, true>("PP SA3 persistent, loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_pp<3, 3, false, true>("PP SA3 persistent, compute only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+        }
+        printf("---- B = 1024\n");
+        run_pp<3, 0, false, true>("PP SA3 persistent B=1024", true, emb, rows, dim, q, 1024, out, tmax, tmin);
+        run_pp<3, 3, false, true>("PP SA3 persistent compute only B=1024", true, emb, rows, dim, q, 1024, out, tmax, tmin);
+    }
+    if (want("c")) {   // in-kernel timing trace of the ping-pong variant, wave -> SIMD map, alternate grouping
+        printf("==== (c) ping-pong variant: s_memtime trace and wave grouping\n");
+        CK(hipMemset(dbg, 0, 4096 * 8));
+        run_pp<3, 3, false, true, 0>("[trace] PP compute only, groups = wave >> 2", true, emb, rows, dim, q, 256, out, tmax, tmin, dbg);
+        dump("compute only, wave >> 2");
+        CK(hipMemset(dbg, 0, 4096 * 8));
+        run_pp<3, 0, false, true, 0>("[trace] PP full, groups = wave >> 2", true, emb, rows, dim, q, 256, out, tmax, tmin, dbg);
+        dump("full, wave >> 2");
+        run_pp<3, 0, false, true, 1>("PP SA3 persistent, groups = wave & 1", true, emb, rows, dim, q, 256, out, tmax, tmin);
+        run_pp<3, 3, false, true, 1>("PP SA3 persistent, compute only, groups = wave & 1", true, emb, rows, dim, q, 256, out, tmax, tmin);
+    }
+    if (want("d")) {   // blocked query layout, query loads alone
+        printf("==== (d) query tile stored [k-step][query][64]\n");
+        clear(256);
+        run_pp<3, 0, false, true, 0, true>("[check] PP SA3 persistent, blocked queries", true, emb, rows, dim, qb, 256, out, tmax, tmin);
+        check(256, "PP SA3 blocked queries B=256");
+        for (int rep = 0; rep < 2; ++rep) {
+            run_pp<3, 0, false, true, 0, false>("PP SA3 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_pp<3, 0, false, true, 0, true>("PP SA3 persistent, blocked queries", true, emb, rows, dim, qb, 256, out, tmax, tmin);
+            run_pp<3, 1, false, true, 0, false>("PP SA3 loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_pp<3, 1, false, true, 0, true>("PP SA3 loads only, blocked queries", true, emb, rows, dim, qb, 256, out, tmax, tmin);
+            run_pp<3, 4, false, true, 0, false>("PP SA3 query loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_pp<3, 4, false, true, 0, true>("PP SA3 query loads only, blocked queries", true, emb, rows, dim, qb, 256, out, tmax, tmin);
+        }
+    }
+    if (want("e")) {   // X2 = the round-4 schedule + loader split + persistence, against the round-4 structure on the same data
+        printf("==== (e) X2 against the round-4 structure\n");
+        clear(256);
+        run_x2<0, true>("[check] X2 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
+        check(256, "X2 persistent B=256");
+        for (int rep = 0; rep < 3; ++rep) {
+            printf("---- round %d, B = 256\n", rep);
+            run_asym<4, 8, 4, 2>("round-4 product structure (8 waves 64x128, A3 + B2)", emb, rows, dim, q, 256, tmax_old);
+            run_x2<0, true>("X2 persistent", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_x2<0, true>("X2 one tile per workgroup", false, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_x2<1, true>("X2 persistent, loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+            run_x2<2, true>("X2 persistent, A loads only", true, emb, rows, dim, q, 256, out, tmax, tmin);
+        }
+        printf("---- B = 1024\n");
+        run_x2<0, true>("X2 persistent B=1024", true, emb, rows, dim, q, 1024, out, tmax, tmin);
+        run_x2<0, true>("X2 one tile per workgroup B=1024", false, emb, rows, dim, q, 1024, out, tmax, tmin);
+    }
+    if (want("f")) {   // where the next stages' loads are issued inside a k-step of the round-4 structure
+        printf("==== (f) load-issue placement inside a k-step (round-4 structure)\n");
+        for (int rep = 0; rep < 4; ++rep) {
+            printf("---- round %d, B = 256\n", rep);
+            run_asym<4, 8, 4, 2>("round-4 product structure", emb, rows, dim, q, 256, tmax_old);
+            run_asym2<4, 8, 4, 2, 0>("same, restructured source, issue first (as product)", emb, rows, dim, q, 256, tmax_old);
+            run_asym2<4, 8, 4, 2, 1>("issue behind the first fragment reads", emb, rows, dim, q, 256, tmax_old);
+            run_asym2<4, 8, 4, 2, 2>("issue between the halves", emb, rows, dim, q, 256, tmax_old);
+            run_asym2<4, 8, 4, 2, 3>("issue behind the second half's reads", emb, rows, dim, q, 256, tmax_old);
+        }
     }
     return 0;
 }

@@ -37,7 +37,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         pytest.skip("gcc not available")
     structs = {"hrag_graph_desc": _lib.GraphDesc, "hrag_embed_desc": _lib.EmbedDesc,
                "hrag_fact_desc": _lib.FactDesc, "hrag_opts": _lib.Opts, "hrag_timings": _lib.Timings,
-               "hrag_shard_layout": _lib.ShardLayout}
+               "hrag_shard_layout": _lib.ShardLayout, "hrag_stats": _lib.Stats, "hrag_comm": _lib.Comm}
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "hrag.h"', "int main(void) {"]
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')

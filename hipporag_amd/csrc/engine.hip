@@ -338,7 +338,11 @@ static bool accel_plan16(int iters, float damping, int *k1_out, int *k2_out) {
     // x4: the plain iteration beats its own bound a^iters on well-mixing graphs (16k-vertex test graphs: 2e-7 after 20
     // sweeps, bound 9.5e-7) while a Chebyshev plan sits ON its bound (equi-oscillation); the margin keeps the accelerated
     // result within ~5x of the plain one there (measured 1.1e-6 .. 5e-6 without it)
-    const double target = 4.0 * std::pow(al, -(double)iters), cap = 2048.0;
+    // round 6 (tools/soak_random.py, seed 8803: damping 0.6, 28 sweeps -> 18 on a mean-degree-6 graph with 5 % passages read
+    // 1.07e-5 on one query at margin 4): above damping 0.55 the polynomial's error floor on the small passage scores is
+    // closer to the bar, so the margin there is 16 (the case: 19 sweeps)
+    const double margin = al > 0.55 ? 16.0 : 4.0;
+    const double target = margin * std::pow(al, -(double)iters), cap = 2048.0;
     int best = iters, bk1 = 0, bk2 = 0;
     for (int k1 = 3; k1 <= 14; ++k1)
         for (int k2 = 2; k2 <= 14; ++k2) {

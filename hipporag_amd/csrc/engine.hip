@@ -297,7 +297,8 @@ Ppr16Args ppr16_args(const hrag_engine *e, const uint16_t *x, uint16_t *y, const
 // polynomial vanishes at 0) and (ii) the convergence measure reads the update of a plain sweep that FOLLOWS a plain
 // sweep -- the quantity it reads without the flag (csrc/shard.hip ppr8_plan_accel on why).  Error bound of the plan:
 // 1 / (T_K1(1/a) T_{K2+1}(1/a)) a^2, each Chebyshev factor capped at 2^11 (the fp16 rounding of the stage's iterate);
-// the smallest K1 + K2 that reaches a^iters / 4 is taken: a = 0.5, iters = 20 -> K1 = 6, K2 = 5, 14 sweeps.  Only with
+// the smallest K1 + K2 that reaches a^iters / 16 is taken (accel_plan16 on the margin): a = 0.5, iters = 20 -> K1 = 7, K2 = 6,
+// 16 sweeps (rounds 4 - 5: a^iters / 4, 14 sweeps).  Only with
 // ppr_tol = 0 (`ppr_iters` names an accuracy).  Under a tolerance these states keep the plain plan (+ its device-side
 // extension): after a Chebyshev stage h is less converged ELEMENTWISE than after as many plain sweeps (equi-oscillation
 // puts error into every mode), the correction c is correspondingly larger, and its fp16 rounding (2^-11 |c| / 64) puts a
@@ -338,10 +339,11 @@ static bool accel_plan16(int iters, float damping, int *k1_out, int *k2_out) {
     // x4: the plain iteration beats its own bound a^iters on well-mixing graphs (16k-vertex test graphs: 2e-7 after 20
     // sweeps, bound 9.5e-7) while a Chebyshev plan sits ON its bound (equi-oscillation); the margin keeps the accelerated
     // result within ~5x of the plain one there (measured 1.1e-6 .. 5e-6 without it)
-    // round 6 (tools/soak_random.py, seed 8803: damping 0.6, 28 sweeps -> 18 on a mean-degree-6 graph with 5 % passages read
-    // 1.07e-5 on one query at margin 4): above damping 0.55 the polynomial's error floor on the small passage scores is
-    // closer to the bar, so the margin there is 16 (the case: 19 sweeps)
-    const double margin = al > 0.55 ? 16.0 : 4.0;
+    // round 6: two 10 - 20 minute runs of tools/soak_random.py found the margin of 4 too thin on sparse graphs with few
+    // passages (mean degree 6, 5 % passages): damping 0.6, 28 -> 18 sweeps: 1.07e-5 on one query of 4 253 cases; damping
+    // 0.5, 20 -> 14 sweeps at B = 5: 1.33e-5 on one of 8 876.  A fixed-count accelerated call has no measurement to fall
+    // back on, so the margin is 16 everywhere (damping 0.5: 15 - 16 sweeps for 20; the two cases replay at < 4e-6)
+    const double margin = 16.0;
     const double target = margin * std::pow(al, -(double)iters), cap = 2048.0;
     int best = iters, bk1 = 0, bk2 = 0;
     for (int k1 = 3; k1 <= 14; ++k1)

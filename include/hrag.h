@@ -48,7 +48,9 @@ extern "C" {
  *        tolerance call at the same 20 sweeps are no longer bit-identical;
  *   0.7  hrag_workspace_create, hrag_engine_stats (hrag_stats), hrag_ppr_sweeps flag 256 (gather replay); hrag_comm +
  *        hrag_shard_score_facts_all / hrag_shard_retrieve / hrag_shard_workspace_bytes (one call per phase on a row shard);
- *        hrag_shard_ppr_sweep enforces the ascending (step, group) order of a session with measured stage scales. */
+ *        hrag_shard_ppr_sweep enforces the ascending (step, group) order of a session with measured stage scales;
+ *        later in 0.7 (no signature change): the accelerated two-stage fp16 plan (HRAG_OPT_ACCEL, batch <= 64, ppr_tol = 0)
+ *        carries a margin of 16 instead of 4: 16 sweeps stand for 20 at damping 0.5 (14 before). */
 #define HRAG_VERSION_MAJOR 0
 #define HRAG_VERSION_MINOR 7
 
@@ -183,7 +185,7 @@ typedef struct hrag_fact_desc {
                                       /* against 5.5e-7) and up to 3x their truncation error on small hub-heavy ones: use the */
                                       /* contract where a bound is needed.  Off by default: ppr_iters is then the literal     */
                                       /* sweep count (BASELINE.json's 20).  Runtime-switchable.  The two-stage fp16 states    */
-                                      /* (batch <= 64) accelerate too (14 sweeps for 20), with ppr_tol = 0 and damping <= 0.62 only.  The library */
+                                      /* (batch <= 64) accelerate too (16 sweeps for 20; 14 up to the first 0.7 builds), ppr_tol = 0 and damping <= 0.62 only.  The library */
                                       /* cannot see whether the CSR it was given came from a symmetric adjacency: setting the */
                                       /* flag on a DIRECTED graph is a caller error (complex spectrum: the steps may converge */
                                       /* more slowly than the plan assumes; the contract would flag it, ppr_tol = 0 would     */

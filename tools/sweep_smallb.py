@@ -72,7 +72,7 @@ def main():
         torch.cuda.synchronize()
         ph = eng.timings()
         eng.set_profiling(False)
-        # HRAG_OPT_ACCEL (tolerance 0: ppr_iters names the accuracy; 14 sweeps on the fp16 states)
+        # HRAG_OPT_ACCEL (tolerance 0: ppr_iters names the accuracy; 16 sweeps on the fp16 states)
         from hipporag_amd._lib import OPT_ACCEL
         eng.set_flags(OPT_ACCEL, True)
         for _ in range(3):

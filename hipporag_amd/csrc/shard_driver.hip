@@ -220,6 +220,15 @@ hrag_status hrag_shard_retrieve(hrag_engine *e, const hrag_comm *comm, const uin
     //      group g's previous exchange
     void *bufs[3] = {state0, state1, state2};
     std::vector<char> pending((size_t)lay.n_groups, 0);
+    // an error return between exchange_begin and exchange_wait must not leave the host's collective handles open (the
+    // next call on the same hrag_comm would start from a half-finished exchange): wait for what was begun, ignore the rc
+    struct Drain {
+        const hrag_comm *c; std::vector<char> &p; hrag_stream st;
+        ~Drain() {
+            for (size_t g = 0; g < p.size(); ++g)
+                if (p[g]) { (void)c->exchange_wait(c->user, (int32_t)g, st); p[g] = 0; }
+        }
+    } drain{comm, pending, stream};
     auto begin_x = [&](int buf, int g) -> hrag_status {
         if (w > 1) {
             char *region = static_cast<char *>(bufs[buf]) + (size_t)g * (size_t)lay.group_bytes;

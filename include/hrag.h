@@ -655,6 +655,8 @@ hrag_status hrag_shard_finish(hrag_engine *e, const float *min_dev, const float 
  *                   stream of the host's as long as it is ordered behind `stream` at the time of the call) ...
  *   exchange_wait   ... and make `stream` wait for the exchange of `group` (every block then holds its owner's rows).
  *                   At most one exchange per group is in flight; group g's exchange overlaps the sweeps of the others.
+ *                   When a driver returns an error it first calls exchange_wait for every exchange it had begun (rc
+ *                   ignored), so the host's collective handles are never left open behind a failed call.
  * ------------------------------------------------------------------------------------------ */
 #define HRAG_COMM_F32 0
 #define HRAG_COMM_F64 1

@@ -330,3 +330,65 @@ def test_the_one_call_drivers_with_emulated_ranks_equal_the_python_host_loop(gpu
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
     assert np.all(got[4] == 0)
+
+
+def test_a_failing_collective_leaves_no_exchange_open(gpu_device):
+    """hrag_shard_retrieve returns an error in the middle of the sweeps (the contract's all-reduce fails while every
+    exchange group has an exchange in flight): the driver waits for every exchange it had begun before it returns
+    (csrc/shard_driver.hip `Drain`; include/hrag.h hrag_comm), so the host's collective handles are never left open.
+    Shard 0 of a 2-shard index with a stub comm (no peer: the collectives do nothing -- the control flow is under test,
+    not the numbers)."""
+    import torch
+    from hipporag_amd import dist as hd
+    from hipporag_amd.engine import ShardStages
+    kg, pass_bits, fact_bits, _ = make_case(9000, 90000, 64, seed=733)
+    sidx = hd.shard_index(kg.csr, kg.passage_vertex, 2, kg.subj_vertex, kg.obj_vertex, kg.num_chunks)
+    b = 130
+
+    class StubComm:
+        rank, world = 0, 2
+
+        def __init__(self):
+            self.reduces, self.begun, self.waited, self.fail_at = 0, 0, 0, None
+
+        def all_reduce(self, t, op):
+            self.reduces += 1
+            if self.fail_at is not None and self.reduces >= self.fail_at:
+                raise RuntimeError("injected collective failure")
+
+        def all_gather(self, t):
+            return [t, t]
+
+        def exchange(self, buf, lay, group):
+            self.begun += 1
+            return ("handle", group)
+
+        def wait(self, handle):
+            if handle is not None:
+                self.waited += 1
+
+    qf = _bf16(synth.make_queries_np(fact_bits, b, seed=3)[0], gpu_device)
+    qp = _bf16(synth.make_queries_np(pass_bits, b, seed=4)[0], gpu_device)
+    cnt = torch.full((b,), 5, dtype=torch.int32, device=gpu_device)
+    seng = hd.build_shard_engine(sidx, pass_bits, fact_bits, 0, max_batch=b, max_topk=40)
+    try:
+        comm = StubComm()
+        nat = hd.NativeShardedRetriever(ShardStages(seng), comm, groups=2)
+        idx, sc = nat.score_facts(qf, k=5)
+        kw = dict(ppr_iters=20, k=40, ppr_tol=1.5e-6, ppr_max_iters=29, check_saturation=False)
+        nat.retrieve(qp, idx, sc, cnt, **kw)                       # a clean call: every exchange begun is waited for
+        torch.cuda.synchronize()
+        assert comm.begun > 0 and comm.begun == comm.waited and not nat._pend
+        before = comm.reduces
+        comm.reduces, comm.begun, comm.waited = 0, 0, 0
+        comm.fail_at = 5          # min, max, zmax, mass pass; the 5th all-reduce is the contract's measure, mid-sweeps
+        with pytest.raises(RuntimeError, match="injected"):
+            nat.retrieve(qp, idx, sc, cnt, **kw)
+        torch.cuda.synchronize()
+        assert before >= 5 and comm.begun >= 2                     # both groups had an exchange in flight
+        assert comm.begun == comm.waited and not nat._pend, (comm.begun, comm.waited)
+        comm.fail_at = None                                        # and the handle is usable afterwards
+        nat.retrieve(qp, idx, sc, cnt, **kw)
+        torch.cuda.synchronize()
+    finally:
+        seng.close()

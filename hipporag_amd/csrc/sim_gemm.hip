@@ -296,6 +296,102 @@ __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restric
 // batch, so the counters zeroed at allocation stay where every launch expects them.
 constexpr int kSelRec = 32 + kFusedMaxK * BM * 2;
 
+// Wide batches (the index-time KNN: 4096 queries x 16 tiles over 6.8 k tiles; round 6): many (tile, query) pairs name the
+// SAME tile, and pass 3 read it once per pair -- 38.7 GB per launch at the synonymy call's shape, 6.9 ms beside a 16 ms
+// GEMM (profiles/r06w_knn_*.json).  The pairs are bucketed by tile (histogram, one-workgroup scan, scatter: three small
+// launches; the order INSIDE a bucket is whatever the atomics give, which no result depends on) and pass 3 becomes one
+// workgroup per (tile, up to 16 of its queries): the tile is read once per 16 pairs and the 16 columns of the MFMA carry
+// 16 different queries instead of 16 copies of one (tile_rescore_grouped_kernel).  pair id = b * k + r; bucket n_tiles
+// collects the "no tile" entries (id -1), which still have to arrive at their query's counter.
+constexpr int kPairChunk = 16;
+__global__ __launch_bounds__(256) void pair_hist_kernel(const int32_t *__restrict__ rec, int32_t n_pairs, int32_t k,
+                                                        int32_t n_tiles, int32_t *__restrict__ hist) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pairs) return;
+    const int t = rec[(size_t)(p / k) * kSelRecInts + (p % k)];
+    atomicAdd(hist + (t >= 0 ? t : n_tiles), 1);
+}
+// one workgroup, in place over n buckets: hist[i] (count) -> first position of bucket i; chunk[i] = number of 16-pair
+// chunks of the buckets before i, chunk[n] = all chunks
+__global__ __launch_bounds__(1024) void pair_scan_kernel(int32_t *__restrict__ hist, int32_t *__restrict__ chunk, int32_t n) {
+    __shared__ int32_t part[1024], partc[1024];
+    const int tid = threadIdx.x;
+    const int seg = (n + 1023) / 1024, lo = min(tid * seg, n), hi = min(lo + seg, n);
+    int32_t sum = 0, sumc = 0;
+    for (int i = lo; i < hi; ++i) {
+        sum += hist[i];
+        sumc += (hist[i] + kPairChunk - 1) / kPairChunk;
+    }
+    part[tid] = sum;
+    partc[tid] = sumc;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int32_t v = tid >= o ? part[tid - o] : 0, vc = tid >= o ? partc[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        partc[tid] += vc;
+        __syncthreads();
+    }
+    int32_t run = part[tid] - sum, runc = partc[tid] - sumc;
+    for (int i = lo; i < hi; ++i) {
+        const int32_t c = hist[i];
+        hist[i] = run;
+        chunk[i] = runc;
+        run += c;
+        runc += (c + kPairChunk - 1) / kPairChunk;
+    }
+    if (tid == 1023) chunk[n] = partc[1023];
+}
+// cursor[t] (= first position of bucket t) advances to the END of bucket t
+__global__ __launch_bounds__(256) void pair_scatter_kernel(const int32_t *__restrict__ rec, int32_t n_pairs, int32_t k,
+                                                           int32_t n_tiles, int32_t *__restrict__ cursor,
+                                                           int32_t *__restrict__ order) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pairs) return;
+    const int t = rec[(size_t)(p / k) * kSelRecInts + (p % k)];
+    order[atomicAdd(cursor + (t >= 0 ? t : n_tiles), 1)] = p;
+}
+
+// The exact top-k of one query's k x 128 candidate keys (written by the workgroups that rescored its tiles), by the
+// workgroup that arrived last at the query's counter: shared by both forms of pass 3.
+__device__ __forceinline__ void select_from_candidates(int32_t *my, int b, int32_t k, uint64_t *cand, uint64_t *red,
+                                                       const float *__restrict__ mn_in, const float *__restrict__ mx_in,
+                                                       int32_t idx_offset, int32_t normalize, int32_t *__restrict__ idx_out,
+                                                       float *__restrict__ val_out, int tid) {
+    unsigned long long *gc = reinterpret_cast<unsigned long long *>(my + 32);
+    int n_cand = 0;
+    for (int i = 0; i < k; ++i) n_cand += my[i] >= 0 ? BM : 0;   // selected tiles are a prefix of the list
+    for (int i = tid; i < n_cand; i += 256)
+        cand[i] = __hip_atomic_load(gc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(my + 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const float mn = mn_in[b], mx = mx_in[b];
+    uint64_t prev = ~0ull;
+    for (int rr = 0; rr < k; ++rr) {
+        uint64_t best = 0;
+        for (int i = tid; i < n_cand; i += 256) {
+            const uint64_t key = cand[i];
+            if (key < prev && key > best) best = key;
+        }
+        best = block_max_u64(best, red, tid);
+        if (tid == 0) {
+            int32_t idx = -1;
+            float val = 0.f;
+            if (best) {
+                idx = (int32_t)(uint32_t)best + idx_offset;
+                val = ordered_to_f32((uint32_t)(best >> 32));
+                if (normalize) {
+                    const float range = mx - mn;
+                    val = range == 0.f ? 1.f : __fdiv_rn(val - mn, range);   // misc_utils.py:130-139
+                }
+            }
+            idx_out[(size_t)b * k + rr] = idx;
+            val_out[(size_t)b * k + rr] = val;
+        }
+        prev = best ? best : 0;
+    }
+}
+
 // Pass 3, one workgroup per (selected tile, query) -- round 1 ran the k tiles of a query one after the other in one
 // workgroup, a chain of ~240 dependent loads (0.10 ms at cfg 3, 69 us at cfg 2); now the k tiles are k workgroups, and
 // the one that arrives LAST (agent-scope counter; candidate keys travel as sc1 stores / loads: the workgroups sit on
@@ -358,36 +454,95 @@ __global__ __launch_bounds__(256) void tile_rescore_kernel(const uint16_t *__res
         s_last = __hip_atomic_fetch_add(my + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k - 1;
     __syncthreads();
     if (!s_last) return;
-    int n_cand = 0;
-    for (int i = 0; i < k; ++i) n_cand += my[i] >= 0 ? BM : 0;   // selected tiles are a prefix of the list
-    for (int i = tid; i < n_cand; i += 256)
-        cand[i] = __hip_atomic_load(gc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0) __hip_atomic_store(my + 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const float mn = mn_in[b], mx = mx_in[b];
-    uint64_t prev = ~0ull;
-    for (int rr = 0; rr < k; ++rr) {
-        uint64_t best = 0;
-        for (int i = tid; i < n_cand; i += 256) {
-            const uint64_t key = cand[i];
-            if (key < prev && key > best) best = key;
-        }
-        best = block_max_u64(best, red, tid);
-        if (tid == 0) {
-            int32_t idx = -1;
-            float val = 0.f;
-            if (best) {
-                idx = (int32_t)(uint32_t)best + idx_offset;
-                val = ordered_to_f32((uint32_t)(best >> 32));
-                if (normalize) {
-                    const float range = mx - mn;
-                    val = range == 0.f ? 1.f : __fdiv_rn(val - mn, range);   // misc_utils.py:130-139
+    select_from_candidates(my, b, k, cand, red, mn_in, mx_in, idx_offset, normalize, idx_out, val_out, tid);
+}
+
+// Pass 3 for wide batches: one workgroup per (tile, chunk of <= 16 of the queries that selected it).  Same fragments, same
+// k order, same MFMA per score as tile_rescore_kernel -- a column of the 16 x 16 result never sees its neighbours -- so
+// every key is bit-identical; only the column <-> query assignment differs (16 queries instead of one repeated).
+// bucket_end / chunk_start / order: pair_scan_kernel, pair_scatter_kernel.  The grid is an upper bound of the chunks.
+template <bool F16>
+__global__ __launch_bounds__(256) void tile_rescore_grouped_kernel(const uint16_t *__restrict__ emb, int64_t rows, int32_t dim,
+                                                                   const uint16_t *__restrict__ q, int32_t *__restrict__ rec,
+                                                                   const float *__restrict__ mn_in,
+                                                                   const float *__restrict__ mx_in, int32_t k,
+                                                                   int32_t idx_offset, int32_t normalize,
+                                                                   int32_t *__restrict__ idx_out, float *__restrict__ val_out,
+                                                                   const int32_t *__restrict__ bucket_end,
+                                                                   const int32_t *__restrict__ chunk_start,
+                                                                   const int32_t *__restrict__ order, int32_t n_tiles) {
+    __shared__ uint64_t cand[kFusedMaxK * BM];
+    __shared__ uint64_t red[4];
+    __shared__ int s_done[kPairChunk];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x;
+    if (w >= chunk_start[n_tiles + 1]) return;
+    int lo = 0, hi = n_tiles + 1;              // chunk_start[lo] <= w < chunk_start[hi]: the LAST bucket that starts at or
+    while (hi - lo > 1) {                      // before w is the non-empty one
+        const int mid = (lo + hi) >> 1;
+        if (chunk_start[mid] <= w) lo = mid;
+        else hi = mid;
+    }
+    const int t = lo;
+    const int first = (t == 0 ? 0 : bucket_end[t - 1]) + (w - chunk_start[t]) * kPairChunk;
+    const int n = min(kPairChunk, bucket_end[t] - first);
+    if (t < n_tiles) {
+        const int col = lane & 15;
+        const int p = order[first + min(col, n - 1)];        // columns beyond the chunk repeat its last query (not stored)
+        const int bq = p / k, rq = p % k;
+        const uint16_t *qrow = q + (size_t)bq * dim;
+        const int64_t row0 = (int64_t)t * BM + wave * 32;
+        const int64_t arow0 = row0 + (lane & 15), arow1 = arow0 + 16;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < dim; k0 += BK) {
+            uint4 ua0[BK / 32], ua1[BK / 32], ub[BK / 32];
+#pragma unroll
+            for (int s = 0; s < BK / 32; ++s) {
+                const int kcol = k0 + s * 32 + 8 * (lane >> 4);
+                ua0[s] = ua1[s] = ub[s] = make_uint4(0, 0, 0, 0);
+                if (kcol < dim) {
+                    ub[s] = *reinterpret_cast<const uint4 *>(qrow + kcol);
+                    if (arow0 < rows) ua0[s] = *reinterpret_cast<const uint4 *>(emb + (size_t)arow0 * dim + kcol);
+                    if (arow1 < rows) ua1[s] = *reinterpret_cast<const uint4 *>(emb + (size_t)arow1 * dim + kcol);
                 }
             }
-            idx_out[(size_t)b * k + rr] = idx;
-            val_out[(size_t)b * k + rr] = val;
+#pragma unroll
+            for (int s = 0; s < BK / 32; ++s) {
+                acc0 = mfma32<F16>(ua0[s], ub[s], acc0);
+                acc1 = mfma32<F16>(ua1[s], ub[s], acc1);
+            }
         }
-        prev = best ? best : 0;
+        if (col < n) {
+            unsigned long long *gc = reinterpret_cast<unsigned long long *>(rec + (size_t)bq * kSelRec + 32) + rq * BM;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int at = wave * 32 + 4 * (lane >> 4) + reg;
+                const int64_t m0 = row0 + 4 * (lane >> 4) + reg, m1 = m0 + 16;
+                __hip_atomic_store(gc + at, m0 < rows ? rank_key(acc0[reg], (uint32_t)m0) : 0ull, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gc + at + 16, m1 < rows ? rank_key(acc1[reg], (uint32_t)m1) : 0ull, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wavefront: its keys have left the CU
+    __syncthreads();
+    if (tid < kPairChunk) {
+        int done = -1;
+        if (tid < n) {
+            const int b = order[first + tid] / k;
+            if (__hip_atomic_fetch_add(rec + (size_t)b * kSelRec + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k - 1)
+                done = b;
+        }
+        s_done[tid] = done;
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {            // the queries this chunk completed (each query completes exactly once)
+        const int b = s_done[j];
+        if (b < 0) continue;
+        select_from_candidates(rec + (size_t)b * kSelRec, b, k, cand, red, mn_in, mx_in, idx_offset, normalize, idx_out,
+                               val_out, tid);
+        __syncthreads();
     }
 }
 
@@ -400,6 +555,12 @@ int64_t sim_fused_sel_ints(int32_t batch) { static_assert(kSelRec == kSelRecInts
 // environment keeps every shape on sim_gemm_kernel (read once)
 bool sim_gemm_force_small_tiles() {
     static const bool v = [] { const char *e = experiment_env("HRAG_SIM_SMALL_TILES"); return e && e[0] == '1'; }();
+    return v;
+}
+
+// A/B switch for measurements: HRAG_RESCORE_GROUPED=0 keeps pass 3 one workgroup per (tile, query) at every batch (read once)
+bool rescore_grouping_disabled() {
+    static const bool v = [] { const char *e = experiment_env("HRAG_RESCORE_GROUPED"); return e && e[0] == '0'; }();
     return v;
 }
 
@@ -436,7 +597,29 @@ hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim
     hipLaunchKernelGGL(tile_select_kernel, dim3((unsigned)batch), dim3(256), 0, s, tmax, tmin, (int32_t)tiles_m,
                        batch, k, sel, mn, mx);
     HRAG_LAUNCH_CHECK();
-    if (dtype == HRAG_FP16)
+    // wide batches: pass 3 grouped by tile (see pair_hist_kernel); the tile minima are dead after tile_select_kernel and
+    // lend their memory: [n_tiles + 1] bucket cursors, [n_tiles + 2] chunk starts, then the ordered pair ids
+    const int64_t n_pairs = (int64_t)batch * k;
+    const bool grouped = tiles_m >= 64 && n_pairs >= 4 * tiles_m && n_pairs < (1ll << 30) &&
+                         n_pairs + 2 * tiles_m + 3 <= tiles_m * (int64_t)batch && !rescore_grouping_disabled();
+    if (grouped) {
+        int32_t *cursor = reinterpret_cast<int32_t *>(tmin), *chunk = cursor + tiles_m + 1, *ord = chunk + tiles_m + 2;
+        const unsigned pb = (unsigned)ceil_div(n_pairs, 256);
+        const dim3 grid3((unsigned)(ceil_div(n_pairs, kPairChunk) + tiles_m + 1));     // >= the number of chunks
+        HRAG_HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)(tiles_m + 1) * sizeof(int32_t), s));
+        hipLaunchKernelGGL(pair_hist_kernel, dim3(pb), dim3(256), 0, s, sel, (int32_t)n_pairs, k, (int32_t)tiles_m, cursor);
+        HRAG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, cursor, chunk, (int32_t)tiles_m + 1);
+        HRAG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(pair_scatter_kernel, dim3(pb), dim3(256), 0, s, sel, (int32_t)n_pairs, k, (int32_t)tiles_m, cursor, ord);
+        HRAG_LAUNCH_CHECK();
+        if (dtype == HRAG_FP16)
+            hipLaunchKernelGGL(tile_rescore_grouped_kernel<true>, grid3, dim3(256), 0, s, emb, rows, dim, q, sel, mn, mx, k,
+                               idx_offset, normalize, idx_out, val_out, cursor, chunk, ord, (int32_t)tiles_m);
+        else
+            hipLaunchKernelGGL(tile_rescore_grouped_kernel<false>, grid3, dim3(256), 0, s, emb, rows, dim, q, sel, mn, mx, k,
+                               idx_offset, normalize, idx_out, val_out, cursor, chunk, ord, (int32_t)tiles_m);
+    } else if (dtype == HRAG_FP16)
         hipLaunchKernelGGL(tile_rescore_kernel<true>, dim3((unsigned)k, (unsigned)batch), dim3(256), 0, s, emb, rows, dim,
                            q, sel, mn, mx, k, idx_offset, normalize, idx_out, val_out);
     else

@@ -172,7 +172,8 @@ def test_score_facts_matches_oracle(case, gpu_device):
 @pytest.mark.parametrize("rows,dim,b,k", [(6000, 192, 70, 5), (1000, 768, 130, 16), (129, 72, 65, 5), (100, 64, 200, 16),
                                           (40000, 256, 256, 5), (7, 64, 66, 5),
                                           (6000, 192, 40, 5), (1000, 768, 17, 16), (300, 64, 64, 5),   # 64-query tiles
-                                          (1_100_000, 32, 66, 5)])       # > 8192 tiles: the select rounds re-read memory
+                                          (1_100_000, 32, 66, 5),        # > 8192 tiles: the select rounds re-read memory
+                                          (20000, 128, 1024, 16), (9000, 64, 300, 16)])   # pass 3 in tile order (>= 4 pairs per tile)
 def test_score_facts_fused_is_bit_identical_to_gemm_plus_topk(gpu_device, rows, dim, b, k):
     """Batches > 16 take the fused path (tile maxima -> k tiles -> recomputed scores, csrc/sim_gemm.hip)
     without the [B, F] score matrix: ids and normalised scores must equal the two-step path

@@ -331,6 +331,12 @@ static inline bool two_stage_ok(int iters, float damping) {
     return std::pow((double)damping, (double)k1) <= 2.2e-3;
 }
 
+// A/B switch for measurements: HRAG_P8_GROUPWISE=0 keeps the fp8-state sweeps of a batch > 256 in one launch (read once)
+static bool p8_groupwise_enabled() {
+    static const bool v = [] { const char *x = experiment_env("HRAG_P8_GROUPWISE"); return !(x && x[0] == '0'); }();
+    return v;
+}
+
 static bool accel_plan16(int iters, float damping, int *k1_out, int *k2_out) {
     const double al = (double)damping;
     // damping above ~0.6: the equi-oscillating error of a Chebyshev stage sits on the SMALL passage scores as well, and
@@ -1334,8 +1340,17 @@ static hrag_status retrieve_impl(hrag_engine *e, const uint16_t *q_pass, const f
     // PPR (HippoRAG.py:1736-1743): fixed-count leaky power iteration
     if (f8) {
         // `f8_iters` sweeps + the conditional steps of the convergence contract (their gate words decide on the device)
+        // more than 256 queries: one launch per group of two slabs instead of one launch over all of them -- a launch then
+        // gathers from ONE group's 256 MB of state (configs[2]'s working set, which the Infinity Cache still helps with)
+        // instead of B / 256 times that: batch 1024 on configs[2]'s graph 69.8 -> 67.0 ms per call, 14.67 k -> 15.28 k queries/s
+        // (profiles/r06w_bench_cfg4_groupwise_ab.json: the rate of four batches of 256); results
+        // are bit-identical (the row shards have always issued their sweeps per group: tests/test_gpu_full_size.py)
+        const bool per_group = e->p8.n_groups > 1 && p8_groupwise_enabled();
         for (int it = 0; it < e->p8.n_steps; ++it) {
-            HRAG_TRY(ppr8_sweep(e, it, -1, nullptr, s));
+            if (per_group)
+                for (int g = 0; g < e->p8.n_groups; ++g) HRAG_TRY(ppr8_sweep(e, it, g, nullptr, s));
+            else
+                HRAG_TRY(ppr8_sweep(e, it, -1, nullptr, s));
             HRAG_TRY(ppr8_decide(e, it, s));
         }
     } else if (f16) {

@@ -14,8 +14,9 @@
 //           elements are >= L).
 //   pass 2: keys >= L are appended to an LDS candidate buffer (expected k..~1.3k entries),
 //           bitonic-sorted descending, and the first k are written out.
-// If an adversarial distribution overflows the buffer the exact k-th key is found by bisection on
-// the key space (counting passes) and pass 2 is repeated; correctness never depends on luck.
+// If the candidates overflow the buffer (an adversarial distribution, or simply a large k on a long row) the bound is
+// refined by radix histograms over the key space (10 bits per streaming pass, round 6; bisection before) until they fit,
+// and pass 2 is repeated; correctness never depends on luck.
 #include <algorithm>
 
 #include "common.h"
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(TK_THREADS) void row_topk_kernel(
     // A lower bound of the kk-th largest key without sorting the 2048 thread-local maxima (66 barrier stages, ~25 us --
     // most of the kernel on short rows): every wavefront finds the r-th largest of ITS 128 keys, r = ceil(kk / 16), by
     // rank counting over shuffles (keys are unique); the minimum over the 16 wavefronts has at least 16 r >= kk keys
-    // above or at it.  (A wavefront with fewer than r real keys answers 0: everything is collected, and the bisection
+    // above or at it.  (A wavefront with fewer than r real keys answers 0: everything is collected, and the refinement
     // below takes over if that does not fit.)
     __shared__ uint64_t wave_rth[TK_THREADS / 64];
     {
@@ -181,21 +182,9 @@ __global__ __launch_bounds__(TK_THREADS) void row_topk_kernel(
     for (int w = 1; w < TK_THREADS / 64; ++w) thresh = wave_rth[w] < thresh ? wave_rth[w] : thresh;
     __syncthreads();
 
-    // ---- pass 2: collect candidates >= thresh (bisect first if they would not fit)
-    auto count_ge = [&](uint64_t t) -> unsigned int {
-        if (tid == 0) s_count = 0;
-        __syncthreads();
-        unsigned int c = 0;
-        for_each_in_row(s, n, tid, [&](float v, uint32_t i) { c += rank_key(v, i) >= t ? 1u : 0u; });
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if ((tid & 63) == 0 && c) atomicAdd(&s_count, c);
-        __syncthreads();
-        const unsigned int r = s_count;
-        __syncthreads();
-        return r;
-    };
-    // collect straight away (the usual case: k .. ~1.3 k candidates); only when they do NOT fit is the exact kk-th
-    // key found by bisection (counting passes) and the collection repeated -- one streaming pass less than counting first
+    // ---- pass 2: collect candidates >= thresh (refine the bound first if they would not fit)
+    // collect straight away (the usual case: k .. ~1.3 k candidates); only when they do NOT fit is the
+    // bound refined (below) and the collection repeated -- one streaming pass less than counting first
     auto collect = [&](uint64_t t) -> unsigned int {
         if (tid == 0) s_count = 0;
         __syncthreads();
@@ -213,16 +202,53 @@ __global__ __launch_bounds__(TK_THREADS) void row_topk_kernel(
     };
     unsigned int cnt = collect(thresh);
     if (cnt > TK_CAP) {
-        // exact kk-th largest key by bisection: count(>= lo) >= kk always holds
-        uint64_t lo = thresh, hi = ~0ull;
-        while (lo < hi) {
-            const uint64_t mid = lo + ((hi - lo) >> 1) + 1;
-            if (count_ge(mid) >= (unsigned int)kk)
-                lo = mid;
-            else
-                hi = mid - 1;
+        // More than TK_CAP keys at or above the bound (large k on a long row: k = 2047 of 875 k in the index-time KNN puts
+        // the bound at the weakest of all thread-local maxima, ~1 - 2 % of the row).  Until round 6 the exact kk-th key was
+        // then found by bisection on the 64-bit key space -- up to 64 counting passes over the row, 35 of the 44 ms of a
+        // 1000-query KNN block.  Radix refinement instead: a 1024-bin histogram of the keys inside [lo, hi] (LDS atomics; the
+        // candidate buffer lends its memory), the bin that holds the kk-th largest is the next [lo, hi]; stop as soon as
+        // count(key >= lo) fits the buffer -- 10 bits per pass and no need for the exact key: 2 - 3 passes.
+        // Invariant: count(key > hi) = above < kk <= above + count(lo <= key <= hi).
+        unsigned int *hist = reinterpret_cast<unsigned int *>(buf);
+        static_assert(TK_THREADS == 1024, "one thread per histogram bin");
+        uint64_t lo = thresh, hi = rank_key(mx, 0xffffffffu);
+        unsigned int above = 0;
+        for (;;) {
+            const uint64_t width = hi - lo;
+            int shift = 0;
+            while ((width >> shift) >= 1024) ++shift;              // bins 0 .. width >> shift <= 1023
+            hist[tid] = 0;
+            __syncthreads();
+            for_each_in_row(s, n, tid, [&](float v, uint32_t i) {
+                const uint64_t key = rank_key(v, i);
+                if (key >= lo && key <= hi) atomicAdd(&hist[(unsigned int)((key - lo) >> shift)], 1u);
+            });
+            __syncthreads();
+            for (int o = 1; o < TK_THREADS; o <<= 1) {              // hist[b] := keys in the bins >= b
+                const unsigned int add = tid + o < TK_THREADS ? hist[tid + o] : 0u;
+                __syncthreads();
+                hist[tid] += add;
+                __syncthreads();
+            }
+            // the counts fall with b: exactly one bin b has above + hist[b] >= kk > above + hist[b + 1]
+            const bool here = above + hist[tid] >= (unsigned int)kk;
+            const bool next = tid + 1 < TK_THREADS && above + hist[tid + 1] >= (unsigned int)kk;
+            if (here && !next) s_count = (unsigned int)tid;
+            __syncthreads();
+            const int b = (int)s_count;
+            const unsigned int c_ge = above + hist[b];
+            const unsigned int c_gt = b + 1 < TK_THREADS ? above + hist[b + 1] : above;
+            __syncthreads();
+            const uint64_t blo = lo + ((uint64_t)b << shift);
+            if (c_ge <= (unsigned int)TK_CAP || shift == 0) {       // (shift 0: bins are single keys, c_ge = c_gt + 1 <= kk)
+                thresh = blo;
+                break;
+            }
+            const uint64_t span = ((uint64_t)1 << shift) - 1;
+            above = c_gt;
+            hi = hi - blo > span ? blo + span : hi;
+            lo = blo;
         }
-        thresh = lo;
         cnt = collect(thresh);
     }
     cnt = cnt < (unsigned int)TK_CAP ? cnt : (unsigned int)TK_CAP;

@@ -74,7 +74,8 @@ def _check_topk(gpu_device, scores, k, **kw):
         assert mn.cpu().numpy()[r] == row.min() and mx.cpu().numpy()[r] == row.max()
 
 
-@pytest.mark.parametrize("n,k", [(3, 5), (100, 5), (5000, 200), (300001, 200), (4099, 2048), (1, 1)])
+@pytest.mark.parametrize("n,k", [(3, 5), (100, 5), (5000, 200), (300001, 200), (4099, 2048), (1, 1),
+                                 (300001, 2047), (875000, 2047), (70000, 2048)])   # large k on long rows: the radix refinement
 def test_topk_rows_exact(gpu_device, n, k):
     rng = np.random.default_rng(n + k)
     s = rng.standard_normal((4, n)).astype(np.float32)
@@ -88,7 +89,7 @@ def test_topk_rows_exact(gpu_device, n, k):
 
 def test_topk_rows_adversarial_overflow_path(gpu_device):
     # every large value lives in the slice one thread scans => thread-local maxima give a useless
-    # lower bound => candidate buffer overflows => bisection path must still be exact
+    # lower bound => candidate buffer overflows => the refinement path must still be exact
     n, k = 1 << 18, 200
     rng = np.random.default_rng(0)
     s = rng.random((2, n)).astype(np.float32)

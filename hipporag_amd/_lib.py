@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libhrag.so")
 
 HRAG_OK, HRAG_EINVAL, HRAG_ENOMEM, HRAG_EHIP, HRAG_EBUSY, HRAG_ECAPACITY = range(6)
 SEED_STRIDE = 32
-HRAG_VERSION = 7      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
+HRAG_VERSION = 8      # HRAG_VERSION_MAJOR * 1000 + HRAG_VERSION_MINOR of include/hrag.h
 FLAG_DPR_FALLBACK, FLAG_ZERO_MASS, FLAG_ZERO_PHRASE, FLAG_FP8_SATURATED, FLAG_NOT_CONVERGED = 1, 2, 4, 8, 16
 # the convergence contract's error bound (include/hrag.h): error <= max(PPR_ERR_K * residual, floor of the state type);
 # a tolerance below PPR_TOL_MIN is rejected (HRAG_EINVAL)
@@ -126,6 +126,7 @@ SIGNATURES = {
     "hrag_sim_gemm": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _I32, _P]),
     "hrag_sim_topk_workspace_bytes": (C.c_int64, [_I64, _I32]),
     "hrag_sim_topk": (C.c_int, [_P, _I64, _I32, _P, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
+    "hrag_sim_topk_min_score": (C.c_int, [_P, _I64, _I32, _P, _I32, _I32, _I32, _I32, C.c_float, C.c_float, _P, _I64, _P, _P, _P, _P]),
     "hrag_split_f32": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "hrag_shard_layout_query": (C.c_int, [_P, _I32, _I32, C.POINTER(ShardLayout)]),
     "hrag_shard_score_facts": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P]),

@@ -425,7 +425,8 @@ hrag_status launch_sim_gemm(const uint16_t *emb, int64_t rows, int32_t dim, cons
 bool sim_gemm256_serves(int64_t rows, int32_t dim, int32_t batch);
 bool sim_gemm_force_small_tiles();
 hrag_status launch_sim_gemm256(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch,
-                               float *out, int64_t ld, float *tmax, float *tmin, hipStream_t s, int32_t dtype);
+                               float *out, int64_t ld, float *tmax, float *tmin, hipStream_t s, int32_t dtype,
+                               int64_t row_ld = 0);
 
 // fused similarity + top-k for k <= 16 (no [B, rows] score matrix; bit-identical to the two-step path)
 //   ws: 2 * sim_fused_tiles(rows) * batch floats; sel: sim_fused_sel_ints(batch) ints, zeroed ONCE at allocation
@@ -436,7 +437,8 @@ int64_t sim_fused_sel_ints(int32_t batch);   // ints of the `sel` workspace (zer
 hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
                                   int32_t batch, int32_t k, int32_t idx_offset, int32_t normalize,
                                   float *ws, int32_t *sel, float *mn, float *mx, int32_t *idx_out,
-                                  float *val_out, hipStream_t s, int32_t dtype = HRAG_BF16);
+                                  float *val_out, hipStream_t s, int32_t dtype = HRAG_BF16, int32_t approx_dim = 0,
+                                  float cut = -INFINITY, int32_t *overflow = nullptr);
 
 // sim_gemv.hip : the same for batch <= 8 (streams E once, queries in registers); false = not handled
 bool launch_sim_gemv(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch,

@@ -128,6 +128,25 @@ hrag_status hrag_sim_topk(const uint16_t *emb_dev, int64_t rows, int32_t dim, co
                                  (hipStream_t)stream, dtype);
 }
 
+hrag_status hrag_sim_topk_min_score(const uint16_t *emb_dev, int64_t rows, int32_t dim, const uint16_t *q_dev, int32_t batch,
+                                    int32_t k, int32_t dtype, int32_t approx_dim, float min_score, float margin,
+                                    void *workspace_dev, int64_t workspace_bytes, int32_t *idx_out_dev, float *val_out_dev,
+                                    int32_t *overflow_out_dev, hrag_stream stream) {
+    HRAG_REQUIRE(emb_dev && q_dev && workspace_dev && idx_out_dev && val_out_dev && overflow_out_dev && rows >= 1 && batch >= 1,
+                 "bad argument");
+    HRAG_REQUIRE(dtype == HRAG_BF16 || dtype == HRAG_FP16, "dtype must be HRAG_BF16 or HRAG_FP16");
+    HRAG_REQUIRE(margin >= 0.f && margin < 1.f && min_score == min_score, "margin %g must lie in [0, 1) and min_score be a number",
+                 (double)margin);
+    HRAG_REQUIRE(approx_dim == 0 || margin > 0.f, "a prefix first pass (approx_dim %d) needs the margin that bounds its error", approx_dim);
+    HRAG_REQUIRE(workspace_bytes >= hrag_sim_topk_workspace_bytes(rows, batch), "workspace too small: %lld < %lld bytes",
+                 (long long)workspace_bytes, (long long)hrag_sim_topk_workspace_bytes(rows, batch));
+    int32_t *sel = static_cast<int32_t *>(workspace_dev);
+    float *mn = reinterpret_cast<float *>(sel + sim_fused_sel_ints(batch)), *mx = mn + batch;
+    float *ws = mx + batch;
+    return launch_sim_topk_fused(emb_dev, rows, dim, q_dev, batch, k, 0, 0, ws, sel, mn, mx, idx_out_dev, val_out_dev,
+                                 (hipStream_t)stream, dtype, approx_dim, min_score - margin, overflow_out_dev);
+}
+
 hrag_status hrag_sim_gemm(const uint16_t *emb_dev, int64_t rows, int32_t dim, const uint16_t *q_dev,
                           int32_t batch, float *out_dev, int64_t ld, int32_t accumulate, int32_t dtype,
                           hrag_stream stream) {

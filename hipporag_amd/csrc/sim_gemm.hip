@@ -244,7 +244,11 @@ constexpr int kSelRecInts = 32 + 16 * 128 * 2;   // = kSelRec below: ints per qu
 __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restrict__ tmax,
                                                           const float *__restrict__ tmin, int32_t n_tiles,
                                                           int32_t batch, int32_t k, int32_t *__restrict__ sel,
-                                                          float *__restrict__ mn_out, float *__restrict__ mx_out) {
+                                                          float *__restrict__ mn_out, float *__restrict__ mx_out,
+                                                          float cut, int32_t *__restrict__ overflow) {
+    // cut: tiles whose maximum is below it are not selected (their list entries are -1; the list is in descending order, so
+    // the selected tiles stay a prefix); overflow != nullptr: overflow[b] = a (k + 1)-th tile reaches the cut as well
+    // (the thresholded KNN: the caller takes the dense path for that query).  cut = -inf, overflow = nullptr: the plain top-k.
     __shared__ uint64_t red[4];
     __shared__ float redf[4];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restric
     __syncthreads();
     mn = fminf(fminf(redf[0], redf[1]), fminf(redf[2], redf[3]));
     uint64_t prev = ~0ull;
-    for (int r = 0; r < k; ++r) {
+    for (int r = 0; r < k + (overflow ? 1 : 0); ++r) {
         uint64_t best = 0;   // keys are > 0: ordered(x) of any non-NaN float is >= 0x00800000
         if (in_regs) {
 #pragma unroll
@@ -280,8 +284,13 @@ __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restric
             }
         }
         best = block_max_u64(best, red, tid);
+        const bool keep = best && ordered_to_f32((uint32_t)(best >> 32)) >= cut;
+        if (r == k) {                                   // the extra round of the thresholded form
+            if (tid == 0) overflow[b] = keep ? 1 : 0;
+            break;
+        }
         if (tid == 0) {
-            sel[(size_t)b * kSelRecInts + r] = best ? (int32_t)(uint32_t)best : -1;
+            sel[(size_t)b * kSelRecInts + r] = keep ? (int32_t)(uint32_t)best : -1;
             if (r == 0) {
                 mx_out[b] = best ? ordered_to_f32((uint32_t)(best >> 32)) : -INFINITY;
                 mn_out[b] = mn;
@@ -301,15 +310,26 @@ constexpr int kSelRec = 32 + kFusedMaxK * BM * 2;
 // GEMM (profiles/r06w_knn_*.json).  The pairs are bucketed by tile (histogram, one-workgroup scan, scatter: three small
 // launches; the order INSIDE a bucket is whatever the atomics give, which no result depends on) and pass 3 becomes one
 // workgroup per (tile, up to 16 of its queries): the tile is read once per 16 pairs and the 16 columns of the MFMA carry
-// 16 different queries instead of 16 copies of one (tile_rescore_grouped_kernel).  pair id = b * k + r; bucket n_tiles
-// collects the "no tile" entries (id -1), which still have to arrive at their query's counter.
+// 16 different queries instead of 16 copies of one (tile_rescore_grouped_kernel).  pair id = b * k + r.
 constexpr int kPairChunk = 16;
+// "No tile" entries (id -1: fewer tiles than k, or -- the thresholded form -- tiles below the cut: nearly all of them in the
+// index-time KNN) take no part: a query's arrival counter waits for its VALID tiles only, and a query with none gets its
+// empty result row here.
 __global__ __launch_bounds__(256) void pair_hist_kernel(const int32_t *__restrict__ rec, int32_t n_pairs, int32_t k,
-                                                        int32_t n_tiles, int32_t *__restrict__ hist) {
+                                                        int32_t *__restrict__ hist, int32_t *__restrict__ idx_out,
+                                                        float *__restrict__ val_out) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n_pairs) return;
-    const int t = rec[(size_t)(p / k) * kSelRecInts + (p % k)];
-    atomicAdd(hist + (t >= 0 ? t : n_tiles), 1);
+    const int b = p / k, r = p % k;
+    const int t = rec[(size_t)b * kSelRecInts + r];
+    if (t >= 0) {
+        atomicAdd(hist + t, 1);
+    } else if (r == 0) {                 // the selected tiles are a prefix of the list: none at all
+        for (int j = 0; j < k; ++j) {
+            idx_out[(size_t)b * k + j] = -1;
+            val_out[(size_t)b * k + j] = 0.f;
+        }
+    }
 }
 // one workgroup, in place over n buckets: hist[i] (count) -> first position of bucket i; chunk[i] = number of 16-pair
 // chunks of the buckets before i, chunk[n] = all chunks
@@ -344,12 +364,11 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(int32_t *__restrict__ h
 }
 // cursor[t] (= first position of bucket t) advances to the END of bucket t
 __global__ __launch_bounds__(256) void pair_scatter_kernel(const int32_t *__restrict__ rec, int32_t n_pairs, int32_t k,
-                                                           int32_t n_tiles, int32_t *__restrict__ cursor,
-                                                           int32_t *__restrict__ order) {
+                                                           int32_t *__restrict__ cursor, int32_t *__restrict__ order) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n_pairs) return;
     const int t = rec[(size_t)(p / k) * kSelRecInts + (p % k)];
-    order[atomicAdd(cursor + (t >= 0 ? t : n_tiles), 1)] = p;
+    if (t >= 0) order[atomicAdd(cursor + t, 1)] = p;
 }
 
 // The exact top-k of one query's k x 128 candidate keys (written by the workgroups that rescored its tiles), by the
@@ -476,8 +495,8 @@ __global__ __launch_bounds__(256) void tile_rescore_grouped_kernel(const uint16_
     __shared__ int s_done[kPairChunk];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w = blockIdx.x;
-    if (w >= chunk_start[n_tiles + 1]) return;
-    int lo = 0, hi = n_tiles + 1;              // chunk_start[lo] <= w < chunk_start[hi]: the LAST bucket that starts at or
+    if (w >= chunk_start[n_tiles]) return;
+    int lo = 0, hi = n_tiles;                  // chunk_start[lo] <= w < chunk_start[hi]: the LAST bucket that starts at or
     while (hi - lo > 1) {                      // before w is the non-empty one
         const int mid = (lo + hi) >> 1;
         if (chunk_start[mid] <= w) lo = mid;
@@ -486,7 +505,7 @@ __global__ __launch_bounds__(256) void tile_rescore_grouped_kernel(const uint16_
     const int t = lo;
     const int first = (t == 0 ? 0 : bucket_end[t - 1]) + (w - chunk_start[t]) * kPairChunk;
     const int n = min(kPairChunk, bucket_end[t] - first);
-    if (t < n_tiles) {
+    {
         const int col = lane & 15;
         const int p = order[first + min(col, n - 1)];        // columns beyond the chunk repeat its last query (not stored)
         const int bq = p / k, rq = p % k;
@@ -531,7 +550,10 @@ __global__ __launch_bounds__(256) void tile_rescore_grouped_kernel(const uint16_
         int done = -1;
         if (tid < n) {
             const int b = order[first + tid] / k;
-            if (__hip_atomic_fetch_add(rec + (size_t)b * kSelRec + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k - 1)
+            const int32_t *my = rec + (size_t)b * kSelRec;
+            int n_valid = 0;                                 // the query's counter waits for its valid tiles (a prefix)
+            for (int i = 0; i < k; ++i) n_valid += my[i] >= 0 ? 1 : 0;
+            if (__hip_atomic_fetch_add(rec + (size_t)b * kSelRec + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_valid - 1)
                 done = b;
         }
         s_done[tid] = done;
@@ -569,8 +591,17 @@ bool rescore_grouping_disabled() {
 hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q,
                                   int32_t batch, int32_t k, int32_t idx_offset, int32_t normalize,
                                   float *ws, int32_t *sel, float *mn, float *mx, int32_t *idx_out,
-                                  float *val_out, hipStream_t s, int32_t dtype) {
+                                  float *val_out, hipStream_t s, int32_t dtype, int32_t approx_dim, float cut,
+                                  int32_t *overflow) {
     HRAG_REQUIRE(dim > 0 && dim % 8 == 0, "embedding dim %d must be a positive multiple of 8", dim);
+    // Thresholded form (the index-time KNN, round 6): the caller only reads results at or above a score.  cut: tiles whose
+    // maximum is below it are never rescored; approx_dim > 0: pass 1 runs over the first approx_dim elements of every row
+    // only -- the caller guarantees |full product - prefix product| <= (its threshold - cut) -- and pass 3 rescores the tiles
+    // that reach the cut over all `dim` elements, so every returned score is the exact chain and every row at or above the
+    // caller's threshold is among the candidates unless overflow[b] says that more than k tiles reached the cut.
+    HRAG_REQUIRE(approx_dim == 0 || (approx_dim > 0 && approx_dim <= dim && normalize == 0),
+                 "fused top-k: approx_dim %d must lie in (0, dim] and needs normalize = 0", approx_dim);
+    if (approx_dim > 0 && !(sim_gemm256_serves(rows, approx_dim, batch) && !sim_gemm_force_small_tiles())) approx_dim = 0;
     HRAG_REQUIRE(k >= 1 && k <= kFusedMaxK && rows >= 1 && batch >= 1, "fused top-k: bad k / rows / batch");
     const int64_t tiles_m = ceil_div(rows, BM);
     float *tmax = ws, *tmin = ws + (size_t)tiles_m * batch;
@@ -588,14 +619,16 @@ hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim
             hipLaunchKernelGGL((sim_gemm_kernel<BN_, WM_, WN_, true, false>), grid, dim3(256), 0, s, emb, rows, \
                                dim, q, batch, nullptr, 0, tn, 0, tmax, tmin);                                 \
     } while (0)
-    if (sim_gemm256_serves(rows, dim, batch) && !(sim_gemm_force_small_tiles()))
+    if (approx_dim > 0)
+        HRAG_TRY(launch_sim_gemm256(emb, rows, approx_dim, q, batch, nullptr, 0, tmax, tmin, s, dtype, dim));
+    else if (sim_gemm256_serves(rows, dim, batch) && !(sim_gemm_force_small_tiles()))
         HRAG_TRY(launch_sim_gemm256(emb, rows, dim, q, batch, nullptr, 0, tmax, tmin, s, dtype));
     else if (batch > 64) LAUNCH_TM(128, 2, 2);
     else LAUNCH_TM(64, 4, 1);
 #undef LAUNCH_TM
     HRAG_LAUNCH_CHECK();
     hipLaunchKernelGGL(tile_select_kernel, dim3((unsigned)batch), dim3(256), 0, s, tmax, tmin, (int32_t)tiles_m,
-                       batch, k, sel, mn, mx);
+                       batch, k, sel, mn, mx, cut, overflow);
     HRAG_LAUNCH_CHECK();
     // wide batches: pass 3 grouped by tile (see pair_hist_kernel); the tile minima are dead after tile_select_kernel and
     // lend their memory: [n_tiles + 1] bucket cursors, [n_tiles + 2] chunk starts, then the ordered pair ids
@@ -605,13 +638,13 @@ hrag_status launch_sim_topk_fused(const uint16_t *emb, int64_t rows, int32_t dim
     if (grouped) {
         int32_t *cursor = reinterpret_cast<int32_t *>(tmin), *chunk = cursor + tiles_m + 1, *ord = chunk + tiles_m + 2;
         const unsigned pb = (unsigned)ceil_div(n_pairs, 256);
-        const dim3 grid3((unsigned)(ceil_div(n_pairs, kPairChunk) + tiles_m + 1));     // >= the number of chunks
+        const dim3 grid3((unsigned)(ceil_div(n_pairs, kPairChunk) + tiles_m));         // >= the number of chunks
         HRAG_HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)(tiles_m + 1) * sizeof(int32_t), s));
-        hipLaunchKernelGGL(pair_hist_kernel, dim3(pb), dim3(256), 0, s, sel, (int32_t)n_pairs, k, (int32_t)tiles_m, cursor);
+        hipLaunchKernelGGL(pair_hist_kernel, dim3(pb), dim3(256), 0, s, sel, (int32_t)n_pairs, k, cursor, idx_out, val_out);
         HRAG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, cursor, chunk, (int32_t)tiles_m + 1);
+        hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, s, cursor, chunk, (int32_t)tiles_m);
         HRAG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(pair_scatter_kernel, dim3(pb), dim3(256), 0, s, sel, (int32_t)n_pairs, k, (int32_t)tiles_m, cursor, ord);
+        hipLaunchKernelGGL(pair_scatter_kernel, dim3(pb), dim3(256), 0, s, sel, (int32_t)n_pairs, k, cursor, ord);
         HRAG_LAUNCH_CHECK();
         if (dtype == HRAG_FP16)
             hipLaunchKernelGGL(tile_rescore_grouped_kernel<true>, grid3, dim3(256), 0, s, emb, rows, dim, q, sel, mn, mx, k,

@@ -80,7 +80,9 @@ __global__ __launch_bounds__(512, 1) void sim_gemm256_kernel(const uint16_t *__r
                                                              int32_t dim, const uint16_t *__restrict__ q,
                                                              int32_t batch, float *__restrict__ out, int64_t ld,
                                                              int32_t n_tiles_n, float *__restrict__ tmax,
-                                                             float *__restrict__ tmin) {
+                                                             float *__restrict__ tmin, int64_t emb_ld, int64_t q_ld) {
+    // emb_ld / q_ld: elements between consecutive rows (>= dim).  dim < ld = a PREFIX of every row: the thresholded KNN's
+    // first pass reads the hi halves of the split layout only (csrc/sim_gemm.hip launch_sim_topk_fused)
     constexpr int MI = 4, WGM = 4, WGN = 2, NW = WGM * WGN;
     constexpr int BN = WGN * NJ * 16;
     constexpr int A_BYTES = BM2 * 128, B_BYTES = BN * 128;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(512, 1) void sim_gemm256_kernel(const uint16_t *__r
             const int blk = wave * A_LOADS + i;
             int64_t r = m0 + blk * 8 + lrow;
             r = r < rows ? r : rows - 1;                 // rows beyond the matrix: any valid row (never stored)
-            glds16<true>(emb + (size_t)r * dim + k0 + lchunk * 8, sa + (uint32_t)(blk * 1024));
+            glds16<true>(emb + (size_t)r * emb_ld + k0 + lchunk * 8, sa + (uint32_t)(blk * 1024));
         }
     };
     auto issue_b = [&](int stage, int k0) {
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(512, 1) void sim_gemm256_kernel(const uint16_t *__r
             const int blk = wave * (BN / 8 / NW) + i;
             int r = b0 + blk * 8 + lrow;
             r = r < batch ? r : batch - 1;
-            glds16<false>(q + (size_t)r * dim + k0 + lchunk * 8, sb + (uint32_t)(blk * 1024));
+            glds16<false>(q + (size_t)r * q_ld + k0 + lchunk * 8, sb + (uint32_t)(blk * 1024));
         }
     };
 
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(512, 1) void sim_gemm256_kernel(const uint16_t *__r
 
 template <int NJ, bool TILEMAX, bool F16>
 hrag_status launch256(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch, float *out,
-                      int64_t ld, float *tmax, float *tmin, hipStream_t s) {
+                      int64_t ld, float *tmax, float *tmin, hipStream_t s, int64_t row_ld) {
     constexpr int BN = NJ * 32;
     constexpr int lds_bytes = 3 * BM2 * 128 + 2 * BN * 128;   // three embedding stages, two query stages
     static_assert(lds_bytes >= 2 * 4 * BN * (int)sizeof(float), "the tile-max reduction reuses the stage memory");
@@ -246,7 +248,7 @@ hrag_status launch256(const uint16_t *emb, int64_t rows, int32_t dim, const uint
     const int64_t tiles_m = ceil_div(rows, BM2);
     const int tn = (int)ceil_div(batch, BN);
     hipLaunchKernelGGL(kernel, dim3((unsigned)(round_up(tiles_m, 8) * tn)), dim3(512), lds_bytes, s, emb, rows, dim, q,
-                       batch, out, ld, tn, tmax, tmin);
+                       batch, out, ld, tn, tmax, tmin, row_ld, row_ld);
     HRAG_LAUNCH_CHECK();
     return HRAG_OK;
 }
@@ -259,10 +261,12 @@ bool sim_gemm256_serves(int64_t rows, int32_t dim, int32_t batch) {
 
 // tmax / tmin != nullptr: pass 1 of the fused fact top-k (per 128-row tile max / min, [ceil(rows / 128)][batch])
 hrag_status launch_sim_gemm256(const uint16_t *emb, int64_t rows, int32_t dim, const uint16_t *q, int32_t batch,
-                               float *out, int64_t ld, float *tmax, float *tmin, hipStream_t s, int32_t dtype) {
+                               float *out, int64_t ld, float *tmax, float *tmin, hipStream_t s, int32_t dtype,
+                               int64_t row_ld) {
+    if (row_ld <= 0) row_ld = dim;      // rows of both operands are row_ld elements apart; the product runs over the first dim
     const bool f16 = dtype == HRAG_FP16, tm = tmax != nullptr;
     const bool wide = batch > 128;
-#define GO(NJ_, TM_, F_) return launch256<NJ_, TM_, F_>(emb, rows, dim, q, batch, out, ld, tmax, tmin, s)
+#define GO(NJ_, TM_, F_) return launch256<NJ_, TM_, F_>(emb, rows, dim, q, batch, out, ld, tmax, tmin, s, row_ld)
     if (wide) {
         if (tm) { if (f16) GO(8, true, true); else GO(8, true, false); }
         else { if (f16) GO(8, false, true); else GO(8, false, false); }

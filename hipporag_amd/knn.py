@@ -22,6 +22,10 @@ import numpy as np
 from . import _lib
 from ._lib import check
 
+# bound on |x . q - hi(x) . hi(q)| for unit vectors in the split layout: |lo| <= 2^-11 |x| per vector, two cross terms
+# (9.8e-4) + the dropped lo . lo term and the fp32 accumulation (< 1e-5): what the thresholded first pass may miss by
+_PREFIX_MARGIN = 1.2e-3
+
 
 def retrieve_knn(query_ids: List[str], key_ids: List[str], query_vecs, key_vecs, k: int = 2047,
                  query_batch_size: int = 1000, key_batch_size: int = 10000, *, precision: str = "f32",
@@ -92,15 +96,27 @@ def retrieve_knn(query_ids: List[str], key_ids: List[str], query_vecs, key_vecs,
         if min_score is not None:
             i16 = torch.empty((b, fused_k), dtype=torch.int32, device=dev)
             v16 = torch.empty((b, fused_k), dtype=torch.float32, device=dev)
-            check(lib.hrag_sim_topk(keys.data_ptr(), n_keys, kdim, qq.data_ptr(), b, fused_k, dtype, ws.data_ptr(),
-                                    ws_bytes, i16.data_ptr(), v16.data_ptr(), stream))
+            over = torch.empty((b,), dtype=torch.int32, device=dev)
+            # the thresholded fused top-16 (include/hrag.h hrag_sim_topk_min_score): tiles below the threshold are never
+            # rescored, and on the split layout the tile maxima come from the hi . qhi third alone -- the other two
+            # thirds move a score by at most 2 * 2^-11 = 9.8e-4 for unit vectors (margin 1.2e-3) -- a third of the MFMA
+            # work; what is rescored is rescored over all 3 * dim elements, so every returned score is the exact chain
+            check(lib.hrag_sim_topk_min_score(keys.data_ptr(), n_keys, kdim, qq.data_ptr(), b, fused_k, dtype,
+                                              dim if split else 0, float(min_score), _PREFIX_MARGIN if split else 0.0,
+                                              ws.data_ptr(), ws_bytes, i16.data_ptr(), v16.data_ptr(), over.data_ptr(),
+                                              stream))
             keep = v16 >= float(min_score)
             w = min(int(keep.sum(1).max().item()), kk)
             if w:
                 out_idx[lo_q: lo_q + b, :w] = torch.where(keep[:, :w], i16[:, :w], torch.full_like(i16[:, :w], -1)).cpu().numpy()
                 out_sc[lo_q: lo_q + b, :w] = torch.where(keep[:, :w], v16[:, :w], torch.zeros_like(v16[:, :w])).cpu().numpy()
-            more = torch.nonzero(keep[:, fused_k - 1]).flatten() if (kk > fused_k and n_keys > fused_k) else None
-            if more is None or more.numel() == 0:
+            # the dense path for the queries the fused form cannot answer: a 16th neighbour still above the threshold, or
+            # more than 16 tiles that reach it
+            need = over != 0
+            if kk > fused_k and n_keys > fused_k:
+                need = need | keep[:, fused_k - 1]
+            more = torch.nonzero(need).flatten()
+            if more.numel() == 0:
                 continue
             # the rare queries whose 16th neighbour is still above the threshold: the dense path, for them only
             qq = qq[more].contiguous()

@@ -50,9 +50,10 @@ extern "C" {
  *        hrag_shard_score_facts_all / hrag_shard_retrieve / hrag_shard_workspace_bytes (one call per phase on a row shard);
  *        hrag_shard_ppr_sweep enforces the ascending (step, group) order of a session with measured stage scales;
  *        later in 0.7 (no signature change): the accelerated two-stage fp16 plan (HRAG_OPT_ACCEL, batch <= 64, ppr_tol = 0)
- *        carries a margin of 16 instead of 4: 16 sweeps stand for 20 at damping 0.5 (14 before). */
+ *        carries a margin of 16 instead of 4: 16 sweeps stand for 20 at damping 0.5 (14 before);
+ *   0.8  hrag_sim_topk_min_score (the thresholded fused top-k of the index-time KNN: prefix first pass + cut). */
 #define HRAG_VERSION_MAJOR 0
-#define HRAG_VERSION_MINOR 7
+#define HRAG_VERSION_MINOR 8
 
 typedef enum hrag_status {
     HRAG_OK = 0,
@@ -452,6 +453,23 @@ int64_t hrag_sim_topk_workspace_bytes(int64_t rows, int32_t batch);
 hrag_status hrag_sim_topk(const uint16_t *emb_dev, int64_t rows, int32_t dim, const uint16_t *q_dev, int32_t batch,
                           int32_t k, int32_t dtype, void *workspace_dev, int64_t workspace_bytes,
                           int32_t *idx_out_dev, float *val_out_dev, hrag_stream stream);
+/* The THRESHOLDED form (ABI 0.8; add_synonymy_edges reads neighbours down to synonymy_edge_sim_threshold only,
+ * HippoRAG.py:1004-1007): the caller trusts results at or above min_score and nothing below it.
+ *   - tiles whose maximum is below min_score - margin are never rescored;
+ *   - approx_dim > 0: pass 1 (the tile maxima) runs over the first approx_dim elements of every row and query only; the
+ *     caller states in `margin` a bound on |full product - prefix product|.  For the split layout of hrag_split_f32 with
+ *     approx_dim = dim / 3 the prefix is hi . qhi and the rest, lo . qhi + hi . qlo, is at most 2 * 2^-11 |x| |q| = 9.8e-4
+ *     for unit vectors: margin 1.2e-3, a third of the MFMA work.  approx_dim = 0: pass 1 over all of dim (margin may be 0);
+ *   - pass 3 rescores the tiles that reach the cut over all `dim` elements: every returned score is the exact chain of
+ *     hrag_sim_gemm, and every row with score >= min_score is returned (in score order, ahead of anything below
+ *     min_score) UNLESS overflow_out_dev[b] != 0 (more than k tiles reached the cut) or the k-th returned score is itself
+ *     >= min_score: for those queries the caller takes hrag_sim_gemm + hrag_topk_rows.  Entries below min_score are
+ *     NOT the global ranking (rows of unselected tiles are missing among them).
+ * k <= 16; workspace as hrag_sim_topk; overflow_out_dev int32 [B]. */
+hrag_status hrag_sim_topk_min_score(const uint16_t *emb_dev, int64_t rows, int32_t dim, const uint16_t *q_dev, int32_t batch,
+                                    int32_t k, int32_t dtype, int32_t approx_dim, float min_score, float margin,
+                                    void *workspace_dev, int64_t workspace_bytes, int32_t *idx_out_dev,
+                                    float *val_out_dev, int32_t *overflow_out_dev, hrag_stream stream);
 /* fp32 [rows, dim] -> the fp16 [rows, 3 * dim] layout of an HRAG_F32_SPLIT engine: [hi | lo | hi] for embedding rows,
  * [hi | hi | lo] with as_query != 0 (new rows for hrag_engine_gather_embeddings; the engine converts its own inputs);
  * normalize != 0: rows are L2-normalised first (x / max(||x||, 1e-12), the KNN's F.normalize). */

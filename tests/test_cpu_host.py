@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hrag_version() == _lib.HRAG_VERSION == 7            # 0 * 1000 + 7 (round 6: hrag_workspace_create, hrag_engine_stats, gather-replay flag)
+    assert lib.hrag_version() == _lib.HRAG_VERSION == 8            # 0 * 1000 + 8 (round 6: workspaces, stats, shard drivers; hrag_sim_topk_min_score)
 
 
 def test_ctypes_structs_match_the_header_layout(tmp_path):

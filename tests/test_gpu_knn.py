@@ -139,3 +139,41 @@ def test_index_from_openie_computes_its_synonymy_edges_on_the_gpu(gpu_device):
     assert set(graphs[0]) == set(graphs[1])
     for k in graphs[1]:
         assert abs(graphs[0][k] - graphs[1][k]) <= 4e-6 * max(1.0, abs(graphs[1][k])), k
+
+
+def test_thresholded_knn_prefix_first_pass_straddling_the_threshold(gpu_device):
+    """retrieve_knn(min_score=t) at a shape where the thresholded fused top-16 runs its first pass over the hi . qhi third
+    of the split layout (include/hrag.h hrag_sim_topk_min_score: 256-row GEMM, dim % 64 == 0, batch > 64): neighbours
+    planted with cosines within 5e-3 of the threshold on BOTH sides -- inside and outside the 1.2e-3 margin of the prefix
+    pass -- scattered over many 128-row tiles; queries with more than 16 qualifying tiles (the overflow flag) and with
+    more than 16 qualifying rows (the dense path).  Every prefix above the threshold must equal the full lists'."""
+    from hipporag_amd.knn import retrieve_knn
+    rng = np.random.default_rng(11)
+    dim, n_base, n_fill = 128, 200, 12000
+
+    def unit(x):
+        return x / np.linalg.norm(x, axis=-1, keepdims=True)
+
+    base = unit(rng.standard_normal((n_base, dim)))
+    rows = [base]
+    for i in range(n_base):
+        n_dup = (3, 10, 24, 40)[i % 4]                       # 24 / 40: more than 16 rows (and tiles) above the threshold
+        u = unit(rng.standard_normal((n_dup, dim)))
+        u = unit(u - (u @ base[i])[:, None] * base[i])       # orthogonal to the base vector
+        c = rng.uniform(0.795, 0.805, n_dup)[:, None]        # cosines straddling 0.8
+        rows.append(c * base[i] + np.sqrt(1 - c * c) * u)
+    keys = np.concatenate(rows + [unit(rng.standard_normal((n_fill, dim)))]).astype(np.float32)
+    perm = rng.permutation(len(keys))                        # the neighbours of a query land in many tiles
+    keys = keys[perm]
+    q = keys[np.argsort(perm)[:n_base]]                      # the base vectors, wherever they went
+    full_i, full_s = retrieve_knn(None, None, q, keys, k=64, query_batch_size=100, return_arrays=True)
+    thr_i, thr_s = retrieve_knn(None, None, q, keys, k=64, query_batch_size=100, return_arrays=True, min_score=0.8)
+    n_above = (full_s >= 0.8).sum(1)
+    assert n_above.min() >= 1 and n_above.max() > 16 and ((n_above > 1) & (n_above < 16)).sum() > 20
+    near = np.abs(full_s - 0.8) < 1.2e-3                     # scores inside the prefix pass's margin exist on both sides
+    assert (near & (full_s >= 0.8)).any() and (near & (full_s < 0.8)).any()
+    for r in range(len(q)):
+        n = int(n_above[r])
+        np.testing.assert_array_equal(thr_i[r, :n], full_i[r, :n])
+        np.testing.assert_array_equal(thr_s[r, :n], full_s[r, :n])
+        assert np.all(thr_i[r, n:] == -1) and np.all(thr_s[r, n:] == 0)

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restric
             }
         }
         best = block_max_u64(best, red, tid);
-        const bool keep = best && ordered_to_f32((uint32_t)(best >> 32)) >= cut;
+        const bool keep = best && !(ordered_to_f32((uint32_t)(best >> 32)) < cut);      // (a NaN maximum is kept, as without a cut)
         if (r == k) {                                   // the extra round of the thresholded form
             if (tid == 0) overflow[b] = keep ? 1 : 0;
             break;
@@ -296,7 +296,14 @@ __global__ __launch_bounds__(256) void tile_select_kernel(const float *__restric
                 mn_out[b] = mn;
             }
         }
-        prev = best ? best : 0;
+        if (!keep) {        // the maxima come in descending order: nothing further reaches the cut (or nothing is left)
+            if (tid == 0) {
+                for (int rr = r + 1; rr < k; ++rr) sel[(size_t)b * kSelRecInts + rr] = -1;
+                if (overflow) overflow[b] = 0;
+            }
+            break;
+        }
+        prev = best;
     }
 }
 

@@ -89,43 +89,14 @@ def retrieve_knn(query_ids: List[str], key_ids: List[str], query_vecs, key_vecs,
         # threshold: the fused top-16 (tile maxima + rescore, exact) answers the others
         ws_bytes = int(lib.hrag_sim_topk_workspace_bytes(n_keys, min(qb, nq)))
         ws = torch.zeros((ws_bytes,), dtype=torch.uint8, device=dev)
-    for lo_q in range(0, nq, qb):
-        q = torch.from_numpy(qv_all[lo_q: lo_q + qb]).to(dev).contiguous()
-        b = q.shape[0]
-        qq = prepare(q, True)
-        if min_score is not None:
-            i16 = torch.empty((b, fused_k), dtype=torch.int32, device=dev)
-            v16 = torch.empty((b, fused_k), dtype=torch.float32, device=dev)
-            over = torch.empty((b,), dtype=torch.int32, device=dev)
-            # the thresholded fused top-16 (include/hrag.h hrag_sim_topk_min_score): tiles below the threshold are never
-            # rescored, and on the split layout the tile maxima come from the hi . qhi third alone -- the other two
-            # thirds move a score by at most 2 * 2^-11 = 9.8e-4 for unit vectors (margin 1.2e-3) -- a third of the MFMA
-            # work; what is rescored is rescored over all 3 * dim elements, so every returned score is the exact chain
-            check(lib.hrag_sim_topk_min_score(keys.data_ptr(), n_keys, kdim, qq.data_ptr(), b, fused_k, dtype,
-                                              dim if split else 0, float(min_score), _PREFIX_MARGIN if split else 0.0,
-                                              ws.data_ptr(), ws_bytes, i16.data_ptr(), v16.data_ptr(), over.data_ptr(),
-                                              stream))
-            keep = v16 >= float(min_score)
-            w = min(int(keep.sum(1).max().item()), kk)
-            if w:
-                out_idx[lo_q: lo_q + b, :w] = torch.where(keep[:, :w], i16[:, :w], torch.full_like(i16[:, :w], -1)).cpu().numpy()
-                out_sc[lo_q: lo_q + b, :w] = torch.where(keep[:, :w], v16[:, :w], torch.zeros_like(v16[:, :w])).cpu().numpy()
-            # the dense path for the queries the fused form cannot answer: a 16th neighbour still above the threshold, or
-            # more than 16 tiles that reach it
-            need = over != 0
-            if kk > fused_k and n_keys > fused_k:
-                need = need | keep[:, fused_k - 1]
-            more = torch.nonzero(need).flatten()
-            if more.numel() == 0:
-                continue
-            # the rare queries whose 16th neighbour is still above the threshold: the dense path, for them only
-            qq = qq[more].contiguous()
-            b = qq.shape[0]
-            rows_out = (lo_q + more).cpu().numpy()
-        else:
-            rows_out = None
-        if scores is None:
-            scores = torch.empty((min(qb, nq), ld), dtype=torch.float32, device=dev)
+
+    def dense(qq, rows_out):
+        """[b, n_keys] score block + exact row top-k for the prepared queries qq; rows_out: their rows of the result
+        (thresholded mode: cut to the prefix above min_score)"""
+        nonlocal scores
+        b = qq.shape[0]
+        if scores is None or scores.shape[0] < b:
+            scores = torch.empty((b, ld), dtype=torch.float32, device=dev)
         s = scores[:b]
         check(lib.hrag_sim_gemm(keys.data_ptr(), n_keys, kdim, qq.data_ptr(), b, s.data_ptr(), ld, 0, dtype, stream))
         idx = torch.empty((b, kk), dtype=torch.int32, device=dev)
@@ -140,9 +111,47 @@ def retrieve_knn(query_ids: List[str], key_ids: List[str], query_vecs, key_vecs,
             if w:
                 out_idx[rows_out, :w] = torch.where(keep[:, :w], idx[:, :w], torch.full_like(idx[:, :w], -1)).cpu().numpy()
                 out_sc[rows_out, :w] = torch.where(keep[:, :w], val[:, :w], torch.zeros_like(val[:, :w])).cpu().numpy()
-            continue
-        out_idx[lo_q: lo_q + b] = idx.cpu().numpy()
-        out_sc[lo_q: lo_q + b] = val.cpu().numpy()
+            return
+        out_idx[rows_out] = idx.cpu().numpy()
+        out_sc[rows_out] = val.cpu().numpy()
+
+    if min_score is not None:
+        # The thresholded fused top-16 (include/hrag.h hrag_sim_topk_min_score): tiles below the threshold are never
+        # rescored, and on the split layout the tile maxima come from the hi . qhi third alone -- the other two thirds
+        # move a score by at most 2 * 2^-11 = 9.8e-4 for unit vectors (margin 1.2e-3) -- a third of the MFMA work; what
+        # is rescored is rescored over all 3 * dim elements, so every returned score is the exact chain.  Every block is
+        # ENQUEUED before anything is read back (16 candidates per query stay on the device: 128 bytes each), so the
+        # device never waits for the host between blocks (round 6: the per-block read-back cost 20 % of the call).
+        i16 = torch.empty((nq, fused_k), dtype=torch.int32, device=dev)
+        v16 = torch.empty((nq, fused_k), dtype=torch.float32, device=dev)
+        over = torch.empty((nq,), dtype=torch.int32, device=dev)
+        for lo_q in range(0, nq, qb):
+            q = torch.from_numpy(qv_all[lo_q: lo_q + qb]).to(dev).contiguous()
+            b = q.shape[0]
+            qq = prepare(q, True)
+            check(lib.hrag_sim_topk_min_score(keys.data_ptr(), n_keys, kdim, qq.data_ptr(), b, fused_k, dtype,
+                                              dim if split else 0, float(min_score), _PREFIX_MARGIN if split else 0.0,
+                                              ws.data_ptr(), ws_bytes, i16[lo_q: lo_q + b].data_ptr(),
+                                              v16[lo_q: lo_q + b].data_ptr(), over[lo_q: lo_q + b].data_ptr(), stream))
+        keep = v16 >= float(min_score)
+        w = min(int(keep.sum(1).max().item()), kk)
+        if w:
+            out_idx[:, :w] = torch.where(keep[:, :w], i16[:, :w], torch.full_like(i16[:, :w], -1)).cpu().numpy()
+            out_sc[:, :w] = torch.where(keep[:, :w], v16[:, :w], torch.zeros_like(v16[:, :w])).cpu().numpy()
+        # the dense path for the queries the fused form cannot answer: more than 16 tiles that reach the threshold, or a
+        # 16th neighbour still above it
+        need = over != 0
+        if kk > fused_k and n_keys > fused_k:
+            need = need | keep[:, fused_k - 1]
+        more = torch.nonzero(need).flatten().cpu().numpy()
+        db = max(1, min(1024, int(query_batch_size)))
+        for lo_m in range(0, len(more), db):
+            rows_out = more[lo_m: lo_m + db]
+            dense(prepare(torch.from_numpy(qv_all[rows_out]).to(dev).contiguous(), True), rows_out)
+    else:
+        for lo_q in range(0, nq, qb):
+            q = torch.from_numpy(qv_all[lo_q: lo_q + qb]).to(dev).contiguous()
+            dense(prepare(q, True), slice(lo_q, lo_q + q.shape[0]))
     if return_arrays:
         return out_idx, out_sc
     results: Dict[str, Tuple[List[str], List[float]]] = {}

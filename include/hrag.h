@@ -445,8 +445,9 @@ hrag_status hrag_sim_gemm(const uint16_t *emb_dev, int64_t rows, int32_t dim, co
 /* The k <= 16 best rows per query WITHOUT the score matrix (the engine-less form of hrag_score_facts' fused path: the
  * GEMM epilogue keeps every 128-row tile's maximum, the k tiles with the largest maxima are rescored with the same MFMA
  * chain -- exact, bit-identical to hrag_sim_gemm + hrag_topk_rows): idx int32 [B, k], raw scores fp32 [B, k].
- * retrieve_knn(min_score=...) uses it: when a query's 16th best score is below the synonymy threshold, its neighbours
- * above the threshold are all among these 16 and no [B, rows] block is ever written (embed_utils.py:53-73 materialises
+ * When a query's 16th best score is below the synonymy threshold, its neighbours above the threshold are all among these
+ * 16 and no [B, rows] block is ever written (retrieve_knn(min_score=...) ran on this call until ABI 0.8 and runs on the
+ * thresholded form below since) (embed_utils.py:53-73 materialises
  * it block by block).  workspace_dev: hrag_sim_topk_workspace_bytes(rows, batch) bytes, ZEROED ONCE by the caller
  * before the first call (the call leaves it reusable). */
 int64_t hrag_sim_topk_workspace_bytes(int64_t rows, int32_t batch);

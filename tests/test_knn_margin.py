@@ -43,3 +43,51 @@ def test_the_prefix_pass_misses_by_less_than_its_margin():
     assert worst_lo <= 2.0 ** -11 * 1.001 + 1e-6, worst_lo                 # |lo| <= 2^-11 |x|
     assert worst <= 2 * 2.0 ** -11 * 1.002 + 2e-6, worst                   # the bound of include/hrag.h: 9.8e-4
     assert worst < _PREFIX_MARGIN - 1e-4                                   # and the margin leaves room for the fp32 chain
+
+
+def test_the_thresholded_selection_restated_returns_every_row_above_the_threshold():
+    """The selection rule of hrag_sim_topk_min_score restated in numpy: tile maxima of the PREFIX scores, the (at most 16)
+    tiles whose maximum reaches threshold - margin, exact scores for the rows of those tiles only, an overflow flag when
+    a 17th tile reaches the cut.  With neighbours planted within 5e-3 of the threshold on both sides: for every query
+    without the flag the rows found above the threshold are exactly ALL rows above it (so the caller's dense fallback is
+    needed for the flagged queries only), and far fewer tiles are rescored than the 16 per query of the exact form."""
+    rng = np.random.default_rng(3)
+    dim, n_base, thr, tile = 128, 60, 0.8, 128
+    base = _unit(rng.standard_normal((n_base, dim)))
+    rows = [base]
+    for i in range(n_base):
+        n_dup = (2, 9, 30)[i % 3]
+        u = _unit(rng.standard_normal((n_dup, dim)))
+        u = _unit(u - (u @ base[i])[:, None] * base[i])
+        c = rng.uniform(thr - 5e-3, thr + 5e-3, n_dup)[:, None].astype(np.float32)
+        rows.append(c * base[i] + np.sqrt(1 - c * c) * u)
+    keys = _unit(np.concatenate(rows + [_unit(rng.standard_normal((6000, dim)))]))
+    perm = rng.permutation(len(keys))
+    keys = keys[perm]
+    q = keys[np.argsort(perm)[:n_base]]
+    hi, lo = _split(keys)
+    qhi, qlo = _split(q)
+    prefix = hi @ qhi.T                                              # [keys, queries]
+    exact = prefix + lo @ qhi.T + hi @ qlo.T
+    n_tiles = -(-len(keys) // tile)
+    pad = np.full((n_tiles * tile - len(keys), len(q)), -np.inf)
+    tmax = np.concatenate([prefix, pad]).reshape(n_tiles, tile, len(q)).max(1)      # [tiles, queries]
+    cut = thr - _PREFIX_MARGIN
+    flagged, rescored = 0, 0
+    for j in range(len(q)):
+        order = np.argsort(-tmax[:, j], kind="stable")
+        reach = order[tmax[order, j] >= cut]
+        overflow = len(reach) > 16
+        sel = reach[:16]
+        rescored += len(sel)
+        cand = np.concatenate([np.arange(t * tile, min((t + 1) * tile, len(keys))) for t in sel]) if len(sel) else np.empty(0, int)
+        found = set(cand[exact[cand, j] >= thr].tolist())
+        want = set(np.flatnonzero(exact[:, j] >= thr).tolist())
+        if overflow:
+            flagged += 1
+            assert found <= want
+        else:
+            assert found == want, j
+    assert 0 < flagged < len(q) // 2 and rescored < 16 * len(q) // 2
+    near = np.abs(exact - thr) < _PREFIX_MARGIN
+    assert (near & (exact >= thr)).any() and (near & (exact < thr)).any()    # the margin was exercised on both sides
